@@ -1,0 +1,190 @@
+/*
+ * posecnn_hip.h — C-ABI of libposecnn_hip.so, the MI355X (gfx950) replacement for the
+ * PoseCNN TF1 custom-op plugins on the single-frame inference hot path.
+ *
+ * Every entry point replaces one `REGISTER_OP` + GPU `OpKernel::Compute` + `*Laucher`
+ * triple of the reference (citations are relative to the reference tree):
+ *
+ *   pcnn_hough_voting_*     lib/hough_voting_gpu_layer/hough_voting_gpu_op.cc:37-52,321-429
+ *                           lib/hough_voting_gpu_layer/hough_voting_gpu_op.cu.cc:615-797
+ *   pcnn_roi_pool_*         lib/roi_pooling_layer/roi_pooling_op.cc:29-50,306-347
+ *                           lib/roi_pooling_layer/roi_pooling_op_gpu.cu.cc:103-131,232-254
+ *   pcnn_hard_label_*       lib/hard_label_layer/hard_label_op.cc:30-44,143-188
+ *                           lib/hard_label_layer/hard_label_op_gpu.cu.cc:32-51,66-85
+ *   pcnn_average_distance_* lib/average_distance_loss/average_distance_loss_op.cc:38-54,253-314
+ *                           lib/average_distance_loss/average_distance_loss_op_gpu.cu.cc:256-377
+ *   pcnn_backproject_*      lib/backprojecting_layer/backprojecting_op.cc:30-53,295-383
+ *                           lib/backprojecting_layer/backprojecting_op_gpu.cu.cc:129-155,220-244
+ *
+ * Conventions
+ *   - Plain C: raw DEVICE pointers, ints, floats. No torch/TF types cross this boundary.
+ *   - Tensors are dense, row-major, NHWC exactly as the reference ops see them; f32 / int32.
+ *   - The library never allocates, frees, synchronises or exits. The caller owns inputs,
+ *     outputs and workspace; `pcnn_*_workspace_bytes` sizes the workspace. Workspace and
+ *     outputs need 16-byte alignment.
+ *   - All work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream)
+ *     and is legal inside hipGraph capture (no host round trips, no device-wide syncs; the
+ *     reference launchers block ≥6x per image, hough_voting_gpu_op.cu.cc:647-784).
+ *   - Return value: PCNN_OK (0) or a negative pcnn_status. Argument errors mirror the
+ *     reference's OP_REQUIRES / attribute checks; nothing is launched when an error is returned.
+ *     `pcnn_last_error_string()` (thread-local) describes the most recent failure.
+ *   - Results are bit-identical to oracle/ (the CPU restatement of the reference GPU kernels
+ *     with canonical orderings) — custom kernels are built -ffp-contract=off.
+ */
+#ifndef POSECNN_HIP_H_
+#define POSECNN_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCNN_ABI_VERSION 1
+
+/* hough_voting_gpu_op.cc:31-32 */
+#define PCNN_VERTEX_CHANNELS 3
+#define PCNN_MAX_ROI 128
+/* rows of the scratch outputs the reference allocates: MAX_ROI * 9 (hough_voting_gpu_op.cc:94) */
+#define PCNN_HOUGH_ROWS_CAPACITY (PCNN_MAX_ROI * 9)
+/* average_distance_loss_op.cc:33 */
+#define PCNN_POSE_CHANNELS 4
+
+typedef enum pcnn_status {
+  PCNN_OK = 0,
+  PCNN_EINVAL = -1,     /* bad shape / attribute (reference: errors::InvalidArgument) */
+  PCNN_EWORKSPACE = -2, /* workspace NULL, misaligned or too small */
+  PCNN_EHIP = -3,       /* a HIP launch failed (reference: fprintf + exit(-1)) */
+  PCNN_ENULL = -4       /* a required pointer is NULL */
+} pcnn_status;
+
+int pcnn_abi_version(void);
+const char* pcnn_last_error_string(void);
+const char* pcnn_status_string(int status);
+
+/* ------------------------------------------------------------------------------------------
+ * Hough voting  (REGISTER_OP("Houghvotinggpu"), hough_voting_gpu_op.cc:37-52)
+ *
+ *   label    int32 [B,H,W]          bottom_label
+ *   vertex   f32   [B,H,W,3*C]      bottom_vertex  (u, v, log depth per class)
+ *   extents  f32   [C,3]            bottom_extents
+ *   meta     f32   [B,num_meta]     bottom_meta_data ([B,1,1,48]); uses fx=0, px=2, fy=4, py=5
+ *   gt       f32   [num_gt,13]      bottom_gt = (batch, cls, box4, quat wxyz, trans3); may be NULL iff num_gt==0
+ *
+ *   top_box    f32   [PCNN_HOUGH_ROWS_CAPACITY,7]   (batch, cls, x1, y1, x2, y2, votes)
+ *   top_pose   f32   [PCNN_HOUGH_ROWS_CAPACITY,7]   (1,0,0,0, tx, ty, tz)
+ *   top_target f32   [PCNN_HOUGH_ROWS_CAPACITY,4*C]
+ *   top_weight f32   [PCNN_HOUGH_ROWS_CAPACITY,4*C]
+ *   top_domain int32 [PCNN_HOUGH_ROWS_CAPACITY]
+ *   num_rois   int32 [2]   [0] = rows the reference would return (>=1: a single all-zero dummy
+ *                          row when nothing was detected, hough_voting_gpu_op.cc:381-383),
+ *                          [1] = true detection row count (may be 0)
+ *
+ * All five outputs are zero-filled by the call (reset_outputs, .cu.cc:579-588); rows beyond
+ * num_rois[0] stay zero. Row order is canonical: image ascending, then maxima ascending
+ * (class slot, cell index) — the reference's order is atomicAdd-dependent.
+ * attrs: is_train>=0, threshold_vote, threshold_percentage, skip_pixels>=1; inlier_threshold
+ * and label_threshold are the constants 0.9 / 500 of hough_voting_gpu_op.cc:356-357.
+ * ------------------------------------------------------------------------------------------ */
+int pcnn_hough_voting_workspace_bytes(int batch, int height, int width, int num_classes,
+                                      float threshold_vote, int skip_pixels, size_t* bytes);
+
+int pcnn_hough_voting_fwd(const int32_t* label, const float* vertex, const float* extents,
+                          const float* meta, const float* gt,
+                          int batch, int height, int width, int num_classes,
+                          int num_meta, int num_gt,
+                          int is_train, float threshold_vote, float threshold_percentage,
+                          int skip_pixels, float inlier_threshold, int label_threshold,
+                          float* top_box, float* top_pose, float* top_target, float* top_weight,
+                          int32_t* top_domain, int32_t* num_rois,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* HoughvotinggpuGrad (hough_voting_gpu_op.cc:440-484, set_gradients .cu.cc:608-612): zeros. */
+int pcnn_hough_voting_bwd(float* grad_label, float* grad_vertex,
+                          int batch, int height, int width, int num_classes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * ROI pooling  (REGISTER_OP("RoiPool"), roi_pooling_op.cc:29-38)
+ *   data  f32 [B,H,W,C] NHWC;  rois f32 [R,roi_cols] with roi_cols>=6: (batch, cls, x1,y1,x2,y2,..)
+ *   top   f32 [R,PH,PW,C]  (C -> 1 when pool_channel==1);  argmax int32 same shape, may be NULL
+ *   argmax is image-relative: (h*W+w)*C + c, -1 for an empty bin (roi_pooling_op_gpu.cu.cc:75-99).
+ * ------------------------------------------------------------------------------------------ */
+int pcnn_roi_pool_fwd(const float* data, const float* rois,
+                      int batch, int height, int width, int channels,
+                      int num_rois, int roi_cols,
+                      int pooled_height, int pooled_width, float spatial_scale, int pool_channel,
+                      float* top, int32_t* argmax, void* stream);
+
+/* RoiPoolGrad (roi_pooling_op.cc:384-461, roi_pooling_op_gpu.cu.cc:135-254): bottom_diff [B,H,W,C]. */
+int pcnn_roi_pool_bwd(const float* top_diff, const float* rois, const int32_t* argmax,
+                      int batch, int height, int width, int channels,
+                      int num_rois, int roi_cols,
+                      int pooled_height, int pooled_width, float spatial_scale, int pool_channel,
+                      float* bottom_diff, void* stream);
+
+/* Fused pool5 + pool4 -> add ('pool_score', vgg16_convs.py:177-187): two RoiPool calls with
+ * pool_channel=0 and their element-wise sum, without materialising either pooled tensor.
+ * out f32 [R,PH,PW,C]; data_a [B,Ha,Wa,C] with scale_a, data_b [B,Hb,Wb,C] with scale_b. */
+int pcnn_roi_pool_add2_fwd(const float* data_a, int height_a, int width_a, float scale_a,
+                           const float* data_b, int height_b, int width_b, float scale_b,
+                           const float* rois, int batch, int channels, int num_rois, int roi_cols,
+                           int pooled_height, int pooled_width, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Hard label  (REGISTER_OP("Hardlabel"), hard_label_op.cc:30-35; GPU semantics .cu.cc:17-29)
+ *   prob f32 [N,C] (N = B*H*W), gt int32 [N] in {-1, 0..C-1}; out f32 [N,C]; threshold > 0.
+ * ------------------------------------------------------------------------------------------ */
+int pcnn_hard_label_fwd(const float* prob, const int32_t* gt, int64_t num_pixels, int num_classes,
+                        float threshold, float* out, void* stream);
+
+/* HardlabelGrad (hard_label_op_gpu.cu.cc:55-85): both gradients are zero. */
+int pcnn_hard_label_bwd(float* grad_prob, float* grad_gt, int64_t num_pixels, int num_classes,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Average distance loss  (REGISTER_OP("Averagedistance"), average_distance_loss_op.cc:38-47)
+ *   prediction/target/weight f32 [R,4*C]; point f32 [C,P,3]; symmetry f32 [C]; margin >= 0
+ *   loss f32 [1]; bottom_diff f32 [R,4*C]
+ * ------------------------------------------------------------------------------------------ */
+int pcnn_average_distance_workspace_bytes(int num_rois, int num_classes, int num_points,
+                                          size_t* bytes);
+
+int pcnn_average_distance_fwd(const float* prediction, const float* target, const float* weight,
+                              const float* point, const float* symmetry,
+                              int num_rois, int num_classes, int num_points, float margin,
+                              float* loss, float* bottom_diff,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
+/* AveragedistanceGrad (average_distance_loss_op_gpu.cu.cc:347-377): out = grad[0] * bottom_diff. */
+int pcnn_average_distance_bwd(const float* grad, const float* bottom_diff, int num_rois,
+                              int channels, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backprojecting  (REGISTER_OP("Backproject"), backprojecting_op.cc:30-43)
+ *   data f32 [B,H,W,Cd]; label f32 [B,H,W,Cl]; depth f32 [B,H,W]; meta f32 [B,num_meta] (>=48);
+ *   label_3d f32 [B,G,G,G,Cl];  top_data, top_flag f32 [B,G,G,G,Cd]; top_label f32 [B,G,G,G,Cl]
+ * ------------------------------------------------------------------------------------------ */
+int pcnn_backproject_fwd(const float* data, const float* label, const float* depth,
+                         const float* meta, const float* label_3d,
+                         int batch, int height, int width, int channels, int num_classes,
+                         int num_meta, int grid_size, int kernel_size, float threshold,
+                         float* top_data, float* top_label, float* top_flag, void* stream);
+
+/* BackprojectGrad (backprojecting_op_gpu.cu.cc:159-244): bottom_diff [B,H,W,Cd] from top_diff [B,G,G,G,Cd]. */
+int pcnn_backproject_bwd(const float* top_diff, const float* depth, const float* meta,
+                         int batch, int height, int width, int channels, int num_meta,
+                         int grid_size, float* bottom_diff, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused label head epilogue (vgg16_convs.py:140-149, network.py:432-434,474-488):
+ *   score f32 [N,C] (already bias+ReLU'd) -> prob_normalized f32 [N,C] (softmax, max-subtracted),
+ *   label_2d int32 [N] (first argmax of prob_normalized). prob may be NULL (label only).
+ * ------------------------------------------------------------------------------------------ */
+int pcnn_softmax_argmax_fwd(const float* score, int64_t num_pixels, int num_classes,
+                            float* prob, int32_t* label, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POSECNN_HIP_H_ */

@@ -1,0 +1,825 @@
+/*
+ * pcnn_oracle.c — CPU oracle for the PoseCNN custom-op hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY. Nothing under posecnn_amd/ may include, link, import or execute this
+ * file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load it (as the
+ * checker / the timed CPU baseline, never as the product path).
+ *
+ * PARITY UNPINNED BY THE REFERENCE'S OWN TESTS: the reference has no golden vectors, known-answer
+ * tests or unit tests for this path and cannot be executed here (TensorFlow 1.x,
+ * CUDA, Eigen, OpenCV absent). This file restates, in plain C, the reference's *GPU* kernels
+ * (`*_op_gpu.cu.cc`), which BASELINE.json names as the parity target. The oracle is pinned instead by
+ * (a) oracle/_ref: the reference's own kernel bodies compiled for the CPU by oracle/Makefile from
+ * the sources where they lie (see oracle/ref_shim/), when /root/reference is present;
+ * (b) an independent numpy restatement (tests/np_ref.py); (c) hand-derived known answers
+ * (tests/test_oracle_kat.py).
+ *
+ * Canonical choices where the reference is order dependent (atomicAdd order, thrust): serial
+ * execution order — ascending pixel index for the per-class pixel arrays, ascending cell index for
+ * maxima, ascending (image, maximum) for output rows, sequential ascending sums.  FP contraction:
+ * none (build with -ffp-contract=off); expf: the canonical pcnn_exp_f32 below (the bits of CUDA's
+ * expf are unknowable here; both this file and the HIP kernels evaluate the same IEEE double
+ * sequence, so they agree bit for bit).
+ *
+ * Each function cites the reference file:line it follows (paths relative to the reference tree).
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define VERTEX_CHANNELS 3
+#define MAX_ROI 128
+#define POSE_CHANNELS 4
+
+/* ------------------------------------------------------------------------------------------ */
+/* canonical expf: exp evaluated in IEEE double (range reduction + degree-13 Taylor/Horner),     */
+/* rounded once to float.  |rel err| ~1e-16 before the final rounding.                           */
+/* ------------------------------------------------------------------------------------------ */
+float oracle_expf(float xf)
+{
+  if (xf != xf) return xf;
+  double x = (double)xf;
+  if (x > 130.0) x = 130.0;   /* -> +inf after the float conversion */
+  if (x < -150.0) x = -150.0; /* -> 0 */
+  const double LOG2E = 1.4426950408889634074;
+  const double LN2_HI = 6.93147180369123816490e-01;
+  const double LN2_LO = 1.90821492927058770002e-10;
+  double kd = floor(x * LOG2E + 0.5);
+  double r = (x - kd * LN2_HI) - kd * LN2_LO;
+  double p = 1.6059043836821614599e-10; /* 1/13! */
+  p = p * r + 2.0876756987868098979e-09; /* 1/12! */
+  p = p * r + 2.5052108385441718775e-08; /* 1/11! */
+  p = p * r + 2.7557319223985890653e-07; /* 1/10! */
+  p = p * r + 2.7557319223985892511e-06; /* 1/9! */
+  p = p * r + 2.4801587301587301566e-05; /* 1/8! */
+  p = p * r + 1.9841269841269841253e-04; /* 1/7! */
+  p = p * r + 1.3888888888888889419e-03; /* 1/6! */
+  p = p * r + 8.3333333333333332177e-03; /* 1/5! */
+  p = p * r + 4.1666666666666664354e-02; /* 1/4! */
+  p = p * r + 1.6666666666666665741e-01; /* 1/3! */
+  p = p * r + 0.5;
+  p = p * r + 1.0;
+  p = p * r + 1.0;
+  int k = (int)kd;
+  uint64_t bits = (uint64_t)(k + 1023) << 52;
+  double two_k;
+  memcpy(&two_k, &bits, sizeof two_k);
+  return (float)(p * two_k);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Hough voting                                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+
+/* angle_distance, hough_voting_gpu_op.cu.cc:32-42 */
+static inline float angle_distance(int cx, int cy, int x, int y, float u, float v)
+{
+  float dx = (float)(cx - x);
+  float dy = (float)(cy - y);
+  float n1 = sqrtf(u * u + v * v);
+  float n2 = sqrtf(dx * dx + dy * dy);
+  float dot = u * dx + v * dy;
+  return dot / (n1 * n2);
+}
+
+/* project_box, hough_voting_gpu_op.cu.cc:84-120 (factor = 0.6 at every call site :285,317) */
+static float project_box(int cls, const float* extents, const float* meta, float distance)
+{
+  float xHalf = (float)((double)extents[cls * 3 + 0] * 0.5);
+  float yHalf = (float)((double)extents[cls * 3 + 1] * 0.5);
+  float zHalf = (float)((double)extents[cls * 3 + 2] * 0.5);
+  float bb[24];
+  bb[0] = xHalf;   bb[1] = yHalf;   bb[2] = zHalf + distance;
+  bb[3] = -xHalf;  bb[4] = yHalf;   bb[5] = zHalf + distance;
+  bb[6] = xHalf;   bb[7] = -yHalf;  bb[8] = zHalf + distance;
+  bb[9] = -xHalf;  bb[10] = -yHalf; bb[11] = zHalf + distance;
+  bb[12] = xHalf;  bb[13] = yHalf;  bb[14] = -zHalf + distance;
+  bb[15] = -xHalf; bb[16] = yHalf;  bb[17] = -zHalf + distance;
+  bb[18] = xHalf;  bb[19] = -yHalf; bb[20] = -zHalf + distance;
+  bb[21] = -xHalf; bb[22] = -yHalf; bb[23] = -zHalf + distance;
+  float fx = meta[0], fy = meta[4], px = meta[2], py = meta[5];
+  float minX = 1e8f, maxX = -1e8f, minY = 1e8f, maxY = -1e8f;
+  for (int i = 0; i < 8; i++) {
+    float x = fx * (bb[i * 3] / bb[i * 3 + 2]) + px;
+    float y = fy * (bb[i * 3 + 1] / bb[i * 3 + 2]) + py;
+    minX = fminf(minX, x);
+    minY = fminf(minY, y);
+    maxX = fmaxf(maxX, x);
+    maxY = fmaxf(maxY, y);
+  }
+  float width = maxX - minX + 1;
+  float height = maxY - minY + 1;
+  return fmaxf(width, height) * 0.6f;
+}
+
+/* IoU, hough_voting_gpu_op.cu.cc:73-82 */
+static float box_iou(const float* a, const float* b)
+{
+  float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
+  float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+  float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);
+  float interS = width * height;
+  float Sa = (a[2] - a[0] + 1) * (a[3] - a[1] + 1);
+  float Sb = (b[2] - b[0] + 1) * (b[3] - b[1] + 1);
+  return interS / (Sa + Sb - interS);
+}
+
+/* compute_box_overlap, hough_voting_gpu_op.cu.cc:123-172. The rotation is Eigen's
+ * Quaternionf(w,x,y,z).toRotationMatrix() (Eigen/src/Geometry/Quaternion.h, unpinned version):
+ * tx=2x.. twx=tx*w.. R00=1-(tyy+tzz) ...; the 3x3 * 3x8 product is summed k = 0,1,2. */
+static float compute_box_overlap(int cls, const float* extents, const float* meta,
+                                 const float* pose, const float* box)
+{
+  float xHalf = (float)((double)extents[cls * 3 + 0] * 0.5);
+  float yHalf = (float)((double)extents[cls * 3 + 1] * 0.5);
+  float zHalf = (float)((double)extents[cls * 3 + 2] * 0.5);
+  float bb[8][3] = {{xHalf, yHalf, zHalf},   {-xHalf, yHalf, zHalf},  {xHalf, -yHalf, zHalf},
+                    {-xHalf, -yHalf, zHalf}, {xHalf, yHalf, -zHalf},  {-xHalf, yHalf, -zHalf},
+                    {xHalf, -yHalf, -zHalf}, {-xHalf, -yHalf, -zHalf}};
+  float qw = pose[6], qx = pose[7], qy = pose[8], qz = pose[9];
+  float tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+  float twx = tx * qw, twy = ty * qw, twz = tz * qw;
+  float txx = tx * qx, txy = ty * qx, txz = tz * qx;
+  float tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+  float R[3][3];
+  R[0][0] = 1 - (tyy + tzz); R[0][1] = txy - twz;       R[0][2] = txz + twy;
+  R[1][0] = txy + twz;       R[1][1] = 1 - (txx + tzz); R[1][2] = tyz - twx;
+  R[2][0] = txz - twy;       R[2][1] = tyz + twx;       R[2][2] = 1 - (txx + tyy);
+  float fx = meta[0], fy = meta[4], px = meta[2], py = meta[5];
+  float x1 = 1e8f, x2 = -1e8f, y1 = 1e8f, y2 = -1e8f;
+  for (int i = 0; i < 8; i++) {
+    float X = (R[0][0] * bb[i][0] + R[0][1] * bb[i][1] + R[0][2] * bb[i][2]) + pose[10];
+    float Y = (R[1][0] * bb[i][0] + R[1][1] * bb[i][1] + R[1][2] * bb[i][2]) + pose[11];
+    float Z = (R[2][0] * bb[i][0] + R[2][1] * bb[i][1] + R[2][2] * bb[i][2]) + pose[12];
+    float x = fx * (X / Z) + px;
+    float y = fy * (Y / Z) + py;
+    x1 = fminf(x1, x);
+    y1 = fminf(y1, y);
+    x2 = fmaxf(x2, x);
+    y2 = fmaxf(y2, y);
+  }
+  float box_gt[4] = {x1, y1, x2, y2};
+  return box_iou(box, box_gt);
+}
+
+typedef struct {
+  int x, y;
+  float u, v, d, thr;
+} hv_pixel;
+
+/* One Hough cell: compute_hough_kernel, hough_voting_gpu_op.cu.cc:253-333, restricted to the
+ * sampled pixels pix[0..m) (= arrays[cls][0::skip] in ascending pixel order). The box test and
+ * the angle test are both pure, so evaluating the (cheap) box test first is result-identical. */
+static float cell_votes(const hv_pixel* pix, int m, int cx, int cy, float inlier, float* sumd)
+{
+  float votes = 0.f, distance = 0.f;
+  for (int i = 0; i < m; i++) {
+    float dx = fabsf((float)(pix[i].x - cx));
+    float dy = fabsf((float)(pix[i].y - cy));
+    if (dx < pix[i].thr && dy < pix[i].thr) {
+      if (angle_distance(cx, cy, pix[i].x, pix[i].y, pix[i].u, pix[i].v) > inlier) {
+        votes++;
+        distance += pix[i].d;
+      }
+    }
+  }
+  *sumd = distance;
+  return votes;
+}
+
+/* second loop of compute_hough_kernel (:296-331): hough_data = (distance, 2*bb_height, 2*bb_width) */
+static void cell_data(const hv_pixel* pix, int m, int cx, int cy, float inlier, int cls,
+                      const float* extents, const float* meta, float votes, float sumd,
+                      float* hd3)
+{
+  hd3[0] = hd3[1] = hd3[2] = 0.f; /* cudaMemset(hough_data, 0, ...) :706 */
+  if (votes > 0) {
+    float distance = sumd / votes;
+    float bb_width = -1, bb_height = -1;
+    float threshold = project_box(cls, extents, meta, distance);
+    for (int i = 0; i < m; i++) {
+      if (angle_distance(cx, cy, pix[i].x, pix[i].y, pix[i].u, pix[i].v) > inlier) {
+        float dx = fabsf((float)(pix[i].x - cx));
+        float dy = fabsf((float)(pix[i].y - cy));
+        if (dx > bb_width && dx < threshold && dy < threshold) bb_width = dx;
+        if (dy > bb_height && dx < threshold && dy < threshold) bb_height = dy;
+      }
+    }
+    hd3[0] = distance;
+    hd3[1] = 2 * bb_height;
+    hd3[2] = 2 * bb_width;
+  }
+}
+
+/* compute_rois_kernel, hough_voting_gpu_op.cu.cc:386-576, for one maximum; appends 1 or 9 rows. */
+static void emit_rois(int x, int y, int cls, float votes, const float* hd3, const float* extents,
+                      const float* meta, const float* gt, int num_gt, int is_train,
+                      int batch_index, int C, float* top_box, float* top_pose, float* top_target,
+                      float* top_weight, int* top_domain, int* num_rois)
+{
+  float scale = 0.05f;
+  float fx = meta[0], fy = meta[4], px = meta[2], py = meta[5];
+  float rx = ((float)x - px) / fx;
+  float ry = ((float)y - py) / fy;
+  float bb_distance = hd3[0], bb_height = hd3[1], bb_width = hd3[2];
+  double k = 0.5 + (double)scale;
+  int roi_index = *num_rois;
+  *num_rois += is_train ? 9 : 1;
+  float* b = top_box + (size_t)roi_index * 7;
+  b[0] = (float)batch_index;
+  b[1] = (float)cls;
+  b[2] = (float)((double)x - (double)bb_width * k);
+  b[3] = (float)((double)y - (double)bb_height * k);
+  b[4] = (float)((double)x + (double)bb_width * k);
+  b[5] = (float)((double)y + (double)bb_height * k);
+  b[6] = votes;
+  int nrows = is_train ? 9 : 1;
+  for (int i = 0; i < nrows; i++) {
+    float* p = top_pose + (size_t)(roi_index + i) * 7;
+    p[0] = 1; p[1] = 0; p[2] = 0; p[3] = 0;
+    p[4] = rx * bb_distance;
+    p[5] = ry * bb_distance;
+    p[6] = bb_distance;
+    if (is_train) top_domain[roi_index + i] = (num_gt == 0) ? 1 : 0;
+  }
+  if (!is_train) return;
+
+  /* pose target :440-466 */
+  for (int i = 0; i < num_gt; i++) {
+    int gt_batch = (int)gt[i * 13 + 0];
+    int gt_id = (int)gt[i * 13 + 1];
+    if (cls == gt_id && batch_index == gt_batch) {
+      float overlap = compute_box_overlap(cls, extents, meta, gt + i * 13, b + 2);
+      if ((double)overlap > 0.2) { /* `overlap > 0.2`: float promoted to double (:449) */
+        for (int j = 0; j < 9; j++) {
+          for (int q = 0; q < 4; q++) {
+            top_target[(size_t)(roi_index + j) * 4 * C + 4 * cls + q] = gt[i * 13 + 6 + q];
+            top_weight[(size_t)(roi_index + j) * 4 * C + 4 * cls + q] = 1;
+          }
+        }
+        break;
+      }
+    }
+  }
+
+  /* jittered boxes :468-554; `0.05 * ww` is double arithmetic */
+  float x1 = b[2], y1 = b[3], x2 = b[4], y2 = b[5];
+  float ww = x2 - x1, hh = y2 - y1;
+  static const int sx[8] = {-1, +1, -1, +1, 0, -1, 0, +1};
+  static const int sy[8] = {-1, -1, +1, +1, -1, 0, +1, 0};
+  for (int j = 0; j < 8; j++) {
+    float* r = top_box + (size_t)(roi_index + 1 + j) * 7;
+    r[0] = (float)batch_index;
+    r[1] = (float)cls;
+    if (sx[j] < 0) r[2] = (float)((double)x1 - 0.05 * (double)ww);
+    else if (sx[j] > 0) r[2] = (float)((double)x1 + 0.05 * (double)ww);
+    else r[2] = x1;
+    if (sy[j] < 0) r[3] = (float)((double)y1 - 0.05 * (double)hh);
+    else if (sy[j] > 0) r[3] = (float)((double)y1 + 0.05 * (double)hh);
+    else r[3] = y1;
+    r[4] = r[2] + ww;
+    r[5] = r[3] + hh;
+    r[6] = votes;
+  }
+}
+
+/* Collect arrays[cls][0::skip] with per-pixel u, v, d=exp(.), thr=project_box(d): the loop
+ * header of compute_hough_kernel (:269-285) hoisted per pixel (pure functions of the pixel). */
+static int collect_pixels(const int* labelmap, const float* vertmap, const float* extents,
+                          const float* meta, int H, int W, int C, int cls, int skip, hv_pixel* out)
+{
+  int rank = 0, m = 0;
+  for (int i = 0; i < H * W; i++) {
+    if (labelmap[i] != cls) continue;
+    if (rank % skip == 0) {
+      int x = i % W, y = i / W;
+      size_t off = (size_t)VERTEX_CHANNELS * cls + (size_t)VERTEX_CHANNELS * C * ((size_t)y * W + x);
+      hv_pixel p;
+      p.x = x; p.y = y;
+      p.u = vertmap[off];
+      p.v = vertmap[off + 1];
+      p.d = oracle_expf(vertmap[off + 2]);
+      p.thr = project_box(cls, extents, meta, p.d);
+      out[m++] = p;
+    }
+    rank++;
+  }
+  return m;
+}
+
+/*
+ * HoughvotinggpuOp<GpuDevice>::Compute + HoughVotingLaucher
+ * (hough_voting_gpu_op.cc:321-429, hough_voting_gpu_op.cu.cc:615-797).
+ * Outputs have PCNN capacity MAX_ROI*9 rows and are zero-filled (reset_outputs :579-588).
+ * num_rois[0] = rows the op returns (>=1, dummy row), num_rois[1] = true count.
+ * hs_debug (optional, may be NULL): [B][C][H*W] votes of every slot class, for cross checks.
+ */
+int oracle_hough_voting(const int* label, const float* vertex, const float* extents,
+                        const float* meta, const float* gt, int B, int H, int W, int C,
+                        int num_meta, int num_gt, int is_train, float vote_thr, float per_thr,
+                        int skip, float inlier, int label_thr, float* top_box, float* top_pose,
+                        float* top_target, float* top_weight, int* top_domain, int* num_rois,
+                        float* hs_debug)
+{
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || skip <= 0) return -1;
+  const int cap_rows = MAX_ROI * 9;
+  memset(top_box, 0, sizeof(float) * cap_rows * 7);
+  memset(top_pose, 0, sizeof(float) * cap_rows * 7);
+  memset(top_target, 0, sizeof(float) * (size_t)cap_rows * 4 * C);
+  memset(top_weight, 0, sizeof(float) * (size_t)cap_rows * 4 * C);
+  memset(top_domain, 0, sizeof(int) * cap_rows);
+  int rows = 0;
+  const int HW = H * W;
+  const int index_size = MAX_ROI / B; /* :733 */
+
+  hv_pixel* pix = (hv_pixel*)malloc(sizeof(hv_pixel) * (size_t)(HW / skip + 2));
+  float* hs = (float*)malloc(sizeof(float) * (size_t)HW);
+  float* sd = (float*)malloc(sizeof(float) * (size_t)HW);
+  int* sizes = (int*)malloc(sizeof(int) * C);
+
+  for (int n = 0; n < B; n++) {
+    const int* labelmap = label + (size_t)n * HW;
+    const float* vertmap = vertex + (size_t)n * HW * VERTEX_CHANNELS * C;
+    const float* md = meta + (size_t)n * num_meta;
+
+    /* step 1 :626-663 */
+    memset(sizes, 0, sizeof(int) * C);
+    for (int i = 0; i < HW; i++) {
+      int c = labelmap[i];
+      if (c > 0 && c < C) sizes[c]++;
+    }
+    int count = 0;
+    int slots[256];
+    for (int c = 1; c < C; c++)
+      if (sizes[c] > label_thr) slots[count++] = c;
+    if (count == 0) continue;
+
+    int num_max = 0; /* maxima accepted for this image, <= index_size */
+    int total_max = 0;
+    for (int s = 0; s < count; s++) {
+      int cls = slots[s];
+      int m = collect_pixels(labelmap, vertmap, extents, md, H, W, C, cls, skip, pix);
+      /* step 2 :686-714 */
+#pragma omp parallel for schedule(dynamic, 16)
+      for (int cy = 0; cy < H; cy++)
+        for (int cx = 0; cx < W; cx++)
+          hs[cy * W + cx] = cell_votes(pix, m, cx, cy, inlier, &sd[cy * W + cx]);
+      if (hs_debug) memcpy(hs_debug + ((size_t)n * C + cls) * HW, hs, sizeof(float) * HW);
+
+      /* step 3 + 4 :723-785 */
+      if (vote_thr > 0) {
+        /* compute_max_indexes_kernel :335-383, cells in ascending index order */
+        for (int cy = 0; cy < H; cy++) {
+          for (int cx = 0; cx < W; cx++) {
+            float v = hs[cy * W + cx];
+            if (!(v > vote_thr)) continue;
+            int flag = 0;
+            for (int x = cx - 3; x <= cx + 3 && !flag; x++)
+              for (int y = cy - 3; y <= cy + 3; y++)
+                if (x >= 0 && x < W && y >= 0 && y < H && hs[y * W + x] > v) { flag = 1; break; }
+            if (flag) continue;
+            float hd3[3];
+            cell_data(pix, m, cx, cy, inlier, cls, extents, md, v, sd[cy * W + cx], hd3);
+            if (!(hd3[1] > 0 && hd3[2] > 0)) continue;
+            if (v / (hd3[1] * hd3[2]) < per_thr) continue;
+            total_max++;
+            if (num_max < index_size) {
+              num_max++;
+              emit_rois(cx, cy, cls, v, hd3, extents, md, gt, num_gt, is_train, n, C, top_box,
+                        top_pose, top_target, top_weight, top_domain, &rows);
+            }
+          }
+        }
+      } else {
+        /* thrust::max_element :752-762: first maximum */
+        int best = 0;
+        for (int i = 1; i < HW; i++)
+          if (hs[i] > hs[best]) best = i;
+        total_max++;
+        if (num_max < index_size) {
+          num_max++;
+          int cx = best % W, cy = best / W;
+          float hd3[3];
+          cell_data(pix, m, cx, cy, inlier, cls, extents, md, hs[best], sd[best], hd3);
+          emit_rois(cx, cy, cls, hs[best], hd3, extents, md, gt, num_gt, is_train, n, C, top_box,
+                    top_pose, top_target, top_weight, top_domain, &rows);
+        }
+      }
+    }
+    (void)total_max;
+  }
+  free(pix); free(hs); free(sd); free(sizes);
+  num_rois[1] = rows;
+  num_rois[0] = rows == 0 ? 1 : rows; /* hough_voting_gpu_op.cc:381-383 */
+  return 0;
+}
+
+/* Full-fidelity Hough space of one (image, class): votes and hough_data for EVERY cell, exactly
+ * as compute_hough_kernel writes them (no lazy evaluation). For cross checks at small sizes. */
+int oracle_hough_space(const int* labelmap, const float* vertmap, const float* extents,
+                       const float* meta, int H, int W, int C, int cls, int skip, float inlier,
+                       float* hough_space, float* hough_data)
+{
+  hv_pixel* pix = (hv_pixel*)malloc(sizeof(hv_pixel) * (size_t)(H * W / skip + 2));
+  int m = collect_pixels(labelmap, vertmap, extents, meta, H, W, C, cls, skip, pix);
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int cy = 0; cy < H; cy++)
+    for (int cx = 0; cx < W; cx++) {
+      float sumd;
+      float v = cell_votes(pix, m, cx, cy, inlier, &sumd);
+      hough_space[cy * W + cx] = v;
+      cell_data(pix, m, cx, cy, inlier, cls, extents, meta, v, sumd, hough_data + 3 * (cy * W + cx));
+    }
+  free(pix);
+  return m;
+}
+
+float oracle_project_box(int cls, const float* extents, const float* meta, float distance)
+{
+  return project_box(cls, extents, meta, distance);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* ROI pooling: ROIPoolForward, roi_pooling_op_gpu.cu.cc:20-101                                */
+/* ------------------------------------------------------------------------------------------ */
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+
+int oracle_roi_pool(const float* data, const float* rois, int B, int H, int W, int C, int R,
+                    int roi_cols, int PH, int PW, float scale, int pool_channel, float* top,
+                    int* argmax)
+{
+  const int Cout = pool_channel ? 1 : C;
+#pragma omp parallel for
+  for (int n = 0; n < R; n++) {
+    const float* roi = rois + (size_t)n * roi_cols;
+    int roi_batch_ind = (int)roi[0];
+    int roi_cls = (int)roi[1];
+    int roi_start_w = (int)roundf(roi[2] * scale);
+    int roi_start_h = (int)roundf(roi[3] * scale);
+    int roi_end_w = (int)roundf(roi[4] * scale);
+    int roi_end_h = (int)roundf(roi[5] * scale);
+    int roi_width = imax(roi_end_w - roi_start_w + 1, 1);
+    int roi_height = imax(roi_end_h - roi_start_h + 1, 1);
+    float bin_size_h = (float)roi_height / (float)PH;
+    float bin_size_w = (float)roi_width / (float)PW;
+    /* canonical guard: the GPU op reads out of bounds for a bad batch index (the CPU op CHECKs,
+       roi_pooling_op.cc:146-147); such ROIs pool to 0 / argmax -1 */
+    const int bad = roi_batch_ind < 0 || roi_batch_ind >= B;
+    const float* img = data + (size_t)(bad ? 0 : roi_batch_ind) * C * H * W;
+    for (int ph = 0; ph < PH; ph++)
+      for (int pw = 0; pw < PW; pw++) {
+        int hstart = (int)floorf((float)ph * bin_size_h);
+        int wstart = (int)floorf((float)pw * bin_size_w);
+        int hend = (int)ceilf((float)(ph + 1) * bin_size_h);
+        int wend = (int)ceilf((float)(pw + 1) * bin_size_w);
+        hstart = imin(imax(hstart + roi_start_h, 0), H);
+        hend = imin(imax(hend + roi_start_h, 0), H);
+        wstart = imin(imax(wstart + roi_start_w, 0), W);
+        wend = imin(imax(wend + roi_start_w, 0), W);
+        int is_empty = (hend <= hstart) || (wend <= wstart);
+        for (int c = 0; c < Cout; c++) {
+          float maxval = is_empty ? 0 : -FLT_MAX;
+          int maxidx = -1;
+          int cc = pool_channel ? roi_cls : c;
+          if (bad || cc < 0 || cc >= C) {
+            size_t index0 = (((size_t)n * PH + ph) * PW + pw) * Cout + c;
+            top[index0] = 0;
+            if (argmax) argmax[index0] = -1;
+            continue;
+          }
+          for (int h = hstart; h < hend; ++h)
+            for (int w = wstart; w < wend; ++w) {
+              int bottom_index = (h * W + w) * C + cc;
+              if (img[bottom_index] > maxval) {
+                maxval = img[bottom_index];
+                maxidx = bottom_index;
+              }
+            }
+          size_t index = (((size_t)n * PH + ph) * PW + pw) * Cout + c;
+          top[index] = maxval;
+          if (argmax) argmax[index] = maxidx;
+        }
+      }
+  }
+  return 0;
+}
+
+/* ROIPoolBackward, roi_pooling_op_gpu.cu.cc:135-229 (gather form, ROIs ascending) */
+int oracle_roi_pool_bwd(const float* top_diff, const float* rois, const int* argmax, int B, int H,
+                        int W, int C, int R, int roi_cols, int PH, int PW, float scale,
+                        int pool_channel, float* bottom_diff)
+{
+#pragma omp parallel for
+  for (long index = 0; index < (long)B * H * W * C; index++) {
+    long t = index;
+    int c = (int)(t % C); t /= C;
+    int w = (int)(t % W); t /= W;
+    int h = (int)(t % H); t /= H;
+    int n = (int)t;
+    float gradient = 0;
+    for (int roi_n = 0; roi_n < R; ++roi_n) {
+      const float* roi = rois + (size_t)roi_n * roi_cols;
+      int roi_batch_ind = (int)roi[0];
+      int roi_cls = (int)roi[1];
+      if (n != roi_batch_ind) continue;
+      if (pool_channel && c != roi_cls) continue;
+      int roi_start_w = (int)roundf(roi[2] * scale);
+      int roi_start_h = (int)roundf(roi[3] * scale);
+      int roi_end_w = (int)roundf(roi[4] * scale);
+      int roi_end_h = (int)roundf(roi[5] * scale);
+      if (!(w >= roi_start_w && w <= roi_end_w && h >= roi_start_h && h <= roi_end_h)) continue;
+      size_t offset = pool_channel ? (size_t)roi_n * PH * PW : (size_t)roi_n * PH * PW * C;
+      const float* otd = top_diff + offset;
+      const int* oam = argmax + offset;
+      int roi_width = imax(roi_end_w - roi_start_w + 1, 1);
+      int roi_height = imax(roi_end_h - roi_start_h + 1, 1);
+      float bin_size_h = (float)roi_height / (float)PH;
+      float bin_size_w = (float)roi_width / (float)PW;
+      int phstart = (int)floorf((float)(h - roi_start_h) / bin_size_h);
+      int phend = (int)ceilf((float)(h - roi_start_h + 1) / bin_size_h);
+      int pwstart = (int)floorf((float)(w - roi_start_w) / bin_size_w);
+      int pwend = (int)ceilf((float)(w - roi_start_w + 1) / bin_size_w);
+      phstart = imin(imax(phstart, 0), PH);
+      phend = imin(imax(phend, 0), PH);
+      pwstart = imin(imax(pwstart, 0), PW);
+      pwend = imin(imax(pwend, 0), PW);
+      for (int ph = phstart; ph < phend; ++ph)
+        for (int pw = pwstart; pw < pwend; ++pw) {
+          if (pool_channel) {
+            if (oam[ph * PW + pw] == (h * W + w) * C + c) gradient += otd[ph * PW + pw];
+          } else {
+            if (oam[(ph * PW + pw) * C + c] == (h * W + w) * C + c)
+              gradient += otd[(ph * PW + pw) * C + c];
+          }
+        }
+    }
+    bottom_diff[index] = gradient;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Hard label: HardlabelForward, hard_label_op_gpu.cu.cc:17-29                                  */
+/* ------------------------------------------------------------------------------------------ */
+int oracle_hard_label(const float* prob, const int* gt, long N, int C, float threshold, float* out)
+{
+#pragma omp parallel for
+  for (long index = 0; index < N; index++) {
+    for (int c = 0; c < C; c++) out[index * C + c] = 0.0f;
+    int gt_label = gt[index];
+    /* labels outside [-1, C) index out of bounds in the reference; canonical: ignored */
+    if (gt_label >= 0 && gt_label < C && (gt_label > 0 || prob[index * C + gt_label] < threshold))
+      out[index * C + gt_label] = 1.0f;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Average distance loss: AveragedistanceForward + sum_losses_gradients + thrust::reduce,       */
+/* average_distance_loss_op_gpu.cu.cc:35-206, 210-252, 323-335                                  */
+/* ------------------------------------------------------------------------------------------ */
+static void quat_rot(float s, float u, float v, float w, float* r)
+{
+  r[0] = s * s + u * u - v * v - w * w;
+  r[1] = 2 * (u * v - s * w);
+  r[2] = 2 * (u * w + s * v);
+  r[3] = 2 * (u * v + s * w);
+  r[4] = s * s - u * u + v * v - w * w;
+  r[5] = 2 * (v * w - s * u);
+  r[6] = 2 * (u * w - s * v);
+  r[7] = 2 * (v * w + s * u);
+  r[8] = s * s - u * u - v * v + w * w;
+}
+
+int oracle_average_distance(const float* prediction, const float* target, const float* weight,
+                            const float* point, const float* symmetry, int R, int C, int P,
+                            float margin, float* loss, float* bottom_diff)
+{
+  const int CH = POSE_CHANNELS * C;
+  float* losses = (float*)calloc((size_t)R * P, sizeof(float));
+  float* diffs = (float*)calloc((size_t)R * P * 4, sizeof(float)); /* only the class' 4 channels are ever non-zero */
+  int* cls_of = (int*)malloc(sizeof(int) * (R > 0 ? R : 1));
+  for (int n = 0; n < R; n++) {
+    int index_cls = -1;
+    float rot[54];
+    float s = 0, u = 0, v = 0, w = 0;
+    for (int i = 0; i < CH; i += POSE_CHANNELS) {
+      int index = n * CH + i;
+      if (weight[index] > 0) {
+        index_cls = i / POSE_CHANNELS;
+        quat_rot(target[index], target[index + 1], target[index + 2], target[index + 3], rot);
+        s = prediction[index + 0]; u = prediction[index + 1];
+        v = prediction[index + 2]; w = prediction[index + 3];
+        quat_rot(s, u, v, w, rot + 9);
+        break;
+      }
+    }
+    cls_of[n] = index_cls;
+    if (index_cls == -1) continue;
+    float* d = rot + 18; /* derivatives of Ru w.r.t. (s,u,v,w) :96-139 */
+    d[0] = 2 * s;  d[1] = -2 * w; d[2] = 2 * v;  d[3] = 2 * w;  d[4] = 2 * s;  d[5] = -2 * u; d[6] = -2 * v; d[7] = 2 * u;  d[8] = 2 * s;
+    d += 9;
+    d[0] = 2 * u;  d[1] = 2 * v;  d[2] = 2 * w;  d[3] = 2 * v;  d[4] = -2 * u; d[5] = -2 * s; d[6] = 2 * w;  d[7] = 2 * s;  d[8] = -2 * u;
+    d += 9;
+    d[0] = -2 * v; d[1] = 2 * u;  d[2] = 2 * s;  d[3] = 2 * u;  d[4] = 2 * v;  d[5] = 2 * w;  d[6] = -2 * s; d[7] = 2 * w;  d[8] = -2 * v;
+    d += 9;
+    d[0] = -2 * w; d[1] = -2 * s; d[2] = 2 * u;  d[3] = 2 * s;  d[4] = -2 * w; d[5] = 2 * v;  d[6] = 2 * u;  d[7] = 2 * v;  d[8] = 2 * w;
+
+    const float* pts = point + (size_t)index_cls * P * 3;
+    const int sym = symmetry[index_cls] > 0;
+#pragma omp parallel for schedule(static)
+    for (int p = 0; p < P; p++) {
+      const float* pt = pts + p * 3;
+      float x1 = rot[9 + 0] * pt[0] + rot[9 + 1] * pt[1] + rot[9 + 2] * pt[2];
+      float y1 = rot[9 + 3] * pt[0] + rot[9 + 4] * pt[1] + rot[9 + 5] * pt[2];
+      float z1 = rot[9 + 6] * pt[0] + rot[9 + 7] * pt[1] + rot[9 + 8] * pt[2];
+      int qmin = p;
+      float x2, y2, z2;
+      if (sym) {
+        float dmin = FLT_MAX;
+        for (int i = 0; i < P; i++) {
+          const float* q = pts + i * 3;
+          x2 = rot[0] * q[0] + rot[1] * q[1] + rot[2] * q[2];
+          y2 = rot[3] * q[0] + rot[4] * q[1] + rot[5] * q[2];
+          z2 = rot[6] * q[0] + rot[7] * q[1] + rot[8] * q[2];
+          float distance = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2);
+          if (distance < dmin) { dmin = distance; qmin = i; }
+        }
+      }
+      const float* q = pts + qmin * 3;
+      x2 = rot[0] * q[0] + rot[1] * q[1] + rot[2] * q[2];
+      y2 = rot[3] * q[0] + rot[4] * q[1] + rot[5] * q[2];
+      z2 = rot[6] * q[0] + rot[7] * q[1] + rot[8] * q[2];
+      float distance = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2);
+      if (distance < margin) continue;
+      losses[(size_t)n * P + p] = (float)((double)(distance - margin) / (2.0 * R * P));
+      float* df = diffs + ((size_t)n * P + p) * 4;
+      for (int j = 0; j < 3; j++) {
+        float diff = j == 0 ? x1 - x2 : (j == 1 ? y1 - y2 : z1 - z2);
+        for (int k = 0; k < 3; k++) {
+          float den = (float)(R * P);
+          df[0] += diff * pt[k] * rot[18 + j * 3 + k] / den;
+          df[1] += diff * pt[k] * rot[27 + j * 3 + k] / den;
+          df[2] += diff * pt[k] * rot[36 + j * 3 + k] / den;
+          df[3] += diff * pt[k] * rot[45 + j * 3 + k] / den;
+        }
+      }
+    }
+  }
+  /* sum_losses_gradients :210-252 (p ascending), then thrust::reduce over n (ascending) */
+  float total = 0.f;
+  for (int n = 0; n < R; n++) {
+    for (int c = 0; c < CH; c++) bottom_diff[(size_t)n * CH + c] = 0;
+    int cls = cls_of[n];
+    if (cls >= 0) {
+      for (int k = 0; k < 4; k++) {
+        float acc = 0;
+        for (int p = 0; p < P; p++) acc += diffs[((size_t)n * P + p) * 4 + k];
+        bottom_diff[(size_t)n * CH + 4 * cls + k] = acc;
+      }
+    }
+    float lb = 0;
+    for (int p = 0; p < P; p++) lb += losses[(size_t)n * P + p];
+    total += lb;
+  }
+  loss[0] = total;
+  free(losses); free(diffs); free(cls_of);
+  return 0;
+}
+
+/* AveragedistanceBackward :347-354 */
+int oracle_average_distance_bwd(const float* grad, const float* bottom_diff, int R, int channels,
+                                float* out)
+{
+  for (long i = 0; i < (long)R * channels; i++) out[i] = grad[0] * bottom_diff[i];
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Backprojecting: BackprojectForward, backprojecting_op_gpu.cu.cc:17-126                       */
+/* ------------------------------------------------------------------------------------------ */
+int oracle_backproject(const float* data, const float* label, const float* depth,
+                       const float* meta, const float* label_3d, int B, int H, int W, int Cd,
+                       int Cl, int num_meta, int G, int ksize, float threshold, float* top_data,
+                       float* top_label, float* top_flag)
+{
+  const long nvox = (long)B * G * G * G;
+#pragma omp parallel for schedule(static)
+  for (long vox = 0; vox < nvox; vox++) {
+    long t = vox;
+    int w = (int)(t % G); t /= G;
+    int h = (int)(t % G); t /= G;
+    int d = (int)(t % G); t /= G;
+    int n = (int)t;
+    const float* md = meta + (size_t)n * num_meta;
+    float X = d * md[42] + md[45];
+    float Y = h * md[43] + md[46];
+    float Z = w * md[44] + md[47];
+    float X1 = md[18] * X + md[19] * Y + md[20] * Z + md[21];
+    float Y1 = md[22] * X + md[23] * Y + md[24] * Z + md[25];
+    float Z1 = md[26] * X + md[27] * Y + md[28] * Z + md[29];
+    float x1 = md[0] * X1 + md[1] * Y1 + md[2] * Z1;
+    float x2 = md[3] * X1 + md[4] * Y1 + md[5] * Z1;
+    float x3 = md[6] * X1 + md[7] * Y1 + md[8] * Z1;
+    /* `int px = round(x1 / x3)`: out-of-int-range values (x3 == 0) are undefined in the
+       reference; the canonical conversion saturates and maps NaN to 0 (GPU cvt semantics). */
+    float fpx = roundf(x1 / x3), fpy = roundf(x2 / x3);
+    int px = fpx != fpx ? 0 : (fpx >= 2147483648.f ? INT32_MAX : (fpx <= -2147483648.f ? INT32_MIN : (int)fpx));
+    int py = fpy != fpy ? 0 : (fpy >= 2147483648.f ? INT32_MAX : (fpy <= -2147483648.f ? INT32_MIN : (int)fpy));
+    float* td = top_data + vox * Cd;
+    float* tf = top_flag + vox * Cd;
+    float* tl = top_label + vox * Cl;
+    for (int c = 0; c < Cd; c++) td[c] = 0;
+    for (int c = 0; c < Cl; c++) tl[c] = 0;
+    int count = 0;
+    /* window bounds in 64-bit: px +- ksize may overflow int for saturated px */
+    long xlo = (long)px - ksize, xhi = (long)px + ksize, ylo = (long)py - ksize, yhi = (long)py + ksize;
+    if (xlo < 0) xlo = 0;
+    if (ylo < 0) ylo = 0;
+    if (xhi > W - 1) xhi = W - 1;
+    if (yhi > H - 1) yhi = H - 1;
+    for (long x = xlo; x <= xhi; x++)
+      for (long y = ylo; y <= yhi; y++) {
+        long index_pixel = (long)n * H * W + y * W + x;
+        float dep = depth[index_pixel];
+        if (fabsf(dep - Z1) < threshold) {
+          count++;
+          for (int c = 0; c < Cd; c++) td[c] += data[index_pixel * Cd + c];
+          for (int c = 0; c < Cl; c++) tl[c] += label[index_pixel * Cl + c];
+        }
+      }
+    if (count == 0) {
+      for (int c = 0; c < Cd; c++) tf[c] = 0;
+      for (int c = 0; c < Cl; c++) tl[c] = label_3d[vox * Cl + c];
+    } else {
+      for (int c = 0; c < Cd; c++) { td[c] /= count; tf[c] = 1; }
+      for (int c = 0; c < Cl; c++) tl[c] /= count;
+    }
+  }
+  return 0;
+}
+
+/* BackprojectBackward, backprojecting_op_gpu.cu.cc:159-217 */
+int oracle_backproject_bwd(const float* top_diff, const float* depth, const float* meta, int B,
+                           int H, int W, int Cd, int num_meta, int G, float* bottom_diff)
+{
+#pragma omp parallel for schedule(static)
+  for (long pix = 0; pix < (long)B * H * W; pix++) {
+    long t = pix;
+    int w = (int)(t % W); t /= W;
+    int h = (int)(t % H); t /= H;
+    int n = (int)t;
+    const float* md = meta + (size_t)n * num_meta;
+    float dep = depth[pix];
+    /* backproject the pixel: RX = depth * Kinv * (w, h, 1) */
+    float RX = md[9] * w + md[10] * h + md[11];
+    float RY = md[12] * w + md[13] * h + md[14];
+    float RZ = md[15] * w + md[16] * h + md[17];
+    float X = dep * RX, Y = dep * RY, Z = dep * RZ;
+    float X1 = md[30] * X + md[31] * Y + md[32] * Z + md[33];
+    float Y1 = md[34] * X + md[35] * Y + md[36] * Z + md[37];
+    float Z1 = md[38] * X + md[39] * Y + md[40] * Z + md[41];
+    float fvd = roundf((X1 - md[45]) / md[42]);
+    float fvh = roundf((Y1 - md[46]) / md[43]);
+    float fvw = roundf((Z1 - md[47]) / md[44]);
+    int vd = fvd != fvd ? 0 : (fvd >= 2147483648.f ? INT32_MAX : (fvd <= -2147483648.f ? INT32_MIN : (int)fvd));
+    int vh = fvh != fvh ? 0 : (fvh >= 2147483648.f ? INT32_MAX : (fvh <= -2147483648.f ? INT32_MIN : (int)fvh));
+    int vw = fvw != fvw ? 0 : (fvw >= 2147483648.f ? INT32_MAX : (fvw <= -2147483648.f ? INT32_MIN : (int)fvw));
+    for (int c = 0; c < Cd; c++) {
+      float g = 0;
+      if (vd >= 0 && vd < G && vh >= 0 && vh < G && vw >= 0 && vw < G)
+        g = top_diff[((((long)n * G + vd) * G + vh) * G + vw) * Cd + c];
+      bottom_diff[pix * Cd + c] = g;
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* softmax_high_dimension + argmax_2d, lib/networks/network.py:474-488, 432-434                 */
+/* (tf.reduce_max, tf.exp(x - m), tf.reduce_sum ascending, tf.div, tf.argmax = first maximum)    */
+/* ------------------------------------------------------------------------------------------ */
+int oracle_softmax_argmax(const float* score, long N, int C, float* prob, int* label)
+{
+#pragma omp parallel for
+  for (long i = 0; i < N; i++) {
+    const float* s = score + i * C;
+    float m = s[0];
+    for (int c = 1; c < C; c++) m = fmaxf(m, s[c]);
+    float e[1024];
+    float sum = 0;
+    for (int c = 0; c < C; c++) { e[c] = oracle_expf(s[c] - m); sum += e[c]; }
+    int best = 0;
+    float bestp = e[0] / sum;
+    for (int c = 0; c < C; c++) {
+      float p = e[c] / sum;
+      if (prob) prob[i * C + c] = p;
+      if (p > bestp) { bestp = p; best = c; }
+    }
+    label[i] = best;
+  }
+  return 0;
+}

@@ -1,0 +1,96 @@
+"""ctypes binding of libposecnn_hip.so (the C-ABI declared in include/posecnn_hip.h).
+
+This is the Python-side analogue of the reference's ``tf.load_op_library('<op>.so')`` stubs
+(lib/hough_voting_gpu_layer/hough_voting_gpu_op.py:4-7 and siblings). The library is built
+in-tree by ``__graft_entry__.build()`` / ``make -C posecnn_amd/csrc``. There is NO fallback:
+if the shared object is missing or an entry point fails, the call raises.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libposecnn_hip.so")
+
+PCNN_OK = 0
+PCNN_EINVAL = -1
+PCNN_EWORKSPACE = -2
+PCNN_EHIP = -3
+PCNN_ENULL = -4
+
+MAX_ROI = 128
+HOUGH_ROWS_CAPACITY = MAX_ROI * 9
+VERTEX_CHANNELS = 3
+POSE_CHANNELS = 4
+
+_P = c_void_p
+
+# name -> (restype, argtypes); must list every symbol of include/posecnn_hip.h
+SIGNATURES = {
+    "pcnn_abi_version": (c_int, []),
+    "pcnn_last_error_string": (c_char_p, []),
+    "pcnn_status_string": (c_char_p, [c_int]),
+    "pcnn_hough_voting_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_float, c_int, POINTER(c_size_t)]),
+    "pcnn_hough_voting_fwd": (c_int, [_P, _P, _P, _P, _P,
+                                      c_int, c_int, c_int, c_int, c_int, c_int,
+                                      c_int, c_float, c_float, c_int, c_float, c_int,
+                                      _P, _P, _P, _P, _P, _P,
+                                      _P, c_size_t, _P]),
+    "pcnn_hough_voting_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "pcnn_roi_pool_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
+                                  c_int, c_int, c_float, c_int, _P, _P, _P]),
+    "pcnn_roi_pool_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
+                                  c_int, c_int, c_float, c_int, _P, _P]),
+    "pcnn_roi_pool_add2_fwd": (c_int, [_P, c_int, c_int, c_float, _P, c_int, c_int, c_float,
+                                       _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "pcnn_hard_label_fwd": (c_int, [_P, _P, c_int64, c_int, c_float, _P, _P]),
+    "pcnn_hard_label_bwd": (c_int, [_P, _P, c_int64, c_int, _P]),
+    "pcnn_average_distance_workspace_bytes": (c_int, [c_int, c_int, c_int, POINTER(c_size_t)]),
+    "pcnn_average_distance_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float,
+                                          _P, _P, _P, c_size_t, _P]),
+    "pcnn_average_distance_bwd": (c_int, [_P, _P, c_int, c_int, _P, _P]),
+    "pcnn_backproject_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
+                                     c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
+    "pcnn_backproject_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "pcnn_softmax_argmax_fwd": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
+}
+
+_lib = None
+
+
+class PoseCNNHipError(RuntimeError):
+    """A libposecnn_hip.so entry point returned a negative pcnn_status."""
+
+    def __init__(self, fn, status, message):
+        super().__init__("%s failed: status %d (%s)" % (fn, status, message))
+        self.status = status
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libposecnn_hip.so not found at %s — build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or "
+                "`make -C posecnn_amd/csrc`. There is no CPU/PyTorch fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is missing: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        if handle.pcnn_abi_version() != 1:
+            raise RuntimeError("libposecnn_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(fn_name, status):
+    if status != PCNN_OK:
+        msg = lib().pcnn_last_error_string()
+        msg = msg.decode("utf-8", "replace") if msg else ""
+        if status in (PCNN_EINVAL, PCNN_ENULL):
+            # the reference raises InvalidArgument for the same conditions (OP_REQUIRES)
+            raise ValueError("%s: %s" % (fn_name, msg))
+        raise PoseCNNHipError(fn_name, status, msg)

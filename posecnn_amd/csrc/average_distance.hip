@@ -1,0 +1,240 @@
+// average_distance.hip — gfx950 PoseCNN pose loss (PLoss / SLoss) forward + analytic dq gradient
+// (replaces TF1 ops "Averagedistance"/"AveragedistanceGrad",
+//  lib/average_distance_loss/average_distance_loss_op.cc:253-314,
+//  average_distance_loss_op_gpu.cu.cc:35-206 (AveragedistanceForward), :210-252
+//  (sum_losses_gradients), :256-343 (launcher), :347-377 (backward)).
+//
+// The reference writes 54 floats of per-(roi, point) rotation scratch, 88 floats of per-point
+// gradient scratch and a loss per point to global memory (~1.5 MB per ROI), then sums them with one
+// thread per output channel. Here:
+//   adl_terms   grid (point slabs, rois): rotations live in registers; for a symmetric class the
+//               nearest-neighbour search walks the gt-rotated model points staged through LDS in
+//               1024-point tiles (every lane reads the same LDS address -> broadcast); per point
+//               only the 5 non-zero terms {loss, dq_s, dq_u, dq_v, dq_w} go to the workspace.
+//   adl_sum     grid (rois): the canonical ascending-p sums (sum_losses_gradients :237-248) from
+//               an LDS copy of the ROI's 5 x P terms; writes the whole 4C-wide gradient row.
+//   adl_total   thrust::reduce over ROIs (:333-335), ascending.
+#include <cfloat>
+
+#include "pcnn_device.h"
+
+namespace {
+
+using namespace pcnn;
+
+constexpr int ADL_THREADS = 256;
+constexpr int ADL_QTILE = 1024;
+
+// quaternion (s,u,v,w) -> rotation, average_distance_loss_op_gpu.cu.cc:62-71
+__device__ __forceinline__ void quat_rot(float s, float u, float v, float w, float* r)
+{
+  r[0] = s * s + u * u - v * v - w * w;
+  r[1] = 2 * (u * v - s * w);
+  r[2] = 2 * (u * w + s * v);
+  r[3] = 2 * (u * v + s * w);
+  r[4] = s * s - u * u + v * v - w * w;
+  r[5] = 2 * (v * w - s * u);
+  r[6] = 2 * (u * w - s * v);
+  r[7] = 2 * (v * w + s * u);
+  r[8] = s * s - u * u - v * v + w * w;
+}
+
+__device__ __forceinline__ int find_class(const float* __restrict__ weight, int n, int C)
+{
+  for (int c = 0; c < C; c++)
+    if (weight[(size_t)n * PCNN_POSE_CHANNELS * C + PCNN_POSE_CHANNELS * c] > 0) return c;
+  return -1;
+}
+
+// terms layout: [R][5][P]
+__global__ __launch_bounds__(ADL_THREADS) void adl_terms_kernel(
+    const float* __restrict__ prediction, const float* __restrict__ target,
+    const float* __restrict__ weight, const float* __restrict__ point,
+    const float* __restrict__ symmetry, float* __restrict__ terms, int R, int C, int P,
+    float margin)
+{
+  __shared__ float s_q[ADL_QTILE * 3];
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * ADL_THREADS + threadIdx.x;
+  const int cls = find_class(weight, n, C);
+  float* tn = terms + (size_t)n * 5 * P;
+  if (cls < 0) {
+    if (p < P)
+      for (int k = 0; k < 5; k++) tn[(size_t)k * P + p] = 0.f;
+    return;
+  }
+  const int qi = n * PCNN_POSE_CHANNELS * C + PCNN_POSE_CHANNELS * cls;
+  float rg[9], ru[9];
+  quat_rot(target[qi], target[qi + 1], target[qi + 2], target[qi + 3], rg);
+  const float s = prediction[qi], u = prediction[qi + 1], v = prediction[qi + 2], w = prediction[qi + 3];
+  quat_rot(s, u, v, w, ru);
+  const float* pts = point + (size_t)cls * P * 3;
+  const bool valid = p < P;
+  float pt0 = 0, pt1 = 0, pt2 = 0;
+  if (valid) { pt0 = pts[p * 3]; pt1 = pts[p * 3 + 1]; pt2 = pts[p * 3 + 2]; }
+  const float x1 = ru[0] * pt0 + ru[1] * pt1 + ru[2] * pt2;
+  const float y1 = ru[3] * pt0 + ru[4] * pt1 + ru[5] * pt2;
+  const float z1 = ru[6] * pt0 + ru[7] * pt1 + ru[8] * pt2;
+
+  int qmin = p;
+  if (symmetry[cls] > 0) {
+    // closest gt-rotated model point, strict '<' from FLT_MAX, first wins (:155-168)
+    float dmin = FLT_MAX;
+    for (int q0 = 0; q0 < P; q0 += ADL_QTILE) {
+      __syncthreads();
+      for (int j = threadIdx.x; j < ADL_QTILE; j += ADL_THREADS) {
+        int q = q0 + j;
+        if (q < P) {
+          float a = pts[q * 3], b = pts[q * 3 + 1], c = pts[q * 3 + 2];
+          s_q[j * 3 + 0] = rg[0] * a + rg[1] * b + rg[2] * c;
+          s_q[j * 3 + 1] = rg[3] * a + rg[4] * b + rg[5] * c;
+          s_q[j * 3 + 2] = rg[6] * a + rg[7] * b + rg[8] * c;
+        }
+      }
+      __syncthreads();
+      const int lim = min(ADL_QTILE, P - q0);
+      for (int j = 0; j < lim; j++) {
+        float ex = x1 - s_q[j * 3], ey = y1 - s_q[j * 3 + 1], ez = z1 - s_q[j * 3 + 2];
+        float distance = ex * ex + ey * ey + ez * ez;
+        if (distance < dmin) { dmin = distance; qmin = q0 + j; }
+      }
+    }
+  }
+  if (!valid) return;
+  const float qa = pts[qmin * 3], qb = pts[qmin * 3 + 1], qc = pts[qmin * 3 + 2];
+  const float x2 = rg[0] * qa + rg[1] * qb + rg[2] * qc;
+  const float y2 = rg[3] * qa + rg[4] * qb + rg[5] * qc;
+  const float z2 = rg[6] * qa + rg[7] * qb + rg[8] * qc;
+  const float ex = x1 - x2, ey = y1 - y2, ez = z1 - z2;
+  const float distance = ex * ex + ey * ey + ez * ez;
+  float loss = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+  if (!(distance < margin)) {
+    loss = (float)((double)(distance - margin) / (2.0 * R * P));
+    // derivatives of Ru w.r.t. (s,u,v,w), :96-139
+    const float d0[9] = {2 * s, -2 * w, 2 * v, 2 * w, 2 * s, -2 * u, -2 * v, 2 * u, 2 * s};
+    const float d1[9] = {2 * u, 2 * v, 2 * w, 2 * v, -2 * u, -2 * s, 2 * w, 2 * s, -2 * u};
+    const float d2[9] = {-2 * v, 2 * u, 2 * s, 2 * u, 2 * v, 2 * w, -2 * s, 2 * w, -2 * v};
+    const float d3[9] = {-2 * w, -2 * s, 2 * u, 2 * s, -2 * w, 2 * v, 2 * u, 2 * v, 2 * w};
+    const float den = (float)(R * P);
+    const float pt[3] = {pt0, pt1, pt2};
+    const float df[3] = {ex, ey, ez};
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        g0 += div_rn(df[j] * pt[k] * d0[j * 3 + k], den);
+        g1 += div_rn(df[j] * pt[k] * d1[j * 3 + k], den);
+        g2 += div_rn(df[j] * pt[k] * d2[j * 3 + k], den);
+        g3 += div_rn(df[j] * pt[k] * d3[j * 3 + k], den);
+      }
+  }
+  tn[p] = loss;
+  tn[(size_t)P + p] = g0;
+  tn[(size_t)2 * P + p] = g1;
+  tn[(size_t)3 * P + p] = g2;
+  tn[(size_t)4 * P + p] = g3;
+}
+
+// ascending-p sums; one wave per ROI, lanes 0..4 own one chain each
+__global__ __launch_bounds__(64) void adl_sum_kernel(const float* __restrict__ terms,
+                                                     const float* __restrict__ weight,
+                                                     float* __restrict__ loss_batch,
+                                                     float* __restrict__ bottom_diff, int C, int P)
+{
+  extern __shared__ __attribute__((aligned(16))) float s_t[];  // tile of [5][TILE]
+  constexpr int TILE = 2048;
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const int CH = PCNN_POSE_CHANNELS * C;
+  const int cls = find_class(weight, n, C);
+  for (int c = lane; c < CH; c += 64) bottom_diff[(size_t)n * CH + c] = 0.f;
+  const float* tn = terms + (size_t)n * 5 * P;
+  float acc = 0.f;
+  for (int p0 = 0; p0 < P; p0 += TILE) {
+    const int lim = min(TILE, P - p0);
+    __syncthreads();
+    for (int k = 0; k < 5; k++)
+      for (int j = lane; j < lim; j += 64) s_t[k * TILE + j] = tn[(size_t)k * P + p0 + j];
+    __syncthreads();
+    if (lane < 5) {
+      const float* t = s_t + lane * TILE;
+      for (int j = 0; j < lim; j++) acc += t[j];
+    }
+  }
+  __syncthreads();
+  if (lane == 0) loss_batch[n] = acc;
+  if (lane >= 1 && lane < 5 && cls >= 0) bottom_diff[(size_t)n * CH + PCNN_POSE_CHANNELS * cls + (lane - 1)] = acc;
+}
+
+__global__ void adl_total_kernel(const float* __restrict__ loss_batch, float* __restrict__ loss, int R)
+{
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float total = 0.f;
+    for (int n = 0; n < R; n++) total += loss_batch[n];
+    loss[0] = total;
+  }
+}
+
+__global__ __launch_bounds__(256) void adl_bwd_kernel(const float* __restrict__ grad,
+                                                      const float* __restrict__ bottom_diff,
+                                                      float* __restrict__ out, long long total)
+{
+  const float g = grad[0];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
+    out[i] = g * bottom_diff[i];
+}
+
+size_t adl_ws(int R, int P) { return align_up(sizeof(float) * (size_t)R * 5 * P, 256) + align_up(sizeof(float) * (size_t)(R > 0 ? R : 1), 256); }
+
+}  // namespace
+
+extern "C" int pcnn_average_distance_workspace_bytes(int R, int C, int P, size_t* bytes)
+{
+  PCNN_REQUIRE(bytes, PCNN_ENULL, "average_distance_workspace_bytes: bytes is NULL");
+  PCNN_REQUIRE(R >= 0 && C >= 1 && P >= 1, PCNN_EINVAL, "average_distance: bad shape R=%d C=%d P=%d", R, C, P);
+  *bytes = adl_ws(R, P);
+  return PCNN_OK;
+}
+
+extern "C" int pcnn_average_distance_fwd(const float* prediction, const float* target,
+                                         const float* weight, const float* point,
+                                         const float* symmetry, int R, int C, int P, float margin,
+                                         float* loss, float* bottom_diff, void* workspace,
+                                         size_t workspace_bytes, void* stream_)
+{
+  // attribute check, average_distance_loss_op.cc:262-267
+  PCNN_REQUIRE(margin >= 0, PCNN_EINVAL, "average_distance: Need margin >= 0, got %g", (double)margin);
+  PCNN_REQUIRE(R >= 0 && C >= 1 && P >= 1, PCNN_EINVAL, "average_distance: bad shape R=%d C=%d P=%d", R, C, P);
+  PCNN_REQUIRE((long long)R * P < (1ll << 31), PCNN_EINVAL, "average_distance: R*P overflows int32");
+  PCNN_REQUIRE(loss, PCNN_ENULL, "average_distance: loss is NULL");
+  hipStream_t stream = (hipStream_t)stream_;
+  if (R == 0) {
+    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), stream);
+    if (e != hipSuccess) { pcnn::set_error("average_distance: %s", hipGetErrorString(e)); return PCNN_EHIP; }
+    return PCNN_OK;
+  }
+  PCNN_REQUIRE(prediction && target && weight && point && symmetry && bottom_diff, PCNN_ENULL,
+               "average_distance: NULL pointer");
+  PCNN_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= adl_ws(R, P), PCNN_EWORKSPACE,
+               "average_distance: workspace NULL, misaligned or too small (%zu < %zu)", workspace_bytes, adl_ws(R, P));
+  float* terms = (float*)workspace;
+  float* loss_batch = (float*)((char*)workspace + align_up(sizeof(float) * (size_t)R * 5 * P, 256));
+  hipLaunchKernelGGL(adl_terms_kernel, dim3((P + ADL_THREADS - 1) / ADL_THREADS, R), dim3(ADL_THREADS), 0,
+                     stream, prediction, target, weight, point, symmetry, terms, R, C, P, margin);
+  hipLaunchKernelGGL(adl_sum_kernel, dim3(R), dim3(64), sizeof(float) * 5 * 2048, stream, terms, weight,
+                     loss_batch, bottom_diff, C, P);
+  hipLaunchKernelGGL(adl_total_kernel, dim3(1), dim3(64), 0, stream, loss_batch, loss, R);
+  return pcnn::check_launch("average_distance_fwd");
+}
+
+extern "C" int pcnn_average_distance_bwd(const float* grad, const float* bottom_diff, int R,
+                                         int channels, float* out, void* stream_)
+{
+  PCNN_REQUIRE(R >= 0 && channels >= 1, PCNN_EINVAL, "average_distance_bwd: bad shape");
+  if (R == 0) return PCNN_OK;
+  PCNN_REQUIRE(grad && bottom_diff && out, PCNN_ENULL, "average_distance_bwd: NULL pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  long long total = (long long)R * channels;
+  int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  hipLaunchKernelGGL(adl_bwd_kernel, dim3(blocks), dim3(256), 0, stream, grad, bottom_diff, out, total);
+  return pcnn::check_launch("average_distance_bwd");
+}

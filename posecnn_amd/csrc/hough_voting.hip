@@ -1,0 +1,902 @@
+// hough_voting.hip — gfx950 Hough voting for PoseCNN (replaces the TF1 op "Houghvotinggpu",
+// lib/hough_voting_gpu_layer/hough_voting_gpu_op.cc:321-429 + hough_voting_gpu_op.cu.cc:615-797).
+//
+// This is NOT the reference's launch sequence. The reference runs, per image and serially,
+// compute_arrays (atomic compaction) -> host filter -> compute_hough (one thread per Hough cell,
+// brute force over every sampled class pixel, two passes) -> thrust::max_element per class on
+// the host's clock -> compute_rois, with >=6 blocking host round trips per image. Here the whole
+// batch is five asynchronous launches with no host involvement:
+//
+//   hv_hist     per-chunk class histograms of the label map (+ zero-fill of the outputs)
+//   hv_scatter  deterministic ranks (ascending pixel index, as a serial run of
+//               compute_arrays_kernel :174-187 would produce) from histogram prefixes + wave
+//               ballots; every skip-th pixel of each class that passes label_threshold becomes a
+//               32-byte record {x, y, thr(d), 1/|uv|, u, v, |uv|, d}: everything the inner loop
+//               of compute_hough_kernel :269-285 recomputes per (cell, pixel) pair, hoisted.
+//   hv_vote     gather formulation, 32x32-cell tiles: each workgroup first culls the class'
+//               records against its tile (vote window + a conservative cone test) into LDS, then
+//               every thread evaluates the exact vote predicate for its 4 cells against the
+//               survivors (LDS broadcast reads). Votes are integers, so evaluation order is
+//               free. Only votes are produced; the reference's second pass (mean depth, box
+//               extents, :296-331) is evaluated lazily, at the cells that can reach an output.
+//   hv_select   (threshold_vote <= 0) per class: first argmax over tile maxima
+//               (thrust::max_element :752-762), then one wave recomputes that cell's depth sum
+//               in canonical pixel order and its box extents.
+//   hv_localmax + hv_gather (threshold_vote > 0): compute_max_indexes_kernel :335-383 in
+//               ascending cell order, capacity MAX_ROI / batch.
+//   hv_emit     compute_rois_kernel :386-576, rows in (image, maximum) order.
+//
+// Exactness: the vote predicate is evaluated either by a filter that provably agrees with the
+// exact expression (|q~ - q| << 2e-5) or by the exact expression itself (IEEE div/sqrt, no
+// contraction), so outputs equal the CPU oracle bit for bit.
+#include "pcnn_device.h"
+
+namespace {
+
+using namespace pcnn;
+
+constexpr int HV_CHUNK = 2048;      // label pixels per hist/scatter workgroup (4 waves x 8 x 64)
+constexpr int HV_TILE = 32;         // Hough tile edge (cells)
+constexpr int HV_BATCH = 1024;      // records culled into LDS per round of hv_vote
+constexpr int LM_CHUNK = 1024;      // consecutive Hough cells per hv_localmax workgroup
+constexpr float HV_FILTER_EPS = 2e-5f;
+
+struct __attribute__((aligned(16))) HvRec {
+  float4 a;  // x, y, thr, rn1 (1/|uv|, or NaN when |uv| is outside the filter's safe range)
+  float4 b;  // u, v, |uv|, d
+};
+
+struct __attribute__((aligned(16))) HvMax {
+  int cls;
+  int idx;  // cy * W + cx
+  float votes;
+  float dist;
+  float bh2;  // 2 * bb_height
+  float bw2;  // 2 * bb_width
+  int pad0, pad1;
+};
+
+struct HvLayout {
+  int nchunk, ntx, nty, ntiles, reccap, cap, capmax, nlm;
+  size_t off_hist, off_tot, off_slots, off_nslots, off_recoff, off_rec, off_tilemax, off_maxima,
+      off_nmax, off_hs, off_chunkcnt, off_chunkcand, total;
+};
+
+HvLayout hv_layout(int B, int H, int W, int C, bool need_hs, int skip)
+{
+  HvLayout L;
+  const size_t HW = (size_t)H * W;
+  L.nchunk = (int)((HW + HV_CHUNK - 1) / HV_CHUNK);
+  L.ntx = (W + HV_TILE - 1) / HV_TILE;
+  L.nty = (H + HV_TILE - 1) / HV_TILE;
+  L.ntiles = L.ntx * L.nty;
+  L.reccap = (int)(HW / skip) + C + 1;
+  L.cap = PCNN_MAX_ROI / B;  // index_size, hough_voting_gpu_op.cu.cc:733
+  L.capmax = L.cap > 0 ? L.cap : 1;
+  L.nlm = (int)(((size_t)(C - 1) * HW + LM_CHUNK - 1) / LM_CHUNK);
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+  L.off_hist = take(sizeof(int) * (size_t)B * L.nchunk * C);
+  L.off_tot = take(sizeof(int) * (size_t)B * C);
+  L.off_slots = take(sizeof(int) * (size_t)B * C);
+  L.off_nslots = take(sizeof(int) * (size_t)B);
+  L.off_recoff = take(sizeof(int) * (size_t)B * C);
+  L.off_rec = take(sizeof(HvRec) * (size_t)B * L.reccap);
+  L.off_tilemax = take(sizeof(int2) * (size_t)B * (C - 1) * L.ntiles);
+  L.off_maxima = take(sizeof(HvMax) * (size_t)B * L.capmax);
+  L.off_nmax = take(sizeof(int) * (size_t)B);
+  if (need_hs) {
+    L.off_hs = take(sizeof(float) * (size_t)B * (C - 1) * HW);
+    L.off_chunkcnt = take(sizeof(int) * (size_t)B * L.nlm);
+    L.off_chunkcand = take(sizeof(HvMax) * (size_t)B * L.nlm * L.capmax);
+  } else {
+    L.off_hs = L.off_chunkcnt = L.off_chunkcand = 0;
+  }
+  L.total = o;
+  return L;
+}
+
+// project_box, hough_voting_gpu_op.cu.cc:84-120 with factor 0.6 (:285, :317)
+__device__ float project_box(const float* __restrict__ extents, int cls, float fx, float fy,
+                             float px, float py, float distance)
+{
+  float xHalf = (float)((double)extents[cls * 3 + 0] * 0.5);
+  float yHalf = (float)((double)extents[cls * 3 + 1] * 0.5);
+  float zHalf = (float)((double)extents[cls * 3 + 2] * 0.5);
+  float zf = zHalf + distance;
+  float zb = -zHalf + distance;
+  float minX = 1e8f, maxX = -1e8f, minY = 1e8f, maxY = -1e8f;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    float X = (i & 1) ? -xHalf : xHalf;
+    float Y = (i & 2) ? -yHalf : yHalf;
+    float Z = (i & 4) ? zb : zf;
+    float x = fx * div_rn(X, Z) + px;
+    float y = fy * div_rn(Y, Z) + py;
+    minX = fminf(minX, x);
+    minY = fminf(minY, y);
+    maxX = fmaxf(maxX, x);
+    maxY = fmaxf(maxY, y);
+  }
+  float width = maxX - minX + 1;
+  float height = maxY - minY + 1;
+  return fmaxf(width, height) * 0.6f;
+}
+
+// angle_distance(...) > inlierThreshold, hough_voting_gpu_op.cu.cc:32-42,283 — exact form.
+__device__ __forceinline__ bool angle_pass_exact(float u, float v, float n1, float dx, float dy,
+                                                 float inlier)
+{
+  float n2 = sqrt_rn(dx * dx + dy * dy);
+  float dot = u * dx + v * dy;
+  return div_rn(dot, n1 * n2) > inlier;
+}
+
+// Filtered form: q~ = dot * rsq(|d|^2) / |uv| differs from the exact quotient by < 1e-6 whenever
+// rn1 is finite (|uv| in [1e-15, 1e15]); outside +-HV_FILTER_EPS of the threshold the decision
+// is therefore already the exact one. NaN (rn1 poisoned, d = 0) falls through to the exact form.
+__device__ __forceinline__ bool angle_pass(float u, float v, float n1, float rn1, float dx,
+                                           float dy, float inlier)
+{
+  float dotf = __builtin_fmaf(u, dx, v * dy);
+  float s2f = __builtin_fmaf(dx, dx, dy * dy);
+  float qa = dotf * __builtin_amdgcn_rsqf(s2f) * rn1;
+  if (qa > inlier + HV_FILTER_EPS) return true;
+  if (qa < inlier - HV_FILTER_EPS) return false;
+  return angle_pass_exact(u, v, n1, dx, dy, inlier);
+}
+
+struct ZeroJob {
+  float* p[5];
+  unsigned words[5];
+};
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hv_hist_kernel(const int* __restrict__ label,
+                                                      int* __restrict__ hist, int HW, int C,
+                                                      int nchunk, ZeroJob zj)
+{
+  __shared__ int sh[PCNN_MAX_CLASSES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int chunk = blockIdx.x, n = blockIdx.y;
+  if (tid < PCNN_MAX_CLASSES) sh[tid] = 0;
+
+  // reset_outputs (hough_voting_gpu_op.cu.cc:579-588) folded into the first launch
+  {
+    const unsigned gtid = (blockIdx.y * gridDim.x + blockIdx.x) * 256u + tid;
+    const unsigned gsz = gridDim.x * gridDim.y * 256u;
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+      for (unsigned i = gtid; i < zj.words[a]; i += gsz) zj.p[a][i] = 0.f;
+  }
+  __syncthreads();
+
+  const int base = chunk * HV_CHUNK;
+  const int* lab = label + (size_t)n * HW;
+#pragma unroll
+  for (int k = 0; k < HV_CHUNK / 256; k++) {
+    int i = base + k * 256 + tid;
+    int l = i < HW ? lab[i] : 0;
+    bool valid = l > 0 && l < C;
+    unsigned long long mask = __ballot(valid);
+    while (mask) {
+      int src = __ffsll((long long)mask) - 1;
+      int c0 = __shfl(l, src);
+      unsigned long long m = __ballot(valid && l == c0);
+      if (lane == src) atomicAdd(&sh[c0], __popcll(m));
+      mask &= ~m;
+    }
+  }
+  __syncthreads();
+  if (tid < C) hist[((size_t)n * nchunk + chunk) * C + tid] = sh[tid];
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hv_scatter_kernel(
+    const int* __restrict__ label, const float* __restrict__ vertex,
+    const float* __restrict__ extents, const float* __restrict__ meta,
+    const int* __restrict__ hist, int* __restrict__ tot_g, int* __restrict__ slots_g,
+    int* __restrict__ nslots_g, int* __restrict__ recoff_g, HvRec* __restrict__ rec, int HW, int W,
+    int C, int nchunk, int skip, int label_thr, int num_meta, int reccap)
+{
+  __shared__ int s_pre[PCNN_MAX_CLASSES], s_tot[PCNN_MAX_CLASSES], s_recoff[PCNN_MAX_CLASSES];
+  __shared__ int s_wh[4][PCNN_MAX_CLASSES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk = blockIdx.x, n = blockIdx.y;
+  if (tid < PCNN_MAX_CLASSES) { s_pre[tid] = 0; s_tot[tid] = 0; }
+  __syncthreads();
+  const int* h = hist + (size_t)n * nchunk * C;
+  for (int idx = tid; idx < nchunk * C; idx += 256) {
+    int v = h[idx];
+    if (v) {
+      int k = idx / C, c = idx - k * C;
+      atomicAdd(&s_tot[c], v);
+      if (k < chunk) atomicAdd(&s_pre[c], v);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // class_indexes (hough_voting_gpu_op.cu.cc:653-663): classes with > labelThreshold pixels, ascending
+    int off = 0, ns = 0;
+    s_recoff[0] = -1;
+    for (int c = 1; c < C; c++) {
+      if (s_tot[c] > label_thr) {
+        s_recoff[c] = off;
+        off += (s_tot[c] + skip - 1) / skip;
+        if (chunk == 0) slots_g[n * C + ns] = c;
+        ns++;
+      } else {
+        s_recoff[c] = -1;
+      }
+    }
+    if (chunk == 0) nslots_g[n] = ns;
+  }
+  __syncthreads();
+  if (chunk == 0 && tid < C) {
+    tot_g[n * C + tid] = s_tot[tid];
+    recoff_g[n * C + tid] = s_recoff[tid];
+  }
+
+  // this wave's 512 consecutive pixels, 8 rounds of 64
+  int lab[8];
+  const int wbase = chunk * HV_CHUNK + wave * 512;
+  const int* labp = label + (size_t)n * HW;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    int i = wbase + r * 64 + lane;
+    int l = i < HW ? labp[i] : 0;
+    lab[r] = (l > 0 && l < C) ? l : 0;
+  }
+  // lane c counts class c inside this wave's span
+  int wcnt = 0;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    int l = lab[r];
+    unsigned long long mask = __ballot(l > 0);
+    while (mask) {
+      int src = __ffsll((long long)mask) - 1;
+      int c0 = __shfl(l, src);
+      unsigned long long m = __ballot(l == c0);
+      if (lane == c0) wcnt += __popcll(m);
+      mask &= ~m;
+    }
+  }
+  s_wh[wave][lane] = wcnt;
+  __syncthreads();
+  // lane c: number of class-c pixels with a smaller index than this wave's first pixel
+  int run = lane < C ? s_pre[lane] : 0;
+  for (int w2 = 0; w2 < wave; w2++) run += s_wh[w2][lane];
+
+  const float* md = meta + (size_t)n * num_meta;
+  const float fx = md[0], px = md[2], fy = md[4], py = md[5];
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    int l = lab[r];
+    int my_rank = -1;
+    unsigned long long mask = __ballot(l > 0);
+    while (mask) {
+      int src = __ffsll((long long)mask) - 1;
+      int c0 = __shfl(l, src);
+      unsigned long long m = __ballot(l == c0);
+      int basec = __shfl(run, c0);
+      if (l == c0) my_rank = basec + __popcll(m & lanemask_lt());
+      if (lane == c0) run += __popcll(m);
+      mask &= ~m;
+    }
+    if (l > 0) {
+      int ro = s_recoff[l];
+      if (ro >= 0 && (my_rank % skip) == 0) {
+        int i = wbase + r * 64 + lane;
+        int x = i % W, y = i / W;
+        const float* vp = vertex + ((size_t)n * HW + i) * (PCNN_VERTEX_CHANNELS * C) +
+                          PCNN_VERTEX_CHANNELS * l;
+        float u = vp[0], v = vp[1];
+        float d = exp_f32(vp[2]);
+        float n1 = sqrt_rn(u * u + v * v);
+        float thr = project_box(extents, l, fx, fy, px, py, d);
+        float rn1 = (n1 >= 1e-15f && n1 <= 1e15f) ? div_rn(1.0f, n1) : __builtin_nanf("");
+        HvRec R;
+        R.a = make_float4((float)x, (float)y, thr, rn1);
+        R.b = make_float4(u, v, n1, d);
+        rec[(size_t)n * reccap + ro + my_rank / skip] = R;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hv_vote_kernel(
+    const HvRec* __restrict__ rec, const int* __restrict__ nslots_g,
+    const int* __restrict__ slots_g, const int* __restrict__ tot_g,
+    const int* __restrict__ recoff_g, int2* __restrict__ tilemax, float* __restrict__ hs, int H,
+    int W, int C, int skip, float inlier, int ntx, int ntiles, int reccap, int need_hs)
+{
+  const int n = blockIdx.z, s = blockIdx.y, tile = blockIdx.x;
+  if (s >= nslots_g[n]) return;
+  const int cls = slots_g[n * C + s];
+  const int m = (tot_g[n * C + cls] + skip - 1) / skip;
+  const HvRec* r0 = rec + (size_t)n * reccap + recoff_g[n * C + cls];
+
+  __shared__ float4 sA[HV_BATCH];
+  __shared__ float4 sB[HV_BATCH];
+  __shared__ int s_cnt;
+  __shared__ int s_rv[4], s_ri[4];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tx0 = (tile % ntx) * HV_TILE, ty0 = (tile / ntx) * HV_TILE;
+  const int cx = tx0 + (tid & 31);
+  const int cy0 = ty0 + (tid >> 5);
+  const float cxf = (float)cx;
+  int votes[4] = {0, 0, 0, 0};
+
+  // conservative cone cull: every cell of the tile lies within asin(r / L) of the direction to
+  // the tile centre, so a record whose angle to the centre exceeds acos(inlier) + asin(r / L)
+  // cannot vote here. 1e-3 of slack covers the float evaluation of this test.
+  const bool cone_ok = inlier > 0.f && inlier < 1.f;
+  const float c0 = inlier, s0 = sqrtf(fmaxf(0.f, 1.f - inlier * inlier));
+  const float tcx = (float)tx0 + 15.5f, tcy = (float)ty0 + 15.5f;
+  const float rad = 21.93f + 1.0f;
+
+  for (int b0 = 0; b0 < m; b0 += HV_BATCH) {
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < HV_BATCH / 256; q++) {
+      int ri = b0 + q * 256 + tid;
+      bool keep = false;
+      float4 a, b;
+      if (ri < m) {
+        a = r0[ri].a;
+        int x = (int)a.x, y = (int)a.y;
+        int ddx = max(0, max(tx0 - x, x - (tx0 + HV_TILE - 1)));
+        int ddy = max(0, max(ty0 - y, y - (ty0 + HV_TILE - 1)));
+        if ((float)ddx < a.z && (float)ddy < a.z) {
+          b = r0[ri].b;
+          keep = true;
+          if (cone_ok) {
+            float Dx = tcx - a.x, Dy = tcy - a.y;
+            float L2 = Dx * Dx + Dy * Dy;
+            if (L2 > rad * rad) {
+              float rL = __builtin_amdgcn_rsqf(L2);
+              float sA_ = rad * rL;
+              float cA = sqrtf(fmaxf(0.f, 1.f - sA_ * sA_));
+              float cosDU = (Dx * b.x + Dy * b.y) * rL * a.w;  // NaN when rn1 is poisoned -> keep
+              if (cosDU < c0 * cA - s0 * sA_ - 1e-3f) keep = false;
+            }
+          }
+        }
+      }
+      unsigned long long mask = __ballot(keep);
+      if (mask) {
+        int leader = __ffsll((long long)mask) - 1;
+        int basep = 0;
+        if (lane == leader) basep = atomicAdd(&s_cnt, __popcll(mask));
+        basep = __shfl(basep, leader);
+        if (keep) {
+          int pos = basep + __popcll(mask & lanemask_lt());
+          sA[pos] = a;
+          sB[pos] = b;
+        }
+      }
+    }
+    __syncthreads();
+    const int cnt = s_cnt;
+    for (int k = 0; k < cnt; k++) {
+      const float4 a = sA[k];
+      const float dx = cxf - a.x;
+      if (fabsf(dx) < a.z) {
+        const float4 b = sB[k];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float dy = (float)(cy0 + 8 * j) - a.y;
+          if (fabsf(dy) < a.z) {
+            if (angle_pass(b.x, b.y, b.z, a.w, dx, dy, inlier)) votes[j]++;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // tile maximum: most votes, lowest cell index among equals (first maximum in index order)
+  int bv = -1, bi = 0x7fffffff;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    int cy = cy0 + 8 * j;
+    if (cx < W && cy < H) {
+      int idx = cy * W + cx;
+      if (need_hs) hs[((size_t)n * (C - 1) + s) * ((size_t)H * W) + idx] = (float)votes[j];
+      if (votes[j] > bv || (votes[j] == bv && idx < bi)) { bv = votes[j]; bi = idx; }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    int ov = __shfl_xor(bv, off), oi = __shfl_xor(bi, off);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) { s_rv[wave] = bv; s_ri[wave] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w2 = 1; w2 < 4; w2++)
+      if (s_rv[w2] > bv || (s_rv[w2] == bv && s_ri[w2] < bi)) { bv = s_rv[w2]; bi = s_ri[w2]; }
+    tilemax[((size_t)n * (C - 1) + s) * ntiles + tile] = make_int2(bv, bi);
+  }
+}
+
+// One wave: hough_data of a single cell — second half of compute_hough_kernel (:296-331) plus the
+// depth sum of the first half (:269-294) in canonical (ascending pixel) order.
+__device__ void wave_cell_data(const HvRec* __restrict__ r0, int m, int cx, int cy, int cls,
+                               const float* __restrict__ extents, float fx, float fy, float px,
+                               float py, float inlier, float& votes_out, float& dist,
+                               float& bh2, float& bw2)
+{
+  const int lane = lane_id();
+  const float cxf = (float)cx, cyf = (float)cy;
+  float sumd = 0.f;
+  int cnt = 0;
+  for (int b0 = 0; b0 < m; b0 += 64) {
+    int ri = b0 + lane;
+    bool pass = false;
+    float d = 0.f;
+    if (ri < m) {
+      float4 a = r0[ri].a, b = r0[ri].b;
+      float dx = cxf - a.x, dy = cyf - a.y;
+      d = b.w;
+      pass = fabsf(dx) < a.z && fabsf(dy) < a.z && angle_pass_exact(b.x, b.y, b.z, dx, dy, inlier);
+    }
+    unsigned long long mask = __ballot(pass);
+    cnt += __popcll(mask);
+    while (mask) {
+      int src = __ffsll((long long)mask) - 1;
+      sumd += __shfl(d, src);
+      mask &= mask - 1;
+    }
+  }
+  votes_out = (float)cnt;
+  dist = 0.f; bh2 = 0.f; bw2 = 0.f;
+  if (cnt > 0) {
+    dist = div_rn(sumd, (float)cnt);
+    float thr = project_box(extents, cls, fx, fy, px, py, dist);
+    float bw = -1.f, bh = -1.f;
+    for (int b0 = 0; b0 < m; b0 += 64) {
+      int ri = b0 + lane;
+      if (ri < m) {
+        float4 a = r0[ri].a, b = r0[ri].b;
+        float dx = cxf - a.x, dy = cyf - a.y;
+        if (angle_pass_exact(b.x, b.y, b.z, dx, dy, inlier)) {
+          float ax = fabsf(dx), ay = fabsf(dy);
+          if (ax < thr && ay < thr) { bw = fmaxf(bw, ax); bh = fmaxf(bh, ay); }
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      bw = fmaxf(bw, __shfl_xor(bw, off));
+      bh = fmaxf(bh, __shfl_xor(bh, off));
+    }
+    bh2 = 2 * bh;
+    bw2 = 2 * bw;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hv_select_kernel(
+    const HvRec* __restrict__ rec, const int* __restrict__ nslots_g,
+    const int* __restrict__ slots_g, const int* __restrict__ tot_g,
+    const int* __restrict__ recoff_g, const int2* __restrict__ tilemax,
+    const float* __restrict__ extents, const float* __restrict__ meta, HvMax* __restrict__ maxima,
+    int* __restrict__ nmax_g, int W, int C, int skip, float inlier, int ntiles, int reccap,
+    int cap, int capmax, int num_meta)
+{
+  const int s = blockIdx.x, n = blockIdx.y;
+  const int ns = nslots_g[n];
+  if (s == 0 && threadIdx.x == 0) nmax_g[n] = ns < cap ? ns : cap;
+  if (s >= ns || s >= cap) return;
+  __shared__ int s_rv[4], s_ri[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int2* tm = tilemax + ((size_t)n * (C - 1) + s) * ntiles;
+  int bv = -1, bi = 0x7fffffff;
+  for (int t = tid; t < ntiles; t += 256) {
+    int2 e = tm[t];
+    if (e.x > bv || (e.x == bv && e.y < bi)) { bv = e.x; bi = e.y; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    int ov = __shfl_xor(bv, off), oi = __shfl_xor(bi, off);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) { s_rv[wave] = bv; s_ri[wave] = bi; }
+  __syncthreads();
+  if (wave != 0) return;
+  for (int w2 = 0; w2 < 4; w2++)
+    if (s_rv[w2] > bv || (s_rv[w2] == bv && s_ri[w2] < bi)) { bv = s_rv[w2]; bi = s_ri[w2]; }
+
+  const int cls = slots_g[n * C + s];
+  const int m = (tot_g[n * C + cls] + skip - 1) / skip;
+  const HvRec* r0 = rec + (size_t)n * reccap + recoff_g[n * C + cls];
+  const float* md = meta + (size_t)n * num_meta;
+  float votes, dist, bh2, bw2;
+  wave_cell_data(r0, m, bi % W, bi / W, cls, extents, md[0], md[4], md[2], md[5], inlier, votes,
+                 dist, bh2, bw2);
+  if (lane == 0) {
+    HvMax e;
+    e.cls = cls; e.idx = bi; e.votes = votes; e.dist = dist; e.bh2 = bh2; e.bw2 = bw2;
+    e.pad0 = e.pad1 = 0;
+    maxima[(size_t)n * capmax + s] = e;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// threshold_vote > 0: compute_max_indexes_kernel (:335-383), one thread per Hough cell.
+__global__ __launch_bounds__(256) void hv_localmax_kernel(
+    const HvRec* __restrict__ rec, const int* __restrict__ nslots_g,
+    const int* __restrict__ slots_g, const int* __restrict__ tot_g,
+    const int* __restrict__ recoff_g, const float* __restrict__ hs,
+    const float* __restrict__ extents, const float* __restrict__ meta,
+    int* __restrict__ chunkcnt, HvMax* __restrict__ chunkcand, int H, int W, int C, int skip,
+    float inlier, float vote_thr, float per_thr, int reccap, int capmax, int cap, int nlm,
+    int num_meta)
+{
+  const int chunk = blockIdx.x, n = blockIdx.y;
+  const int HW = H * W;
+  const int ns = nslots_g[n];
+  const long long ncell = (long long)ns * HW;
+  const long long cbase = (long long)chunk * LM_CHUNK;
+  if (cbase >= ncell) return;
+  __shared__ int s_wc[4];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  const float* md = meta + (size_t)n * num_meta;
+  const float fx = md[0], px = md[2], fy = md[4], py = md[5];
+  HvMax* out = chunkcand + ((size_t)n * nlm + chunk) * capmax;
+
+  for (int r = 0; r < LM_CHUNK / 256; r++) {
+    long long g = cbase + r * 256 + tid;
+    bool cand = false;
+    HvMax e;
+    if (g < ncell) {
+      int s = (int)(g / HW), cell = (int)(g - (long long)s * HW);
+      const float* hsl = hs + ((size_t)n * (C - 1) + s) * HW;
+      float v = hsl[cell];
+      if (v > vote_thr) {
+        int cx = cell % W, cy = cell / W;
+        bool greater = false;
+        for (int x = cx - 3; x <= cx + 3; x++)
+          for (int y = cy - 3; y <= cy + 3; y++)
+            if (x >= 0 && x < W && y >= 0 && y < H && hsl[y * W + x] > v) greater = true;
+        if (!greater) {
+          // hough_data of this cell (per-thread serial form of compute_hough_kernel :266-331)
+          int cls = slots_g[n * C + s];
+          int m = (tot_g[n * C + cls] + skip - 1) / skip;
+          const HvRec* r0 = rec + (size_t)n * reccap + recoff_g[n * C + cls];
+          const float cxf = (float)cx, cyf = (float)cy;
+          float sumd = 0.f, cnt = 0.f;
+          for (int i = 0; i < m; i++) {
+            float4 a = r0[i].a, b = r0[i].b;
+            float dx = cxf - a.x, dy = cyf - a.y;
+            if (fabsf(dx) < a.z && fabsf(dy) < a.z &&
+                angle_pass_exact(b.x, b.y, b.z, dx, dy, inlier)) {
+              cnt += 1.f;
+              sumd += b.w;
+            }
+          }
+          if (cnt > 0) {
+            float dist = div_rn(sumd, cnt);
+            float thr = project_box(extents, cls, fx, fy, px, py, dist);
+            float bw = -1.f, bh = -1.f;
+            for (int i = 0; i < m; i++) {
+              float4 a = r0[i].a, b = r0[i].b;
+              float dx = cxf - a.x, dy = cyf - a.y;
+              if (angle_pass_exact(b.x, b.y, b.z, dx, dy, inlier)) {
+                float ax = fabsf(dx), ay = fabsf(dy);
+                if (ax < thr && ay < thr) { bw = fmaxf(bw, ax); bh = fmaxf(bh, ay); }
+              }
+            }
+            float bh2 = 2 * bh, bw2 = 2 * bw;
+            if (bh2 > 0 && bw2 > 0 && !(div_rn(v, bh2 * bw2) < per_thr)) {
+              cand = true;
+              e.cls = cls; e.idx = cell; e.votes = v; e.dist = dist; e.bh2 = bh2; e.bw2 = bw2;
+              e.pad0 = e.pad1 = 0;
+            }
+          }
+        }
+      }
+    }
+    unsigned long long mask = __ballot(cand);
+    if (lane == 0) s_wc[wave] = __popcll(mask);
+    __syncthreads();
+    int pos = s_base + __popcll(mask & lanemask_lt());
+    for (int w2 = 0; w2 < wave; w2++) pos += s_wc[w2];
+    if (cand && pos < cap) out[pos] = e;
+    __syncthreads();
+    if (tid == 0) s_base += s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+    __syncthreads();
+  }
+  if (tid == 0) chunkcnt[(size_t)n * nlm + chunk] = s_base;
+}
+
+// first `cap` candidates of an image in ascending (slot, cell) order
+__global__ __launch_bounds__(256) void hv_gather_kernel(const int* __restrict__ nslots_g,
+                                                        const int* __restrict__ chunkcnt,
+                                                        const HvMax* __restrict__ chunkcand,
+                                                        HvMax* __restrict__ maxima,
+                                                        int* __restrict__ nmax_g, int HW, int nlm,
+                                                        int cap, int capmax)
+{
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const long long ncell = (long long)nslots_g[n] * HW;
+  const int nact = (int)((ncell + LM_CHUNK - 1) / LM_CHUNK);
+  const int per = (nact + 255) / 256;
+  __shared__ int s_sum[256];
+  const int c_lo = tid * per, c_hi = min(nact, c_lo + per);
+  int sum = 0;
+  for (int c = c_lo; c < c_hi; c++) sum += chunkcnt[(size_t)n * nlm + c];
+  s_sum[tid] = sum;
+  __syncthreads();
+  int before = 0;
+  for (int t = 0; t < tid; t++) before += s_sum[t];
+  for (int c = c_lo; c < c_hi && before < cap; c++) {
+    int k = chunkcnt[(size_t)n * nlm + c];
+    for (int j = 0; j < k && before + j < cap; j++)
+      maxima[(size_t)n * capmax + before + j] = chunkcand[((size_t)n * nlm + c) * capmax + j];
+    before += k;
+  }
+  if (tid == 0) {
+    int total = 0;
+    for (int t = 0; t < 256; t++) total += s_sum[t];
+    nmax_g[n] = total < cap ? total : cap;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// IoU (:73-82) and compute_box_overlap (:123-172; Eigen Quaternionf(w,x,y,z).toRotationMatrix())
+__device__ float box_iou(const float* a, const float* b)
+{
+  float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
+  float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+  float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);
+  float interS = width * height;
+  float Sa = (a[2] - a[0] + 1) * (a[3] - a[1] + 1);
+  float Sb = (b[2] - b[0] + 1) * (b[3] - b[1] + 1);
+  return div_rn(interS, Sa + Sb - interS);
+}
+
+__device__ float compute_box_overlap(int cls, const float* __restrict__ extents, float fx, float fy,
+                                     float px, float py, const float* __restrict__ pose,
+                                     const float* box)
+{
+  float xHalf = (float)((double)extents[cls * 3 + 0] * 0.5);
+  float yHalf = (float)((double)extents[cls * 3 + 1] * 0.5);
+  float zHalf = (float)((double)extents[cls * 3 + 2] * 0.5);
+  float qw = pose[6], qx = pose[7], qy = pose[8], qz = pose[9];
+  float tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+  float twx = tx * qw, twy = ty * qw, twz = tz * qw;
+  float txx = tx * qx, txy = ty * qx, txz = tz * qx;
+  float tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+  float R00 = 1 - (tyy + tzz), R01 = txy - twz, R02 = txz + twy;
+  float R10 = txy + twz, R11 = 1 - (txx + tzz), R12 = tyz - twx;
+  float R20 = txz - twy, R21 = tyz + twx, R22 = 1 - (txx + tyy);
+  float x1 = 1e8f, x2 = -1e8f, y1 = 1e8f, y2 = -1e8f;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    float bx = (i & 1) ? -xHalf : xHalf;
+    float by = (i & 2) ? -yHalf : yHalf;
+    float bz = (i & 4) ? -zHalf : zHalf;
+    float X = (R00 * bx + R01 * by + R02 * bz) + pose[10];
+    float Y = (R10 * bx + R11 * by + R12 * bz) + pose[11];
+    float Z = (R20 * bx + R21 * by + R22 * bz) + pose[12];
+    float x = fx * div_rn(X, Z) + px;
+    float y = fy * div_rn(Y, Z) + py;
+    x1 = fminf(x1, x);
+    y1 = fminf(y1, y);
+    x2 = fmaxf(x2, x);
+    y2 = fmaxf(y2, y);
+  }
+  float box_gt[4] = {x1, y1, x2, y2};
+  return box_iou(box, box_gt);
+}
+
+// compute_rois_kernel (:386-576). One thread per (image, maximum); B * cap <= MAX_ROI.
+__global__ __launch_bounds__(128) void hv_emit_kernel(
+    const HvMax* __restrict__ maxima, const int* __restrict__ nmax_g,
+    const float* __restrict__ extents, const float* __restrict__ meta,
+    const float* __restrict__ gt, float* __restrict__ top_box, float* __restrict__ top_pose,
+    float* __restrict__ top_target, float* __restrict__ top_weight, int* __restrict__ top_domain,
+    int* __restrict__ num_rois, int B, int W, int C, int cap, int capmax, int num_meta, int num_gt,
+    int is_train)
+{
+  __shared__ int s_off[PCNN_MAX_ROI + 1];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    int acc = 0;  // cap > 0 implies B <= MAX_ROI
+    if (cap > 0)
+      for (int n = 0; n < B; n++) { s_off[n] = acc; acc += nmax_g[n]; }
+    const int rows = acc * (is_train ? 9 : 1);
+    num_rois[0] = rows == 0 ? 1 : rows;  // dummy row, hough_voting_gpu_op.cc:381-383
+    num_rois[1] = rows;
+  }
+  __syncthreads();
+  if (cap <= 0) return;
+  const int n = tid / cap, k = tid - n * cap;
+  if (n >= B || k >= nmax_g[n]) return;
+  const HvMax e = maxima[(size_t)n * capmax + k];
+  const int rows_per = is_train ? 9 : 1;
+  const int roi_index = (s_off[n] + k) * rows_per;
+  const float* md = meta + (size_t)n * num_meta;
+  const float fx = md[0], px = md[2], fy = md[4], py = md[5];
+  const int x = e.idx % W, y = e.idx / W;
+  const int cls = e.cls;
+  const float rx = div_rn((float)x - px, fx);
+  const float ry = div_rn((float)y - py, fy);
+  const float scale = 0.05f;
+  const double kk = 0.5 + (double)scale;
+  float* b = top_box + (size_t)roi_index * 7;
+  b[0] = (float)n;
+  b[1] = (float)cls;
+  b[2] = (float)((double)x - (double)e.bw2 * kk);
+  b[3] = (float)((double)y - (double)e.bh2 * kk);
+  b[4] = (float)((double)x + (double)e.bw2 * kk);
+  b[5] = (float)((double)y + (double)e.bh2 * kk);
+  b[6] = e.votes;
+  for (int i = 0; i < rows_per; i++) {
+    float* p = top_pose + (size_t)(roi_index + i) * 7;
+    p[0] = 1; p[1] = 0; p[2] = 0; p[3] = 0;
+    p[4] = rx * e.dist;
+    p[5] = ry * e.dist;
+    p[6] = e.dist;
+    if (is_train) top_domain[roi_index + i] = (num_gt == 0) ? 1 : 0;
+  }
+  if (!is_train) return;
+
+  for (int i = 0; i < num_gt; i++) {
+    int gt_batch = (int)gt[i * 13 + 0];
+    int gt_id = (int)gt[i * 13 + 1];
+    if (cls == gt_id && n == gt_batch) {
+      float overlap = compute_box_overlap(cls, extents, fx, fy, px, py, gt + i * 13, b + 2);
+      if ((double)overlap > 0.2) {
+        for (int j = 0; j < 9; j++)
+          for (int q = 0; q < 4; q++) {
+            top_target[(size_t)(roi_index + j) * 4 * C + 4 * cls + q] = gt[i * 13 + 6 + q];
+            top_weight[(size_t)(roi_index + j) * 4 * C + 4 * cls + q] = 1.f;
+          }
+        break;
+      }
+    }
+  }
+  const float x1 = b[2], y1 = b[3], x2 = b[4], y2 = b[5];
+  const float ww = x2 - x1, hh = y2 - y1;
+  const int sx[8] = {-1, +1, -1, +1, 0, -1, 0, +1};
+  const int sy[8] = {-1, -1, +1, +1, -1, 0, +1, 0};
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    float* r = top_box + (size_t)(roi_index + 1 + j) * 7;
+    r[0] = (float)n;
+    r[1] = (float)cls;
+    float r2 = x1, r3 = y1;
+    if (sx[j] < 0) r2 = (float)((double)x1 - 0.05 * (double)ww);
+    if (sx[j] > 0) r2 = (float)((double)x1 + 0.05 * (double)ww);
+    if (sy[j] < 0) r3 = (float)((double)y1 - 0.05 * (double)hh);
+    if (sy[j] > 0) r3 = (float)((double)y1 + 0.05 * (double)hh);
+    r[2] = r2;
+    r[3] = r3;
+    r[4] = r2 + ww;
+    r[5] = r3 + hh;
+    r[6] = e.votes;
+  }
+}
+
+int validate_common(int B, int H, int W, int C, int skip)
+{
+  PCNN_REQUIRE(B >= 1, PCNN_EINVAL, "hough_voting: label must be 3-dimensional with batch >= 1 (got %d)", B);
+  PCNN_REQUIRE(H >= 1 && W >= 1, PCNN_EINVAL, "hough_voting: bad image size %dx%d", H, W);
+  PCNN_REQUIRE((long long)H * W < (1ll << 24), PCNN_EINVAL, "hough_voting: image too large (%dx%d)", H, W);
+  PCNN_REQUIRE(C >= 2 && C <= PCNN_MAX_CLASSES, PCNN_EINVAL,
+               "hough_voting: num_classes must be in [2, %d] (got %d)", PCNN_MAX_CLASSES, C);
+  PCNN_REQUIRE(skip >= 1, PCNN_EINVAL, "hough_voting: skip_pixels must be >= 1 (got %d)", skip);
+  return PCNN_OK;
+}
+
+}  // namespace
+
+extern "C" int pcnn_hough_voting_workspace_bytes(int batch, int height, int width,
+                                                 int num_classes, float threshold_vote,
+                                                 int skip_pixels, size_t* bytes)
+{
+  PCNN_REQUIRE(bytes != nullptr, PCNN_ENULL, "hough_voting_workspace_bytes: bytes is NULL");
+  int st = validate_common(batch, height, width, num_classes, skip_pixels);
+  if (st != PCNN_OK) return st;
+  *bytes = hv_layout(batch, height, width, num_classes, threshold_vote > 0, skip_pixels).total;
+  return PCNN_OK;
+}
+
+extern "C" int pcnn_hough_voting_fwd(const int32_t* label, const float* vertex,
+                                     const float* extents, const float* meta, const float* gt,
+                                     int B, int H, int W, int C, int num_meta, int num_gt,
+                                     int is_train, float vote_thr, float per_thr, int skip,
+                                     float inlier, int label_thr, float* top_box, float* top_pose,
+                                     float* top_target, float* top_weight, int32_t* top_domain,
+                                     int32_t* num_rois, void* workspace, size_t workspace_bytes,
+                                     void* stream_)
+{
+  int st = validate_common(B, H, W, C, skip);
+  if (st != PCNN_OK) return st;
+  PCNN_REQUIRE(is_train >= 0, PCNN_EINVAL, "hough_voting: Need is_train >= 0, got %d", is_train);
+  PCNN_REQUIRE(num_meta >= 6, PCNN_EINVAL, "hough_voting: meta_data needs >= 6 values per image (got %d)", num_meta);
+  PCNN_REQUIRE(num_gt >= 0, PCNN_EINVAL, "hough_voting: num_gt < 0");
+  PCNN_REQUIRE(label && vertex && extents && meta, PCNN_ENULL, "hough_voting: NULL input");
+  PCNN_REQUIRE(gt || num_gt == 0, PCNN_ENULL, "hough_voting: gt is NULL but num_gt = %d", num_gt);
+  PCNN_REQUIRE(top_box && top_pose && top_target && top_weight && top_domain && num_rois,
+               PCNN_ENULL, "hough_voting: NULL output");
+  const bool need_hs = vote_thr > 0;
+  const HvLayout L = hv_layout(B, H, W, C, need_hs, skip);
+  PCNN_REQUIRE(workspace && aligned16(workspace), PCNN_EWORKSPACE,
+               "hough_voting: workspace NULL or not 16-byte aligned");
+  PCNN_REQUIRE(workspace_bytes >= L.total, PCNN_EWORKSPACE,
+               "hough_voting: workspace too small (%zu < %zu)", workspace_bytes, L.total);
+
+  hipStream_t stream = (hipStream_t)stream_;
+  char* ws = (char*)workspace;
+  int* hist = (int*)(ws + L.off_hist);
+  int* tot = (int*)(ws + L.off_tot);
+  int* slots = (int*)(ws + L.off_slots);
+  int* nslots = (int*)(ws + L.off_nslots);
+  int* recoff = (int*)(ws + L.off_recoff);
+  HvRec* rec = (HvRec*)(ws + L.off_rec);
+  int2* tilemax = (int2*)(ws + L.off_tilemax);
+  HvMax* maxima = (HvMax*)(ws + L.off_maxima);
+  int* nmax = (int*)(ws + L.off_nmax);
+  float* hs = need_hs ? (float*)(ws + L.off_hs) : nullptr;
+  int* chunkcnt = need_hs ? (int*)(ws + L.off_chunkcnt) : nullptr;
+  HvMax* chunkcand = need_hs ? (HvMax*)(ws + L.off_chunkcand) : nullptr;
+  const int HW = H * W;
+
+  ZeroJob zj;
+  zj.p[0] = top_box;    zj.words[0] = PCNN_HOUGH_ROWS_CAPACITY * 7;
+  zj.p[1] = top_pose;   zj.words[1] = PCNN_HOUGH_ROWS_CAPACITY * 7;
+  zj.p[2] = top_target; zj.words[2] = PCNN_HOUGH_ROWS_CAPACITY * 4 * C;
+  zj.p[3] = top_weight; zj.words[3] = PCNN_HOUGH_ROWS_CAPACITY * 4 * C;
+  zj.p[4] = (float*)top_domain; zj.words[4] = PCNN_HOUGH_ROWS_CAPACITY;
+
+  hipLaunchKernelGGL(hv_hist_kernel, dim3(L.nchunk, B), dim3(256), 0, stream, label, hist, HW, C,
+                     L.nchunk, zj);
+  hipLaunchKernelGGL(hv_scatter_kernel, dim3(L.nchunk, B), dim3(256), 0, stream, label, vertex,
+                     extents, meta, hist, tot, slots, nslots, recoff, rec, HW, W, C, L.nchunk,
+                     skip, label_thr, num_meta, L.reccap);
+  hipLaunchKernelGGL(hv_vote_kernel, dim3(L.ntiles, C - 1, B), dim3(256), 0, stream, rec, nslots,
+                     slots, tot, recoff, tilemax, hs, H, W, C, skip, inlier, L.ntx, L.ntiles,
+                     L.reccap, need_hs ? 1 : 0);
+  if (!need_hs) {
+    hipLaunchKernelGGL(hv_select_kernel, dim3(C - 1, B), dim3(256), 0, stream, rec, nslots, slots,
+                       tot, recoff, tilemax, extents, meta, maxima, nmax, W, C, skip, inlier,
+                       L.ntiles, L.reccap, L.cap, L.capmax, num_meta);
+  } else {
+    hipLaunchKernelGGL(hv_localmax_kernel, dim3(L.nlm, B), dim3(256), 0, stream, rec, nslots,
+                       slots, tot, recoff, hs, extents, meta, chunkcnt, chunkcand, H, W, C, skip,
+                       inlier, vote_thr, per_thr, L.reccap, L.capmax, L.cap, L.nlm, num_meta);
+    hipLaunchKernelGGL(hv_gather_kernel, dim3(B), dim3(256), 0, stream, nslots, chunkcnt,
+                       chunkcand, maxima, nmax, HW, L.nlm, L.cap, L.capmax);
+  }
+  hipLaunchKernelGGL(hv_emit_kernel, dim3(1), dim3(128), 0, stream, maxima, nmax, extents, meta,
+                     gt, top_box, top_pose, top_target, top_weight, top_domain, num_rois, B, W, C,
+                     L.cap, L.capmax, num_meta, num_gt, is_train);
+  return check_launch("hough_voting_fwd");
+}
+
+extern "C" int pcnn_hough_voting_bwd(float* grad_label, float* grad_vertex, int B, int H, int W,
+                                     int C, void* stream_)
+{
+  PCNN_REQUIRE(grad_label && grad_vertex, PCNN_ENULL, "hough_voting_bwd: NULL output");
+  PCNN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && C >= 1, PCNN_EINVAL, "hough_voting_bwd: bad shape");
+  hipStream_t stream = (hipStream_t)stream_;
+  // set_gradients, hough_voting_gpu_op.cu.cc:608-612
+  hipError_t e = hipMemsetAsync(grad_label, 0, sizeof(float) * (size_t)B * H * W, stream);
+  if (e == hipSuccess)
+    e = hipMemsetAsync(grad_vertex, 0, sizeof(float) * (size_t)B * H * W * PCNN_VERTEX_CHANNELS * C, stream);
+  if (e != hipSuccess) {
+    set_error("hough_voting_bwd: %s", hipGetErrorString(e));
+    return PCNN_EHIP;
+  }
+  return PCNN_OK;
+}

@@ -1,0 +1,91 @@
+// pcnn_device.h — shared device-side helpers for the gfx950 kernels of libposecnn_hip.so.
+//
+// Numerics contract: every kernel in this library is compiled with
+// -ffp-contract=off and uses IEEE-correct f32 divide / sqrt, so that a result is a pure function
+// of the reference's expression tree (hough_voting_gpu_op.cu.cc etc.) with one rounding per
+// operation.  Fused multiply-adds appear only where written explicitly (__builtin_fmaf) inside
+// conservative *filters* whose outcome is re-derived exactly when it could matter.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/posecnn_hip.h"
+
+#define PCNN_WAVE 64
+#define PCNN_MAX_CLASSES 64  // per-class state lives in one wave's lanes / small LDS arrays
+
+namespace pcnn {
+
+// ---- error plumbing (host) -------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);  // hipGetLastError -> PCNN_EHIP
+
+#define PCNN_REQUIRE(cond, status, ...)  \
+  do {                                   \
+    if (!(cond)) {                       \
+      ::pcnn::set_error(__VA_ARGS__);    \
+      return (status);                   \
+    }                                    \
+  } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- exact f32 primitives --------------------------------------------------------------------
+__device__ __forceinline__ float div_rn(float a, float b) { return __fdiv_rn(a, b); }
+__device__ __forceinline__ float sqrt_rn(float a) { return __fsqrt_rn(a); }
+
+// Canonical expf: exp evaluated in IEEE double — range reduction by ln2 (hi/lo),
+// degree-13 Taylor polynomial in Horner form, scale by 2^k — then ONE rounding to float.  Every
+// operation is a basic IEEE double op, so the host restatement of the same sequence agrees bit
+// for bit.  (The bits of CUDA's expf, which the reference calls at
+// hough_voting_gpu_op.cu.cc:280, are not reproducible off NVIDIA hardware.)
+__device__ __forceinline__ float exp_f32(float xf)
+{
+  if (xf != xf) return xf;
+  double x = (double)xf;
+  if (x > 130.0) x = 130.0;
+  if (x < -150.0) x = -150.0;
+  const double LOG2E = 1.4426950408889634074;
+  const double LN2_HI = 6.93147180369123816490e-01;
+  const double LN2_LO = 1.90821492927058770002e-10;
+  double kd = floor(x * LOG2E + 0.5);
+  double r = (x - kd * LN2_HI) - kd * LN2_LO;
+  double p = 1.6059043836821614599e-10;
+  p = p * r + 2.0876756987868098979e-09;
+  p = p * r + 2.5052108385441718775e-08;
+  p = p * r + 2.7557319223985890653e-07;
+  p = p * r + 2.7557319223985892511e-06;
+  p = p * r + 2.4801587301587301566e-05;
+  p = p * r + 1.9841269841269841253e-04;
+  p = p * r + 1.3888888888888889419e-03;
+  p = p * r + 8.3333333333333332177e-03;
+  p = p * r + 4.1666666666666664354e-02;
+  p = p * r + 1.6666666666666665741e-01;
+  p = p * r + 0.5;
+  p = p * r + 1.0;
+  p = p * r + 1.0;
+  int k = (int)kd;
+  double two_k = __longlong_as_double((long long)(k + 1023) << 52);
+  return (float)(p * two_k);
+}
+
+// float -> int as the reference's `int v = round(x)` behaves on the GPU: saturating, NaN -> 0.
+__device__ __forceinline__ int round_to_int_sat(float x)
+{
+  float r = roundf(x);
+  if (r != r) return 0;
+  if (r >= 2147483648.f) return INT32_MAX;
+  if (r <= -2147483648.f) return INT32_MIN;
+  return (int)r;
+}
+
+// ---- wave helpers (wave = 64 lanes on gfx950) --------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ unsigned long long lanemask_lt()
+{
+  return (1ull << lane_id()) - 1ull;
+}
+
+}  // namespace pcnn

@@ -1,0 +1,336 @@
+"""Host-side operator surface of the PoseCNN custom layers on MI355X.
+
+Names, argument order and attribute names mirror the reference's layer wrappers in
+lib/networks/network.py (`hough_voting_gpu` :256-259, `roi_pool` :321-332, `hard_label` :338-340,
+`average_distance_loss` :236-238, `backproject` :224-226) and the output tuples follow the
+`REGISTER_OP` output order of each `*_op.cc`. Tensors are NHWC, float32 / int32, resident on the
+GPU; every call enqueues hand-written gfx950 kernels from libposecnn_hip.so on torch's current
+stream. There is no eager/PyTorch fallback: a missing library or a CPU tensor raises.
+"""
+import ctypes
+from ctypes import c_size_t
+
+import torch
+
+from . import _lib
+from ._lib import HOUGH_ROWS_CAPACITY, MAX_ROI, POSE_CHANNELS, VERTEX_CHANNELS, check, lib
+
+__all__ = [
+    "hough_voting_gpu", "hough_voting_gpu_padded", "roi_pool", "roi_pool_add2", "hard_label",
+    "average_distance_loss", "backproject", "softmax_argmax", "Workspace",
+]
+
+INLIER_THRESHOLD = 0.9  # hough_voting_gpu_op.cc:356
+LABEL_THRESHOLD = 500   # hough_voting_gpu_op.cc:357
+
+
+def _dev(t, name, dtype):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU (got %s); posecnn_amd has no CPU path" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s (got %s)" % (name, dtype, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+class Workspace:
+    """Caller-owned scratch (the reference uses context->allocate_temp inside every launcher,
+    e.g. hough_voting_gpu_op.cu.cc:633-640). Grows monotonically; one per stream."""
+
+    def __init__(self):
+        self._buf = None
+
+    def get(self, nbytes, device):
+        if self._buf is None or self._buf.numel() < nbytes or self._buf.device != device:
+            self._buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        return self._buf
+
+
+_default_ws = {}
+
+
+def _ws(device, key):
+    k = (device.index, key, torch.cuda.current_stream(device).cuda_stream)
+    if k not in _default_ws:
+        _default_ws[k] = Workspace()
+    return _default_ws[k]
+
+
+# ------------------------------------------------------------------------------------------------
+def hough_voting_gpu_padded(label_2d, vertex_pred, extents, meta_data, poses, is_train, threshold,
+                            per_threshold, skip_pixels, workspace=None, out=None,
+                            inlier_threshold=INLIER_THRESHOLD, label_threshold=LABEL_THRESHOLD):
+    """Sync-free form: returns capacity-sized buffers and the device-side row counts.
+
+    Returns (top_box[1152,7], top_pose[1152,7], top_target[1152,4C], top_weight[1152,4C],
+    top_domain[1152] int32, num_rois[2] int32) where num_rois[0] is the number of rows the
+    reference op returns (>= 1) and num_rois[1] the true detection row count.
+    """
+    label_2d = _dev(label_2d, "label_2d", torch.int32)
+    vertex_pred = _dev(vertex_pred, "vertex_pred", torch.float32)
+    extents = _dev(extents, "extents", torch.float32)
+    meta_data = _dev(meta_data, "meta_data", torch.float32)
+    if label_2d.dim() != 3:
+        raise ValueError("label must be 3-dimensional")  # hough_voting_gpu_op.cc:328-329
+    if vertex_pred.dim() != 4:
+        raise ValueError("vertex must be 4-dimensional")  # :331-332
+    B, H, W = label_2d.shape
+    if tuple(vertex_pred.shape[:3]) != (B, H, W) or vertex_pred.shape[3] % VERTEX_CHANNELS:
+        raise ValueError("vertex must be [B,H,W,3*num_classes] matching label")
+    C = vertex_pred.shape[3] // VERTEX_CHANNELS
+    if extents.numel() != C * 3:
+        raise ValueError("extents must be [num_classes,3]")
+    num_meta = meta_data.shape[-1]
+    if meta_data.numel() != B * num_meta:
+        raise ValueError("meta_data must be [B,1,1,num_meta]")
+    if poses is None or poses.numel() == 0:
+        num_gt, gt = 0, None
+    else:
+        gt = _dev(poses, "poses", torch.float32)
+        if gt.dim() != 2 or gt.shape[1] != 13:
+            raise ValueError("poses (gt) must be [N,13]")
+        num_gt = gt.shape[0]
+    dev = label_2d.device
+    L = lib()
+    nbytes = c_size_t(0)
+    check("pcnn_hough_voting_workspace_bytes",
+          L.pcnn_hough_voting_workspace_bytes(B, H, W, C, float(threshold), int(skip_pixels), ctypes.byref(nbytes)))
+    ws = (workspace or _ws(dev, "hough")).get(nbytes.value, dev)
+    if out is None:
+        cap = HOUGH_ROWS_CAPACITY
+        out = (torch.empty((cap, 7), dtype=torch.float32, device=dev),
+               torch.empty((cap, 7), dtype=torch.float32, device=dev),
+               torch.empty((cap, POSE_CHANNELS * C), dtype=torch.float32, device=dev),
+               torch.empty((cap, POSE_CHANNELS * C), dtype=torch.float32, device=dev),
+               torch.empty((cap,), dtype=torch.int32, device=dev),
+               torch.empty((2,), dtype=torch.int32, device=dev))
+    top_box, top_pose, top_target, top_weight, top_domain, num_rois = out
+    check("pcnn_hough_voting_fwd",
+          L.pcnn_hough_voting_fwd(_ptr(label_2d), _ptr(vertex_pred), _ptr(extents), _ptr(meta_data), _ptr(gt),
+                                  B, H, W, C, num_meta, num_gt,
+                                  int(is_train), float(threshold), float(per_threshold), int(skip_pixels),
+                                  float(inlier_threshold), int(label_threshold),
+                                  _ptr(top_box), _ptr(top_pose), _ptr(top_target), _ptr(top_weight),
+                                  _ptr(top_domain), _ptr(num_rois),
+                                  _ptr(ws), ws.numel(), _stream(label_2d)))
+    return out
+
+
+def hough_voting_gpu(label_2d, vertex_pred, extents, meta_data, poses, is_train, threshold,
+                     per_threshold, skip_pixels, name=None, workspace=None, **consts):
+    """Drop-in for `Network.hough_voting_gpu` (network.py:256-259): returns exactly-sized
+    (top_box[R,7], top_pose[R,7], top_target[R,4C], top_weight[R,4C], top_domain[R]).
+    Like the reference (hough_voting_gpu_op.cc:379-383) this reads the row count back to the host.
+    """
+    top_box, top_pose, top_target, top_weight, top_domain, num_rois = hough_voting_gpu_padded(
+        label_2d, vertex_pred, extents, meta_data, poses, is_train, threshold, per_threshold,
+        skip_pixels, workspace=workspace, **consts)
+    r = int(num_rois[0].item())
+    return top_box[:r], top_pose[:r], top_target[:r], top_weight[:r], top_domain[:r]
+
+
+# ------------------------------------------------------------------------------------------------
+class _RoiPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, data, rois, pooled_height, pooled_width, spatial_scale, pool_channel):
+        B, H, W, C = data.shape
+        R, cols = rois.shape
+        Cout = 1 if pool_channel else C
+        top = torch.empty((R, pooled_height, pooled_width, Cout), dtype=torch.float32, device=data.device)
+        argmax = torch.empty((R, pooled_height, pooled_width, Cout), dtype=torch.int32, device=data.device)
+        check("pcnn_roi_pool_fwd",
+              lib().pcnn_roi_pool_fwd(_ptr(data), _ptr(rois), B, H, W, C, R, cols, int(pooled_height),
+                                      int(pooled_width), float(spatial_scale), int(pool_channel),
+                                      _ptr(top), _ptr(argmax), _stream(data)))
+        ctx.save_for_backward(rois, argmax)
+        ctx.cfg = (B, H, W, C, R, cols, int(pooled_height), int(pooled_width), float(spatial_scale), int(pool_channel))
+        ctx.mark_non_differentiable(argmax)
+        return top, argmax
+
+    @staticmethod
+    def backward(ctx, grad_top, _grad_argmax):
+        rois, argmax = ctx.saved_tensors
+        B, H, W, C, R, cols, PH, PW, scale, pc = ctx.cfg
+        grad_top = grad_top.contiguous()
+        bottom = torch.empty((B, H, W, C), dtype=torch.float32, device=grad_top.device)
+        check("pcnn_roi_pool_bwd",
+              lib().pcnn_roi_pool_bwd(_ptr(grad_top), _ptr(rois), _ptr(argmax), B, H, W, C, R, cols, PH, PW,
+                                      scale, pc, _ptr(bottom), _stream(grad_top)))
+        return bottom, None, None, None, None, None
+
+
+def roi_pool(data, rois, pooled_height, pooled_width, spatial_scale, pool_channel, name=None):
+    """Drop-in for `Network.roi_pool` (network.py:321-332): NHWC max pooling of 7-column ROIs.
+    Returns (top_data[R,PH,PW,C or 1], argmax int32)."""
+    data = _dev(data, "data", torch.float32)
+    rois = _dev(rois, "rois", torch.float32)
+    if data.dim() != 4:
+        raise ValueError("data must be 4-dimensional")  # roi_pooling_op.cc:313-314
+    if rois.dim() != 2:
+        raise ValueError("rois must be 2-dimensional")  # :317-318
+    return _RoiPoolFn.apply(data, rois, pooled_height, pooled_width, spatial_scale, pool_channel)
+
+
+def roi_pool_add2(data_a, scale_a, data_b, scale_b, rois, pooled_height=7, pooled_width=7):
+    """Fused `pool_score` = roi_pool(conv5_3, 1/16) + roi_pool(conv4_3, 1/8)
+    (vgg16_convs.py:177-187), inference only (no argmax)."""
+    data_a = _dev(data_a, "data_a", torch.float32)
+    data_b = _dev(data_b, "data_b", torch.float32)
+    rois = _dev(rois, "rois", torch.float32)
+    B, Ha, Wa, C = data_a.shape
+    Bb, Hb, Wb, Cb = data_b.shape
+    if (B, C) != (Bb, Cb):
+        raise ValueError("feature maps must share batch and channel dimensions")
+    R, cols = rois.shape
+    out = torch.empty((R, pooled_height, pooled_width, C), dtype=torch.float32, device=data_a.device)
+    check("pcnn_roi_pool_add2_fwd",
+          lib().pcnn_roi_pool_add2_fwd(_ptr(data_a), Ha, Wa, float(scale_a), _ptr(data_b), Hb, Wb, float(scale_b),
+                                       _ptr(rois), B, C, R, cols, int(pooled_height), int(pooled_width),
+                                       _ptr(out), _stream(data_a)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+def hard_label(prob, gt_label, threshold, name=None):
+    """Drop-in for `Network.hard_label` (network.py:338-340); GPU-kernel semantics
+    (hard_label_op_gpu.cu.cc:17-29). prob [B,H,W,C] f32, gt_label [B,H,W] int32 -> [B,H,W,C]."""
+    prob = _dev(prob, "prob", torch.float32)
+    gt_label = _dev(gt_label, "gt_label", torch.int32)
+    C = prob.shape[-1]
+    N = prob.numel() // C
+    if gt_label.numel() != N:
+        raise ValueError("gt_label must have one entry per pixel of prob")
+    out = torch.empty_like(prob)
+    check("pcnn_hard_label_fwd",
+          lib().pcnn_hard_label_fwd(_ptr(prob), _ptr(gt_label), N, C, float(threshold), _ptr(out), _stream(prob)))
+    return out
+
+
+def softmax_argmax(score, want_prob=True):
+    """softmax_high_dimension + argmax_2d (network.py:474-488, 432-434) in one pass.
+    score [..., C] f32 -> (prob_normalized [..., C] or None, label_2d [...] int32)."""
+    score = _dev(score, "score", torch.float32)
+    C = score.shape[-1]
+    N = score.numel() // C
+    prob = torch.empty_like(score) if want_prob else None
+    label = torch.empty(score.shape[:-1], dtype=torch.int32, device=score.device)
+    check("pcnn_softmax_argmax_fwd",
+          lib().pcnn_softmax_argmax_fwd(_ptr(score), N, C, _ptr(prob), _ptr(label), _stream(score)))
+    return prob, label
+
+
+# ------------------------------------------------------------------------------------------------
+class _AverageDistanceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, prediction, target, weight, point, symmetry, margin):
+        R, CH = prediction.shape
+        C, P = point.shape[0], point.shape[1]
+        dev = prediction.device
+        loss = torch.empty((1,), dtype=torch.float32, device=dev)
+        bottom_diff = torch.empty((R, CH), dtype=torch.float32, device=dev)
+        nbytes = c_size_t(0)
+        check("pcnn_average_distance_workspace_bytes",
+              lib().pcnn_average_distance_workspace_bytes(R, C, P, ctypes.byref(nbytes)))
+        ws = _ws(dev, "adl").get(nbytes.value, dev)
+        check("pcnn_average_distance_fwd",
+              lib().pcnn_average_distance_fwd(_ptr(prediction), _ptr(target), _ptr(weight), _ptr(point),
+                                              _ptr(symmetry), R, C, P, float(margin), _ptr(loss),
+                                              _ptr(bottom_diff), _ptr(ws), ws.numel(), _stream(prediction)))
+        ctx.save_for_backward(bottom_diff)
+        ctx.mark_non_differentiable(bottom_diff)
+        return loss, bottom_diff
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_diff):
+        (bottom_diff,) = ctx.saved_tensors
+        R, CH = bottom_diff.shape
+        grad_loss = grad_loss.contiguous()
+        out = torch.empty_like(bottom_diff)
+        if R > 0:
+            check("pcnn_average_distance_bwd",
+                  lib().pcnn_average_distance_bwd(_ptr(grad_loss), _ptr(bottom_diff), R, CH, _ptr(out),
+                                                  _stream(bottom_diff)))
+        return out, None, None, None, None, None
+
+
+def average_distance_loss(poses_pred, poses_target, poses_weight, points, symmetry, margin, name=None):
+    """Drop-in for `Network.average_distance_loss` (network.py:236-238).
+    Returns (loss[1], bottom_diff[R,4C])."""
+    poses_pred = _dev(poses_pred, "prediction", torch.float32)
+    poses_target = _dev(poses_target, "target", torch.float32)
+    poses_weight = _dev(poses_weight, "weight", torch.float32)
+    points = _dev(points, "point", torch.float32)
+    symmetry = _dev(symmetry, "symmetry", torch.float32)
+    for t, n in ((poses_pred, "prediction"), (poses_target, "target"), (poses_weight, "weight")):
+        if t.dim() != 2:
+            raise ValueError("%s must be 2-dimensional" % n)  # average_distance_loss_op.cc:278-285
+    if points.dim() != 3:
+        raise ValueError("point must be 3-dimensional")
+    if symmetry.dim() != 1:
+        raise ValueError("symmetry must be 1-dimensional")
+    if poses_pred.shape[1] != POSE_CHANNELS * points.shape[0]:
+        raise ValueError("prediction must be [R, 4*num_classes]")
+    return _AverageDistanceFn.apply(poses_pred, poses_target, poses_weight, points, symmetry, margin)
+
+
+# ------------------------------------------------------------------------------------------------
+class _BackprojectFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, data, label, depth, meta_data, label_3d, grid_size, kernel_size, threshold):
+        B, H, W, Cd = data.shape
+        Cl = label.shape[3]
+        num_meta = meta_data.shape[-1]
+        G = int(grid_size)
+        dev = data.device
+        top_data = torch.empty((B, G, G, G, Cd), dtype=torch.float32, device=dev)
+        top_flag = torch.empty((B, G, G, G, Cd), dtype=torch.float32, device=dev)
+        top_label = torch.empty((B, G, G, G, Cl), dtype=torch.float32, device=dev)
+        check("pcnn_backproject_fwd",
+              lib().pcnn_backproject_fwd(_ptr(data), _ptr(label), _ptr(depth), _ptr(meta_data), _ptr(label_3d),
+                                         B, H, W, Cd, Cl, num_meta, G, int(kernel_size), float(threshold),
+                                         _ptr(top_data), _ptr(top_label), _ptr(top_flag), _stream(data)))
+        ctx.save_for_backward(depth, meta_data)
+        ctx.cfg = (B, H, W, Cd, num_meta, G)
+        ctx.mark_non_differentiable(top_label, top_flag)
+        return top_data, top_label, top_flag
+
+    @staticmethod
+    def backward(ctx, grad_data, _gl, _gf):
+        depth, meta_data = ctx.saved_tensors
+        B, H, W, Cd, num_meta, G = ctx.cfg
+        grad_data = grad_data.contiguous()
+        bottom = torch.empty((B, H, W, Cd), dtype=torch.float32, device=grad_data.device)
+        check("pcnn_backproject_bwd",
+              lib().pcnn_backproject_bwd(_ptr(grad_data), _ptr(depth), _ptr(meta_data), B, H, W, Cd, num_meta, G,
+                                         _ptr(bottom), _stream(grad_data)))
+        return bottom, None, None, None, None, None, None, None
+
+
+def backproject(data, label, depth, meta_data, label_3d, grid_size, kernel_size, threshold, name=None):
+    """Drop-in for `Network.backproject` (network.py:224-226).
+    Returns (top_data[B,G,G,G,Cd], top_label[B,G,G,G,Cl], top_flag[B,G,G,G,Cd])."""
+    data = _dev(data, "data", torch.float32)
+    label = _dev(label, "label", torch.float32)
+    depth = _dev(depth, "depth", torch.float32)
+    meta_data = _dev(meta_data, "meta_data", torch.float32)
+    label_3d = _dev(label_3d, "label_3d", torch.float32)
+    if data.dim() != 4:
+        raise ValueError("data must be 4-dimensional")       # backprojecting_op.cc:332-333
+    if label.dim() != 4:
+        raise ValueError("label must be 4-dimensional")      # :335-336
+    if depth.dim() != 4:
+        raise ValueError("depth must be 4-dimensional")      # :338-339
+    if meta_data.dim() != 4:
+        raise ValueError("meta data must be 4-dimensional")  # :341-342
+    if label_3d.dim() != 5:
+        raise ValueError("label 3D must be 5-dimensional")   # :344-345
+    return _BackprojectFn.apply(data, label, depth, meta_data, label_3d, grid_size, kernel_size, threshold)

@@ -1,0 +1,178 @@
+"""numpy/ctypes front-end of oracle/liboracle.so — TEST INFRASTRUCTURE ONLY (see the header of
+oracle/pcnn_oracle.c). Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+import ctypes
+import os
+from ctypes import POINTER, c_float, c_int, c_long, c_void_p
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+_lib = None
+
+MAX_ROI = 128
+CAP = MAX_ROI * 9
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            import subprocess
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+        _lib = ctypes.CDLL(_SO)
+        _lib.oracle_expf.restype = c_float
+        _lib.oracle_expf.argtypes = [c_float]
+        _lib.oracle_project_box.restype = c_float
+        _lib.oracle_project_box.argtypes = [c_int, c_void_p, c_void_p, c_float]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(c_void_p) if a is not None else c_void_p(0)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def expf(x):
+    x = np.asarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    L = lib()
+    flat_in, flat_out = x.ravel(), out.ravel()
+    for i in range(flat_in.size):
+        flat_out[i] = L.oracle_expf(c_float(float(flat_in[i])))
+    return out
+
+
+def project_box(cls, extents, meta, distance):
+    extents, meta = _f32(extents), _f32(meta)
+    return float(lib().oracle_project_box(int(cls), _p(extents), _p(meta), c_float(float(distance))))
+
+
+def hough_voting(label, vertex, extents, meta, gt, is_train, vote_thr, per_thr, skip,
+                 inlier=0.9, label_thr=500, want_hs=False, padded=False):
+    label, vertex, extents, meta = _i32(label), _f32(vertex), _f32(extents), _f32(meta)
+    B, H, W = label.shape
+    C = vertex.shape[3] // 3
+    num_meta = meta.shape[-1]
+    meta = meta.reshape(B, num_meta)
+    if gt is None or len(gt) == 0:
+        gt_a, num_gt = None, 0
+    else:
+        gt_a = _f32(gt)
+        num_gt = gt_a.shape[0]
+    top_box = np.empty((CAP, 7), np.float32)
+    top_pose = np.empty((CAP, 7), np.float32)
+    top_target = np.empty((CAP, 4 * C), np.float32)
+    top_weight = np.empty((CAP, 4 * C), np.float32)
+    top_domain = np.empty((CAP,), np.int32)
+    num_rois = np.zeros(2, np.int32)
+    hs = np.zeros((B, C, H * W), np.float32) if want_hs else None
+    st = lib().oracle_hough_voting(_p(label), _p(vertex), _p(extents), _p(meta), _p(gt_a),
+                                   B, H, W, C, num_meta, num_gt, int(is_train), c_float(vote_thr),
+                                   c_float(per_thr), int(skip), c_float(inlier), int(label_thr),
+                                   _p(top_box), _p(top_pose), _p(top_target), _p(top_weight),
+                                   _p(top_domain), _p(num_rois), _p(hs))
+    assert st == 0
+    if padded:
+        res = (top_box, top_pose, top_target, top_weight, top_domain, num_rois)
+    else:
+        r = int(num_rois[0])
+        res = (top_box[:r], top_pose[:r], top_target[:r], top_weight[:r], top_domain[:r])
+    return res + (hs,) if want_hs else res
+
+
+def hough_space(labelmap, vertmap, extents, meta, cls, skip, inlier=0.9):
+    labelmap, vertmap, extents, meta = _i32(labelmap), _f32(vertmap), _f32(extents), _f32(meta)
+    H, W = labelmap.shape
+    C = vertmap.shape[2] // 3
+    hs = np.empty((H, W), np.float32)
+    hd = np.empty((H, W, 3), np.float32)
+    m = lib().oracle_hough_space(_p(labelmap), _p(vertmap), _p(extents), _p(meta), H, W, C, int(cls),
+                                 int(skip), c_float(inlier), _p(hs), _p(hd))
+    return hs, hd, m
+
+
+def roi_pool(data, rois, PH, PW, scale, pool_channel):
+    data, rois = _f32(data), _f32(rois)
+    B, H, W, C = data.shape
+    R, cols = rois.shape
+    Cout = 1 if pool_channel else C
+    top = np.empty((R, PH, PW, Cout), np.float32)
+    argmax = np.empty((R, PH, PW, Cout), np.int32)
+    lib().oracle_roi_pool(_p(data), _p(rois), B, H, W, C, R, cols, PH, PW, c_float(scale),
+                          int(pool_channel), _p(top), _p(argmax))
+    return top, argmax
+
+
+def roi_pool_bwd(top_diff, rois, argmax, B, H, W, C, PH, PW, scale, pool_channel):
+    top_diff, rois, argmax = _f32(top_diff), _f32(rois), _i32(argmax)
+    R, cols = rois.shape
+    out = np.empty((B, H, W, C), np.float32)
+    lib().oracle_roi_pool_bwd(_p(top_diff), _p(rois), _p(argmax), B, H, W, C, R, cols, PH, PW,
+                              c_float(scale), int(pool_channel), _p(out))
+    return out
+
+
+def hard_label(prob, gt, threshold):
+    prob, gt = _f32(prob), _i32(gt)
+    C = prob.shape[-1]
+    N = prob.size // C
+    out = np.empty_like(prob)
+    lib().oracle_hard_label(_p(prob), _p(gt), c_long(N), C, c_float(threshold), _p(out))
+    return out
+
+
+def average_distance(pred, target, weight, point, symmetry, margin):
+    pred, target, weight, point, symmetry = map(_f32, (pred, target, weight, point, symmetry))
+    R = pred.shape[0]
+    C, P = point.shape[0], point.shape[1]
+    loss = np.zeros(1, np.float32)
+    diff = np.zeros((R, 4 * C), np.float32)
+    lib().oracle_average_distance(_p(pred), _p(target), _p(weight), _p(point), _p(symmetry), R, C, P,
+                                  c_float(margin), _p(loss), _p(diff))
+    return loss, diff
+
+
+def average_distance_bwd(grad, bottom_diff):
+    grad, bottom_diff = _f32(grad), _f32(bottom_diff)
+    out = np.empty_like(bottom_diff)
+    lib().oracle_average_distance_bwd(_p(grad), _p(bottom_diff), bottom_diff.shape[0], bottom_diff.shape[1], _p(out))
+    return out
+
+
+def backproject(data, label, depth, meta, label_3d, G, ksize, threshold):
+    data, label, depth, meta, label_3d = map(_f32, (data, label, depth, meta, label_3d))
+    B, H, W, Cd = data.shape
+    Cl = label.shape[3]
+    num_meta = meta.shape[-1]
+    top_data = np.empty((B, G, G, G, Cd), np.float32)
+    top_flag = np.empty((B, G, G, G, Cd), np.float32)
+    top_label = np.empty((B, G, G, G, Cl), np.float32)
+    lib().oracle_backproject(_p(data), _p(label), _p(depth), _p(meta), _p(label_3d), B, H, W, Cd, Cl,
+                             num_meta, G, int(ksize), c_float(threshold), _p(top_data), _p(top_label), _p(top_flag))
+    return top_data, top_label, top_flag
+
+
+def backproject_bwd(top_diff, depth, meta, B, H, W, Cd, G):
+    top_diff, depth, meta = map(_f32, (top_diff, depth, meta))
+    num_meta = meta.shape[-1]
+    out = np.empty((B, H, W, Cd), np.float32)
+    lib().oracle_backproject_bwd(_p(top_diff), _p(depth), _p(meta), B, H, W, Cd, num_meta, G, _p(out))
+    return out
+
+
+def softmax_argmax(score):
+    score = _f32(score)
+    C = score.shape[-1]
+    N = score.size // C
+    prob = np.empty_like(score)
+    label = np.empty(score.shape[:-1], np.int32)
+    lib().oracle_softmax_argmax(_p(score), c_long(N), C, _p(prob), _p(label))
+    return prob, label

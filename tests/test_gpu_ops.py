@@ -1,0 +1,276 @@
+"""GPU parity tests for roi_pool, hard_label, average_distance_loss, backproject and the label-head
+epilogue: libposecnn_hip.so via posecnn_amd.ops vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+import oracle
+from posecnn_amd import config, synth
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def T(gpu, a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def same(got, want, name=""):
+    got, want = np.ascontiguousarray(got), np.ascontiguousarray(want)
+    assert got.shape == want.shape, name
+    if got.dtype.kind == "f":
+        ok = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    else:
+        ok = got == want
+    assert ok.all(), "%s: %d mismatches, first at %s: gpu %s oracle %s" % (
+        name, (~ok).sum(), np.argwhere(~ok)[0], got[~ok][:3], want[~ok][:3])
+
+
+def random_rois(rng, R, B, C, W, H, cols=7):
+    rois = np.zeros((R, cols), F)
+    rois[:, 0] = rng.integers(0, B, R)
+    rois[:, 1] = rng.integers(0, C, R)
+    x1 = rng.uniform(-60, W - 20, R); y1 = rng.uniform(-60, H - 20, R)
+    rois[:, 2], rois[:, 3] = x1, y1
+    rois[:, 4] = x1 + rng.uniform(-30, 0.6 * W, R)
+    rois[:, 5] = y1 + rng.uniform(-30, 0.6 * H, R)
+    rois[:4, 2:6] = np.round(rois[:4, 2:6] / 16) * 16 + 8  # x.5 after the 1/16 scale
+    return rois
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,scale", [((2, 30, 40, 512), 1 / 16.0), ((2, 60, 80, 512), 1 / 8.0), ((3, 15, 20, 64), 1 / 16.0)])
+def test_roi_pool_forward(gpu, shape, scale):
+    from posecnn_amd import ops
+    rng = np.random.default_rng(11)
+    B, H, W, C = shape
+    data = rng.standard_normal(shape).astype(F)
+    rois = random_rois(rng, 23, B, 22, 640, 480)
+    top, arg = ops.roi_pool(T(gpu, data), T(gpu, rois), 7, 7, scale, 0)
+    wt, wa = oracle.roi_pool(data, rois, 7, 7, scale, 0)
+    same(N(top), wt, "top")
+    same(N(arg), wa, "argmax")
+
+
+def test_roi_pool_generic_paths(gpu):
+    from posecnn_amd import ops
+    rng = np.random.default_rng(12)
+    data = rng.standard_normal((2, 12, 17, 22)).astype(F)  # C % 4 != 0 -> scalar kernel
+    data[0, 3, 4, :] = np.nan
+    data[1, 5, 6, :] = -np.inf
+    rois = random_rois(rng, 31, 2, 22, 17 * 4, 12 * 4)
+    rois[5, 0] = 9    # bad batch index
+    rois[6, 1] = 40   # bad class (matters only for pool_channel)
+    for pc in (0, 1):
+        for (ph, pw) in ((7, 7), (3, 5), (1, 1)):
+            top, arg = ops.roi_pool(T(gpu, data), T(gpu, rois), ph, pw, 0.25, pc)
+            wt, wa = oracle.roi_pool(data, rois, ph, pw, 0.25, pc)
+            same(N(top), wt, "top pc=%d" % pc)
+            same(N(arg), wa, "argmax pc=%d" % pc)
+    # 5-column-plus layout of the stale reference test is rejected: needs >= 6 columns
+    with pytest.raises(ValueError):
+        ops.roi_pool(T(gpu, data), T(gpu, rois[:, :5]), 7, 7, 0.25, 0)
+    # zero ROIs
+    top, arg = ops.roi_pool(T(gpu, data), T(gpu, rois[:0]), 7, 7, 0.25, 0)
+    assert top.shape == (0, 7, 7, 22)
+
+
+def test_roi_pool_add2_equals_two_pools(gpu):
+    from posecnn_amd import ops
+    rng = np.random.default_rng(13)
+    c5 = rng.standard_normal((2, 30, 40, 512)).astype(F)
+    c4 = rng.standard_normal((2, 60, 80, 512)).astype(F)
+    rois = random_rois(rng, 19, 2, 22, 640, 480)
+    out = ops.roi_pool_add2(T(gpu, c5), 1 / 16.0, T(gpu, c4), 1 / 8.0, T(gpu, rois))
+    a, _ = oracle.roi_pool(c5, rois, 7, 7, 1 / 16.0, 0)
+    b, _ = oracle.roi_pool(c4, rois, 7, 7, 1 / 8.0, 0)
+    same(N(out), a + b, "pool_score")
+
+
+def test_roi_pool_backward(gpu):
+    import torch
+    from posecnn_amd import ops
+    rng = np.random.default_rng(14)
+    B, H, W, C = 2, 10, 12, 8
+    data = rng.standard_normal((B, H, W, C)).astype(F)
+    rois = random_rois(rng, 9, B, C, W * 8, H * 8)
+    for pc in (0, 1):
+        d = T(gpu, data).requires_grad_(True)
+        top, arg = ops.roi_pool(d, T(gpu, rois), 3, 3, 0.125, pc)
+        g = rng.standard_normal(tuple(top.shape)).astype(F)
+        top.backward(T(gpu, g))
+        want = oracle.roi_pool_bwd(g, rois, N(arg), B, H, W, C, 3, 3, 0.125, pc)
+        same(N(d.grad), want, "bottom_diff pc=%d" % pc)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1, 480, 640, 22), (2, 33, 47, 22), (1, 5, 7, 3), (1, 1, 1, 16)])
+def test_hard_label(gpu, shape):
+    from posecnn_amd import ops
+    rng = np.random.default_rng(15)
+    prob = rng.random(shape).astype(F)
+    gt = rng.integers(-1, shape[3], shape[:3]).astype(np.int32)
+    gt.ravel()[:3] = [-5, shape[3] + 2, -1]  # out-of-range labels are ignored
+    for thr in (0.3, 1.0):
+        out = ops.hard_label(T(gpu, prob), T(gpu, gt), thr)
+        same(N(out), oracle.hard_label(prob, gt, thr), "hard_label")
+    with pytest.raises(ValueError):
+        ops.hard_label(T(gpu, prob), T(gpu, gt), 0.0)
+
+
+def test_hard_label_one_hot_property_full_batch(gpu):
+    """Size-independent property at bench size (16 frames): each pixel has at most one 1, exactly
+    one when gt > 0, and the checksum equals the count predicted from (gt, prob)."""
+    import torch
+    from posecnn_amd import ops
+    g = torch.Generator(device=gpu).manual_seed(0)
+    prob = torch.rand((16, 480, 640, 22), device=gpu, generator=g)
+    gt = torch.randint(-1, 22, (16, 480, 640), device=gpu, generator=g, dtype=torch.int32)
+    out = ops.hard_label(prob, gt, 0.5)
+    s = out.sum(-1)
+    assert float(s.max()) <= 1.0
+    assert bool((s[gt > 0] == 1).all()) and bool((s[gt == -1] == 0).all())
+    p0 = prob[..., 0]
+    assert float(s[gt == 0].sum()) == float(((p0 < 0.5) & (gt == 0)).sum())
+    assert bool((out.gather(-1, gt.clamp(min=0).long().unsqueeze(-1)).squeeze(-1) == s).all())
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1, 480, 640, 22), (2, 17, 31, 22), (1, 9, 9, 40), (3, 4, 4, 2)])
+def test_softmax_argmax(gpu, shape):
+    from posecnn_amd import ops
+    rng = np.random.default_rng(16)
+    score = np.maximum(rng.standard_normal(shape) * 4, 0).astype(F)  # ReLU'd scores, many ties at 0
+    score.reshape(-1, shape[3])[0] = 0
+    score.reshape(-1, shape[3])[1] = 200  # exp overflow guard: max-subtracted
+    prob, lab = ops.softmax_argmax(T(gpu, score))
+    wp, wl = oracle.softmax_argmax(score)
+    same(N(lab), wl, "label_2d")
+    same(N(prob), wp, "prob_normalized")
+    _, lab2 = ops.softmax_argmax(T(gpu, score), want_prob=False)
+    same(N(lab2), wl, "label only")
+
+
+# ------------------------------------------------------------------------------------------------
+def adl_case(rng, R, C, P, sym_classes=(16, 21)):
+    pts = synth.make_model_points(C, P)
+    sym = np.zeros(C, F)
+    for c in sym_classes:
+        if c < C:
+            sym[c] = 1
+    pred = np.zeros((R, 4 * C), F); tgt = np.zeros((R, 4 * C), F); wgt = np.zeros((R, 4 * C), F)
+    classes = [c for c in (1, 16, 5, 21, 2, 16, 7, 21) if c < C] or [1]
+    for n in range(R):
+        if n % 5 == 4:
+            continue  # rows without a class are skipped (index_cls == -1)
+        c = classes[n % len(classes)]
+        pred[n, 4 * c:4 * c + 4] = np.tanh(rng.standard_normal(4)).astype(F)
+        tgt[n, 4 * c:4 * c + 4] = synth.random_unit_quats(rng, 1)[0]
+        wgt[n, 4 * c:4 * c + 4] = 1
+    return pred, tgt, wgt, pts, sym
+
+
+@pytest.mark.parametrize("R,C,P,margin", [(7, 22, 2620, 0.01), (3, 22, 300, 0.0), (12, 5, 1025, 0.01), (1, 22, 64, 0.01)])
+def test_average_distance_forward(gpu, R, C, P, margin):
+    from posecnn_amd import ops
+    rng = np.random.default_rng(17)
+    pred, tgt, wgt, pts, sym = adl_case(rng, R, C, P, sym_classes=(16, 21) if C == 22 else (2,))
+    loss, diff = ops.average_distance_loss(T(gpu, pred), T(gpu, tgt), T(gpu, wgt), T(gpu, pts), T(gpu, sym), margin)
+    wl, wd = oracle.average_distance(pred, tgt, wgt, pts, sym, margin)
+    assert wl[0] > 0
+    same(N(loss), wl, "loss")
+    same(N(diff), wd, "bottom_diff")
+
+
+def test_average_distance_edge_cases_and_backward(gpu):
+    import torch
+    from posecnn_amd import ops
+    rng = np.random.default_rng(18)
+    pred, tgt, wgt, pts, sym = adl_case(rng, 6, 22, 500)
+    # no row has a class -> loss 0, zero gradient
+    loss, diff = ops.average_distance_loss(T(gpu, pred), T(gpu, tgt), T(gpu, wgt * 0), T(gpu, pts), T(gpu, sym), 0.01)
+    assert float(loss) == 0 and float(diff.abs().sum()) == 0
+    # zero rows
+    loss, diff = ops.average_distance_loss(T(gpu, pred[:0]), T(gpu, tgt[:0]), T(gpu, wgt[:0]), T(gpu, pts), T(gpu, sym), 0.01)
+    assert float(loss) == 0 and diff.shape == (0, 88)
+    # AveragedistanceGrad: out = grad[0] * bottom_diff
+    p = T(gpu, pred).requires_grad_(True)
+    loss, diff = ops.average_distance_loss(p, T(gpu, tgt), T(gpu, wgt), T(gpu, pts), T(gpu, sym), 0.01)
+    (loss * 3.0).sum().backward()
+    want = oracle.average_distance_bwd(np.array([3.0], F), N(diff))
+    same(N(p.grad), want, "grad")
+    with pytest.raises(ValueError):
+        ops.average_distance_loss(T(gpu, pred), T(gpu, tgt), T(gpu, wgt), T(gpu, pts), T(gpu, sym), -0.1)
+
+
+# ------------------------------------------------------------------------------------------------
+def backproject_case(rng, B, H, W, Cd, Cl, G):
+    data = rng.standard_normal((B, H, W, Cd)).astype(F)
+    label = rng.random((B, H, W, Cl)).astype(F)
+    yy, xx = np.mgrid[0:H, 0:W]
+    depth = (1.6 + 0.3 * np.sin(xx / 9.0) + 0.2 * np.cos(yy / 7.0) + 0.01 * rng.standard_normal((B, H, W))).astype(F)
+    label3d = rng.random((B, G, G, G, Cl)).astype(F)
+    K = np.array([[W * 0.9, 0, W / 2.0], [0, W * 0.9, H / 2.0], [0, 0, 1]])
+    a = 0.05
+    w2l = np.array([[np.cos(a), 0, np.sin(a), 0.01], [0, 1, 0, -0.02], [-np.sin(a), 0, np.cos(a), 0.03]], F)
+    l2w = np.array([[np.cos(a), 0, -np.sin(a), -0.01], [0, 1, 0, 0.02], [np.sin(a), 0, np.cos(a), -0.03]], F)
+    step = (2.4 / G, 2.0 / G, 1.2 / G)
+    meta = np.stack([config.make_meta_data(K, voxel_step=step, voxel_min=(-1.2, -1.0, 1.1),
+                                           pose_world2live=w2l, pose_live2world=l2w)] * B)
+    return data, label, depth[..., None], meta, label3d
+
+
+@pytest.mark.parametrize("B,H,W,Cd,Cl,G,k", [(1, 48, 64, 64, 22, 24, 3), (2, 20, 28, 6, 3, 9, 1), (1, 16, 16, 5, 2, 8, 0)])
+def test_backproject_forward(gpu, B, H, W, Cd, Cl, G, k):
+    from posecnn_amd import ops
+    rng = np.random.default_rng(19)
+    data, label, depth, meta, label3d = backproject_case(rng, B, H, W, Cd, Cl, G)
+    m4 = meta.reshape(B, 1, 1, 48)
+    td, tl, tf = ops.backproject(T(gpu, data), T(gpu, label), T(gpu, depth), T(gpu, m4), T(gpu, label3d), G, k, 0.05)
+    wd, wl, wf = oracle.backproject(data, label, depth, meta, label3d, G, k, 0.05)
+    assert wf.sum() > 0
+    same(N(td), wd, "top_data")
+    same(N(tf), wf, "top_flag")
+    same(N(tl), wl, "top_label")
+
+
+def test_backproject_degenerate_projection_and_backward(gpu):
+    import torch
+    from posecnn_amd import ops
+    rng = np.random.default_rng(20)
+    B, H, W, Cd, Cl, G = 1, 16, 20, 4, 3, 6
+    data, label, depth, meta, label3d = backproject_case(rng, B, H, W, Cd, Cl, G)
+    meta0 = meta.copy()
+    meta0[:, 18:30] = 0  # zero pose (as lib/fcn/test.py leaves it): x3 = 0 -> 0/0 -> px = py = 0
+    m4 = meta0.reshape(B, 1, 1, 48)
+    td, tl, tf = ops.backproject(T(gpu, data), T(gpu, label), T(gpu, depth), T(gpu, m4), T(gpu, label3d), G, 2, 5.0)
+    wd, wl, wf = oracle.backproject(data, label, depth, meta0, label3d, G, 2, 5.0)
+    same(N(td), wd, "top_data"); same(N(tf), wf, "top_flag"); same(N(tl), wl, "top_label")
+    # backward (pixel -> voxel gather)
+    m4 = meta.reshape(B, 1, 1, 48)
+    d = T(gpu, data).requires_grad_(True)
+    td, tl, tf = ops.backproject(d, T(gpu, label), T(gpu, depth), T(gpu, m4), T(gpu, label3d), G, 1, 0.05)
+    g = rng.standard_normal(tuple(td.shape)).astype(F)
+    td.backward(T(gpu, g))
+    want = oracle.backproject_bwd(g, depth, meta, B, H, W, Cd, G)
+    assert np.abs(want).sum() > 0
+    same(N(d.grad), want, "bottom_diff")
+
+
+# ------------------------------------------------------------------------------------------------
+def test_device_math_is_ieee(gpu):
+    """The exactness argument rests on IEEE-correct f32 divide/sqrt and on the canonical exp; check
+    them end to end through an op whose output exposes them: softmax over 2 channels gives
+    exp(x)/(1+exp(x)) ... and hough's project_box; here: softmax on wide-range inputs."""
+    from posecnn_amd import ops
+    rng = np.random.default_rng(21)
+    x = np.zeros((200000, 2), F)
+    x[:, 1] = -np.abs(rng.uniform(0, 100, 200000)).astype(F)
+    x[:1000, 1] = -np.linspace(0, 104, 1000).astype(F)
+    prob, lab = ops.softmax_argmax(T(gpu, x))
+    wp, wl = oracle.softmax_argmax(x)
+    same(N(prob), wp, "softmax wide range")
