@@ -100,6 +100,13 @@ int pcnn_hough_voting_fwd(const int32_t* label, const float* vertex, const float
                           int32_t* top_domain, int32_t* num_rois,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* Diagnostics for tests: byte offsets of intermediate buffers inside the workspace.
+ * offsets[8] = { hough space f32 [B][C-1][H*W] (SIZE_MAX unless threshold_vote > 0), pixel records
+ * (32 B each), class totals i32 [B][C], slot classes i32 [B][C], slot counts i32 [B], record
+ * offsets i32 [B][C], tile maxima int2 [B][C-1][tiles], record capacity per image (a count) }. */
+int pcnn_hough_voting_debug_layout(int batch, int height, int width, int num_classes,
+                                   float threshold_vote, int skip_pixels, size_t* offsets);
+
 /* HoughvotinggpuGrad (hough_voting_gpu_op.cc:440-484, set_gradients .cu.cc:608-612): zeros. */
 int pcnn_hough_voting_bwd(float* grad_label, float* grad_vertex,
                           int batch, int height, int width, int num_classes, void* stream);
@@ -183,6 +190,19 @@ int pcnn_backproject_bwd(const float* top_diff, const float* depth, const float*
  * ------------------------------------------------------------------------------------------ */
 int pcnn_softmax_argmax_fwd(const float* score, int64_t num_pixels, int num_classes,
                             float* prob, int32_t* label, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Kernel timing diagnostics (off by default; the reference's only instrumentation is the
+ * wall-clock Timer of lib/utils/timer.py:10-32 around im_segment).
+ * While enabled, every kernel launch of this library is bracketed by hipEventRecord on the launch
+ * stream. pcnn_profile_report synchronises the recorded events and writes a JSON object
+ * {"kernel": {"calls": n, "total_ms": t, "avg_us": a}, ...} into buf (NUL terminated, truncated to
+ * cap); it returns the number of bytes needed. pcnn_profile_enable(0) disables and clears.
+ * Not legal during hipGraph capture.
+ * ------------------------------------------------------------------------------------------ */
+int pcnn_profile_enable(int on);
+int pcnn_profile_reset(void);
+long pcnn_profile_report(char* buf, long cap);
 
 #ifdef __cplusplus
 }

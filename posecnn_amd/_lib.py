@@ -31,6 +31,7 @@ SIGNATURES = {
     "pcnn_last_error_string": (c_char_p, []),
     "pcnn_status_string": (c_char_p, [c_int]),
     "pcnn_hough_voting_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_float, c_int, POINTER(c_size_t)]),
+    "pcnn_hough_voting_debug_layout": (c_int, [c_int, c_int, c_int, c_int, c_float, c_int, POINTER(c_size_t)]),
     "pcnn_hough_voting_fwd": (c_int, [_P, _P, _P, _P, _P,
                                       c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_int, c_float, c_float, c_int, c_float, c_int,
@@ -53,7 +54,27 @@ SIGNATURES = {
                                      c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
     "pcnn_backproject_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pcnn_softmax_argmax_fwd": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
+    "pcnn_profile_enable": (c_int, [c_int]),
+    "pcnn_profile_reset": (c_int, []),
+    "pcnn_profile_report": (ctypes.c_long, [ctypes.c_char_p, ctypes.c_long]),
 }
+
+
+def profile_enable(on=True):
+    """Bracket every library kernel launch with HIP events on its launch stream."""
+    check("pcnn_profile_enable", lib().pcnn_profile_enable(1 if on else 0))
+
+
+def profile_report(reset=True):
+    """-> {kernel_name: {"calls", "total_ms", "avg_us"}} for launches since the last reset."""
+    import json
+    L = lib()
+    n = L.pcnn_profile_report(None, 0)
+    buf = ctypes.create_string_buffer(int(n) + 16)
+    L.pcnn_profile_report(buf, len(buf))
+    if reset:
+        L.pcnn_profile_reset()
+    return json.loads(buf.value.decode())
 
 _lib = None
 

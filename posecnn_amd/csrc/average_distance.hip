@@ -218,11 +218,11 @@ extern "C" int pcnn_average_distance_fwd(const float* prediction, const float* t
                "average_distance: workspace NULL, misaligned or too small (%zu < %zu)", workspace_bytes, adl_ws(R, P));
   float* terms = (float*)workspace;
   float* loss_batch = (float*)((char*)workspace + align_up(sizeof(float) * (size_t)R * 5 * P, 256));
-  hipLaunchKernelGGL(adl_terms_kernel, dim3((P + ADL_THREADS - 1) / ADL_THREADS, R), dim3(ADL_THREADS), 0,
+  PCNN_LAUNCH(adl_terms_kernel, dim3((P + ADL_THREADS - 1) / ADL_THREADS, R), dim3(ADL_THREADS), 0,
                      stream, prediction, target, weight, point, symmetry, terms, R, C, P, margin);
-  hipLaunchKernelGGL(adl_sum_kernel, dim3(R), dim3(64), sizeof(float) * 5 * 2048, stream, terms, weight,
+  PCNN_LAUNCH(adl_sum_kernel, dim3(R), dim3(64), sizeof(float) * 5 * 2048, stream, terms, weight,
                      loss_batch, bottom_diff, C, P);
-  hipLaunchKernelGGL(adl_total_kernel, dim3(1), dim3(64), 0, stream, loss_batch, loss, R);
+  PCNN_LAUNCH(adl_total_kernel, dim3(1), dim3(64), 0, stream, loss_batch, loss, R);
   return pcnn::check_launch("average_distance_fwd");
 }
 
@@ -235,6 +235,6 @@ extern "C" int pcnn_average_distance_bwd(const float* grad, const float* bottom_
   hipStream_t stream = (hipStream_t)stream_;
   long long total = (long long)R * channels;
   int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-  hipLaunchKernelGGL(adl_bwd_kernel, dim3(blocks), dim3(256), 0, stream, grad, bottom_diff, out, total);
+  PCNN_LAUNCH(adl_bwd_kernel, dim3(blocks), dim3(256), 0, stream, grad, bottom_diff, out, total);
   return pcnn::check_launch("average_distance_bwd");
 }

@@ -209,15 +209,15 @@ extern "C" int pcnn_backproject_fwd(const float* data, const float* label, const
   const bool vec = (Cd % 4 == 0) && aligned16(data) && aligned16(top_data) && aligned16(top_flag);
   if (vec) {
     const long long total = nvox * (Cd / 4);
-    hipLaunchKernelGGL(backproject_data_kernel<4>, dim3(grid_for(total)), dim3(256), 0, stream, data,
+    PCNN_LAUNCH(backproject_data_kernel<4>, dim3(grid_for(total)), dim3(256), 0, stream, data,
                        depth, meta, top_data, top_flag, total, H, W, Cd, num_meta, G, ksize, threshold);
   } else {
     const long long total = nvox * Cd;
-    hipLaunchKernelGGL(backproject_data_kernel<1>, dim3(grid_for(total)), dim3(256), 0, stream, data,
+    PCNN_LAUNCH(backproject_data_kernel<1>, dim3(grid_for(total)), dim3(256), 0, stream, data,
                        depth, meta, top_data, top_flag, total, H, W, Cd, num_meta, G, ksize, threshold);
   }
   const long long ltotal = nvox * Cl;
-  hipLaunchKernelGGL(backproject_label_kernel, dim3(grid_for(ltotal)), dim3(256), 0, stream, label, depth,
+  PCNN_LAUNCH(backproject_label_kernel, dim3(grid_for(ltotal)), dim3(256), 0, stream, label, depth,
                      meta, label_3d, top_label, ltotal, H, W, Cl, num_meta, G, ksize, threshold);
   return pcnn::check_launch("backproject_fwd");
 }
@@ -231,7 +231,7 @@ extern "C" int pcnn_backproject_bwd(const float* top_diff, const float* depth, c
   PCNN_REQUIRE(top_diff && depth && meta && bottom_diff, PCNN_ENULL, "backproject_bwd: NULL pointer");
   hipStream_t stream = (hipStream_t)stream_;
   const long long total = (long long)B * H * W * Cd;
-  hipLaunchKernelGGL(backproject_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, top_diff, depth,
+  PCNN_LAUNCH(backproject_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, top_diff, depth,
                      meta, bottom_diff, total, H, W, Cd, num_meta, G);
   return pcnn::check_launch("backproject_bwd");
 }

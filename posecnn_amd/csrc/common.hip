@@ -4,6 +4,12 @@
 // InvalidArgument (hough_voting_gpu_op.cc:328-332) with status codes + a thread-local message.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
 
 #include "pcnn_device.h"
 
@@ -29,7 +35,101 @@ int check_launch(const char* what)
   return PCNN_OK;
 }
 
+// ---- per-kernel timing ----------------------------------------------------------------------
+bool g_profile_on = false;
+
+namespace {
+struct ProfRec {
+  const char* name;
+  hipEvent_t e0, e1;
+};
+std::vector<ProfRec> g_recs;
+std::vector<hipEvent_t> g_pool;
+std::mutex g_prof_mu;
+
+hipEvent_t take_event()
+{
+  if (!g_pool.empty()) {
+    hipEvent_t e = g_pool.back();
+    g_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+}  // namespace
+
+void profile_begin(const char* name, hipStream_t stream)
+{
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfRec r{name, take_event(), take_event()};
+  (void)hipEventRecord(r.e0, stream);
+  g_recs.push_back(r);
+}
+
+void profile_end(hipStream_t stream)
+{
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().e1, stream);
+}
+
 }  // namespace pcnn
+
+extern "C" int pcnn_profile_reset(void)
+{
+  std::lock_guard<std::mutex> lk(pcnn::g_prof_mu);
+  for (auto& r : pcnn::g_recs) {
+    (void)hipEventSynchronize(r.e1);
+    pcnn::g_pool.push_back(r.e0);
+    pcnn::g_pool.push_back(r.e1);
+  }
+  pcnn::g_recs.clear();
+  return PCNN_OK;
+}
+
+extern "C" int pcnn_profile_enable(int on)
+{
+  pcnn_profile_reset();
+  pcnn::g_profile_on = on != 0;
+  return PCNN_OK;
+}
+
+extern "C" long pcnn_profile_report(char* buf, long cap)
+{
+  std::lock_guard<std::mutex> lk(pcnn::g_prof_mu);
+  std::map<std::string, std::pair<long, double>> agg;
+  for (auto& r : pcnn::g_recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+      std::string n(r.name);
+      size_t p = n.rfind("::");
+      if (p != std::string::npos) n = n.substr(p + 2);
+      size_t lt = n.find('<');
+      if (lt != std::string::npos) n = n.substr(0, lt);
+      auto& a = agg[n];
+      a.first += 1;
+      a.second += ms;
+    }
+  }
+  std::string out = "{";
+  bool first = true;
+  for (auto& kv : agg) {
+    char line[256];
+    snprintf(line, sizeof line, "%s\"%s\": {\"calls\": %ld, \"total_ms\": %.6f, \"avg_us\": %.3f}",
+             first ? "" : ", ", kv.first.c_str(), kv.second.first, kv.second.second,
+             1000.0 * kv.second.second / (double)kv.second.first);
+    out += line;
+    first = false;
+  }
+  out += "}";
+  if (buf && cap > 0) {
+    long n = (long)out.size() < cap - 1 ? (long)out.size() : cap - 1;
+    memcpy(buf, out.data(), (size_t)n);
+    buf[n] = 0;
+  }
+  return (long)out.size() + 1;
+}
 
 extern "C" int pcnn_abi_version(void) { return PCNN_ABI_VERSION; }
 

@@ -109,7 +109,7 @@ extern "C" int pcnn_hard_label_fwd(const float* prob, const int32_t* gt, int64_t
   hipStream_t stream = (hipStream_t)stream_;
   long long blocks = (N + HL_PIX - 1) / HL_PIX;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(hard_label_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, prob, gt,
+  PCNN_LAUNCH(hard_label_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, prob, gt,
                      out, (long long)N, C, threshold);
   return pcnn::check_launch("hard_label_fwd");
 }
@@ -142,10 +142,10 @@ extern "C" int pcnn_softmax_argmax_fwd(const float* score, int64_t N, int C, flo
   long long blocks = (N + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
   if (C <= 24)
-    hipLaunchKernelGGL(softmax_argmax_kernel<24>, dim3((unsigned)blocks), dim3(256), 0, stream,
+    PCNN_LAUNCH(softmax_argmax_kernel<24>, dim3((unsigned)blocks), dim3(256), 0, stream,
                        score, prob, label, (long long)N, C);
   else
-    hipLaunchKernelGGL(softmax_argmax_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, stream,
+    PCNN_LAUNCH(softmax_argmax_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, stream,
                        score, prob, label, (long long)N, C);
   return pcnn::check_launch("softmax_argmax_fwd");
 }

@@ -811,6 +811,30 @@ extern "C" int pcnn_hough_voting_workspace_bytes(int batch, int height, int widt
   return PCNN_OK;
 }
 
+// Diagnostics: byte offsets of the intermediate buffers inside the workspace, so tests can check
+// every Hough cell (not only the maxima) against the oracle. offsets[0..7] = hough space
+// (f32 [B][C-1][H*W], only when threshold_vote > 0; else SIZE_MAX), records, class totals,
+// slot classes, slot counts, record offsets, tile maxima, record capacity per image (a count).
+extern "C" int pcnn_hough_voting_debug_layout(int batch, int height, int width, int num_classes,
+                                              float threshold_vote, int skip_pixels,
+                                              size_t* offsets)
+{
+  PCNN_REQUIRE(offsets != nullptr, PCNN_ENULL, "hough_voting_debug_layout: offsets is NULL");
+  int st = validate_common(batch, height, width, num_classes, skip_pixels);
+  if (st != PCNN_OK) return st;
+  const bool need_hs = threshold_vote > 0;
+  const HvLayout L = hv_layout(batch, height, width, num_classes, need_hs, skip_pixels);
+  offsets[0] = need_hs ? L.off_hs : (size_t)-1;
+  offsets[1] = L.off_rec;
+  offsets[2] = L.off_tot;
+  offsets[3] = L.off_slots;
+  offsets[4] = L.off_nslots;
+  offsets[5] = L.off_recoff;
+  offsets[6] = L.off_tilemax;
+  offsets[7] = (size_t)L.reccap;
+  return PCNN_OK;
+}
+
 extern "C" int pcnn_hough_voting_fwd(const int32_t* label, const float* vertex,
                                      const float* extents, const float* meta, const float* gt,
                                      int B, int H, int W, int C, int num_meta, int num_gt,
@@ -859,26 +883,26 @@ extern "C" int pcnn_hough_voting_fwd(const int32_t* label, const float* vertex,
   zj.p[3] = top_weight; zj.words[3] = PCNN_HOUGH_ROWS_CAPACITY * 4 * C;
   zj.p[4] = (float*)top_domain; zj.words[4] = PCNN_HOUGH_ROWS_CAPACITY;
 
-  hipLaunchKernelGGL(hv_hist_kernel, dim3(L.nchunk, B), dim3(256), 0, stream, label, hist, HW, C,
+  PCNN_LAUNCH(hv_hist_kernel, dim3(L.nchunk, B), dim3(256), 0, stream, label, hist, HW, C,
                      L.nchunk, zj);
-  hipLaunchKernelGGL(hv_scatter_kernel, dim3(L.nchunk, B), dim3(256), 0, stream, label, vertex,
+  PCNN_LAUNCH(hv_scatter_kernel, dim3(L.nchunk, B), dim3(256), 0, stream, label, vertex,
                      extents, meta, hist, tot, slots, nslots, recoff, rec, HW, W, C, L.nchunk,
                      skip, label_thr, num_meta, L.reccap);
-  hipLaunchKernelGGL(hv_vote_kernel, dim3(L.ntiles, C - 1, B), dim3(256), 0, stream, rec, nslots,
+  PCNN_LAUNCH(hv_vote_kernel, dim3(L.ntiles, C - 1, B), dim3(256), 0, stream, rec, nslots,
                      slots, tot, recoff, tilemax, hs, H, W, C, skip, inlier, L.ntx, L.ntiles,
                      L.reccap, need_hs ? 1 : 0);
   if (!need_hs) {
-    hipLaunchKernelGGL(hv_select_kernel, dim3(C - 1, B), dim3(256), 0, stream, rec, nslots, slots,
+    PCNN_LAUNCH(hv_select_kernel, dim3(C - 1, B), dim3(256), 0, stream, rec, nslots, slots,
                        tot, recoff, tilemax, extents, meta, maxima, nmax, W, C, skip, inlier,
                        L.ntiles, L.reccap, L.cap, L.capmax, num_meta);
   } else {
-    hipLaunchKernelGGL(hv_localmax_kernel, dim3(L.nlm, B), dim3(256), 0, stream, rec, nslots,
+    PCNN_LAUNCH(hv_localmax_kernel, dim3(L.nlm, B), dim3(256), 0, stream, rec, nslots,
                        slots, tot, recoff, hs, extents, meta, chunkcnt, chunkcand, H, W, C, skip,
                        inlier, vote_thr, per_thr, L.reccap, L.capmax, L.cap, L.nlm, num_meta);
-    hipLaunchKernelGGL(hv_gather_kernel, dim3(B), dim3(256), 0, stream, nslots, chunkcnt,
+    PCNN_LAUNCH(hv_gather_kernel, dim3(B), dim3(256), 0, stream, nslots, chunkcnt,
                        chunkcand, maxima, nmax, HW, L.nlm, L.cap, L.capmax);
   }
-  hipLaunchKernelGGL(hv_emit_kernel, dim3(1), dim3(128), 0, stream, maxima, nmax, extents, meta,
+  PCNN_LAUNCH(hv_emit_kernel, dim3(1), dim3(128), 0, stream, maxima, nmax, extents, meta,
                      gt, top_box, top_pose, top_target, top_weight, top_domain, num_rois, B, W, C,
                      L.cap, L.capmax, num_meta, num_gt, is_train);
   return check_launch("hough_voting_fwd");

@@ -29,12 +29,28 @@ int check_launch(const char* what);  // hipGetLastError -> PCNN_EHIP
     }                                    \
   } while (0)
 
+// ---- launch + optional per-kernel HIP-event timing (pcnn_profile_*) ---------------------------
+extern bool g_profile_on;
+void profile_begin(const char* name, hipStream_t stream);
+void profile_end(hipStream_t stream);
+
+#define PCNN_LAUNCH(kernel, grid, block, shmem, stream, ...)                      \
+  do {                                                                            \
+    if (::pcnn::g_profile_on) ::pcnn::profile_begin(#kernel, (stream));           \
+    hipLaunchKernelGGL(kernel, (grid), (block), (shmem), (stream), __VA_ARGS__);  \
+    if (::pcnn::g_profile_on) ::pcnn::profile_end((stream));                      \
+  } while (0)
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---- exact f32 primitives --------------------------------------------------------------------
-__device__ __forceinline__ float div_rn(float a, float b) { return __fdiv_rn(a, b); }
-__device__ __forceinline__ float sqrt_rn(float a) { return __fsqrt_rn(a); }
+// NOTE: HIP's __fsqrt_rn() is __ocml_native_sqrt_f32 (v_sqrt_f32, ~1 ulp) unless
+// OCML_BASIC_ROUNDED_OPERATIONS is defined — it is NOT correctly rounded. Plain `/` and
+// __builtin_sqrtf are, under -fhip-fp32-correctly-rounded-divide-sqrt (set in the Makefile; the
+// gpu tests check both against the host bit for bit).
+__device__ __forceinline__ float div_rn(float a, float b) { return a / b; }
+__device__ __forceinline__ float sqrt_rn(float a) { return __builtin_sqrtf(a); }
 
 // Canonical expf: exp evaluated in IEEE double — range reduction by ln2 (hi/lo),
 // degree-13 Taylor polynomial in Horner form, scale by 2^k — then ONE rounding to float.  Every

@@ -247,12 +247,12 @@ extern "C" int pcnn_roi_pool_fwd(const float* data, const float* rois, int B, in
                    (!argmax || aligned16(argmax));
   if (vec) {
     const int threads = C >= 512 ? 128 : 64;
-    hipLaunchKernelGGL(roi_pool_fwd_vec4, dim3(R * PH * PW), dim3(threads), 0, stream, data, rois,
+    PCNN_LAUNCH(roi_pool_fwd_vec4, dim3(R * PH * PW), dim3(threads), 0, stream, data, rois,
                        top, argmax, B, H, W, C, roi_cols, PH, PW, scale);
   } else {
     long long total = (long long)R * PH * PW * (pool_channel ? 1 : C);
     int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(roi_pool_fwd_scalar, dim3(blocks), dim3(256), 0, stream, data, rois, top,
+    PCNN_LAUNCH(roi_pool_fwd_scalar, dim3(blocks), dim3(256), 0, stream, data, rois, top,
                        argmax, total, B, H, W, C, roi_cols, PH, PW, scale, pool_channel);
   }
   return check_launch("roi_pool_fwd");
@@ -274,7 +274,7 @@ extern "C" int pcnn_roi_pool_add2_fwd(const float* data_a, int Ha, int Wa, float
                "roi_pool_add2: tensors must be 16-byte aligned");
   hipStream_t stream = (hipStream_t)stream_;
   const int threads = C >= 512 ? 128 : 64;
-  hipLaunchKernelGGL(roi_pool_add2_vec4, dim3(R * PH * PW), dim3(threads), 0, stream, data_a, Ha,
+  PCNN_LAUNCH(roi_pool_add2_vec4, dim3(R * PH * PW), dim3(threads), 0, stream, data_a, Ha,
                      Wa, scale_a, data_b, Hb, Wb, scale_b, rois, out, B, C, roi_cols, PH, PW);
   return check_launch("roi_pool_add2_fwd");
 }
@@ -290,7 +290,7 @@ extern "C" int pcnn_roi_pool_bwd(const float* top_diff, const float* rois, const
   hipStream_t stream = (hipStream_t)stream_;
   long long total = (long long)B * H * W * C;
   int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-  hipLaunchKernelGGL(roi_pool_bwd_kernel, dim3(blocks), dim3(256), 0, stream, top_diff, rois,
+  PCNN_LAUNCH(roi_pool_bwd_kernel, dim3(blocks), dim3(256), 0, stream, top_diff, rois,
                      argmax, bottom_diff, total, H, W, C, R, roi_cols, PH, PW, scale, pool_channel);
   return check_launch("roi_pool_bwd");
 }

@@ -1,0 +1,95 @@
+"""Multi-GPU layer: one process per GPU, frames sharded data-parallel, ONE all-gather of the
+fixed-size detection buffer per batch. The reference has no distributed code at
+all (single process, `CUDA_VISIBLE_DEVICES=$1`, experiments/scripts/demo.sh:7); frames are
+independent units (it loops images serially, hough_voting_gpu_op.cc:369-377 and
+lib/fcn/test.py:1867), so the only exchange step is returning detections.
+
+Backend 'nccl' is RCCL on ROCm (xGMI); 'gloo' is used for the CPU tests. The payload is
+(cap+1) x 14 floats per rank (~7 KB at cap = 128): latency-bound, so it is issued as a single
+`all_gather_into_tensor` with the row count packed into the last row instead of a second
+collective.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+DET_COLS = 14  # box7 | pose7
+
+
+def init_from_env(backend=None):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (torchrun contract).
+    Returns (rank, world_size, local_rank). world_size 1 needs no process group."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n_frames, rank, world):
+    """Contiguous shard [lo, hi) of a global batch: rank r takes frames [r*N/W, (r+1)*N/W)."""
+    lo = (n_frames * rank) // world
+    hi = (n_frames * (rank + 1)) // world
+    return lo, hi
+
+
+def pack_detections(rows, count, frame_offset=0):
+    """rows [cap, 14] (+ device count [1]) -> [cap+1, 14] with the count in [-1, 0] and the
+    image index column shifted to global frame numbering."""
+    cap = rows.shape[0]
+    buf = torch.zeros((cap + 1, DET_COLS), dtype=torch.float32, device=rows.device)
+    buf[:cap] = rows
+    if frame_offset:
+        valid = (torch.arange(cap, device=rows.device) < count).to(rows.dtype)
+        buf[:cap, 0] += valid * float(frame_offset)
+    buf[cap, 0] = count.to(torch.float32).reshape(())
+    return buf
+
+
+def all_gather_detections(rows, count, frame_offset=0, group=None):
+    """Every rank ends up with all ranks' detections: returns (rows [W, cap, 14], counts [W] int64).
+    A no-op (plus reshape) at world size 1."""
+    buf = pack_detections(rows, count, frame_offset)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        gathered = buf.unsqueeze(0)
+    else:
+        flat = torch.empty((world * buf.shape[0], buf.shape[1]), dtype=buf.dtype, device=buf.device)
+        dist.all_gather_into_tensor(flat, buf, group=group)  # rank-major concatenation (RCCL and gloo)
+        gathered = flat.view(world, buf.shape[0], buf.shape[1])
+    cap = rows.shape[0]
+    return gathered[:, :cap], gathered[:, cap, 0].round().to(torch.int64)
+
+
+def flatten_gathered(rows, counts):
+    """[W, cap, 14] + counts -> [sum(counts), 14] in rank (= global frame) order, on the host."""
+    rows = rows.cpu().numpy()
+    counts = counts.cpu().numpy()
+    import numpy as np
+    parts = [rows[r, :int(counts[r])] for r in range(rows.shape[0])]
+    return np.concatenate(parts) if parts else np.zeros((0, DET_COLS), np.float32)
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value, device):
+    """MAX all-reduce of a python float (timing contract of bench.py)."""
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -1,0 +1,220 @@
+"""Single-frame inference driver: the part of lib/fcn/test.py that sits directly on the hot path
+(`_get_image_blob` :37-110, `im_segment_single_frame` :113-239) plus the tiny host helpers it
+calls (`lib/utils/nms.py:3-32`, `lib/utils/blob.py:48-71`), re-expressed for a batched,
+device-resident pipeline:
+
+  * `im_segment_single_frame` keeps the reference's signature/returns for one frame;
+  * `im_segment_batch` runs B frames in one pass and keeps everything on the GPU — the Hough layer
+    is called in its sync-free padded form, ROI pooling / fc6-8 run on the padded row capacity
+    (rows past the count are all-zero ROIs and are masked out afterwards), NMS and the pose
+    combine are done once per batch on the few hundred bytes of detections.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .config import PIXEL_MEANS, make_meta_data
+
+__all__ = ["pad_im", "unpad_im", "nms", "_get_image_blob", "im_segment_single_frame",
+           "im_segment_batch", "combine_poses", "Detections"]
+
+
+def pad_im(im, factor, value=0):
+    """lib/utils/blob.py:48-59"""
+    height, width = im.shape[0], im.shape[1]
+    pad_height = int(np.ceil(height / float(factor)) * factor - height)
+    pad_width = int(np.ceil(width / float(factor)) * factor - width)
+    if im.ndim == 3:
+        return np.pad(im, ((0, pad_height), (0, pad_width), (0, 0)), "constant", constant_values=value)
+    return np.pad(im, ((0, pad_height), (0, pad_width)), "constant", constant_values=value)
+
+
+def unpad_im(im, factor, orig_shape=None):
+    """lib/utils/blob.py:62-71. The reference recomputes the pad from the *padded* size, which is
+    always 0; callers there pass the original frame size implicitly. `orig_shape` makes it explicit."""
+    if orig_shape is not None:
+        return im[:orig_shape[0], :orig_shape[1]]
+    height, width = im.shape[0], im.shape[1]
+    pad_height = int(np.ceil(height / float(factor)) * factor - height)
+    pad_width = int(np.ceil(width / float(factor)) * factor - width)
+    return im[0:height - pad_height, 0:width - pad_width]
+
+
+def nms(dets, thresh):
+    """lib/utils/nms.py:3-32 — class-aware greedy NMS on 7-column ROIs
+    (batch, cls, x1, y1, x2, y2, score): a box is suppressed only by a higher-scoring box of the
+    same class with IoU > thresh (areas with +1). Returns kept row indices, best first."""
+    dets = np.asarray(dets)
+    cls = dets[:, 1]
+    x1, y1, x2, y2 = dets[:, 2], dets[:, 3], dets[:, 4], dets[:, 5]
+    scores = dets[:, 6]
+    areas = (x2 - x1 + 1) * (y2 - y1 + 1)
+    order = scores.argsort()[::-1]
+    keep = []
+    while order.size > 0:
+        i = order[0]
+        keep.append(int(i))
+        xx1 = np.maximum(x1[i], x1[order[1:]])
+        yy1 = np.maximum(y1[i], y1[order[1:]])
+        xx2 = np.minimum(x2[i], x2[order[1:]])
+        yy2 = np.minimum(y2[i], y2[order[1:]])
+        w = np.maximum(0.0, xx2 - xx1 + 1)
+        h = np.maximum(0.0, yy2 - yy1 + 1)
+        inter = w * h
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ovr = inter / (areas[i] + areas[order[1:]] - inter)
+        inds = np.where(~((ovr > thresh) & (cls[order[1:]] == cls[i])))[0]
+        order = order[inds + 1]
+    return keep
+
+
+def _get_image_blob(im, im_depth, scale=1.0):
+    """lib/fcn/test.py:37-110 for INPUT in {COLOR, RGBD} and SCALES_BASE = (1.0,):
+    BGR float32 minus PIXEL_MEANS; depth tower input = clip(depth/2000, 0, 1)*255 tiled to 3
+    channels minus the same means. Returns (blob[1,H,W,3], blob_depth[1,H,W,3], im_scale)."""
+    assert scale == 1.0, "only SCALES_BASE = (1.0,) is on the demo/test path (lov_color_2d.yml:39)"
+    im_orig = im.astype(np.float32, copy=True)
+    im_orig -= PIXEL_MEANS
+    blob = im_orig[np.newaxis]
+    blob_depth = None
+    if im_depth is not None:
+        d = im_depth.astype(np.float32, copy=True)
+        d = np.clip(d / 2000.0, 0, 1) * 255
+        d = np.tile(d[:, :, np.newaxis], (1, 1, 3))
+        d -= PIXEL_MEANS
+        blob_depth = d[np.newaxis]
+    return blob, blob_depth, scale
+
+
+def combine_poses(rois, poses_init, poses_pred):
+    """lib/fcn/test.py:197-211: NMS(0.5), then poses[i,:4] = poses_tanh[i, 4c:4c+4] (raw tanh)."""
+    keep = nms(rois, 0.5)
+    rois = rois[keep, :]
+    poses = poses_init[keep, :].copy()
+    poses_pred = poses_pred[keep, :]
+    for i in range(rois.shape[0]):
+        class_id = int(rois[i, 1])
+        if class_id >= 0:
+            poses[i, :4] = poses_pred[i, 4 * class_id:4 * class_id + 4]
+    return rois, poses, keep
+
+
+def _feed(net, data, data_p, K, extents, points, symmetry, num_classes, device):
+    B, H, W, _ = data.shape
+    meta = np.stack([make_meta_data(K)] * B).reshape(B, 1, 1, 48)
+    def t(a, dt=torch.float32):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=device, dtype=dt)
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(device)
+
+    feed = {
+        "data": data if isinstance(data, torch.Tensor) else t(data),
+        "gt_label_2d": torch.ones((B, H, W), dtype=torch.int32, device=device),  # fake label blob of ones (:154)
+        "keep_prob": 1.0,
+        "poses": torch.zeros((1, 13), dtype=torch.float32, device=device),       # pose_blob (:156)
+        "extents": t(extents), "meta_data": t(meta), "points": t(points), "symmetry": t(symmetry),
+    }
+    if data_p is not None:
+        feed["data_p"] = data_p if isinstance(data_p, torch.Tensor) else t(data_p)
+    return feed
+
+
+def im_segment_single_frame(net, im, im_depth, meta_data, extents, points, symmetry, num_classes, device="cuda"):
+    """lib/fcn/test.py:113-239 (TEST.VERTEX_REG_2D and TEST.POSE_REG set, as in lov_color_2d.yml).
+    `im` is BGR uint8 (OpenCV order), already padded to a multiple of 16 by the caller (:1870).
+    Returns (labels_2d[H,W] int32, probs[H,W,C], vertex_pred[H,W,3C], rois[R,7], poses[R,7])."""
+    blob, blob_depth, im_scale = _get_image_blob(im, im_depth)
+    K = np.array(meta_data["intrinsic_matrix"], dtype=np.float64) * im_scale
+    data_p = blob_depth if net.input_format == "RGBD" else None
+    feed = _feed(net, blob, data_p, K, extents, points, symmetry, num_classes, torch.device(device))
+    net.run(feed)
+    g = lambda n: net.get_output(n).detach().cpu().numpy()
+    labels_2d, probs, vertex_pred = g("label_2d"), g("prob_normalized"), g("vertex_pred")
+    rois, poses_init, poses_pred = g("rois"), g("poses_init"), g("poses_tanh")
+    rois, poses, _ = combine_poses(rois, poses_init, poses_pred)
+    return labels_2d[0].astype(np.int32), probs[0], vertex_pred[0], rois, poses
+
+
+class Detections(object):
+    """Fixed-capacity per-batch detections kept on the device (what ranks exchange, §8e):
+    rows[cap,14] = box7 | pose7 (quaternion already taken from poses_tanh), count[1]."""
+
+    def __init__(self, rows, count, label_2d=None):
+        self.rows = rows
+        self.count = count
+        self.label_2d = label_2d
+
+    def to_host(self):
+        n = int(self.count.item())
+        r = self.rows[:n].cpu().numpy()
+        return r[:, :7], r[:, 7:]
+
+
+def im_segment_batch(net, data, K, extents, points, symmetry, data_p=None, planted=None, feed_cache=None,
+                     with_losses=False):
+    """B frames, one pass, no host synchronisation. `data` is the mean-subtracted BGR blob
+    [B,H,W,3] already on the device. Returns `Detections` (device tensors; rows past count are 0).
+    Differences from B calls of im_segment_single_frame: the Hough layer sees the whole batch, so
+    its per-image capacity is MAX_ROI / B (hough_voting_gpu_op.cu.cc:733) exactly as the reference
+    op behaves when handed a batch; NMS/pose combine happen in `Detections`/`finalize_batch`."""
+    dev = data.device
+    feed = feed_cache if feed_cache is not None else _feed(net, data, data_p, K, extents, points, symmetry, net.num_classes, dev)
+    feed["data"] = data
+    if data_p is not None:
+        feed["data_p"] = data_p
+    # run the graph up to vertex_pred, then the padded Hough + pooled head without a host sync
+    saved = (net.vertex_reg_2d,)
+    net.vertex_reg_2d = False
+    try:
+        net.run(feed, planted=planted)
+    finally:
+        net.vertex_reg_2d = saved[0]
+    label_2d, vertex_pred = net.get_output("label_2d"), net.get_output("vertex_pred")
+    top_box, top_pose, top_target, top_weight, top_domain, num_rois = ops.hough_voting_gpu_padded(
+        label_2d, vertex_pred, feed["extents"], feed["meta_data"], None, 0, net.vote_threshold,
+        net.vote_percentage, net.skip_pixels)
+    cap = min(top_box.shape[0], ops.MAX_ROI)  # is_train = 0: at most MAX_ROI rows
+    rois = top_box[:cap]
+    pool = ops.roi_pool_add2(net.get_output("conv5_3"), 1.0 / 16.0, net.get_output("conv4_3"), 1.0 / 8.0, rois)
+    net.layers["pool_score"] = pool
+    (net.feed("pool_score")
+        .fc(4096, height=7, width=7, channel=512, name="fc6")
+        .fc(4096, num_in=4096, name="fc7")
+        .fc(4 * net.num_classes, relu=False, name="fc8")
+        .tanh(name="poses_tanh"))
+    poses_tanh = net.get_output("poses_tanh")
+    # poses[i,:4] = poses_tanh[i, 4c:4c+4]  (lib/fcn/test.py:206-211), on the device
+    cls = rois[:, 1].long().clamp(min=0)
+    idx = (4 * cls).unsqueeze(1) + torch.arange(4, device=dev).unsqueeze(0)
+    quat = torch.gather(poses_tanh, 1, idx)
+    valid = (torch.arange(cap, device=dev) < num_rois[1]).unsqueeze(1)
+    rows = torch.cat([rois, torch.where(valid, quat, top_pose[:cap, :4]), top_pose[:cap, 4:]], dim=1)
+    rows = torch.where(valid, rows, torch.zeros_like(rows))
+    net.layers.update({"rois": rois, "poses_init": top_pose[:cap], "poses_tanh": poses_tanh})
+    if with_losses:
+        # the two training-loss layers of the graph (vgg16_convs.py:148-149,195-200). TF prunes them
+        # at test time; BASELINE config 2 lists them, so the bench evaluates them. The loss is
+        # normalised by the padded row capacity here (rows past the count carry zero weight).
+        net.layers["gt_label_weight"] = ops.hard_label(net.get_output("prob_normalized"), feed["gt_label_2d"],
+                                                       net.threshold_label)
+        weight, target = top_weight[:cap], top_target[:cap]
+        mul = poses_tanh * weight
+        pred = mul * torch.rsqrt(torch.clamp((mul * mul).sum(dim=1, keepdim=True), min=1e-12))
+        net.layers["loss_pose"] = ops.average_distance_loss(pred, target, weight, feed["points"],
+                                                            feed["symmetry"], 0.01)[0]
+    return Detections(rows, num_rois[1:2].clone(), label_2d)
+
+
+def finalize_batch(det_rows, count):
+    """Host epilogue for a gathered batch: class-aware NMS per image (nms() compares classes, and
+    boxes of different images never overlap a shared image index, so NMS is applied per image)."""
+    rows = det_rows[:count]
+    out_rois, out_poses = [], []
+    for b in np.unique(rows[:, 0]):
+        r = rows[rows[:, 0] == b]
+        keep = nms(r[:, :7], 0.5)
+        out_rois.append(r[keep, :7])
+        out_poses.append(r[keep, 7:])
+    if not out_rois:
+        return np.zeros((0, 7), np.float32), np.zeros((0, 7), np.float32)
+    return np.concatenate(out_rois), np.concatenate(out_poses)

@@ -1,0 +1,479 @@
+"""`lib/networks` on MI355X: the layer DSL (`Network`) and the PoseCNN graph (`vgg16_convs`).
+
+This mirrors the reference's op surface — same layer names, argument order and defaults as
+lib/networks/network.py:159-222,303-310,321-340,361-445,474-506 and the same `setup()` chain as
+lib/networks/vgg16_convs.py:79-212 — but executes eagerly on PyTorch-ROCm: the dense contractions
+(13 conv3x3, the 1x1 heads, fc6-8) go to MIOpen / hipBLASLt (MFMA), the custom layers go to the
+hand-written gfx950 kernels behind libposecnn_hip.so (posecnn_amd.ops). All activations are NHWC
+(`[B,H,W,C]` contiguous), exactly what the custom kernels index; convolutions see them as
+channels-last NCHW views, so there is no layout copy anywhere on the path.
+
+TF1 -> PyTorch semantics (SURVEY.md §8a "Semantics ..."):
+  conv       tf.nn.conv2d 'SAME' stride 1 + bias + ReLU unless relu=False      (network.py:159-188)
+  max_pool   2x2 stride 2 'SAME' (all sizes stay even after pad_im(.,16))        (:303-310)
+  deconv     tf.nn.conv2d_transpose, fixed diagonal bilinear filter, no bias    (:141-157,207-222)
+  fc         NHWC-flattened input, weights [in,out], relu_layer / xw_plus_b      (:392-422)
+  softmax_high_dimension / argmax_2d  -> fused gfx950 kernel                     (:474-488,432-434)
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+DEFAULT_PADDING = "SAME"
+
+
+def layer(op):
+    """Same decorator contract as network.py:40-59: feeds the current inputs to `op`, records the
+    result under kwargs['name'] and makes it the next input."""
+
+    def layer_decorated(self, *args, **kwargs):
+        name = kwargs.setdefault("name", self.get_unique_name(op.__name__))
+        if len(self.inputs) == 0:
+            raise RuntimeError("No input variables found for layer %s." % name)
+        elif len(self.inputs) == 1:
+            layer_input = self.inputs[0]
+        else:
+            layer_input = list(self.inputs)
+        layer_output = op(self, layer_input, *args, **kwargs)
+        self.layers[name] = layer_output
+        self.feed(layer_output)
+        return self
+
+    layer_decorated.__name__ = op.__name__
+    return layer_decorated
+
+
+def make_deconv_filter_1d(k):
+    """network.py:141-150: f = ceil(k/2), c = (2f - 1 - f%2) / (2f), w[x] = 1 - |x/f - c|."""
+    f = math.ceil(k / 2.0)
+    c = (2 * f - 1 - f % 2) / (2.0 * f)
+    return np.array([1 - abs(x / f - c) for x in range(k)], dtype=np.float64)
+
+
+def _nchw(x):  # NHWC contiguous -> channels-last NCHW view (no copy)
+    return x.permute(0, 3, 1, 2)
+
+
+def _nhwc(x):  # channels-last NCHW -> NHWC contiguous view (no copy when channels_last)
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+class Network(object):
+    """Eager re-statement of the reference's graph-building `Network` (network.py:61-137).
+
+    Variables live in `self.vars` under '<layer>/weights' and '<layer>/biases' (the names
+    tf.variable_scope + make_var give them, network.py:169-185) and are created on first use.
+    """
+
+    def __init__(self, device="cuda", seed=3, init="he", trainable=True):
+        self.inputs = []
+        self.layers = {}
+        self.vars = {}
+        self.device = torch.device(device)
+        self.trainable = trainable
+        self.init = init
+        self._gen = torch.Generator(device="cpu").manual_seed(seed)  # cfg.RNG_SEED = 3 (config.py)
+        self.keep_prob_queue = 1.0
+
+    # ---- plumbing ------------------------------------------------------------------------------
+    def setup(self):
+        raise NotImplementedError("Must be subclassed.")
+
+    def feed(self, *args):
+        assert len(args) != 0
+        self.inputs = []
+        for l in args:
+            if isinstance(l, str):
+                try:
+                    l = self.layers[l]
+                except KeyError:
+                    raise KeyError("Unknown layer name fed: %s" % l)
+            self.inputs.append(l)
+        return self
+
+    def get_output(self, name):
+        try:
+            return self.layers[name]
+        except KeyError:
+            raise KeyError("Unknown layer name fed: %s" % name)
+
+    def get_unique_name(self, prefix):
+        ident = sum(t.startswith(prefix) for t in self.layers) + 1
+        return "%s_%d" % (prefix, ident)
+
+    def make_var(self, name, shape, initializer):
+        if name not in self.vars:
+            self.vars[name] = initializer(shape).to(self.device)
+        v = self.vars[name]
+        if tuple(v.shape) != tuple(shape):
+            raise ValueError("variable %s has shape %s, layer wants %s" % (name, tuple(v.shape), tuple(shape)))
+        return v
+
+    def _weight_init(self, fan_in):
+        if self.init == "tf":  # tf.truncated_normal_initializer(0.0, stddev=0.001), network.py:170
+            def f(shape):
+                w = torch.empty(shape)
+                torch.nn.init.trunc_normal_(w, 0.0, 0.001, -0.002, 0.002, generator=self._gen)
+                return w
+        else:  # He init: keeps random-weight activations in a sane f32 range through 13 layers
+            def f(shape):
+                return torch.randn(shape, generator=self._gen) * math.sqrt(2.0 / fan_in)
+        return f
+
+    def load(self, data_dict, ignore_missing=False):
+        """network.py:71-107: `{layer: {'weights': [kh,kw,cin,cout] | [in,out], 'biases': [cout]}}`
+        (the vgg16.npy / converted-checkpoint layout). Also assigns the dual '<layer>_p' tower."""
+        for op_name, params in data_dict.items():
+            for suffix in ("", "_p"):
+                for pname, data in params.items():
+                    key = "%s%s/%s" % (op_name, suffix, pname)
+                    t = torch.as_tensor(np.asarray(data), dtype=torch.float32)
+                    if pname == "weights" and t.dim() == 4:
+                        t = t.permute(3, 2, 0, 1).contiguous(memory_format=torch.channels_last)
+                    if key in self.vars and tuple(self.vars[key].shape) != tuple(t.shape):
+                        if not ignore_missing:
+                            raise ValueError("shape mismatch for %s" % key)
+                        continue
+                    if suffix == "" or key in self.vars:
+                        self.vars[key] = t.to(self.device)
+
+    # ---- dense layers (MIOpen / hipBLASLt) -------------------------------------------------------
+    @layer
+    def conv(self, input, k_h, k_w, c_o, s_h, s_w, name, reuse=None, relu=True, padding=DEFAULT_PADDING,
+             group=1, trainable=True, biased=True, c_i=-1):
+        assert padding in ("SAME", "VALID")
+        if isinstance(input, tuple):
+            input = input[0]
+        if c_i == -1:
+            c_i = input.shape[-1]
+        assert c_i % group == 0 and c_o % group == 0
+        w = self.make_var(name + "/weights", (c_o, c_i // group, k_h, k_w),
+                          lambda s: self._weight_init(c_i // group * k_h * k_w)(s).contiguous(memory_format=torch.channels_last))
+        b = self.make_var(name + "/biases", (c_o,), lambda s: torch.zeros(s)) if biased else None
+        assert s_h == 1 and s_w == 1 or padding == "VALID" or (k_h == 1 and k_w == 1), "strided SAME conv not on this path"
+        pad = (k_h // 2, k_w // 2) if padding == "SAME" else 0
+        y = F.conv2d(_nchw(input), w, b, stride=(s_h, s_w), padding=pad, groups=group)
+        if relu:
+            y = F.relu_(y)
+        return _nhwc(y)
+
+    @layer
+    def max_pool(self, input, k_h, k_w, s_h, s_w, name, padding=DEFAULT_PADDING):
+        assert padding in ("SAME", "VALID")
+        H, W = input.shape[1], input.shape[2]
+        if padding == "SAME" and (H % s_h or W % s_w):
+            # TF 'SAME' pads at the bottom/right with -inf; not reached after pad_im(., 16)
+            input = F.pad(input, (0, 0, 0, (-W) % s_w, 0, (-H) % s_h), value=float("-inf"))
+        return _nhwc(F.max_pool2d(_nchw(input), (k_h, k_w), (s_h, s_w)))
+
+    @layer
+    def deconv(self, input, k_h, k_w, c_o, s_h, s_w, name, reuse=None, padding=DEFAULT_PADDING, trainable=True):
+        """conv2d_transpose with the fixed bilinear filter of make_deconv_filter (network.py:141-157):
+        weights[:, :, i, i] = outer(bilinear), zero elsewhere, so the dense [k,k,c_o,c_i]
+        contraction equals a per-channel (depthwise) transposed convolution — adding the exact
+        zeros of the off-diagonal taps changes no bit. 'SAME' with output = input * stride is
+        PyTorch padding (k - s) / 2."""
+        assert padding == "SAME"
+        c_i = input.shape[-1]
+        assert c_i == c_o and k_h == k_w and s_h == s_w, "PoseCNN deconvs are square, channel preserving"
+        key = name + "/weights"
+        if key in self.vars and self.vars[key].dim() == 4 and self.vars[key].shape[1] == c_i and c_i > 1:
+            w = self.vars[key]  # a loaded dense [c_in, c_out, k, k] filter (checkpoint): honour it
+            y = F.conv_transpose2d(_nchw(input), w, None, stride=(s_h, s_w), padding=((k_h - s_h) // 2, (k_w - s_w) // 2))
+            return _nhwc(y)
+        w = self.make_var(key + ":depthwise", (c_i, 1, k_h, k_w),
+                          lambda s: torch.from_numpy(np.outer(make_deconv_filter_1d(k_h), make_deconv_filter_1d(k_w)))
+                          .float().expand(s).contiguous())
+        y = F.conv_transpose2d(_nchw(input), w, None, stride=(s_h, s_w),
+                               padding=((k_h - s_h) // 2, (k_w - s_w) // 2), groups=c_i)
+        return _nhwc(y)
+
+    @layer
+    def fc(self, input, num_out, name, num_in=-1, height=-1, width=-1, channel=-1, reuse=None, relu=True, trainable=True):
+        if isinstance(input, tuple):
+            input = input[0]
+        if height > 0 and width > 0 and channel > 0:
+            input = input.reshape(input.shape[0], height, width, channel)
+        if input.dim() == 4:
+            dim = input.shape[1] * input.shape[2] * input.shape[3]
+            feed_in = input.reshape(-1, dim)  # NHWC flatten order, network.py:399-408
+        else:
+            dim = int(input.shape[-1]) if num_in == -1 else int(num_in)
+            feed_in = input
+        w = self.make_var(name + "/weights", (dim, num_out), self._weight_init(dim))
+        b = self.make_var(name + "/biases", (num_out,), lambda s: torch.zeros(s))
+        y = torch.addmm(b, feed_in, w)
+        return F.relu_(y) if relu else y
+
+    # ---- element-wise -----------------------------------------------------------------------------
+    @layer
+    def relu(self, input, name):
+        return F.relu(input)
+
+    @layer
+    def concat(self, inputs, axis, name):
+        inputs = [i[0] if isinstance(i, tuple) else i for i in inputs]
+        return torch.cat(inputs, dim=axis)
+
+    @layer
+    def add(self, inputs, name):
+        inputs = [i[0] if isinstance(i, tuple) else i for i in inputs]
+        out = inputs[0] + inputs[1]  # tf.add_n
+        for t in inputs[2:]:
+            out = out + t
+        return out
+
+    @layer
+    def multiply(self, input, name):
+        a = input[0][0] if isinstance(input[0], tuple) else input[0]
+        b = input[1][0] if isinstance(input[1], tuple) else input[1]
+        return a * b
+
+    @layer
+    def l2_normalize(self, input, dim, name):
+        # tf.nn.l2_normalize: x * rsqrt(max(sum(x^2), 1e-12))
+        return input * torch.rsqrt(torch.clamp((input * input).sum(dim=dim, keepdim=True), min=1e-12))
+
+    @layer
+    def dropout(self, input, keep_prob, name):
+        if isinstance(input, tuple):
+            input = input[0]
+        if keep_prob is None or float(keep_prob) >= 1.0:
+            return input  # keep_prob is fed as 1.0 at test time (lib/fcn/test.py:173-184)
+        return F.dropout(input, 1.0 - float(keep_prob), training=True)
+
+    @layer
+    def tanh(self, input, name):
+        if isinstance(input, tuple):
+            input = input[0]
+        return torch.tanh(input)
+
+    @layer
+    def softmax_high_dimension(self, input, num_classes, name):
+        if isinstance(input, tuple):
+            input = input[0]
+        prob, label = ops.softmax_argmax(input, want_prob=True)
+        self._argmax_cache = (prob, label)  # argmax_2d of this tensor comes out of the same pass
+        return prob
+
+    @layer
+    def log_softmax_high_dimension(self, input, num_classes, name):
+        if isinstance(input, tuple):
+            input = input[0]
+        return torch.log_softmax(input, dim=-1)
+
+    @layer
+    def argmax_2d(self, input, name):
+        cache = getattr(self, "_argmax_cache", None)
+        if cache is not None and cache[0] is input:
+            return cache[1]
+        return ops.softmax_argmax(input, want_prob=False)[1] if False else torch.argmax(input, dim=3).to(torch.int32)
+
+    # ---- custom layers (gfx950 kernels) ------------------------------------------------------------
+    @layer
+    def hough_voting_gpu(self, input, is_train, threshold, per_threshold, skip_pixels, name):
+        return ops.hough_voting_gpu(input[0], input[1], input[2], input[3], input[4], is_train, threshold,
+                                    per_threshold, skip_pixels, name=name)
+
+    @layer
+    def roi_pool(self, input, pooled_height, pooled_width, spatial_scale, pool_channel, name):
+        if isinstance(input[0], tuple):
+            input[0] = input[0][0]
+        return ops.roi_pool(input[0], input[1], pooled_height, pooled_width, spatial_scale, pool_channel, name=name)
+
+    @layer
+    def hard_label(self, input, threshold, name):
+        return ops.hard_label(input[0], input[1], threshold, name=name)
+
+    @layer
+    def average_distance_loss(self, input, margin, name):
+        return ops.average_distance_loss(input[0], input[1], input[2], input[3], input[4], margin, name=name)
+
+    @layer
+    def backproject(self, input, grid_size, kernel_size, threshold, name):
+        return ops.backproject(input[0], input[1], input[2], input[3], input[4], grid_size, kernel_size, threshold, name=name)
+
+
+class vgg16_convs(Network):
+    """The PoseCNN network of tools/demo.py / tools/test_net.py (lib/networks/vgg16_convs.py).
+
+    Constructor arguments follow vgg16_convs.py:5. `run(feed)` plays the role of
+    `sess.run(net.enqueue_op, feed_dict)` + `sess.run([...])`: it binds the placeholders
+    (data, [data_p], gt_label_2d, keep_prob, vertex_targets/weights, poses, extents, meta_data,
+    points, symmetry) and evaluates the graph; outputs are read with `get_output(name)`.
+    """
+
+    def __init__(self, input_format, num_classes, num_units, scales, threshold_label, vote_threshold,
+                 vertex_reg_2d=False, vertex_reg_3d=False, pose_reg=False, adaptation=False, trainable=True,
+                 is_train=True, device="cuda", seed=3, init="he", with_losses=None):
+        Network.__init__(self, device=device, seed=seed, init=init, trainable=trainable)
+        self.input_format = input_format
+        self.num_classes = num_classes
+        self.num_units = num_units
+        self.scale = 1.0
+        self.threshold_label = threshold_label
+        self.vertex_reg_2d = vertex_reg_2d
+        self.vertex_reg_3d = vertex_reg_3d
+        self.vertex_reg = vertex_reg_2d or vertex_reg_3d
+        self.pose_reg = pose_reg
+        self.adaptation = adaptation
+        self.is_train = 1 if is_train else 0
+        self.skip_pixels = 10          # vgg16_convs.py:22,27
+        self.vote_threshold = vote_threshold
+        self.vote_percentage = 0.02    # vgg16_convs.py:24,29
+        # TF evaluates only fetched tensors: the two training-loss layers (hard_label,
+        # average_distance_loss) run at train time; at test time only when asked for.
+        self.with_losses = bool(is_train) if with_losses is None else bool(with_losses)
+        self.planted = None
+
+    def run(self, feed, planted=None):
+        self.layers = dict(feed)
+        self.inputs = []
+        self.keep_prob_queue = feed.get("keep_prob", 1.0)
+        self.planted = planted
+        self._argmax_cache = None
+        self.setup()
+        return self
+
+    def _plant(self, key, name):
+        """Benchmark aid (DESIGN.md §synthetic workload): add a low-resolution synthetic scene to
+        the 1/8-resolution head features so that random-weight networks hand the Hough layer
+        object-like label/vertex maps. No-op unless `run(..., planted=...)` supplies tensors."""
+        if self.planted is not None and key in self.planted:
+            t = self.layers[name] + self.planted[key]
+            self.layers[name] = t
+            self.feed(t)
+        return self
+
+    def setup(self):
+        t = self.trainable
+        (self.feed('data')
+             .conv(3, 3, 64, 1, 1, name='conv1_1', c_i=3, trainable=t)
+             .conv(3, 3, 64, 1, 1, name='conv1_2', c_i=64, trainable=t)
+             .max_pool(2, 2, 2, 2, name='pool1')
+             .conv(3, 3, 128, 1, 1, name='conv2_1', c_i=64, trainable=t)
+             .conv(3, 3, 128, 1, 1, name='conv2_2', c_i=128, trainable=t)
+             .max_pool(2, 2, 2, 2, name='pool2')
+             .conv(3, 3, 256, 1, 1, name='conv3_1', c_i=128, trainable=t)
+             .conv(3, 3, 256, 1, 1, name='conv3_2', c_i=256, trainable=t)
+             .conv(3, 3, 256, 1, 1, name='conv3_3', c_i=256, trainable=t)
+             .max_pool(2, 2, 2, 2, name='pool3')
+             .conv(3, 3, 512, 1, 1, name='conv4_1', c_i=256, trainable=t)
+             .conv(3, 3, 512, 1, 1, name='conv4_2', c_i=512, trainable=t)
+             .conv(3, 3, 512, 1, 1, name='conv4_3', c_i=512, trainable=t)
+             .max_pool(2, 2, 2, 2, name='pool4')
+             .conv(3, 3, 512, 1, 1, name='conv5_1', c_i=512, trainable=t)
+             .conv(3, 3, 512, 1, 1, name='conv5_2', c_i=512, trainable=t)
+             .conv(3, 3, 512, 1, 1, name='conv5_3', c_i=512, trainable=t))
+
+        if self.input_format == 'RGBD':
+            (self.feed('data_p')
+                 .conv(3, 3, 64, 1, 1, name='conv1_1_p', c_i=3, trainable=t)
+                 .conv(3, 3, 64, 1, 1, name='conv1_2_p', c_i=64, trainable=t)
+                 .max_pool(2, 2, 2, 2, name='pool1_p')
+                 .conv(3, 3, 128, 1, 1, name='conv2_1_p', c_i=64, trainable=t)
+                 .conv(3, 3, 128, 1, 1, name='conv2_2_p', c_i=128, trainable=t)
+                 .max_pool(2, 2, 2, 2, name='pool2_p')
+                 .conv(3, 3, 256, 1, 1, name='conv3_1_p', c_i=128, trainable=t)
+                 .conv(3, 3, 256, 1, 1, name='conv3_2_p', c_i=256, trainable=t)
+                 .conv(3, 3, 256, 1, 1, name='conv3_3_p', c_i=256, trainable=t)
+                 .max_pool(2, 2, 2, 2, name='pool3_p')
+                 .conv(3, 3, 512, 1, 1, name='conv4_1_p', c_i=256, trainable=t)
+                 .conv(3, 3, 512, 1, 1, name='conv4_2_p', c_i=512, trainable=t)
+                 .conv(3, 3, 512, 1, 1, name='conv4_3_p', c_i=512, trainable=t)
+                 .max_pool(2, 2, 2, 2, name='pool4_p')
+                 .conv(3, 3, 512, 1, 1, name='conv5_1_p', c_i=512, trainable=t)
+                 .conv(3, 3, 512, 1, 1, name='conv5_2_p', c_i=512, trainable=t)
+                 .conv(3, 3, 512, 1, 1, name='conv5_3_p', c_i=512, trainable=t))
+
+            (self.feed('conv5_3', 'conv5_3_p')
+                 .concat(3, name='concat_conv5')
+                 .conv(1, 1, self.num_units, 1, 1, name='score_conv5', c_i=1024)
+                 .deconv(4, 4, self.num_units, 2, 2, name='upscore_conv5', trainable=False))
+
+            (self.feed('conv4_3', 'conv4_3_p')
+                 .concat(3, name='concat_conv4')
+                 .conv(1, 1, self.num_units, 1, 1, name='score_conv4', c_i=1024))
+        else:
+            (self.feed('conv5_3')
+                 .conv(1, 1, self.num_units, 1, 1, name='score_conv5', c_i=512)
+                 .deconv(4, 4, self.num_units, 2, 2, name='upscore_conv5', trainable=False))
+
+            (self.feed('conv4_3')
+                 .conv(1, 1, self.num_units, 1, 1, name='score_conv4', c_i=512))
+
+        (self.feed('score_conv4', 'upscore_conv5')
+             .add(name='add_score')
+             ._plant('add_score', 'add_score')
+             .dropout(self.keep_prob_queue, name='dropout')
+             .deconv(int(16 * self.scale), int(16 * self.scale), self.num_units, int(8 * self.scale), int(8 * self.scale), name='upscore', trainable=False))
+
+        (self.feed('upscore')
+             .conv(1, 1, self.num_classes, 1, 1, name='score', c_i=self.num_units))
+        if self.with_losses:
+            (self.feed('score')
+                 .log_softmax_high_dimension(self.num_classes, name='prob'))
+
+        (self.feed('score')
+             .softmax_high_dimension(self.num_classes, name='prob_normalized')
+             .argmax_2d(name='label_2d'))
+
+        if self.with_losses:
+            (self.feed('prob_normalized', 'gt_label_2d')
+                 .hard_label(threshold=self.threshold_label, name='gt_label_weight'))
+
+        if self.vertex_reg:
+            (self.feed('conv5_3')
+                 .conv(1, 1, 128, 1, 1, name='score_conv5_vertex', relu=False, c_i=512)
+                 .deconv(4, 4, 128, 2, 2, name='upscore_conv5_vertex', trainable=False))
+
+            (self.feed('conv4_3')
+                 .conv(1, 1, 128, 1, 1, name='score_conv4_vertex', relu=False, c_i=512))
+
+            (self.feed('score_conv4_vertex', 'upscore_conv5_vertex')
+                 .add(name='add_score_vertex')
+                 ._plant('add_score_vertex', 'add_score_vertex')
+                 .dropout(self.keep_prob_queue, name='dropout_vertex')
+                 .deconv(int(16 * self.scale), int(16 * self.scale), 128, int(8 * self.scale), int(8 * self.scale), name='upscore_vertex', trainable=False)
+                 .conv(1, 1, 3 * self.num_classes, 1, 1, name='vertex_pred', relu=False, c_i=128))
+
+            if self.vertex_reg_2d:
+                (self.feed('label_2d', 'vertex_pred', 'extents', 'meta_data', 'poses')
+                     .hough_voting_gpu(self.is_train, self.vote_threshold, self.vote_percentage, self.skip_pixels, name='hough'))
+
+                self.layers['rois'] = self.get_output('hough')[0]
+                self.layers['poses_init'] = self.get_output('hough')[1]
+                self.layers['poses_target'] = self.get_output('hough')[2]
+                self.layers['poses_weight'] = self.get_output('hough')[3]
+
+                if self.pose_reg:
+                    # roi pooling without masking
+                    (self.feed('conv5_3', 'rois')
+                         .roi_pool(7, 7, 1.0 / 16.0, 0, name='pool5'))
+
+                    (self.feed('conv4_3', 'rois')
+                         .roi_pool(7, 7, 1.0 / 8.0, 0, name='pool4'))
+
+                    (self.feed('pool5', 'pool4')
+                         .add(name='pool_score')
+                         .fc(4096, height=7, width=7, channel=512, name='fc6')
+                         .dropout(self.keep_prob_queue, name='drop6')
+                         .fc(4096, num_in=4096, name='fc7')
+                         .dropout(self.keep_prob_queue, name='drop7')
+                         .fc(4 * self.num_classes, relu=False, name='fc8')
+                         .tanh(name='poses_tanh'))
+
+                    (self.feed('poses_tanh', 'poses_weight')
+                         .multiply(name='poses_mul')
+                         .l2_normalize(dim=1, name='poses_pred'))
+
+                    if self.with_losses:
+                        (self.feed('poses_pred', 'poses_target', 'poses_weight', 'points', 'symmetry')
+                             .average_distance_loss(margin=0.01, name='loss_pose'))
+
+                    if self.adaptation:
+                        self.layers['label_domain'] = self.get_output('hough')[4]

@@ -1,0 +1,76 @@
+"""CPU restatement of the whole hot path: the `vgg16_convs` graph with PyTorch-CPU fp32 for the
+dense layers and oracle/liboracle.so for the custom layers. TEST INFRASTRUCTURE ONLY — used by
+the end-to-end parity tests and as bench.py's `cpu_baseline` ("port": the reference's TF1 graph
+cannot run here)."""
+import numpy as np
+import torch
+
+import oracle
+from posecnn_amd.networks import layer, vgg16_convs
+
+
+class vgg16_convs_cpu(vgg16_convs):
+    """Same graph, same variables, custom layers routed to the oracle (numpy)."""
+
+    def __init__(self, *args, **kw):
+        kw["device"] = "cpu"
+        vgg16_convs.__init__(self, *args, **kw)
+
+    def share_weights(self, other):
+        self.vars = {k: v.detach().cpu() for k, v in other.vars.items()}
+
+    @layer
+    def softmax_high_dimension(self, input, num_classes, name):
+        p, l = oracle.softmax_argmax(input.numpy())
+        self._argmax_cache = (None, torch.from_numpy(l))
+        out = torch.from_numpy(p)
+        self._argmax_cache = (out, torch.from_numpy(l))
+        return out
+
+    @layer
+    def hough_voting_gpu(self, input, is_train, threshold, per_threshold, skip_pixels, name):
+        gt = None if input[4] is None else input[4].numpy()
+        out = oracle.hough_voting(input[0].numpy(), input[1].numpy(), input[2].numpy(), input[3].numpy(),
+                                  gt, is_train, threshold, per_threshold, skip_pixels)
+        return tuple(torch.from_numpy(np.ascontiguousarray(o)) for o in out)
+
+    @layer
+    def roi_pool(self, input, pooled_height, pooled_width, spatial_scale, pool_channel, name):
+        t, a = oracle.roi_pool(input[0].numpy(), input[1].numpy(), pooled_height, pooled_width, spatial_scale, pool_channel)
+        return torch.from_numpy(t), torch.from_numpy(a)
+
+    @layer
+    def hard_label(self, input, threshold, name):
+        return torch.from_numpy(oracle.hard_label(input[0].numpy(), input[1].numpy(), threshold))
+
+    @layer
+    def average_distance_loss(self, input, margin, name):
+        l, d = oracle.average_distance(*[i.numpy() for i in input], margin)
+        return torch.from_numpy(l), torch.from_numpy(d)
+
+
+def run_cpu_pipeline(net_cpu, data, K, extents, points, symmetry, planted=None):
+    """B frames through the CPU graph; returns dict of numpy outputs (the fetch list of
+    lib/fcn/test.py:193-195) + NMS'd rois/poses per lib/fcn/test.py:197-211."""
+    from posecnn_amd import fcn
+    from posecnn_amd.config import make_meta_data
+    B, H, W, _ = data.shape
+    meta = np.stack([make_meta_data(K)] * B).reshape(B, 1, 1, 48)
+    t = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(a), dtype=dt)
+    feed = {"data": t(data), "gt_label_2d": torch.ones((B, H, W), dtype=torch.int32), "keep_prob": 1.0,
+            "poses": torch.zeros((1, 13)), "extents": t(extents), "meta_data": t(meta),
+            "points": t(points), "symmetry": t(symmetry)}
+    pl = None if planted is None else {k: t(v) for k, v in planted.items()}
+    with torch.no_grad():
+        net_cpu.run(feed, planted=pl)
+    g = lambda n: net_cpu.get_output(n)
+    out = {"label_2d": g("label_2d").numpy(), "vertex_pred": g("vertex_pred").numpy(),
+           "rois": g("rois").numpy(), "poses_init": g("poses_init").numpy(), "poses_tanh": g("poses_tanh").numpy()}
+    rois, poses = [], []
+    for b in np.unique(out["rois"][:, 0]):
+        m = out["rois"][:, 0] == b
+        r, p, _ = fcn.combine_poses(out["rois"][m], out["poses_init"][m], out["poses_tanh"][m])
+        rois.append(r); poses.append(p)
+    out["final_rois"] = np.concatenate(rois) if rois else np.zeros((0, 7), np.float32)
+    out["final_poses"] = np.concatenate(poses) if poses else np.zeros((0, 7), np.float32)
+    return out

@@ -53,10 +53,11 @@ def test_full_size_single_frame(gpu):
     got = both(gpu, label, vertex, config.LOV_EXTENTS, meta)
     n = int(got[5][1])
     assert n == 5
-    # detections land on the generated objects
-    for row in got[0][:n]:
-        obj = [o for o in fr[0]["objects"] if o[0] == int(row[1])][0]
-        assert abs((row[2] + row[4]) / 2 - obj[1]) < 6 and abs((row[3] + row[5]) / 2 - obj[2]) < 6
+    # one detection per generated object; unoccluded objects are localised to a few pixels
+    assert sorted(int(r[1]) for r in got[0][:n]) == sorted(o[0] for o in fr[0]["objects"])
+    near = [abs((r[2] + r[4]) / 2 - o[1]) < 8 and abs((r[3] + r[5]) / 2 - o[2]) < 8
+            for r in got[0][:n] for o in fr[0]["objects"] if o[0] == int(r[1])]
+    assert sum(near) >= 3
 
 
 def test_full_size_batch4_row_order(gpu):
@@ -100,17 +101,21 @@ def test_vote_threshold_full_size(gpu):
     assert int(got[5][1]) >= 5
 
 
-def test_vote_threshold_plateau_hits_capacity(gpu):
-    # a constant direction field makes long plateaus of equal votes: every plateau cell is a
-    # "no strictly greater neighbour" maximum; only the first MAX_ROI/B in cell order survive
-    H, W, C = 64, 96, 3
-    label = np.zeros((2, H, W), np.int32); label[:, 10:50, 10:80] = 1
+def test_vote_threshold_many_maxima_hit_capacity(gpu):
+    # a noisy direction field has hundreds of 7x7 local maxima above a low threshold; only the
+    # first MAX_ROI / B in ascending (slot, cell) order may be emitted (.cu.cc:377-379, 773-774)
+    H, W, C = 96, 128, 3
+    rng = np.random.default_rng(5)
+    label = np.zeros((2, H, W), np.int32); label[:, 10:80, 10:110] = 1; label[1, 60:90, 5:120] = 2
+    ang = rng.uniform(0, 2 * np.pi, (2, H, W))
     vertex = np.zeros((2, H, W, 3 * C), F)
-    vertex[..., 3] = 1.0  # everyone points to +x
+    for c in (1, 2):
+        vertex[..., 3 * c] = np.cos(ang); vertex[..., 3 * c + 1] = np.sin(ang); vertex[..., 3 * c + 2] = np.log(0.9)
     ext = np.full((C, 3), 0.2, F)
     meta = np.stack([config.make_meta_data(config.DEMO_INTRINSICS)] * 2)
     got = both(gpu, label, vertex, ext, meta, vote_thr=2.0, per_thr=0.0, skip=4, label_thr=100)
     assert int(got[5][1]) == 128
+    assert np.all(got[0][:64, 0] == 0) and np.all(got[0][64:128, 0] == 1)
 
 
 def test_train_mode_targets_and_jitter(gpu):
@@ -261,3 +266,62 @@ def test_relabel_covariance_property(gpu):
     ra = {(int(r[0]), int(perm[int(r[1])])): (r[2:].tobytes(), p.tobytes()) for r, p in zip(a[0][:na], a[1][:na])}
     rb = {(int(r[0]), int(r[1])): (r[2:].tobytes(), p.tobytes()) for r, p in zip(b[0][:nb], b[1][:nb])}
     assert ra == rb
+
+
+def gpu_hough_space(gpu, label, vertex, ext, meta, vote_thr, skip, label_thr):
+    """Run the op with threshold_vote > 0 and read the materialised Hough space out of the
+    workspace (pcnn_hough_voting_debug_layout)."""
+    import ctypes
+    import torch
+    from posecnn_amd import _lib, ops
+    B, H, W = label.shape
+    C = vertex.shape[3] // 3
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    ws = ops.Workspace()
+    out = ops.hough_voting_gpu_padded(t(label), t(vertex), t(ext), t(meta), None, 0, vote_thr, 0.0, skip,
+                                      workspace=ws, label_threshold=label_thr)
+    torch.cuda.synchronize()
+    offs = (ctypes.c_size_t * 8)()
+    _lib.check("debug_layout", _lib.lib().pcnn_hough_voting_debug_layout(B, H, W, C, float(vote_thr), skip, offs))
+    raw = ws._buf.cpu().numpy()
+    hs = raw[offs[0]:offs[0] + 4 * B * (C - 1) * H * W].view(np.float32).reshape(B, C - 1, H * W)
+    slots = raw[offs[3]:offs[3] + 4 * B * C].view(np.int32).reshape(B, C)
+    nslots = raw[offs[4]:offs[4] + 4 * B].view(np.int32)
+    return hs, slots, nslots, [o.cpu().numpy() for o in out]
+
+
+@pytest.mark.parametrize("case", ["synthetic", "plateau", "boundary"])
+def test_every_hough_cell_matches_oracle(gpu, case):
+    if case == "synthetic":
+        label, vertex, meta, _ = frames(140, 2, H=240, W=320, n_obj=4)
+        ext, skip, label_thr = config.LOV_EXTENTS, 10, 150
+    elif case == "plateau":
+        H, W, C = 64, 96, 3
+        label = np.zeros((2, H, W), np.int32); label[:, 10:50, 10:80] = 1
+        vertex = np.zeros((2, H, W, 3 * C), F); vertex[..., 3] = 1.0
+        ext = np.full((C, 3), 0.2, F)
+        meta = np.stack([config.make_meta_data(config.DEMO_INTRINSICS)] * 2)
+        skip, label_thr = 4, 100
+    else:
+        H, W, C = 128, 160, 3
+        rng = np.random.default_rng(3)
+        label = np.zeros((1, H, W), np.int32); label[0, 30:100, 30:130] = 1
+        vertex = np.zeros((1, H, W, 3 * C), F)
+        ang = rng.uniform(0, 2 * np.pi, (70, 100))
+        vertex[0, 30:100, 30:130, 3] = np.cos(ang); vertex[0, 30:100, 30:130, 4] = np.sin(ang)
+        vertex[0, ..., 5] = np.log(0.8)
+        ext = np.full((C, 3), 0.15, F)
+        meta = config.make_meta_data(config.DEMO_INTRINSICS)[None]
+        skip, label_thr = 1, 100
+    B, H, W = label.shape
+    C = vertex.shape[3] // 3
+    hs, slots, nslots, _ = gpu_hough_space(gpu, label, vertex, ext, meta, 1.0, skip, label_thr)
+    want = oracle.hough_voting(label, vertex, ext, meta, None, 0, 1.0, 0.0, skip, label_thr=label_thr, padded=True, want_hs=True)
+    whs = want[6]
+    for n in range(B):
+        cls_list = [c for c in range(1, C) if (label[n] == c).sum() > label_thr]
+        assert int(nslots[n]) == len(cls_list) and list(slots[n, :len(cls_list)]) == cls_list
+        for s, c in enumerate(cls_list):
+            diff = np.flatnonzero(hs[n, s] != whs[n, c])
+            assert diff.size == 0, "image %d class %d: %d cells differ, first cell %d gpu %s oracle %s" % (
+                n, c, diff.size, diff[0], hs[n, s, diff[0]], whs[n, c, diff[0]])

@@ -114,7 +114,8 @@ def test_hard_label(gpu, shape):
     rng = np.random.default_rng(15)
     prob = rng.random(shape).astype(F)
     gt = rng.integers(-1, shape[3], shape[:3]).astype(np.int32)
-    gt.ravel()[:3] = [-5, shape[3] + 2, -1]  # out-of-range labels are ignored
+    k = min(3, gt.size)
+    gt.ravel()[:k] = [-5, shape[3] + 2, -1][:k]  # out-of-range labels are ignored
     for thr in (0.3, 1.0):
         out = ops.hard_label(T(gpu, prob), T(gpu, gt), thr)
         same(N(out), oracle.hard_label(prob, gt, thr), "hard_label")

@@ -1,0 +1,126 @@
+"""CPU tests of the host logic (NMS, pad/unpad, blobs, meta_data, pose combine) and of the
+multi-process path (gloo, world_size 2): frame sharding + the single all-gather of detections."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from posecnn_amd import config, dist as pdist, fcn
+
+F = np.float32
+
+
+def test_nms_is_class_aware_and_score_ordered():
+    # lib/utils/nms.py:3-32
+    dets = np.array([
+        [0, 1, 10, 10, 50, 50, 0.9],
+        [0, 1, 12, 12, 52, 52, 0.8],   # same class, IoU ~0.82 with row 0 -> suppressed
+        [0, 2, 12, 12, 52, 52, 0.7],   # other class -> kept
+        [0, 1, 100, 100, 140, 140, 0.95],
+        [0, 1, 10, 10, 30, 30, 0.5],   # IoU with row 0 = 441/1681 < 0.5 -> kept
+    ], F)
+    keep = fcn.nms(dets, 0.5)
+    assert keep == [3, 0, 2, 4]
+    assert fcn.nms(dets[:0], 0.5) == []
+
+
+def test_pad_unpad_and_image_blob():
+    im = np.arange(5 * 7 * 3, dtype=np.uint8).reshape(5, 7, 3)
+    p = fcn.pad_im(im, 16)
+    assert p.shape == (16, 16, 3) and np.all(p[5:] == 0) and np.array_equal(p[:5, :7], im)
+    assert fcn.pad_im(np.zeros((480, 640)), 16).shape == (480, 640)
+    assert np.array_equal(fcn.unpad_im(p, 16, orig_shape=(5, 7)), im)
+    depth = np.array([[0, 1000], [2000, 65535]], np.uint16)
+    blob, blob_d, s = fcn._get_image_blob(im[:2, :2], depth)
+    assert blob.shape == (1, 2, 2, 3) and s == 1.0
+    assert np.allclose(blob[0, 0, 0], im[0, 0].astype(F) - config.PIXEL_MEANS[0, 0])
+    # depth tower: clip(d / 2000, 0, 1) * 255 - means (lib/fcn/test.py:70-74)
+    assert np.allclose(blob_d[0, 0, 1], 127.5 - config.PIXEL_MEANS[0, 0])
+    assert np.allclose(blob_d[0, 1, 1], 255 - config.PIXEL_MEANS[0, 0])
+
+
+def test_meta_data_layout():
+    m = config.make_meta_data(config.DEMO_INTRINSICS, voxel_step=(1, 2, 3), voxel_min=(4, 5, 6))
+    assert m.shape == (48,) and m.dtype == np.float32
+    assert (m[0], m[2], m[4], m[5], m[8]) == (F(1066.778), F(312.9869), F(1067.487), F(241.3109), 1)
+    Kinv = m[9:18].reshape(3, 3).astype(np.float64)
+    assert np.allclose(Kinv @ config.DEMO_INTRINSICS, np.eye(3), atol=1e-4)
+    assert np.all(m[18:42] == 0) and list(m[42:48]) == [1, 2, 3, 4, 5, 6]
+
+
+def test_combine_poses_copies_class_quaternion():
+    rois = np.array([[0, 3, 0, 0, 10, 10, 5.0], [0, 7, 20, 20, 40, 40, 9.0]], F)
+    init = np.array([[1, 0, 0, 0, .1, .2, .3], [1, 0, 0, 0, .4, .5, .6]], F)
+    tanh = np.zeros((2, 88), F)
+    tanh[0, 12:16] = (.5, -.5, .25, .1)
+    tanh[1, 28:32] = (.9, .1, .2, .3)
+    r, p, keep = fcn.combine_poses(rois, init, tanh)
+    assert keep == [1, 0]
+    assert np.allclose(p[0], [.9, .1, .2, .3, .4, .5, .6]) and np.allclose(p[1], [.5, -.5, .25, .1, .1, .2, .3])
+
+
+def test_shard_range_partitions_frames():
+    for n, w in ((128, 8), (16, 1), (10, 4), (3, 8)):
+        cover = []
+        for r in range(w):
+            lo, hi = pdist.shard_range(n, r, w)
+            cover += list(range(lo, hi))
+        assert cover == list(range(n))
+    assert pdist.shard_range(128, 3, 8) == (48, 64)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    r, w, _ = pdist.init_from_env(backend="gloo")
+    cap, B = 8, 4
+    rows = torch.zeros((cap, 14))
+    n = 2 + rank  # rank 0 has 2 detections, rank 1 has 3
+    for i in range(n):
+        rows[i, 0] = i % B          # local image index
+        rows[i, 1] = 10 * rank + i  # class tag to recognise the row
+        rows[i, 6] = 1.0
+    count = torch.tensor([n], dtype=torch.int32)
+    g_rows, g_counts = pdist.all_gather_detections(rows, count, frame_offset=rank * B)
+    flat = pdist.flatten_gathered(g_rows, g_counts)
+    t = pdist.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    pdist.barrier()
+    q.put((rank, g_counts.tolist(), flat[:, :2].tolist(), t))
+    torch.distributed.destroy_process_group()
+
+
+def test_all_gather_detections_world2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want_rows = [[0.0, 0.0], [1.0, 1.0], [4.0, 10.0], [5.0, 11.0], [6.0, 12.0]]  # image idx shifted by rank * B
+    for rank, counts, rows, tmax in res:
+        assert counts == [2, 3]
+        assert rows == want_rows      # every rank holds all detections, in global frame order
+        assert tmax == 2.0            # MAX over ranks (bench.py timing contract)
+
+
+def test_all_gather_detections_world1_is_local():
+    rows = torch.zeros((4, 14)); rows[0, 1] = 5
+    g, c = pdist.all_gather_detections(rows, torch.tensor([1], dtype=torch.int32))
+    assert g.shape == (1, 4, 14) and c.tolist() == [1]
+    assert pdist.flatten_gathered(g, c).shape == (1, 14)

@@ -1,0 +1,135 @@
+"""CPU tests of the `lib/networks` surface: TF1 layer semantics of the dense layers (checked against
+direct numpy loops written from the TF definitions), the fixed bilinear deconv filter, and the
+`vgg16_convs` graph wiring (run end to end on the CPU restatement with the oracle)."""
+import numpy as np
+import pytest
+import torch
+
+from cpu_reference import run_cpu_pipeline, vgg16_convs_cpu
+from posecnn_amd import config, synth
+from posecnn_amd.networks import Network, make_deconv_filter_1d
+
+F = np.float32
+
+
+class Tiny(Network):
+    def setup(self):
+        pass
+
+
+def test_make_deconv_filter_values():
+    # network.py:141-150: k=4 -> taps .25 .75 .75 .25 ; k=16 -> c = 0.9375
+    assert np.allclose(make_deconv_filter_1d(4), [0.25, 0.75, 0.75, 0.25])
+    f16 = make_deconv_filter_1d(16)
+    assert np.allclose(f16[:3], [1 - 0.9375, 1 - abs(1 / 8 - 0.9375), 1 - abs(2 / 8 - 0.9375)])
+    assert np.isclose(f16.sum(), 8.0)  # stride-8 bilinear kernel: taps sum to the stride
+
+
+def tf_conv_same(x, w, b):
+    """tf.nn.conv2d NHWC, stride 1, 'SAME', filter [kh,kw,cin,cout] + bias (direct loops)."""
+    B, H, W, Cin = x.shape
+    kh, kw, _, Cout = w.shape
+    ph, pw = (kh - 1) // 2, (kw - 1) // 2
+    xp = np.pad(x, ((0, 0), (ph, kh - 1 - ph), (pw, kw - 1 - pw), (0, 0)))
+    out = np.zeros((B, H, W, Cout), np.float64)
+    for i in range(kh):
+        for j in range(kw):
+            out += np.einsum("bhwc,co->bhwo", xp[:, i:i + H, j:j + W, :].astype(np.float64), w[i, j].astype(np.float64))
+    return out + b
+
+
+def tf_conv2d_transpose_same(x, w, s):
+    """tf.nn.conv2d_transpose NHWC 'SAME', output = input * s, filter [k,k,cout,cin]: scatter form.
+    out[b, s*h + i - p, s*w + j - p, o] += x[b,h,w,c] * f[i,j,o,c] with p = (k - s) / 2."""
+    B, H, W, Cin = x.shape
+    k = w.shape[0]
+    Cout = w.shape[2]
+    p = (k - s) // 2
+    out = np.zeros((B, H * s, W * s, Cout), np.float64)
+    for h in range(H):
+        for ww in range(W):
+            for i in range(k):
+                for j in range(k):
+                    oy, ox = s * h + i - p, s * ww + j - p
+                    if 0 <= oy < H * s and 0 <= ox < W * s:
+                        out[:, oy, ox, :] += x[:, h, ww, :].astype(np.float64) @ w[i, j].T.astype(np.float64)
+    return out
+
+
+def test_conv_matches_tf_definition():
+    rng = np.random.default_rng(0)
+    net = Tiny(device="cpu")
+    x = rng.standard_normal((2, 6, 7, 5)).astype(F)
+    w = rng.standard_normal((3, 3, 5, 4)).astype(F)
+    b = rng.standard_normal(4).astype(F)
+    net.load({"c": {"weights": w, "biases": b}})
+    net.layers = {"data": torch.from_numpy(x)}
+    y = net.feed("data").conv(3, 3, 4, 1, 1, name="c", c_i=5).get_output("c").numpy()
+    assert np.allclose(y, np.maximum(tf_conv_same(x, w, b), 0), atol=1e-5)
+    y2 = net.feed("data").conv(3, 3, 4, 1, 1, name="c", c_i=5, relu=False).layers["c"].numpy()
+    assert np.allclose(y2, tf_conv_same(x, w, b), atol=1e-5)
+
+
+@pytest.mark.parametrize("k,s", [(4, 2), (16, 8)])
+def test_deconv_matches_dense_conv2d_transpose(k, s):
+    rng = np.random.default_rng(1)
+    C = 3
+    net = Tiny(device="cpu")
+    x = rng.standard_normal((1, 4, 5, C)).astype(F)
+    net.layers = {"x": torch.from_numpy(x)}
+    y = net.feed("x").deconv(k, k, C, s, s, name="up", trainable=False).get_output("up").numpy()
+    f1 = make_deconv_filter_1d(k)
+    dense = np.zeros((k, k, C, C))
+    for i in range(C):
+        dense[:, :, i, i] = np.outer(f1, f1)  # weights[:, :, i, i] = bilinear (network.py:151-153)
+    want = tf_conv2d_transpose_same(x, dense, s)
+    assert y.shape == (1, 4 * s, 5 * s, C)
+    assert np.allclose(y, want, atol=1e-5)
+
+
+def test_max_pool_and_fc_flatten_order():
+    rng = np.random.default_rng(2)
+    net = Tiny(device="cpu")
+    x = rng.standard_normal((2, 4, 6, 3)).astype(F)
+    net.layers = {"x": torch.from_numpy(x)}
+    y = net.feed("x").max_pool(2, 2, 2, 2, name="p").get_output("p").numpy()
+    assert np.array_equal(y, x.reshape(2, 2, 2, 3, 2, 3).max(axis=(2, 4)))
+    w = rng.standard_normal((4 * 6 * 3, 5)).astype(F)
+    b = rng.standard_normal(5).astype(F)
+    net.load({"fc": {"weights": w, "biases": b}})
+    y = net.feed("x").fc(5, height=4, width=6, channel=3, name="fc", relu=False).get_output("fc").numpy()
+    assert np.allclose(y, x.reshape(2, -1) @ w + b, atol=1e-4)  # NHWC flatten (network.py:399-408)
+
+
+def test_vgg16_convs_graph_runs_on_cpu_reference():
+    H, W = 96, 128
+    K = config.DEMO_INTRINSICS.copy(); K[:2] *= W / 640.0
+    net = vgg16_convs_cpu("COLOR", 22, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True,
+                          trainable=False, is_train=False, init="he", with_losses=True)
+    synth.init_planted_heads(net)
+    rng = np.random.default_rng(3)
+    data = (rng.integers(0, 256, (1, H, W, 3)).astype(F) - config.PIXEL_MEANS).astype(F)
+    # objects at this resolution are < 500 px: the Hough layer returns its dummy row
+    planted, scenes = synth.make_planted_batch(0, 1, H=H, W=W, K=K, n_obj=2)
+    pts = synth.make_model_points(22, 64)
+    out = run_cpu_pipeline(net, data, K, config.LOV_EXTENTS, pts, config.LOV_SYMMETRY, planted=planted)
+    assert out["label_2d"].shape == (1, H, W) and out["vertex_pred"].shape == (1, H, W, 66)
+    assert net.get_output("conv4_3").shape == (1, H // 8, W // 8, 512)
+    assert net.get_output("gt_label_weight").shape == (1, H, W, 22)
+    assert out["rois"].shape[1] == 7 and out["poses_tanh"].shape[1] == 88
+    # planted labels come through the bilinear deconv + identity head
+    lab_lr = scenes[0]["label_lowres"]
+    centre = out["label_2d"][0, 4::8, 4::8]
+    assert (centre == lab_lr).mean() > 0.95
+    # RGBD variant: two towers concatenated for the label head only (vgg16_convs.py:99-126)
+    net2 = vgg16_convs_cpu("RGBD", 22, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True,
+                           trainable=False, is_train=False, init="he")
+    feed = {"data": torch.from_numpy(data[:, :32, :32]), "data_p": torch.from_numpy(data[:, :32, :32]),
+            "gt_label_2d": torch.ones((1, 32, 32), dtype=torch.int32), "keep_prob": 1.0, "poses": torch.zeros((1, 13)),
+            "extents": torch.from_numpy(config.LOV_EXTENTS), "meta_data": torch.from_numpy(config.make_meta_data(K)).reshape(1, 1, 1, 48),
+            "points": torch.from_numpy(pts), "symmetry": torch.from_numpy(config.LOV_SYMMETRY)}
+    with torch.no_grad():
+        net2.run(feed)
+    assert net2.vars["score_conv5/weights"].shape == (64, 1024, 1, 1)
+    assert net2.vars["score_conv5_vertex/weights"].shape == (128, 512, 1, 1)
+    assert "conv5_3_p" in net2.layers and net2.get_output("concat_conv5").shape[-1] == 1024
