@@ -192,6 +192,25 @@ int pcnn_softmax_argmax_fwd(const float* score, int64_t num_pixels, int num_clas
                             float* prob, int32_t* label, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fixed bilinear "deconv" (lib/networks/network.py:141-157 make_deconv_filter, :207-222 deconv):
+ * tf.nn.conv2d_transpose 'SAME', stride s, kernel k, with the diagonal bilinear filter, NHWC.
+ *   in f32 [B,H,W,C] -> out f32 [B,H*s,W*s,C];  out = deconv(in) [+ add1] [+ add2] [+ bias[C]] [ReLU]
+ *   (add1/add2/bias may be NULL; they fuse `add_score` (vgg16_convs.py:135-136) and the bias of a
+ *   1x1 conv hoisted in front of the deconv).
+ * pcnn_upscore_softmax_argmax_fwd: label head epilogue without materialising the full-resolution
+ *   score: score = [ReLU](deconv(z) + bias), prob = softmax(score) (network.py:474-488),
+ *   label = first argmax(prob) (:432-434). z f32 [B,H,W,C]; score_out/prob f32 [B,H*s,W*s,C] or
+ *   NULL; label int32 [B,H*s,W*s].
+ * ------------------------------------------------------------------------------------------ */
+int pcnn_deconv_bilinear_fwd(const float* in, int batch, int height, int width, int channels,
+                             int kernel, int stride, const float* add1, const float* add2,
+                             const float* bias, int relu, float* out, void* stream);
+
+int pcnn_upscore_softmax_argmax_fwd(const float* z, const float* bias, int batch, int height,
+                                    int width, int num_classes, int kernel, int stride, int relu,
+                                    float* score_out, float* prob, int32_t* label, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Kernel timing diagnostics (off by default; the reference's only instrumentation is the
  * wall-clock Timer of lib/utils/timer.py:10-32 around im_segment).
  * While enabled, every kernel launch of this library is bracketed by hipEventRecord on the launch

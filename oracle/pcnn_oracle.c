@@ -823,3 +823,55 @@ int oracle_softmax_argmax(const float* score, long N, int C, float* prob, int* l
   }
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Fixed bilinear "deconv": tf.nn.conv2d_transpose 'SAME' with make_deconv_filter's diagonal     */
+/* filter (lib/networks/network.py:141-157, 207-222): out[b, s*i + t - pad, ...] += f[ty]*f[tx]*in */
+/* Canonical arithmetic (no bit-truth exists for cuDNN): gather form, input rows then cols       */
+/* ascending, acc += (fy*fx)*in; then + add1, + add2, + bias, ReLU.                              */
+/* ------------------------------------------------------------------------------------------ */
+static float bilinear_tap(int t, int k)
+{
+  const int f = (k + 1) / 2;
+  const double c = (double)(2 * f - 1 - f % 2) / (2.0 * (double)f);
+  return (float)(1.0 - fabs((double)t / (double)f - c));
+}
+
+int oracle_deconv_bilinear(const float* in, int B, int H, int W, int C, int k, int s,
+                           const float* add1, const float* add2, const float* bias, int relu,
+                           float* out)
+{
+  const int pad = (k - s) / 2, Ho = H * s, Wo = W * s;
+#pragma omp parallel for schedule(static)
+  for (long row = 0; row < (long)B * Ho; row++) {
+    const int b = (int)(row / Ho), oy = (int)(row % Ho);
+    for (int ox = 0; ox < Wo; ox++) {
+      float* o = out + ((size_t)row * Wo + ox) * C;
+      for (int c = 0; c < C; c++) o[c] = 0.f;
+      int iy0 = (oy + pad - k + 1) / s - 1, ix0 = (ox + pad - k + 1) / s - 1;
+      if (iy0 < 0) iy0 = 0;
+      if (ix0 < 0) ix0 = 0;
+      for (int iy = iy0; iy < H && s * iy <= oy + pad; iy++) {
+        const int ty = oy + pad - s * iy;
+        if (ty < 0 || ty >= k) continue;
+        for (int ix = ix0; ix < W && s * ix <= ox + pad; ix++) {
+          const int tx = ox + pad - s * ix;
+          if (tx < 0 || tx >= k) continue;
+          const float w = bilinear_tap(ty, k) * bilinear_tap(tx, k);
+          const float* p = in + (((size_t)b * H + iy) * W + ix) * C;
+          for (int c = 0; c < C; c++) o[c] = o[c] + w * p[c];
+        }
+      }
+      const size_t off = ((size_t)row * Wo + ox) * C;
+      for (int c = 0; c < C; c++) {
+        float v = o[c];
+        if (add1) v = v + add1[off + c];
+        if (add2) v = v + add2[off + c];
+        if (bias) v = v + bias[c];
+        if (relu) v = v > 0.f ? v : 0.f;
+        o[c] = v;
+      }
+    }
+  }
+  return 0;
+}

@@ -54,6 +54,8 @@ SIGNATURES = {
                                      c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
     "pcnn_backproject_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pcnn_softmax_argmax_fwd": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
+    "pcnn_deconv_bilinear_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
+    "pcnn_upscore_softmax_argmax_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "pcnn_profile_enable": (c_int, [c_int]),
     "pcnn_profile_reset": (c_int, []),
     "pcnn_profile_report": (ctypes.c_long, [ctypes.c_char_p, ctypes.c_long]),

@@ -1,0 +1,299 @@
+// upscore.hip — gfx950 kernels for PoseCNN's fixed bilinear "deconv" layers and the label-head
+// epilogue (lib/networks/network.py:141-157 make_deconv_filter, :207-222 deconv;
+// lib/networks/vgg16_convs.py:128-146,152-163).
+//
+// The reference runs tf.nn.conv2d_transpose with a dense [k,k,C,C] filter whose only non-zero
+// taps are weights[:, :, i, i] = outer(bilinear, bilinear): 25 GMAC per frame of multiplications
+// by exact zeros. (Handing the same layer to MIOpen as a depthwise transposed convolution costs
+// 45 ms per call on MI355X — 83 % of the whole pipeline in the first profile, profiles/r01.)
+// The layer is a per-channel 2-tap-per-axis interpolation, i.e. a pure HBM stream:
+//
+//   pcnn_deconv_bilinear_fwd        out = deconv(in) [+ add1] [+ add2] [+ bias] [ReLU]
+//   pcnn_upscore_softmax_argmax_fwd out-of-core label head: score = [ReLU](deconv(z) + bias),
+//                                   prob = softmax(score), label = first argmax(prob); the
+//                                   full-resolution score never touches HBM unless asked for.
+//
+// Canonical arithmetic (there is no bit-truth for cuDNN's conv2d_transpose): per output element
+// acc = 0; for input rows ascending, input cols ascending: acc += (fy*fx) * in — products of the
+// bilinear taps are exact in f32 (multiples of 1/f^2), one rounding per multiply and per add,
+// then + add1, + add2, + bias in that order (the CPU checker restates it).
+#include "pcnn_device.h"
+
+namespace {
+
+using namespace pcnn;
+
+// network.py:144-150: f = ceil(k/2), c = (2f - 1 - f%2) / (2f), w[t] = 1 - |t/f - c|
+// (evaluated in double like the numpy code, then stored as f32 like tf.constant_initializer)
+__host__ __device__ inline float bilinear_tap(int t, int k)
+{
+  const int f = (k + 1) / 2;
+  const double c = (double)(2 * f - 1 - f % 2) / (2.0 * (double)f);
+  return (float)(1.0 - fabs((double)t / (double)f - c));
+}
+
+struct Taps {
+  int i0, n;       // first contributing input index and count (<= 2 when k == 2s); may be clipped
+  float w[4];      // tap weights for i0, i0+1, ...
+};
+
+// output index o of a SAME conv2d_transpose (pad = (k - s) / 2): o = s*i + t - pad, 0 <= t < k
+__device__ __forceinline__ Taps make_taps(int o, int k, int s, int pad, int n_in)
+{
+  Taps T;
+  const int a = o + pad;
+  int lo = (a - k + 1 + s - 1) / s;  // ceil((a - k + 1) / s) for a - k + 1 possibly negative
+  if (a - k + 1 < 0) lo = -((k - 1 - a) / s);
+  int hi = a / s;
+  if (lo < 0) lo = 0;
+  if (hi > n_in - 1) hi = n_in - 1;
+  T.i0 = lo;
+  T.n = hi - lo + 1;
+  if (T.n < 0) T.n = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) T.w[j] = j < T.n ? bilinear_tap(a - s * (lo + j), k) : 0.f;
+  return T;
+}
+
+template <int V>
+struct Vec;
+template <>
+struct Vec<4> { typedef float4 T; };
+template <>
+struct Vec<2> { typedef float2 T; };
+template <>
+struct Vec<1> { typedef float T; };
+
+template <int V>
+__device__ __forceinline__ void load_v(const float* p, float* r)
+{
+  typename Vec<V>::T v = *reinterpret_cast<const typename Vec<V>::T*>(p);
+  const float* f = reinterpret_cast<const float*>(&v);
+#pragma unroll
+  for (int i = 0; i < V; i++) r[i] = f[i];
+}
+template <int V>
+__device__ __forceinline__ void store_v(float* p, const float* r)
+{
+  typename Vec<V>::T v;
+  float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+  for (int i = 0; i < V; i++) f[i] = r[i];
+  *reinterpret_cast<typename Vec<V>::T*>(p) = v;
+}
+
+// one thread = V consecutive channels of one output pixel
+template <int V>
+__global__ __launch_bounds__(256) void deconv_bilinear_kernel(
+    const float* __restrict__ in, const float* __restrict__ add1, const float* __restrict__ add2,
+    const float* __restrict__ bias, float* __restrict__ out, long long total, int H, int W, int C,
+    int k, int s, int relu)
+{
+  const int pad = (k - s) / 2;
+  const int cv = C / V;
+  const int Ho = H * s, Wo = W * s;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * 256) {
+    long long t = idx;
+    const int c = (int)(t % cv) * V; t /= cv;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho); t /= Ho;
+    const int b = (int)t;
+    const Taps ty = make_taps(oy, k, s, pad, H);
+    const Taps tx = make_taps(ox, k, s, pad, W);
+    float acc[V];
+#pragma unroll
+    for (int i = 0; i < V; i++) acc[i] = 0.f;
+    for (int jy = 0; jy < ty.n; jy++)
+      for (int jx = 0; jx < tx.n; jx++) {
+        const float w = ty.w[jy] * tx.w[jx];
+        float v[V];
+        load_v<V>(in + (((long long)b * H + ty.i0 + jy) * W + tx.i0 + jx) * C + c, v);
+#pragma unroll
+        for (int i = 0; i < V; i++) acc[i] = acc[i] + w * v[i];
+      }
+    const long long o = (((long long)b * Ho + oy) * Wo + ox) * C + c;
+    if (add1) {
+      float v[V];
+      load_v<V>(add1 + o, v);
+#pragma unroll
+      for (int i = 0; i < V; i++) acc[i] = acc[i] + v[i];
+    }
+    if (add2) {
+      float v[V];
+      load_v<V>(add2 + o, v);
+#pragma unroll
+      for (int i = 0; i < V; i++) acc[i] = acc[i] + v[i];
+    }
+    if (bias) {
+#pragma unroll
+      for (int i = 0; i < V; i++) acc[i] = acc[i] + bias[c + i];
+    }
+    if (relu) {
+#pragma unroll
+      for (int i = 0; i < V; i++) acc[i] = acc[i] > 0.f ? acc[i] : 0.f;  // tf.nn.relu: max(x, 0)
+    }
+    store_v<V>(out + o, acc);
+  }
+}
+
+// Label head epilogue. A workgroup owns SEG consecutive output pixels of one output row; the
+// (<= 2) x (SEG/s + 2) low-resolution cells it needs sit in LDS; every thread owns one pixel:
+// C interpolated scores in registers -> softmax -> argmax; prob / score rows are parked in LDS and
+// leave as one contiguous run of dword stores.
+constexpr int UP_SEG = 128;
+
+template <int CMAX>
+__global__ __launch_bounds__(UP_SEG) void upscore_softmax_argmax_kernel(
+    const float* __restrict__ z, const float* __restrict__ bias, float* __restrict__ score_out,
+    float* __restrict__ prob, int* __restrict__ label, int H, int W, int C, int k, int s, int relu,
+    int nseg, int s_out_off)
+{
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int pad = (k - s) / 2;
+  const int Ho = H * s, Wo = W * s;
+  const int seg = blockIdx.x % nseg;
+  const int oy = (blockIdx.x / nseg) % Ho;
+  const int b = blockIdx.x / (nseg * Ho);
+  const int ox0 = seg * UP_SEG;
+  const int npx = min(UP_SEG, Wo - ox0);
+  const int tid = threadIdx.x;
+
+  const Taps ty = make_taps(oy, k, s, pad, H);
+  // input columns touched by this segment
+  const Taps tfirst = make_taps(ox0, k, s, pad, W);
+  const Taps tlast = make_taps(ox0 + npx - 1, k, s, pad, W);
+  const int cx0 = tfirst.i0;
+  const int ncx = tlast.i0 + (tlast.n > 0 ? tlast.n : 1) - cx0;
+  float* s_z = smem;                       // [ty.n][ncx][C]
+  float* s_out = smem + s_out_off;         // [UP_SEG][C]
+  for (int i = tid; i < ty.n * ncx * C; i += UP_SEG) {
+    const int c = i % C, cx = (i / C) % ncx, ry = i / (C * ncx);
+    s_z[i] = z[(((long long)b * H + ty.i0 + ry) * W + cx0 + cx) * C + c];
+  }
+  __syncthreads();
+
+  const int ox = ox0 + tid;
+  float e[CMAX];
+  int best = 0;
+  if (tid < npx) {
+    const Taps tx = make_taps(ox, k, s, pad, W);
+#pragma unroll
+    for (int c = 0; c < CMAX; c++) e[c] = 0.f;
+    for (int jy = 0; jy < ty.n; jy++)
+      for (int jx = 0; jx < tx.n; jx++) {
+        const float w = ty.w[jy] * tx.w[jx];
+        const float* zc = s_z + (jy * ncx + (tx.i0 + jx - cx0)) * C;
+#pragma unroll
+        for (int c = 0; c < CMAX; c++)
+          if (c < C) e[c] = e[c] + w * zc[c];
+      }
+#pragma unroll
+    for (int c = 0; c < CMAX; c++)
+      if (c < C) {
+        float v = e[c] + bias[c];
+        if (relu) v = v > 0.f ? v : 0.f;
+        e[c] = v;
+      }
+  }
+  if (score_out) {
+    if (tid < npx)
+#pragma unroll
+      for (int c = 0; c < CMAX; c++)
+        if (c < C) s_out[tid * C + c] = e[c];
+    __syncthreads();
+    float* o = score_out + (((long long)b * Ho + oy) * Wo + ox0) * C;
+    for (int i = tid; i < npx * C; i += UP_SEG) o[i] = s_out[i];
+    __syncthreads();
+  }
+  if (tid < npx) {
+    // softmax_high_dimension (network.py:474-488) + argmax_2d (:432-434)
+    float m = e[0];
+#pragma unroll
+    for (int c = 0; c < CMAX; c++)
+      if (c < C) m = fmaxf(m, e[c]);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; c++)
+      if (c < C) { e[c] = exp_f32(e[c] - m); sum += e[c]; }
+    float bestp = div_rn(e[0], sum);
+#pragma unroll
+    for (int c = 0; c < CMAX; c++)
+      if (c < C) {
+        const float p = div_rn(e[c], sum);
+        e[c] = p;
+        if (p > bestp) { bestp = p; best = c; }
+      }
+    label[((long long)b * Ho + oy) * Wo + ox] = best;
+  }
+  if (prob) {
+    if (tid < npx)
+#pragma unroll
+      for (int c = 0; c < CMAX; c++)
+        if (c < C) s_out[tid * C + c] = e[c];
+    __syncthreads();
+    float* o = prob + (((long long)b * Ho + oy) * Wo + ox0) * C;
+    for (int i = tid; i < npx * C; i += UP_SEG) o[i] = s_out[i];
+  }
+}
+
+int validate(int B, int H, int W, int C, int k, int s)
+{
+  PCNN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && C >= 1, PCNN_EINVAL, "deconv: bad shape %dx%dx%dx%d", B, H, W, C);
+  PCNN_REQUIRE(s >= 1 && k >= s && (k - s) % 2 == 0 && k <= 4 * s, PCNN_EINVAL,
+               "deconv: need stride >= 1, stride <= kernel <= 4*stride and (kernel - stride) even (got k=%d s=%d)", k, s);
+  PCNN_REQUIRE((long long)B * H * s * W * s * C < (1ll << 40), PCNN_EINVAL, "deconv: output too large");
+  return PCNN_OK;
+}
+
+}  // namespace
+
+extern "C" int pcnn_deconv_bilinear_fwd(const float* in, int B, int H, int W, int C, int k, int s,
+                                        const float* add1, const float* add2, const float* bias,
+                                        int relu, float* out, void* stream_)
+{
+  int st = validate(B, H, W, C, k, s);
+  if (st != PCNN_OK) return st;
+  PCNN_REQUIRE(in && out, PCNN_ENULL, "deconv: NULL pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  const bool al = aligned16(in) && aligned16(out) && (!add1 || aligned16(add1)) && (!add2 || aligned16(add2));
+  const long long npix = (long long)B * H * s * W * s;
+  auto grid = [](long long total) { long long b = (total + 255) / 256; return (unsigned)(b < 256 * 64 ? b : 256 * 64); };
+  if (al && C % 4 == 0) {
+    const long long total = npix * (C / 4);
+    PCNN_LAUNCH(deconv_bilinear_kernel<4>, dim3(grid(total)), dim3(256), 0, stream, in, add1, add2, bias, out, total, H, W, C, k, s, relu);
+  } else if (al && C % 2 == 0) {
+    const long long total = npix * (C / 2);
+    PCNN_LAUNCH(deconv_bilinear_kernel<2>, dim3(grid(total)), dim3(256), 0, stream, in, add1, add2, bias, out, total, H, W, C, k, s, relu);
+  } else {
+    const long long total = npix * C;
+    PCNN_LAUNCH(deconv_bilinear_kernel<1>, dim3(grid(total)), dim3(256), 0, stream, in, add1, add2, bias, out, total, H, W, C, k, s, relu);
+  }
+  return check_launch("deconv_bilinear_fwd");
+}
+
+extern "C" int pcnn_upscore_softmax_argmax_fwd(const float* z, const float* bias, int B, int H,
+                                               int W, int C, int k, int s, int relu,
+                                               float* score_out, float* prob, int32_t* label,
+                                               void* stream_)
+{
+  int st = validate(B, H, W, C, k, s);
+  if (st != PCNN_OK) return st;
+  PCNN_REQUIRE(C <= PCNN_MAX_CLASSES, PCNN_EINVAL, "upscore_softmax_argmax: num_classes must be <= %d (got %d)", PCNN_MAX_CLASSES, C);
+  PCNN_REQUIRE(z && bias && label, PCNN_ENULL, "upscore_softmax_argmax: NULL pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int Wo = W * s, Ho = H * s;
+  const int nseg = (Wo + UP_SEG - 1) / UP_SEG;
+  const long long blocks = (long long)B * Ho * nseg;
+  PCNN_REQUIRE(blocks < (1ll << 31), PCNN_EINVAL, "upscore_softmax_argmax: grid too large");
+  const int rows = (k + s - 1) / s;                      // input rows per output row
+  const int ncx_max = (UP_SEG - 1) / s + rows + 1;       // input columns per segment
+  const int s_out_off = (rows * ncx_max * C + 3) / 4 * 4;
+  const size_t sh = sizeof(float) * ((size_t)s_out_off + (size_t)UP_SEG * C);
+  PCNN_REQUIRE(sh <= 160 * 1024, PCNN_EINVAL, "upscore_softmax_argmax: tile does not fit LDS");
+  if (C <= 24)
+    PCNN_LAUNCH(upscore_softmax_argmax_kernel<24>, dim3((unsigned)blocks), dim3(UP_SEG), sh, stream, z, bias, score_out, prob, label, H, W, C, k, s, relu, nseg, s_out_off);
+  else
+    PCNN_LAUNCH(upscore_softmax_argmax_kernel<64>, dim3((unsigned)blocks), dim3(UP_SEG), sh, stream, z, bias, score_out, prob, label, H, W, C, k, s, relu, nseg, s_out_off);
+  return check_launch("upscore_softmax_argmax_fwd");
+}

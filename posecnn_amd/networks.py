@@ -185,12 +185,16 @@ class Network(object):
             w = self.vars[key]  # a loaded dense [c_in, c_out, k, k] filter (checkpoint): honour it
             y = F.conv_transpose2d(_nchw(input), w, None, stride=(s_h, s_w), padding=((k_h - s_h) // 2, (k_w - s_w) // 2))
             return _nhwc(y)
-        w = self.make_var(key + ":depthwise", (c_i, 1, k_h, k_w),
-                          lambda s: torch.from_numpy(np.outer(make_deconv_filter_1d(k_h), make_deconv_filter_1d(k_w)))
-                          .float().expand(s).contiguous())
-        y = F.conv_transpose2d(_nchw(input), w, None, stride=(s_h, s_w),
-                               padding=((k_h - s_h) // 2, (k_w - s_w) // 2), groups=c_i)
-        return _nhwc(y)
+        # the fixed filter: hand-written gfx950 interpolation kernel (MIOpen's depthwise
+        # conv_transpose took 45 ms per call here — 83 % of the first profiled pipeline)
+        return self._deconv_bilinear(input, k_h, s_h)
+
+    # hooks the CPU checker overrides (tests/cpu_reference.py)
+    def _deconv_bilinear(self, x, k, s, add1=None, add2=None, bias=None, relu=False):
+        return ops.deconv_bilinear(x, k, s, add1=add1, add2=add2, bias=bias, relu=relu)
+
+    def _upscore_softmax_argmax(self, z, bias, k, s, relu=True, want_score=False, want_prob=True):
+        return ops.upscore_softmax_argmax(z, bias, k, s, relu=relu, want_score=want_score, want_prob=want_prob)
 
     @layer
     def fc(self, input, num_out, name, num_in=-1, height=-1, width=-1, channel=-1, reuse=None, relu=True, trainable=True):
@@ -309,8 +313,14 @@ class vgg16_convs(Network):
 
     def __init__(self, input_format, num_classes, num_units, scales, threshold_label, vote_threshold,
                  vertex_reg_2d=False, vertex_reg_3d=False, pose_reg=False, adaptation=False, trainable=True,
-                 is_train=True, device="cuda", seed=3, init="he", with_losses=None):
+                 is_train=True, device="cuda", seed=3, init="he", with_losses=None, fused_heads=True,
+                 want_prob=True):
         Network.__init__(self, device=device, seed=seed, init=init, trainable=trainable)
+        # fused_heads=False evaluates the heads in the reference's literal op order
+        # (deconv -> 1x1 conv -> softmax -> argmax); True (default) uses the algebraically
+        # identical low-resolution form + fused gfx950 epilogue (see setup()).
+        self.fused_heads = fused_heads
+        self.want_prob = want_prob  # prob_normalized is a fetched output in lib/fcn/test.py:193-195
         self.input_format = input_format
         self.num_classes = num_classes
         self.num_units = num_units
@@ -338,6 +348,14 @@ class vgg16_convs(Network):
         self._argmax_cache = None
         self.setup()
         return self
+
+    def _conv1x1_lowres(self, x, name, c_o, c_i):
+        """The 1x1 conv `name` (same variables as Network.conv would create) applied WITHOUT bias
+        or ReLU; returns (z, bias) for the fused deconv epilogue."""
+        w = self.make_var(name + "/weights", (c_o, c_i, 1, 1),
+                          lambda s: self._weight_init(c_i)(s).contiguous(memory_format=torch.channels_last))
+        b = self.make_var(name + "/biases", (c_o,), lambda s: torch.zeros(s))
+        return _nhwc(F.conv2d(_nchw(x), w, None)), b
 
     def _plant(self, key, name):
         """Benchmark aid (DESIGN.md §synthetic workload): add a low-resolution synthetic scene to
@@ -409,18 +427,38 @@ class vgg16_convs(Network):
         (self.feed('score_conv4', 'upscore_conv5')
              .add(name='add_score')
              ._plant('add_score', 'add_score')
-             .dropout(self.keep_prob_queue, name='dropout')
-             .deconv(int(16 * self.scale), int(16 * self.scale), self.num_units, int(8 * self.scale), int(8 * self.scale), name='upscore', trainable=False))
+             .dropout(self.keep_prob_queue, name='dropout'))
 
-        (self.feed('upscore')
-             .conv(1, 1, self.num_classes, 1, 1, name='score', c_i=self.num_units))
-        if self.with_losses:
+        if self.fused_heads:
+            # deconv and the 1x1 `score` conv are both linear and act on different axes, so
+            # conv1x1(deconv(x)) + b == deconv(conv1x1(x)) + b exactly in real arithmetic (borders
+            # included): run the 64->C contraction at 1/8 resolution (64x fewer MACs) and let one
+            # gfx950 kernel do deconv + bias + ReLU + softmax + argmax without ever writing the
+            # [B,480,640,64] `upscore` or the full-resolution `score` to HBM.
+            z, b = self._conv1x1_lowres(self.get_output('dropout'), 'score', self.num_classes, self.num_units)
+            k, s = int(16 * self.scale), int(8 * self.scale)
+            score, prob, label = self._upscore_softmax_argmax(z, b, k, s, relu=True, want_score=self.with_losses,
+                                                             want_prob=self.want_prob)
+            if score is not None:
+                self.layers['score'] = score
+            self.layers['prob_normalized'] = prob
+            self.layers['label_2d'] = label
+            if self.with_losses:
+                (self.feed('score')
+                     .log_softmax_high_dimension(self.num_classes, name='prob'))
+        else:
+            (self.feed('dropout')
+                 .deconv(int(16 * self.scale), int(16 * self.scale), self.num_units, int(8 * self.scale), int(8 * self.scale), name='upscore', trainable=False))
+
+            (self.feed('upscore')
+                 .conv(1, 1, self.num_classes, 1, 1, name='score', c_i=self.num_units))
+            if self.with_losses:
+                (self.feed('score')
+                     .log_softmax_high_dimension(self.num_classes, name='prob'))
+
             (self.feed('score')
-                 .log_softmax_high_dimension(self.num_classes, name='prob'))
-
-        (self.feed('score')
-             .softmax_high_dimension(self.num_classes, name='prob_normalized')
-             .argmax_2d(name='label_2d'))
+                 .softmax_high_dimension(self.num_classes, name='prob_normalized')
+                 .argmax_2d(name='label_2d'))
 
         if self.with_losses:
             (self.feed('prob_normalized', 'gt_label_2d')
@@ -437,9 +475,16 @@ class vgg16_convs(Network):
             (self.feed('score_conv4_vertex', 'upscore_conv5_vertex')
                  .add(name='add_score_vertex')
                  ._plant('add_score_vertex', 'add_score_vertex')
-                 .dropout(self.keep_prob_queue, name='dropout_vertex')
-                 .deconv(int(16 * self.scale), int(16 * self.scale), 128, int(8 * self.scale), int(8 * self.scale), name='upscore_vertex', trainable=False)
-                 .conv(1, 1, 3 * self.num_classes, 1, 1, name='vertex_pred', relu=False, c_i=128))
+                 .dropout(self.keep_prob_queue, name='dropout_vertex'))
+            if self.fused_heads:
+                # same commutation as the label head: 128->3C at 1/8 resolution, then one
+                # interpolation pass writes vertex_pred (+ bias); `upscore_vertex` is never built
+                zv, bv = self._conv1x1_lowres(self.get_output('dropout_vertex'), 'vertex_pred', 3 * self.num_classes, 128)
+                self.layers['vertex_pred'] = self._deconv_bilinear(zv, int(16 * self.scale), int(8 * self.scale), bias=bv)
+            else:
+                (self.feed('dropout_vertex')
+                     .deconv(int(16 * self.scale), int(16 * self.scale), 128, int(8 * self.scale), int(8 * self.scale), name='upscore_vertex', trainable=False)
+                     .conv(1, 1, 3 * self.num_classes, 1, 1, name='vertex_pred', relu=False, c_i=128))
 
             if self.vertex_reg_2d:
                 (self.feed('label_2d', 'vertex_pred', 'extents', 'meta_data', 'poses')

@@ -17,7 +17,8 @@ from ._lib import HOUGH_ROWS_CAPACITY, MAX_ROI, POSE_CHANNELS, VERTEX_CHANNELS, 
 
 __all__ = [
     "hough_voting_gpu", "hough_voting_gpu_padded", "roi_pool", "roi_pool_add2", "hard_label",
-    "average_distance_loss", "backproject", "softmax_argmax", "Workspace",
+    "average_distance_loss", "backproject", "softmax_argmax", "deconv_bilinear",
+    "upscore_softmax_argmax", "Workspace",
 ]
 
 INLIER_THRESHOLD = 0.9  # hough_voting_gpu_op.cc:356
@@ -226,6 +227,44 @@ def softmax_argmax(score, want_prob=True):
     check("pcnn_softmax_argmax_fwd",
           lib().pcnn_softmax_argmax_fwd(_ptr(score), N, C, _ptr(prob), _ptr(label), _stream(score)))
     return prob, label
+
+
+def deconv_bilinear(input, kernel, stride, add1=None, add2=None, bias=None, relu=False):
+    """The fixed bilinear `deconv` layer (network.py:207-222 with make_deconv_filter :141-157) as a
+    per-channel interpolation: [B,H,W,C] -> [B,H*s,W*s,C], optionally fused with up to two addends
+    (same shape as the output), a per-channel bias and ReLU."""
+    input = _dev(input, "input", torch.float32)
+    if input.dim() != 4:
+        raise ValueError("deconv input must be 4-dimensional")
+    B, H, W, C = input.shape
+    out = torch.empty((B, H * stride, W * stride, C), dtype=torch.float32, device=input.device)
+    a1 = _dev(add1, "add1", torch.float32) if add1 is not None else None
+    a2 = _dev(add2, "add2", torch.float32) if add2 is not None else None
+    bs = _dev(bias, "bias", torch.float32) if bias is not None else None
+    for t in (a1, a2):
+        if t is not None and tuple(t.shape) != tuple(out.shape):
+            raise ValueError("addend must have the output shape %s" % (tuple(out.shape),))
+    check("pcnn_deconv_bilinear_fwd",
+          lib().pcnn_deconv_bilinear_fwd(_ptr(input), B, H, W, C, int(kernel), int(stride), _ptr(a1), _ptr(a2),
+                                         _ptr(bs), 1 if relu else 0, _ptr(out), _stream(input)))
+    return out
+
+
+def upscore_softmax_argmax(z, bias, kernel, stride, relu=True, want_score=False, want_prob=True):
+    """Label-head epilogue in one pass: score = [ReLU](deconv(z) + bias) -> softmax -> first argmax.
+    z [B,H,W,C] f32. Returns (score or None, prob or None, label int32 [B,H*s,W*s])."""
+    z = _dev(z, "z", torch.float32)
+    bias = _dev(bias, "bias", torch.float32)
+    B, H, W, C = z.shape
+    Ho, Wo = H * stride, W * stride
+    dev = z.device
+    score = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=dev) if want_score else None
+    prob = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=dev) if want_prob else None
+    label = torch.empty((B, Ho, Wo), dtype=torch.int32, device=dev)
+    check("pcnn_upscore_softmax_argmax_fwd",
+          lib().pcnn_upscore_softmax_argmax_fwd(_ptr(z), _ptr(bias), B, H, W, C, int(kernel), int(stride),
+                                                1 if relu else 0, _ptr(score), _ptr(prob), _ptr(label), _stream(z)))
+    return score, prob, label
 
 
 # ------------------------------------------------------------------------------------------------

@@ -19,6 +19,15 @@ class vgg16_convs_cpu(vgg16_convs):
     def share_weights(self, other):
         self.vars = {k: v.detach().cpu() for k, v in other.vars.items()}
 
+    def _deconv_bilinear(self, x, k, s, add1=None, add2=None, bias=None, relu=False):
+        n = lambda t: None if t is None else t.numpy()
+        return torch.from_numpy(oracle.deconv_bilinear(x.numpy(), k, s, n(add1), n(add2), n(bias), relu))
+
+    def _upscore_softmax_argmax(self, z, bias, k, s, relu=True, want_score=False, want_prob=True):
+        score, prob, label = oracle.upscore_softmax_argmax(z.numpy(), bias.numpy(), k, s, relu)
+        return (torch.from_numpy(score) if want_score else None, torch.from_numpy(prob) if want_prob else None,
+                torch.from_numpy(label))
+
     @layer
     def softmax_high_dimension(self, input, num_classes, name):
         p, l = oracle.softmax_argmax(input.numpy())

@@ -176,3 +176,20 @@ def softmax_argmax(score):
     label = np.empty(score.shape[:-1], np.int32)
     lib().oracle_softmax_argmax(_p(score), c_long(N), C, _p(prob), _p(label))
     return prob, label
+
+
+def deconv_bilinear(x, k, s, add1=None, add2=None, bias=None, relu=False):
+    x = _f32(x)
+    B, H, W, C = x.shape
+    out = np.empty((B, H * s, W * s, C), np.float32)
+    a1 = _f32(add1) if add1 is not None else None
+    a2 = _f32(add2) if add2 is not None else None
+    bs = _f32(bias) if bias is not None else None
+    lib().oracle_deconv_bilinear(_p(x), B, H, W, C, int(k), int(s), _p(a1), _p(a2), _p(bs), int(bool(relu)), _p(out))
+    return out
+
+
+def upscore_softmax_argmax(z, bias, k, s, relu=True):
+    score = deconv_bilinear(z, k, s, bias=bias, relu=relu)
+    prob, label = softmax_argmax(score)
+    return score, prob, label

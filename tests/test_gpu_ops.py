@@ -275,3 +275,41 @@ def test_device_math_is_ieee(gpu):
     prob, lab = ops.softmax_argmax(T(gpu, x))
     wp, wl = oracle.softmax_argmax(x)
     same(N(prob), wp, "softmax wide range")
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,k,s", [((2, 30, 40, 64), 4, 2), ((1, 60, 80, 128), 16, 8), ((2, 7, 9, 66), 16, 8),
+                                       ((1, 5, 6, 22), 4, 2), ((1, 3, 4, 5), 2, 2), ((1, 4, 4, 3), 6, 2)])
+def test_deconv_bilinear(gpu, shape, k, s):
+    from posecnn_amd import ops
+    rng = np.random.default_rng(22)
+    x = rng.standard_normal(shape).astype(F)
+    B, H, W, C = shape
+    out = ops.deconv_bilinear(T(gpu, x), k, s)
+    same(N(out), oracle.deconv_bilinear(x, k, s), "deconv")
+    a1 = rng.standard_normal((B, H * s, W * s, C)).astype(F)
+    a2 = rng.standard_normal((B, H * s, W * s, C)).astype(F)
+    bias = rng.standard_normal(C).astype(F)
+    out = ops.deconv_bilinear(T(gpu, x), k, s, add1=T(gpu, a1), add2=T(gpu, a2), bias=T(gpu, bias), relu=True)
+    same(N(out), oracle.deconv_bilinear(x, k, s, a1, a2, bias, True), "deconv + adds + bias + relu")
+    # interior pixels of the stride-s bilinear kernel interpolate: a constant image stays constant
+    if k == 2 * s and H > 2 and W > 2:
+        ones = np.ones(shape, F)
+        y = N(ops.deconv_bilinear(T(gpu, ones), k, s))
+        assert np.all(y[:, s:-s, s:-s] == 1.0)
+
+
+@pytest.mark.parametrize("shape,relu", [((2, 60, 80, 22), True), ((1, 7, 9, 22), True), ((1, 5, 5, 40), False), ((1, 30, 33, 3), True)])
+def test_upscore_softmax_argmax(gpu, shape, relu):
+    from posecnn_amd import ops
+    rng = np.random.default_rng(23)
+    z = (rng.standard_normal(shape) * 3).astype(F)
+    bias = rng.standard_normal(shape[3]).astype(F)
+    score, prob, label = ops.upscore_softmax_argmax(T(gpu, z), T(gpu, bias), 16, 8, relu=relu, want_score=True)
+    ws, wp, wl = oracle.upscore_softmax_argmax(z, bias, 16, 8, relu)
+    same(N(score), ws, "score")
+    same(N(label), wl, "label_2d")
+    same(N(prob), wp, "prob_normalized")
+    s2, p2, l2 = ops.upscore_softmax_argmax(T(gpu, z), T(gpu, bias), 16, 8, relu=relu, want_score=False, want_prob=False)
+    assert s2 is None and p2 is None
+    same(N(l2), wl, "label only")

@@ -13,11 +13,11 @@ pytestmark = pytest.mark.gpu
 F = np.float32
 
 
-def build(gpu, input_format="COLOR"):
+def build(gpu, input_format="COLOR", fused_heads=True):
     from cpu_reference import vgg16_convs_cpu
     from posecnn_amd.networks import vgg16_convs
     net = vgg16_convs(input_format, 22, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True,
-                      trainable=False, is_train=False, device=gpu, seed=3, init="he")
+                      trainable=False, is_train=False, device=gpu, seed=3, init="he", fused_heads=fused_heads)
     synth.init_planted_heads(net)
     cpu = vgg16_convs_cpu(input_format, 22, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True,
                           trainable=False, is_train=False, init="he")
@@ -75,7 +75,7 @@ def test_single_frame_api_and_graph_outputs(gpu):
     import torch
     from posecnn_amd import fcn
     H, W = 240, 320
-    net, _ = build(gpu)
+    net, _ = build(gpu, fused_heads=False)  # literal op order: every reference layer name exists
     K = config.DEMO_INTRINSICS.copy(); K[:2] *= W / 640.0
     rng = np.random.default_rng(1)
     im = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
@@ -103,3 +103,41 @@ def test_single_frame_api_and_graph_outputs(gpu):
         assert name in net.layers, name
     assert net.get_output("conv5_3").shape == (1, H // 16, W // 16, 512)
     assert net.get_output("upscore").shape == (1, H, W, 64)
+
+
+def test_fused_heads_equal_literal_op_order(gpu):
+    """fused_heads=True (1x1 conv at 1/8 resolution, then the deconv epilogue kernel) against the
+    reference's literal order (deconv -> 1x1 conv -> softmax -> argmax): the same linear map, so
+    outputs agree to fp32 rounding and labels agree except where two classes tie to ~1e-7."""
+    import torch
+    from posecnn_amd import fcn
+    from posecnn_amd.networks import vgg16_convs
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    B, H, W = 1, 240, 320
+    K = config.DEMO_INTRINSICS.copy(); K[:2] *= W / 640.0
+    rng = np.random.default_rng(5)
+    data = torch.from_numpy((rng.integers(0, 256, (B, H, W, 3)).astype(F) - config.PIXEL_MEANS).astype(F)).to(gpu)
+    planted_np, _ = synth.make_planted_batch(21, B, H=H, W=W, K=K, n_obj=3)
+    planted = {k: torch.from_numpy(v).to(gpu) for k, v in planted_np.items()}
+    pts = synth.make_model_points(22, 64)
+    outs = []
+    nets = []
+    for fused in (True, False):
+        net = vgg16_convs("COLOR", 22, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True, trainable=False,
+                          is_train=False, device=gpu, seed=3, init="he", fused_heads=fused)
+        synth.init_planted_heads(net)
+        if nets:
+            net.vars = nets[0].vars
+        nets.append(net)
+        feed = fcn._feed(net, data, None, K, config.LOV_EXTENTS, pts, config.LOV_SYMMETRY, 22, gpu)
+        with torch.no_grad():
+            net.run(feed, planted=planted)
+        outs.append({k: net.get_output(k).cpu().numpy() for k in ("label_2d", "prob_normalized", "vertex_pred", "rois", "poses_tanh")})
+    a, b = outs
+    assert (a["label_2d"] == b["label_2d"]).mean() >= 0.9995
+    assert np.abs(a["prob_normalized"] - b["prob_normalized"]).max() < 1e-4
+    assert np.abs(a["vertex_pred"] - b["vertex_pred"]).max() < 1e-4 * max(1.0, np.abs(b["vertex_pred"]).max())
+    assert a["rois"].shape == b["rois"].shape and np.array_equal(a["rois"][:, :2], b["rois"][:, :2])
+    assert np.abs(a["rois"][:, 2:6] - b["rois"][:, 2:6]).max() < 2.0
+    assert "upscore" not in nets[0].layers and "upscore" in nets[1].layers

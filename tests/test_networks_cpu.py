@@ -74,7 +74,7 @@ def test_conv_matches_tf_definition():
 def test_deconv_matches_dense_conv2d_transpose(k, s):
     rng = np.random.default_rng(1)
     C = 3
-    net = Tiny(device="cpu")
+    net = vgg16_convs_cpu("COLOR", 22, 64, (1.0,), 1.0, -1.0)  # the deconv layer -> oracle restatement
     x = rng.standard_normal((1, 4, 5, C)).astype(F)
     net.layers = {"x": torch.from_numpy(x)}
     y = net.feed("x").deconv(k, k, C, s, s, name="up", trainable=False).get_output("up").numpy()
