@@ -206,6 +206,11 @@ int pcnn_deconv_bilinear_fwd(const float* in, int batch, int height, int width, 
                              int kernel, int stride, const float* add1, const float* add2,
                              const float* bias, int relu, float* out, void* stream);
 
+/* y = [ReLU](x + bias[c]) over [num_pixels, channels] NHWC rows; y may alias x. The bias_add + relu
+ * of Network.conv (network.py:181-187) in one pass. */
+int pcnn_bias_act_fwd(const float* x, const float* bias, int64_t num_pixels, int channels, int relu,
+                      float* y, void* stream);
+
 int pcnn_upscore_softmax_argmax_fwd(const float* z, const float* bias, int batch, int height,
                                     int width, int num_classes, int kernel, int stride, int relu,
                                     float* score_out, float* prob, int32_t* label, void* stream);

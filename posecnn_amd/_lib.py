@@ -55,6 +55,7 @@ SIGNATURES = {
     "pcnn_backproject_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pcnn_softmax_argmax_fwd": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
     "pcnn_deconv_bilinear_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
+    "pcnn_bias_act_fwd": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
     "pcnn_upscore_softmax_argmax_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "pcnn_profile_enable": (c_int, [c_int]),
     "pcnn_profile_reset": (c_int, []),

@@ -327,6 +327,8 @@ __global__ __launch_bounds__(256) void hv_vote_kernel(
   const int cx = tx0 + (tid & 31);
   const int cy0 = ty0 + (tid >> 5);
   const float cxf = (float)cx;
+  const float cyf[4] = {(float)cy0, (float)(cy0 + 8), (float)(cy0 + 16), (float)(cy0 + 24)};
+  const float q_hi = inlier + HV_FILTER_EPS, q_lo = inlier - HV_FILTER_EPS;
   int votes[4] = {0, 0, 0, 0};
 
   // conservative cone cull: every cell of the tile lies within asin(r / L) of the direction to
@@ -381,19 +383,33 @@ __global__ __launch_bounds__(256) void hv_vote_kernel(
     }
     __syncthreads();
     const int cnt = s_cnt;
+    // Branch-free inner loop: the filter value q~ is computed for all 4 cells of the thread and
+    // turned into votes by mask arithmetic; the exact expression is evaluated only when some lane
+    // of the wave has a cell inside +-HV_FILTER_EPS of the threshold (or a NaN), which is rare.
+    float4 a = sA[0], b = sB[0];
     for (int k = 0; k < cnt; k++) {
-      const float4 a = sA[k];
+      const float4 an = sA[k + 1 < cnt ? k + 1 : k], bn = sB[k + 1 < cnt ? k + 1 : k];  // prefetch
       const float dx = cxf - a.x;
-      if (fabsf(dx) < a.z) {
-        const float4 b = sB[k];
+      const bool inx = fabsf(dx) < a.z;
+      if (__any(inx)) {
+        const float udx = b.x * dx, dx2 = dx * dx;
+        unsigned amb = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const float dy = (float)(cy0 + 8 * j) - a.y;
-          if (fabsf(dy) < a.z) {
-            if (angle_pass(b.x, b.y, b.z, a.w, dx, dy, inlier)) votes[j]++;
-          }
+          const float dy = cyf[j] - a.y;
+          const bool in = inx & (fabsf(dy) < a.z);
+          const float qa = __builtin_fmaf(b.y, dy, udx) * __builtin_amdgcn_rsqf(__builtin_fmaf(dy, dy, dx2)) * a.w;
+          const bool hi = qa > q_hi, lo = qa < q_lo;
+          votes[j] += (int)(in & hi);
+          amb |= (unsigned)(in & !hi & !lo) << j;
+        }
+        if (__any(amb != 0)) {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if ((amb >> j) & 1) votes[j] += angle_pass_exact(b.x, b.y, b.z, dx, cyf[j] - a.y, inlier) ? 1 : 0;
         }
       }
+      a = an; b = bn;
     }
     __syncthreads();
   }
@@ -507,20 +523,82 @@ __global__ __launch_bounds__(256) void hv_select_kernel(
   }
   if (lane == 0) { s_rv[wave] = bv; s_ri[wave] = bi; }
   __syncthreads();
-  if (wave != 0) return;
   for (int w2 = 0; w2 < 4; w2++)
     if (s_rv[w2] > bv || (s_rv[w2] == bv && s_ri[w2] < bi)) { bv = s_rv[w2]; bi = s_ri[w2]; }
 
+  // hough_data of the winning cell (second half of compute_hough_kernel :296-331 and the depth sum
+  // of the first half :269-294). All 256 threads evaluate the exact vote predicate; the depths of
+  // the voters are compacted IN PIXEL ORDER into LDS and summed by one lane, because the reference
+  // accumulates `distance += d` sequentially and float addition does not reassociate.
+  constexpr int SEL_CAP = 2048;
+  __shared__ float s_d[SEL_CAP];
+  __shared__ int s_wc[4];
+  __shared__ float s_res[4];
+  __shared__ float s_bw[4], s_bh[4];
   const int cls = slots_g[n * C + s];
   const int m = (tot_g[n * C + cls] + skip - 1) / skip;
   const HvRec* r0 = rec + (size_t)n * reccap + recoff_g[n * C + cls];
   const float* md = meta + (size_t)n * num_meta;
-  float votes, dist, bh2, bw2;
-  wave_cell_data(r0, m, bi % W, bi / W, cls, extents, md[0], md[4], md[2], md[5], inlier, votes,
-                 dist, bh2, bw2);
-  if (lane == 0) {
+  const float fx = md[0], px = md[2], fy = md[4], py = md[5];
+  const float cxf = (float)(bi % W), cyf = (float)(bi / W);
+  float sumd = 0.f;  // meaningful in thread 0
+  int total = 0, fill = 0;
+  for (int b0 = 0; b0 < m; b0 += 256) {
+    const int ri = b0 + tid;
+    bool pass = false;
+    float d = 0.f;
+    if (ri < m) {
+      const float4 a = r0[ri].a, b = r0[ri].b;
+      const float dx = cxf - a.x, dy = cyf - a.y;
+      d = b.w;
+      pass = fabsf(dx) < a.z && fabsf(dy) < a.z && angle_pass_exact(b.x, b.y, b.z, dx, dy, inlier);
+    }
+    const unsigned long long mask = __ballot(pass);
+    if (lane == 0) s_wc[wave] = __popcll(mask);
+    __syncthreads();
+    int pos = fill + __popcll(mask & lanemask_lt());
+    for (int w2 = 0; w2 < wave; w2++) pos += s_wc[w2];
+    if (pass) s_d[pos] = d;
+    fill += s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+    __syncthreads();
+    if (fill > SEL_CAP - 256 || b0 + 256 >= m) {
+      if (tid == 0)
+        for (int i = 0; i < fill; i++) sumd += s_d[i];
+      total += fill;
+      fill = 0;
+      __syncthreads();
+    }
+  }
+  float dist = 0.f, bh2 = 0.f, bw2 = 0.f;
+  if (tid == 0) s_res[0] = total > 0 ? div_rn(sumd, (float)total) : 0.f;
+  __syncthreads();
+  if (total > 0) {
+    dist = s_res[0];
+    const float thr = project_box(extents, cls, fx, fy, px, py, dist);
+    float bw = -1.f, bh = -1.f;
+    for (int ri = tid; ri < m; ri += 256) {
+      const float4 a = r0[ri].a, b = r0[ri].b;
+      const float dx = cxf - a.x, dy = cyf - a.y;
+      if (angle_pass_exact(b.x, b.y, b.z, dx, dy, inlier)) {
+        const float ax = fabsf(dx), ay = fabsf(dy);
+        if (ax < thr && ay < thr) { bw = fmaxf(bw, ax); bh = fmaxf(bh, ay); }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      bw = fmaxf(bw, __shfl_xor(bw, off));
+      bh = fmaxf(bh, __shfl_xor(bh, off));
+    }
+    if (lane == 0) { s_bw[wave] = bw; s_bh[wave] = bh; }
+    __syncthreads();
+    bw = fmaxf(fmaxf(s_bw[0], s_bw[1]), fmaxf(s_bw[2], s_bw[3]));
+    bh = fmaxf(fmaxf(s_bh[0], s_bh[1]), fmaxf(s_bh[2], s_bh[3]));
+    bh2 = 2 * bh;
+    bw2 = 2 * bw;
+  }
+  if (tid == 0) {
     HvMax e;
-    e.cls = cls; e.idx = bi; e.votes = votes; e.dist = dist; e.bh2 = bh2; e.bw2 = bw2;
+    e.cls = cls; e.idx = bi; e.votes = (float)total; e.dist = dist; e.bh2 = bh2; e.bw2 = bw2;
     e.pad0 = e.pad1 = 0;
     maxima[(size_t)n * capmax + s] = e;
   }

@@ -82,37 +82,64 @@ __device__ __forceinline__ void store_v(float* p, const float* r)
   *reinterpret_cast<typename Vec<V>::T*>(p) = v;
 }
 
-// one thread = V consecutive channels of one output pixel
+// A workgroup owns DC_SEG consecutive output pixels of one output row (all channels): the row taps
+// are wave-uniform, the column taps sit in a small LDS table, and the npx*C output floats leave as
+// one contiguous run of V-wide stores. Inputs are 1/s^2 of the output and stay L2-resident.
+constexpr int DC_SEG = 64;
+
 template <int V>
 __global__ __launch_bounds__(256) void deconv_bilinear_kernel(
     const float* __restrict__ in, const float* __restrict__ add1, const float* __restrict__ add2,
-    const float* __restrict__ bias, float* __restrict__ out, long long total, int H, int W, int C,
-    int k, int s, int relu)
+    const float* __restrict__ bias, float* __restrict__ out, int H, int W, int C, int k, int s,
+    int relu, int nseg)
 {
+  __shared__ int s_i0[DC_SEG], s_n[DC_SEG];
+  __shared__ float s_w[DC_SEG][4];
   const int pad = (k - s) / 2;
   const int cv = C / V;
   const int Ho = H * s, Wo = W * s;
-  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * 256) {
-    long long t = idx;
-    const int c = (int)(t % cv) * V; t /= cv;
-    const int ox = (int)(t % Wo); t /= Wo;
-    const int oy = (int)(t % Ho); t /= Ho;
-    const int b = (int)t;
-    const Taps ty = make_taps(oy, k, s, pad, H);
-    const Taps tx = make_taps(ox, k, s, pad, W);
+  const int tid = threadIdx.x;
+  const int seg = blockIdx.x % nseg;
+  const int oy = (blockIdx.x / nseg) % Ho;
+  const int b = blockIdx.x / (nseg * Ho);
+  const int ox0 = seg * DC_SEG;
+  const int npx = min(DC_SEG, Wo - ox0);
+  if (tid < npx) {
+    const Taps t = make_taps(ox0 + tid, k, s, pad, W);
+    s_i0[tid] = t.i0;
+    s_n[tid] = t.n;
+#pragma unroll
+    for (int j = 0; j < 4; j++) s_w[tid][j] = t.w[j];
+  }
+  const Taps ty = make_taps(oy, k, s, pad, H);
+  __syncthreads();
+  const float* inb = in + (size_t)b * H * W * C;
+  const size_t obase = (((size_t)b * Ho + oy) * Wo + ox0) * C;
+  const int total = npx * cv;
+  for (int idx = tid; idx < total; idx += 256) {
+    const int px = idx / cv;
+    const int c = (idx - px * cv) * V;
+    const int i0 = s_i0[px], nx = s_n[px];
     float acc[V];
 #pragma unroll
     for (int i = 0; i < V; i++) acc[i] = 0.f;
-    for (int jy = 0; jy < ty.n; jy++)
-      for (int jx = 0; jx < tx.n; jx++) {
-        const float w = ty.w[jy] * tx.w[jx];
-        float v[V];
-        load_v<V>(in + (((long long)b * H + ty.i0 + jy) * W + tx.i0 + jx) * C + c, v);
 #pragma unroll
-        for (int i = 0; i < V; i++) acc[i] = acc[i] + w * v[i];
+    for (int jy = 0; jy < 4; jy++) {
+      if (jy < ty.n) {
+        const float* row = inb + (size_t)(ty.i0 + jy) * W * C + c;
+#pragma unroll
+        for (int jx = 0; jx < 4; jx++) {
+          if (jx < nx) {
+            const float w = ty.w[jy] * s_w[px][jx];
+            float v[V];
+            load_v<V>(row + (size_t)(i0 + jx) * C, v);
+#pragma unroll
+            for (int i = 0; i < V; i++) acc[i] = acc[i] + w * v[i];
+          }
+        }
       }
-    const long long o = (((long long)b * Ho + oy) * Wo + ox) * C + c;
+    }
+    const size_t o = obase + (size_t)px * C + c;
     if (add1) {
       float v[V];
       load_v<V>(add1 + o, v);
@@ -134,6 +161,29 @@ __global__ __launch_bounds__(256) void deconv_bilinear_kernel(
       for (int i = 0; i < V; i++) acc[i] = acc[i] > 0.f ? acc[i] : 0.f;  // tf.nn.relu: max(x, 0)
     }
     store_v<V>(out + o, acc);
+  }
+}
+
+// y = [ReLU](x + bias[c]) over NHWC rows, in place or out of place: the bias_add + relu pair of
+// Network.conv (network.py:181-187) as one pass instead of two framework kernels.
+template <int V>
+__global__ __launch_bounds__(256) void bias_act_kernel(const float* __restrict__ x,
+                                                       const float* __restrict__ bias,
+                                                       float* __restrict__ y, long long total, int C,
+                                                       int relu)
+{
+  const int cv = C / V;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % cv) * V;
+    float v[V];
+    load_v<V>(x + idx * V, v);
+#pragma unroll
+    for (int i = 0; i < V; i++) {
+      float t = v[i] + bias[c + i];
+      v[i] = relu ? (t > 0.f ? t : 0.f) : t;
+    }
+    store_v<V>(y + idx * V, v);
   }
 }
 
@@ -257,19 +307,33 @@ extern "C" int pcnn_deconv_bilinear_fwd(const float* in, int B, int H, int W, in
   PCNN_REQUIRE(in && out, PCNN_ENULL, "deconv: NULL pointer");
   hipStream_t stream = (hipStream_t)stream_;
   const bool al = aligned16(in) && aligned16(out) && (!add1 || aligned16(add1)) && (!add2 || aligned16(add2));
-  const long long npix = (long long)B * H * s * W * s;
-  auto grid = [](long long total) { long long b = (total + 255) / 256; return (unsigned)(b < 256 * 64 ? b : 256 * 64); };
-  if (al && C % 4 == 0) {
-    const long long total = npix * (C / 4);
-    PCNN_LAUNCH(deconv_bilinear_kernel<4>, dim3(grid(total)), dim3(256), 0, stream, in, add1, add2, bias, out, total, H, W, C, k, s, relu);
-  } else if (al && C % 2 == 0) {
-    const long long total = npix * (C / 2);
-    PCNN_LAUNCH(deconv_bilinear_kernel<2>, dim3(grid(total)), dim3(256), 0, stream, in, add1, add2, bias, out, total, H, W, C, k, s, relu);
-  } else {
-    const long long total = npix * C;
-    PCNN_LAUNCH(deconv_bilinear_kernel<1>, dim3(grid(total)), dim3(256), 0, stream, in, add1, add2, bias, out, total, H, W, C, k, s, relu);
-  }
+  const int Wo = W * s, Ho = H * s;
+  const int nseg = (Wo + DC_SEG - 1) / DC_SEG;
+  const long long blocks = (long long)B * Ho * nseg;
+  PCNN_REQUIRE(blocks < (1ll << 31), PCNN_EINVAL, "deconv: grid too large");
+  if (al && C % 4 == 0)
+    PCNN_LAUNCH(deconv_bilinear_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream, in, add1, add2, bias, out, H, W, C, k, s, relu, nseg);
+  else if (al && C % 2 == 0)
+    PCNN_LAUNCH(deconv_bilinear_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, in, add1, add2, bias, out, H, W, C, k, s, relu, nseg);
+  else
+    PCNN_LAUNCH(deconv_bilinear_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, in, add1, add2, bias, out, H, W, C, k, s, relu, nseg);
   return check_launch("deconv_bilinear_fwd");
+}
+
+extern "C" int pcnn_bias_act_fwd(const float* x, const float* bias, int64_t num_pixels, int channels,
+                                 int relu, float* y, void* stream_)
+{
+  PCNN_REQUIRE(num_pixels >= 0 && channels >= 1, PCNN_EINVAL, "bias_act: bad shape");
+  if (num_pixels == 0) return PCNN_OK;
+  PCNN_REQUIRE(x && bias && y, PCNN_ENULL, "bias_act: NULL pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  auto grid = [](long long total) { long long b = (total + 255) / 256; return (unsigned)(b < 256 * 32 ? b : 256 * 32); };
+  const long long n = (long long)num_pixels * channels;
+  if (channels % 4 == 0 && aligned16(x) && aligned16(y))
+    PCNN_LAUNCH(bias_act_kernel<4>, dim3(grid(n / 4)), dim3(256), 0, stream, x, bias, y, n / 4, channels, relu);
+  else
+    PCNN_LAUNCH(bias_act_kernel<1>, dim3(grid(n)), dim3(256), 0, stream, x, bias, y, n, channels, relu);
+  return check_launch("bias_act_fwd");
 }
 
 extern "C" int pcnn_upscore_softmax_argmax_fwd(const float* z, const float* bias, int B, int H,

@@ -156,10 +156,12 @@ class Network(object):
         b = self.make_var(name + "/biases", (c_o,), lambda s: torch.zeros(s)) if biased else None
         assert s_h == 1 and s_w == 1 or padding == "VALID" or (k_h == 1 and k_w == 1), "strided SAME conv not on this path"
         pad = (k_h // 2, k_w // 2) if padding == "SAME" else 0
-        y = F.conv2d(_nchw(input), w, b, stride=(s_h, s_w), padding=pad, groups=group)
-        if relu:
-            y = F.relu_(y)
-        return _nhwc(y)
+        y = _nhwc(F.conv2d(_nchw(input), w, None, stride=(s_h, s_w), padding=pad, groups=group))
+        if b is None and not relu:
+            return y
+        if b is None:
+            return F.relu_(y)
+        return self._bias_act(y, b, relu)  # bias_add + relu (network.py:181-187) in one pass, in place
 
     @layer
     def max_pool(self, input, k_h, k_w, s_h, s_w, name, padding=DEFAULT_PADDING):
@@ -190,6 +192,9 @@ class Network(object):
         return self._deconv_bilinear(input, k_h, s_h)
 
     # hooks the CPU checker overrides (tests/cpu_reference.py)
+    def _bias_act(self, y, bias, relu):
+        return ops.bias_act_(y, bias, relu)
+
     def _deconv_bilinear(self, x, k, s, add1=None, add2=None, bias=None, relu=False):
         return ops.deconv_bilinear(x, k, s, add1=add1, add2=add2, bias=bias, relu=relu)
 

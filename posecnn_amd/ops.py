@@ -17,7 +17,7 @@ from ._lib import HOUGH_ROWS_CAPACITY, MAX_ROI, POSE_CHANNELS, VERTEX_CHANNELS, 
 
 __all__ = [
     "hough_voting_gpu", "hough_voting_gpu_padded", "roi_pool", "roi_pool_add2", "hard_label",
-    "average_distance_loss", "backproject", "softmax_argmax", "deconv_bilinear",
+    "average_distance_loss", "backproject", "softmax_argmax", "deconv_bilinear", "bias_act_",
     "upscore_softmax_argmax", "Workspace",
 ]
 
@@ -227,6 +227,18 @@ def softmax_argmax(score, want_prob=True):
     check("pcnn_softmax_argmax_fwd",
           lib().pcnn_softmax_argmax_fwd(_ptr(score), N, C, _ptr(prob), _ptr(label), _stream(score)))
     return prob, label
+
+
+def bias_act_(x, bias, relu=True):
+    """In place: x[..., c] = [ReLU](x[..., c] + bias[c]) for an NHWC-contiguous tensor."""
+    x = _dev(x, "x", torch.float32)
+    bias = _dev(bias, "bias", torch.float32)
+    C = x.shape[-1]
+    if bias.numel() != C:
+        raise ValueError("bias must have one entry per channel")
+    check("pcnn_bias_act_fwd",
+          lib().pcnn_bias_act_fwd(_ptr(x), _ptr(bias), x.numel() // C, C, 1 if relu else 0, _ptr(x), _stream(x)))
+    return x
 
 
 def deconv_bilinear(input, kernel, stride, add1=None, add2=None, bias=None, relu=False):

@@ -19,6 +19,10 @@ class vgg16_convs_cpu(vgg16_convs):
     def share_weights(self, other):
         self.vars = {k: v.detach().cpu() for k, v in other.vars.items()}
 
+    def _bias_act(self, y, bias, relu):
+        y = y + bias
+        return torch.relu(y) if relu else y
+
     def _deconv_bilinear(self, x, k, s, add1=None, add2=None, bias=None, relu=False):
         n = lambda t: None if t is None else t.numpy()
         return torch.from_numpy(oracle.deconv_bilinear(x.numpy(), k, s, n(add1), n(add2), n(bias), relu))

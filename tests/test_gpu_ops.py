@@ -313,3 +313,19 @@ def test_upscore_softmax_argmax(gpu, shape, relu):
     s2, p2, l2 = ops.upscore_softmax_argmax(T(gpu, z), T(gpu, bias), 16, 8, relu=relu, want_score=False, want_prob=False)
     assert s2 is None and p2 is None
     same(N(l2), wl, "label only")
+
+
+@pytest.mark.parametrize("shape", [(2, 30, 40, 512), (1, 7, 9, 22), (3, 5, 5, 64)])
+def test_bias_act_inplace(gpu, shape):
+    from posecnn_amd import ops
+    rng = np.random.default_rng(24)
+    x = rng.standard_normal(shape).astype(F)
+    b = rng.standard_normal(shape[-1]).astype(F)
+    for relu in (True, False):
+        t = T(gpu, x)
+        out = ops.bias_act_(t, T(gpu, b), relu)
+        assert out.data_ptr() == t.data_ptr()
+        want = x + b
+        if relu:
+            want = np.maximum(want, 0)
+        same(N(out), want.astype(F), "bias_act relu=%s" % relu)

@@ -58,7 +58,7 @@ def tf_conv2d_transpose_same(x, w, s):
 
 def test_conv_matches_tf_definition():
     rng = np.random.default_rng(0)
-    net = Tiny(device="cpu")
+    net = vgg16_convs_cpu("COLOR", 22, 64, (1.0,), 1.0, -1.0)
     x = rng.standard_normal((2, 6, 7, 5)).astype(F)
     w = rng.standard_normal((3, 3, 5, 4)).astype(F)
     b = rng.standard_normal(4).astype(F)
