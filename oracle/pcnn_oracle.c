@@ -5,14 +5,14 @@
  * file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load it (as the
  * checker / the timed CPU baseline, never as the product path).
  *
- * PARITY UNPINNED BY THE REFERENCE'S OWN TESTS: the reference has no golden vectors, known-answer
- * tests or unit tests for this path and cannot be executed here (TensorFlow 1.x,
- * CUDA, Eigen, OpenCV absent). This file restates, in plain C, the reference's *GPU* kernels
- * (`*_op_gpu.cu.cc`), which BASELINE.json names as the parity target. The oracle is pinned instead by
- * (a) oracle/_ref: the reference's own kernel bodies compiled for the CPU by oracle/Makefile from
- * the sources where they lie (see oracle/ref_shim/), when /root/reference is present;
- * (b) an independent numpy restatement (tests/np_ref.py); (c) hand-derived known answers
- * (tests/test_oracle_kat.py).
+ * PINNING: the reference has no golden vectors, known-answer tests or unit tests for this path
+ *  and its TF ops cannot be built here. This file restates, in plain C, the
+ * reference's *GPU* kernels (`*_op_gpu.cu.cc`), which BASELINE.json names as the parity target, and
+ * is pinned by (a) oracle/_ref: the reference's own __global__ kernel bodies compiled unchanged for
+ * the CPU from the sources where they lie (oracle/ref_shim/) — tests/test_oracle_vs_reference.py
+ * requires bit-identical outputs for all five ops, forward and backward; (b) an independent numpy
+ * restatement (tests/np_ref.py); (c) hand-derived known answers (tests/test_oracle_kat.py).
+ * The dense layers of the graph (TF/cuDNN conv, matmul) have no such pin: "parity unpinned" there.
  *
  * Canonical choices where the reference is order dependent (atomicAdd order, thrust): serial
  * execution order — ascending pixel index for the per-class pixel arrays, ascending cell index for
