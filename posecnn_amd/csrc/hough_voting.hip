@@ -37,13 +37,15 @@ using namespace pcnn;
 
 constexpr int HV_CHUNK = 2048;      // label pixels per hist/scatter workgroup (4 waves x 8 x 64)
 constexpr int HV_TILE = 32;         // Hough tile edge (cells)
-constexpr int HV_BATCH = 1024;      // records culled into LDS per round of hv_vote
+constexpr int HV_BATCH = 512;       // records culled into LDS per round of hv_vote
 constexpr int LM_CHUNK = 1024;      // consecutive Hough cells per hv_localmax workgroup
 constexpr float HV_FILTER_EPS = 2e-5f;
 
 struct __attribute__((aligned(16))) HvRec {
   float4 a;  // x, y, thr, rn1 (1/|uv|, or NaN when |uv| is outside the filter's safe range)
   float4 b;  // u, v, |uv|, d
+  float4 c;  // ra, rb, g, mode: the record's vote cone cut by a row dy is the dx-interval with ends
+             // dy*ra, dy*rb (see cone_interval); mode 0 = no closed form (evaluate cells one by one)
 };
 
 struct __attribute__((aligned(16))) HvMax {
@@ -146,6 +148,38 @@ __device__ __forceinline__ bool angle_pass(float u, float v, float n1, float rn1
   return angle_pass_exact(u, v, n1, dx, dy, inlier);
 }
 
+// The vote predicate of a record (x, y, u, v) for the cell at (x + dx, y + dy) is
+//   (u dx + v dy) / (n1 * sqrt(dx^2 + dy^2)) > c        (c = inlierThreshold, n1 = fl|uv|).
+// For fixed dy != 0 the cells that satisfy it form ONE interval in dx (a convex cone cut by a line).
+// Squaring:  A dx^2 + 2 u v dy dx + (v^2 - c^2 n1^2) dy^2 > 0  with  A = u^2 - c^2 n1^2, and
+// u dx + v dy > 0. Its roots are dy * ra and dy * rb with
+//   ra, rb = (-u v +- n1 sqrt(c^2 (u^2 + v^2 - c^2 n1^2))) / A      (discriminant always >= 0).
+//   A < 0: the interval between the roots, if the dot product at their midpoint (= dy * g) is > 0;
+//   A > 0: the half line beyond the larger root (u > 0) or below the smaller one (u < 0).
+// Evaluated once per record in double, so the f32 ends dy*ra, dy*rb are within ~1e-4 cell of the
+// real roots; hv_vote treats cells within 0.01 of an end as uncertain and decides those with the
+// exact f32 predicate, so the interval form can never disagree with the per-cell definition.
+__device__ float4 cone_coefficients(float u, float v, float n1, float rn1, float inlier)
+{
+  float4 c = make_float4(0.f, 0.f, 0.f, 0.f);  // mode 0
+  if (!(rn1 == rn1) || !(inlier > 0.f && inlier < 1.f)) return c;
+  const double U = u, V = v, N = n1, cc = (double)inlier;
+  const double k = cc * cc;
+  const double A = U * U - k * N * N;
+  if (!(fabs(A) > 1e-4 * N * N)) return c;  // a cone edge (nearly) parallel to the rows
+  const double disc = k * (U * U + V * V - k * N * N);
+  if (!(disc >= 0.0)) return c;
+  const double D = N * sqrt(disc);
+  const double ra = (-U * V + D) / A, rb = (-U * V - D) / A;
+  const double g = U * (ra + rb) * 0.5 + V;
+  c.x = (float)ra;
+  c.y = (float)rb;
+  c.z = (float)g;
+  c.w = A < 0.0 ? 1.f : (U > 0.0 ? 2.f : 3.f);
+  if (!(fabsf(c.x) < 1e6f) || !(fabsf(c.y) < 1e6f)) c.w = 0.f;
+  return c;
+}
+
 struct ZeroJob {
   float* p[5];
   unsigned words[5];
@@ -197,7 +231,7 @@ __global__ __launch_bounds__(256) void hv_scatter_kernel(
     const float* __restrict__ extents, const float* __restrict__ meta,
     const int* __restrict__ hist, int* __restrict__ tot_g, int* __restrict__ slots_g,
     int* __restrict__ nslots_g, int* __restrict__ recoff_g, HvRec* __restrict__ rec, int HW, int W,
-    int C, int nchunk, int skip, int label_thr, int num_meta, int reccap)
+    int C, int nchunk, int skip, int label_thr, int num_meta, int reccap, float inlier)
 {
   __shared__ int s_pre[PCNN_MAX_CLASSES], s_tot[PCNN_MAX_CLASSES], s_recoff[PCNN_MAX_CLASSES];
   __shared__ int s_wh[4][PCNN_MAX_CLASSES];
@@ -298,6 +332,7 @@ __global__ __launch_bounds__(256) void hv_scatter_kernel(
         HvRec R;
         R.a = make_float4((float)x, (float)y, thr, rn1);
         R.b = make_float4(u, v, n1, d);
+        R.c = cone_coefficients(u, v, n1, rn1, inlier);
         rec[(size_t)n * reccap + ro + my_rank / skip] = R;
       }
     }
@@ -305,6 +340,13 @@ __global__ __launch_bounds__(256) void hv_scatter_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Adds +1 over columns [c_lo, c_hi] (tile-relative, inclusive, already clipped) of a tile row.
+__device__ __forceinline__ void diff_add(int* row, int c_lo, int c_hi)
+{
+  atomicAdd(row + c_lo, 1);
+  atomicAdd(row + c_hi + 1, -1);
+}
+
 __global__ __launch_bounds__(256) void hv_vote_kernel(
     const HvRec* __restrict__ rec, const int* __restrict__ nslots_g,
     const int* __restrict__ slots_g, const int* __restrict__ tot_g,
@@ -319,17 +361,14 @@ __global__ __launch_bounds__(256) void hv_vote_kernel(
 
   __shared__ float4 sA[HV_BATCH];
   __shared__ float4 sB[HV_BATCH];
+  __shared__ float4 sC[HV_BATCH];
+  __shared__ int s_diff[HV_TILE][HV_TILE + 1];  // per-row difference array of the tile's votes
   __shared__ int s_cnt;
   __shared__ int s_rv[4], s_ri[4];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tx0 = (tile % ntx) * HV_TILE, ty0 = (tile / ntx) * HV_TILE;
-  const int cx = tx0 + (tid & 31);
-  const int cy0 = ty0 + (tid >> 5);
-  const float cxf = (float)cx;
-  const float cyf[4] = {(float)cy0, (float)(cy0 + 8), (float)(cy0 + 16), (float)(cy0 + 24)};
-  const float q_hi = inlier + HV_FILTER_EPS, q_lo = inlier - HV_FILTER_EPS;
-  int votes[4] = {0, 0, 0, 0};
+  for (int i = tid; i < HV_TILE * (HV_TILE + 1); i += 256) (&s_diff[0][0])[i] = 0;
 
   // conservative cone cull: every cell of the tile lies within asin(r / L) of the direction to
   // the tile centre, so a record whose angle to the centre exceeds acos(inlier) + asin(r / L)
@@ -338,6 +377,11 @@ __global__ __launch_bounds__(256) void hv_vote_kernel(
   const float c0 = inlier, s0 = sqrtf(fmaxf(0.f, 1.f - inlier * inlier));
   const float tcx = (float)tx0 + 15.5f, tcy = (float)ty0 + 15.5f;
   const float rad = 21.93f + 1.0f;
+
+  // vote phase geometry: a half wave (32 lanes = the 32 rows of the tile) per record
+  const int row = tid & 31, half = tid >> 5;
+  const int yrow = ty0 + row;
+  int* drow = &s_diff[row][0];
 
   for (int b0 = 0; b0 < m; b0 += HV_BATCH) {
     if (tid == 0) s_cnt = 0;
@@ -378,41 +422,95 @@ __global__ __launch_bounds__(256) void hv_vote_kernel(
           int pos = basep + __popcll(mask & lanemask_lt());
           sA[pos] = a;
           sB[pos] = b;
+          sC[pos] = r0[ri].c;
         }
       }
     }
     __syncthreads();
     const int cnt = s_cnt;
-    // Branch-free inner loop: the filter value q~ is computed for all 4 cells of the thread and
-    // turned into votes by mask arithmetic; the exact expression is evaluated only when some lane
-    // of the wave has a cell inside +-HV_FILTER_EPS of the threshold (or a NaN), which is rare.
-    float4 a = sA[0], b = sB[0];
-    for (int k = 0; k < cnt; k++) {
-      const float4 an = sA[k + 1 < cnt ? k + 1 : k], bn = sB[k + 1 < cnt ? k + 1 : k];  // prefetch
-      const float dx = cxf - a.x;
-      const bool inx = fabsf(dx) < a.z;
-      if (__any(inx)) {
-        const float udx = b.x * dx, dx2 = dx * dx;
-        unsigned amb = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const float dy = cyf[j] - a.y;
-          const bool in = inx & (fabsf(dy) < a.z);
-          const float qa = __builtin_fmaf(b.y, dy, udx) * __builtin_amdgcn_rsqf(__builtin_fmaf(dy, dy, dx2)) * a.w;
-          const bool hi = qa > q_hi, lo = qa < q_lo;
-          votes[j] += (int)(in & hi);
-          amb |= (unsigned)(in & !hi & !lo) << j;
-        }
-        if (__any(amb != 0)) {
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-            if ((amb >> j) & 1) votes[j] += angle_pass_exact(b.x, b.y, b.z, dx, cyf[j] - a.y, inlier) ? 1 : 0;
+    // Votes are integers and order-free: every (record, row) adds +1 over an interval of columns
+    // through the row's difference array (2 LDS atomics) instead of testing the row's 32 cells.
+    for (int k = half; k < cnt; k += 8) {
+      const float4 a = sA[k], b = sB[k], c = sC[k];
+      const int x = (int)a.x, y = (int)a.y;
+      const int dyi = yrow - y;
+      const float dy = (float)dyi;
+      if (!(fabsf(dy) < a.z)) continue;                       // |dy| < thr (.cu.cc:286-288)
+      // columns with |dx| < thr:  |dx| <= kx,  kx = ceil(thr) - 1
+      const float kxf = fminf(ceilf(a.z) - 1.f, 65536.f);
+      const int kx = (int)kxf;
+      int w_lo = max(x - kx, tx0), w_hi = min(x + kx, tx0 + HV_TILE - 1);  // window ∩ tile columns
+      if (w_lo > w_hi) continue;
+      const int mode = (int)c.w;
+      bool per_cell = (mode == 0);
+      // sure interval [lo, hi] of absolute columns and two ranges [ul0, ul1], [ur0, ur1] of columns
+      // too close to an interval end to trust the closed form: those are decided by the exact
+      // predicate. The f32 predicate can move an end by <= 5 ulp(q) / |dq/dx| = 6.9e-7 r^2 / |dy|
+      // cells (r = distance pixel -> cell); the uncertain half-width is 0.01 + 2e-6 r^2 / |dy|.
+      int lo = 1, hi = 0, ul0 = 1, ul1 = 0, ur0 = 1, ur1 = 0;
+      if (!per_cell) {
+        if (dyi == 0) {
+          // q = sign(dx) * u / n1 for every dx != 0; dx = 0 is 0/0 = NaN -> never a vote
+          const float sgn = b.x * a.w;
+          if (sgn > inlier + 1e-5f) { lo = x + 1; hi = 0x3fffffff; }
+          else if (sgn < -(inlier + 1e-5f)) { lo = -0x3fffffff; hi = x - 1; }
+          else if (fabsf(sgn) < inlier - 1e-5f) { /* empty */ }
+          else per_cell = true;
+        } else {
+          const float r1 = dy * c.x, r2 = dy * c.y;
+          const float rl = fminf(r1, r2), rh = fmaxf(r1, r2);
+          const float BIG = 3.0e9f;
+          float L, R;  // open interval (L, R) in dx; +-BIG = unbounded
+          if (mode == 1) {
+            if (dy * c.z > 0.f) { L = rl; R = rh; } else { L = 1.f; R = -1.f; }
+          } else if (mode == 2) { L = rh; R = BIG; }
+          else { L = -BIG; R = rl; }
+          if (L <= R) {
+            const float ady = fabsf(dy), rdy = 2e-6f / ady;
+            const float dL = L > -BIG ? 0.01f + rdy * (L * L + dy * dy) : 0.f;
+            const float dR = R < BIG ? 0.01f + rdy * (R * R + dy * dy) : 0.f;
+            const float CL = 70000.f;
+            const float slo = fminf(fmaxf(floorf(L + dL) + 1.f, -CL), CL);   // first sure dx
+            const float shi = fminf(fmaxf(ceilf(R - dR) - 1.f, -CL), CL);    // last sure dx
+            lo = x + (int)slo;
+            hi = x + (int)shi;
+            if (L > -BIG) { ul0 = x + (int)fminf(fmaxf(ceilf(L - dL), -CL), CL); ul1 = lo - 1; }
+            if (R < BIG) { ur0 = hi + 1; ur1 = x + (int)fminf(fmaxf(floorf(R + dR), -CL), CL); }
+            if (lo > hi) {  // no sure cell: one exact range from the lowest to the highest candidate
+              ul0 = L > -BIG ? ul0 : w_lo;
+              ul1 = R < BIG ? ur1 : w_hi;
+              ur0 = 1; ur1 = 0;
+            }
+          }
         }
       }
-      a = an; b = bn;
+      if (per_cell) {
+        for (int cxa = w_lo; cxa <= w_hi; cxa++)
+          if (angle_pass_exact(b.x, b.y, b.z, (float)(cxa - x), dy, inlier)) diff_add(drow, cxa - tx0, cxa - tx0);
+        continue;
+      }
+      lo = max(lo, w_lo);
+      hi = min(hi, w_hi);
+      if (lo <= hi) diff_add(drow, lo - tx0, hi - tx0);
+      for (int cxa = max(ul0, w_lo); cxa <= min(ul1, w_hi); cxa++)
+        if (angle_pass_exact(b.x, b.y, b.z, (float)(cxa - x), dy, inlier)) diff_add(drow, cxa - tx0, cxa - tx0);
+      for (int cxa = max(ur0, w_lo); cxa <= min(ur1, w_hi); cxa++)
+        if (angle_pass_exact(b.x, b.y, b.z, (float)(cxa - x), dy, inlier)) diff_add(drow, cxa - tx0, cxa - tx0);
     }
     __syncthreads();
   }
+
+  // difference arrays -> votes (one thread per row), then the tile maximum as before
+  if (tid < HV_TILE) {
+    int acc = 0;
+    for (int cxr = 0; cxr < HV_TILE; cxr++) { acc += s_diff[tid][cxr]; s_diff[tid][cxr] = acc; }
+  }
+  __syncthreads();
+  const int cx = tx0 + (tid & 31);
+  const int cy0 = ty0 + (tid >> 5);
+  int votes[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) votes[j] = s_diff[(tid >> 5) + 8 * j][tid & 31];
 
   // tile maximum: most votes, lowest cell index among equals (first maximum in index order)
   int bv = -1, bi = 0x7fffffff;
@@ -965,7 +1063,7 @@ extern "C" int pcnn_hough_voting_fwd(const int32_t* label, const float* vertex,
                      L.nchunk, zj);
   PCNN_LAUNCH(hv_scatter_kernel, dim3(L.nchunk, B), dim3(256), 0, stream, label, vertex,
                      extents, meta, hist, tot, slots, nslots, recoff, rec, HW, W, C, L.nchunk,
-                     skip, label_thr, num_meta, L.reccap);
+                     skip, label_thr, num_meta, L.reccap, inlier);
   PCNN_LAUNCH(hv_vote_kernel, dim3(L.ntiles, C - 1, B), dim3(256), 0, stream, rec, nslots,
                      slots, tot, recoff, tilemax, hs, H, W, C, skip, inlier, L.ntx, L.ntiles,
                      L.reccap, need_hs ? 1 : 0);
