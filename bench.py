@@ -147,6 +147,7 @@ def main():
     elapsed = pdist.max_over_ranks(t1 - t0, dev)
 
     if rank != 0:
+        pdist.shutdown()
         return
     frames = B * world * a.steps
     ms_per_step = 1000.0 * elapsed / a.steps
@@ -159,6 +160,15 @@ def main():
     hv = kern.get("hv_vote_kernel", {"avg_us": float("nan"), "calls": 0})
     achieved = alg_bytes / (hv["avg_us"] * 1e-6) / 1e9 if hv["calls"] else float("nan")
     hough_us = sum(v["avg_us"] for k, v in kern.items() if k.startswith("hv_"))
+    # HBM traffic of the kernel from PMC counters: collected offline in separate --pmc passes (they
+    # cannot share a run with the timed region) at this same workload; see profiles/README.md
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_hough_pmc.json")))["hv_vote_kernel"]
+        if B == 16 and H == 480 and W == 640:
+            traffic = int((2.0 * pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024)
+    except Exception:
+        pass
     out = {
         "metric": "RGB-D frames/sec (640x480, 21 YCB classes)",
         "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -171,7 +181,8 @@ def main():
                    "input_format": a.input, "parallelism": "dp%d (frames sharded, 1 all-gather of detections)" % world,
                    "detections_per_step": ndet / a.steps},
         "roofline": {"kernel": "hv_vote_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) from separate rocprofv3 --pmc passes (profiles/r01_hough_pmc.json)",
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": hv["avg_us"], "launches": hv["calls"],
                      "note": "Hough voting is VALU/LDS bound, not HBM bound (SURVEY.md §8d): compulsory traffic is ~2 MB/frame",
                      "hough_sequence_us": hough_us, "hough_GBps_whole_sequence": alg_bytes / (hough_us * 1e-6) / 1e9 if hough_us else None},
@@ -183,7 +194,8 @@ def main():
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         except Exception as e:  # the baseline is reported, never required for the GPU number
             out["cpu_baseline"] = {"error": repr(e)}
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    pdist.shutdown()
 
 
 if __name__ == "__main__":

@@ -393,11 +393,11 @@ __global__ __launch_bounds__(256) void hv_vote_kernel(
       float4 a, b;
       if (ri < m) {
         a = r0[ri].a;
+        b = r0[ri].b;  // issued together with `a`: one L2 round trip per round instead of two
         int x = (int)a.x, y = (int)a.y;
         int ddx = max(0, max(tx0 - x, x - (tx0 + HV_TILE - 1)));
         int ddy = max(0, max(ty0 - y, y - (ty0 + HV_TILE - 1)));
         if ((float)ddx < a.z && (float)ddy < a.z) {
-          b = r0[ri].b;
           keep = true;
           if (cone_ok) {
             float Dx = tcx - a.x, Dy = tcy - a.y;

@@ -86,6 +86,11 @@ def barrier():
         dist.barrier()
 
 
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def max_over_ranks(value, device):
     """MAX all-reduce of a python float (timing contract of bench.py)."""
     if not dist.is_initialized():

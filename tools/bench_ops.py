@@ -13,7 +13,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from posecnn_amd import config, ops, synth  # noqa: E402
+from posecnn_amd import _lib, config, ops, synth  # noqa: E402
 
 
 def timeit(fn, iters, warmup=3):
@@ -62,6 +62,21 @@ def main():
             r.update({"rois": nroi, "fg_pixels": nfg, "algorithmic_bytes": alg, "GBps_algorithmic": alg / r["ms_median"] / 1e6,
                       "streamed_field_bytes": 4 * H * W * (1 + 3 * C) * B})
             res["hough"] = r
+        if "hough_empty" in which:
+            # all-background labels: every hv_vote block exits at once -> launch/dispatch floor of the sequence
+            zl = torch.zeros_like(label)
+            _lib.profile_enable(True)
+            r = timeit(lambda: ops.hough_voting_gpu_padded(zl, vertex, ext, meta, None, 0, -1.0, 0.02, 10), a.iters)
+            r["kernels_us"] = {k: round(v["avg_us"], 2) for k, v in _lib.profile_report().items()}
+            _lib.profile_enable(False)
+            res["hough_empty"] = r
+        if "hough" in which:
+            _lib.profile_enable(True)
+            for _ in range(5):
+                ops.hough_voting_gpu_padded(label, vertex, ext, meta, None, 0, -1.0, 0.02, 10)
+            torch.cuda.synchronize()
+            res["hough"]["kernels_us"] = {k: round(v["avg_us"], 2) for k, v in _lib.profile_report().items()}
+            _lib.profile_enable(False)
         if "hough_thr" in which:
             r = timeit(lambda: ops.hough_voting_gpu_padded(label, vertex, ext, meta, None, 0, 50.0, 0.002, 10), a.iters)
             res["hough_vote_threshold_50"] = r
