@@ -325,3 +325,17 @@ def test_every_hough_cell_matches_oracle(gpu, case):
             diff = np.flatnonzero(hs[n, s] != whs[n, c])
             assert diff.size == 0, "image %d class %d: %d cells differ, first cell %d gpu %s oracle %s" % (
                 n, c, diff.size, diff[0], hs[n, s, diff[0]], whs[n, c, diff[0]])
+
+
+def test_linemod_stress_size_960x1280(gpu):
+    """BASELINE configs[4]: 1280x960 inputs, 13 LINEMOD classes + background (C = 14); intrinsics
+    scale with the image (lib/fcn/test.py:130-131). Parity with the oracle at the full size."""
+    H, W, C = 960, 1280, 14
+    K = config.DEMO_INTRINSICS.copy(); K[:2] *= W / 640.0
+    ext = np.vstack([np.zeros((1, 3), F), np.linspace(0.08, 0.25, (C - 1) * 3).reshape(C - 1, 3).astype(F)])
+    label, vertex, fr = synth.make_batch(500, 1, H=H, W=W, C=C, n_obj=4, extents=ext, K=K)
+    meta = config.make_meta_data(K)[None]
+    got = both(gpu, label, vertex, ext, meta)
+    assert int(got[5][1]) == 4
+    # Hough windows at this size exceed 600 px: also exercise the local-maximum path once
+    both(gpu, label, vertex, ext, meta, vote_thr=200.0, per_thr=0.002)
