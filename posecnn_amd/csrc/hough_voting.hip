@@ -732,52 +732,44 @@ __global__ __launch_bounds__(256) void hv_localmax_kernel(
     long long g = cbase + r * 256 + tid;
     bool cand = false;
     HvMax e;
+    int s = 0, cell = 0;
+    float v = 0.f;
+    bool above = false;
     if (g < ncell) {
-      int s = (int)(g / HW), cell = (int)(g - (long long)s * HW);
+      s = (int)(g / HW);
+      cell = (int)(g - (long long)s * HW);
+      v = hs[((size_t)n * (C - 1) + s) * HW + cell];
+      above = v > vote_thr;
+    }
+    // most 256-cell rounds hold no cell above the threshold: one coalesced read, then out
+    if (!__syncthreads_or(above ? 1 : 0)) continue;
+    bool hs_cand = false;  // the conditions of compute_max_indexes_kernel that need only the votes
+    if (above) {
       const float* hsl = hs + ((size_t)n * (C - 1) + s) * HW;
-      float v = hsl[cell];
-      if (v > vote_thr) {
-        int cx = cell % W, cy = cell / W;
-        bool greater = false;
-        for (int x = cx - 3; x <= cx + 3; x++)
-          for (int y = cy - 3; y <= cy + 3; y++)
-            if (x >= 0 && x < W && y >= 0 && y < H && hsl[y * W + x] > v) greater = true;
-        if (!greater) {
-          // hough_data of this cell (per-thread serial form of compute_hough_kernel :266-331)
-          int cls = slots_g[n * C + s];
-          int m = (tot_g[n * C + cls] + skip - 1) / skip;
-          const HvRec* r0 = rec + (size_t)n * reccap + recoff_g[n * C + cls];
-          const float cxf = (float)cx, cyf = (float)cy;
-          float sumd = 0.f, cnt = 0.f;
-          for (int i = 0; i < m; i++) {
-            float4 a = r0[i].a, b = r0[i].b;
-            float dx = cxf - a.x, dy = cyf - a.y;
-            if (fabsf(dx) < a.z && fabsf(dy) < a.z &&
-                angle_pass_exact(b.x, b.y, b.z, dx, dy, inlier)) {
-              cnt += 1.f;
-              sumd += b.w;
-            }
-          }
-          if (cnt > 0) {
-            float dist = div_rn(sumd, cnt);
-            float thr = project_box(extents, cls, fx, fy, px, py, dist);
-            float bw = -1.f, bh = -1.f;
-            for (int i = 0; i < m; i++) {
-              float4 a = r0[i].a, b = r0[i].b;
-              float dx = cxf - a.x, dy = cyf - a.y;
-              if (angle_pass_exact(b.x, b.y, b.z, dx, dy, inlier)) {
-                float ax = fabsf(dx), ay = fabsf(dy);
-                if (ax < thr && ay < thr) { bw = fmaxf(bw, ax); bh = fmaxf(bh, ay); }
-              }
-            }
-            float bh2 = 2 * bh, bw2 = 2 * bw;
-            if (bh2 > 0 && bw2 > 0 && !(div_rn(v, bh2 * bw2) < per_thr)) {
-              cand = true;
-              e.cls = cls; e.idx = cell; e.votes = v; e.dist = dist; e.bh2 = bh2; e.bw2 = bw2;
-              e.pad0 = e.pad1 = 0;
-            }
-          }
-        }
+      int cx = cell % W, cy = cell / W;
+      bool greater = false;
+      for (int x = cx - 3; x <= cx + 3; x++)
+        for (int y = cy - 3; y <= cy + 3; y++)
+          if (x >= 0 && x < W && y >= 0 && y < H && hsl[y * W + x] > v) greater = true;
+      hs_cand = !greater;
+    }
+    // hough_data of each surviving cell, evaluated by the whole wave (the per-thread serial form
+    // kept 63 lanes idle per candidate); depth sum in canonical pixel order (wave_cell_data)
+    unsigned long long cm = __ballot(hs_cand);
+    while (cm) {
+      const int src = __ffsll((long long)cm) - 1;
+      cm &= cm - 1;
+      const int cs = __shfl(s, src), ccell = __shfl(cell, src);
+      const float cv = __shfl(v, src);
+      const int cls = slots_g[n * C + cs];
+      const int m = (tot_g[n * C + cls] + skip - 1) / skip;
+      const HvRec* r0 = rec + (size_t)n * reccap + recoff_g[n * C + cls];
+      float votes, dist, bh2, bw2;
+      wave_cell_data(r0, m, ccell % W, ccell / W, cls, extents, fx, fy, px, py, inlier, votes, dist, bh2, bw2);
+      if (lane == src && bh2 > 0 && bw2 > 0 && !(div_rn(cv, bh2 * bw2) < per_thr)) {
+        cand = true;
+        e.cls = cls; e.idx = ccell; e.votes = cv; e.dist = dist; e.bh2 = bh2; e.bw2 = bw2;
+        e.pad0 = e.pad1 = 0;
       }
     }
     unsigned long long mask = __ballot(cand);
