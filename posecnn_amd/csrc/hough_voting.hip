@@ -61,7 +61,7 @@ struct __attribute__((aligned(16))) HvMax {
 struct HvLayout {
   int nchunk, ntx, nty, ntiles, reccap, cap, capmax, nlm;
   size_t off_hist, off_tot, off_slots, off_nslots, off_recoff, off_rec, off_tilemax, off_maxima,
-      off_nmax, off_hs, off_chunkcnt, off_chunkcand, total;
+      off_nmax, off_hs, off_chunkcnt, off_chunkcand, off_flags, total;
 };
 
 HvLayout hv_layout(int B, int H, int W, int C, bool need_hs, int skip)
@@ -91,8 +91,9 @@ HvLayout hv_layout(int B, int H, int W, int C, bool need_hs, int skip)
     L.off_hs = take(sizeof(float) * (size_t)B * (C - 1) * HW);
     L.off_chunkcnt = take(sizeof(int) * (size_t)B * L.nlm);
     L.off_chunkcand = take(sizeof(HvMax) * (size_t)B * L.nlm * L.capmax);
+    L.off_flags = take((size_t)B * (C - 1) * HW);
   } else {
-    L.off_hs = L.off_chunkcnt = L.off_chunkcand = 0;
+    L.off_hs = L.off_chunkcnt = L.off_chunkcand = L.off_flags = 0;
   }
   L.total = o;
   return L;
@@ -537,49 +538,78 @@ __global__ __launch_bounds__(256) void hv_vote_kernel(
   }
 }
 
+constexpr int WCD_CAP = 1024;  // floats of LDS per wave for wave_cell_data
+
 // One wave: hough_data of a single cell — second half of compute_hough_kernel (:296-331) plus the
 // depth sum of the first half (:269-294) in canonical (ascending pixel) order.
 __device__ void wave_cell_data(const HvRec* __restrict__ r0, int m, int cx, int cy, int cls,
                                const float* __restrict__ extents, float fx, float fy, float px,
-                               float py, float inlier, float& votes_out, float& dist,
-                               float& bh2, float& bw2)
+                               float py, float inlier, float* s_buf, float& votes_out,
+                               float& dist, float& bh2, float& bw2)
 {
   const int lane = lane_id();
   const float cxf = (float)cx, cyf = (float)cy;
   float sumd = 0.f;
-  int cnt = 0;
-  for (int b0 = 0; b0 < m; b0 += 64) {
-    int ri = b0 + lane;
-    bool pass = false;
-    float d = 0.f;
-    if (ri < m) {
-      float4 a = r0[ri].a, b = r0[ri].b;
-      float dx = cxf - a.x, dy = cyf - a.y;
-      d = b.w;
-      pass = fabsf(dx) < a.z && fabsf(dy) < a.z && angle_pass_exact(b.x, b.y, b.z, dx, dy, inlier);
+  int cnt = 0, fill = 0;
+  // 4 x 64 records per trip: the 8 loads are issued before any use, so a trip costs one L2 round
+  // trip; ballots are consumed in ascending record order (k, then lane) = canonical pixel order
+  for (int b0 = 0; b0 < m; b0 += 256) {
+    float4 a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int ri = min(b0 + k * 64 + lane, m - 1);
+      a[k] = r0[ri].a;
+      b[k] = r0[ri].b;
     }
-    unsigned long long mask = __ballot(pass);
-    cnt += __popcll(mask);
-    while (mask) {
-      int src = __ffsll((long long)mask) - 1;
-      sumd += __shfl(d, src);
-      mask &= mask - 1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int ri = b0 + k * 64 + lane;
+      const float dx = cxf - a[k].x, dy = cyf - a[k].y;
+      const float d = b[k].w;
+      const bool pass = ri < m && fabsf(dx) < a[k].z && fabsf(dy) < a[k].z &&
+                        angle_pass_exact(b[k].x, b[k].y, b[k].z, dx, dy, inlier);
+      // voters' depths go to this wave's LDS strip in record order; lane 0 adds them up one by
+      // one (the reference's `distance += d` is a sequential f32 sum). A shuffle per voter costs
+      // ~10x more than an LDS read here.
+      const unsigned long long mask = __ballot(pass);
+      if (pass) s_buf[fill + __popcll(mask & lanemask_lt())] = d;
+      fill += __popcll(mask);
+      __builtin_amdgcn_wave_barrier();  // same-wave LDS: in order in hardware; keep the compiler from reordering
+      if (fill > WCD_CAP - 64) {
+        if (lane == 0)
+          for (int i = 0; i < fill; i++) sumd += s_buf[i];
+        cnt += fill;
+        fill = 0;
+        __builtin_amdgcn_wave_barrier();
+      }
     }
   }
+  if (lane == 0)
+    for (int i = 0; i < fill; i++) sumd += s_buf[i];
+  cnt += fill;
+  sumd = __shfl(sumd, 0);
   votes_out = (float)cnt;
   dist = 0.f; bh2 = 0.f; bw2 = 0.f;
   if (cnt > 0) {
     dist = div_rn(sumd, (float)cnt);
     float thr = project_box(extents, cls, fx, fy, px, py, dist);
     float bw = -1.f, bh = -1.f;
-    for (int b0 = 0; b0 < m; b0 += 64) {
-      int ri = b0 + lane;
-      if (ri < m) {
-        float4 a = r0[ri].a, b = r0[ri].b;
-        float dx = cxf - a.x, dy = cyf - a.y;
-        if (angle_pass_exact(b.x, b.y, b.z, dx, dy, inlier)) {
-          float ax = fabsf(dx), ay = fabsf(dy);
-          if (ax < thr && ay < thr) { bw = fmaxf(bw, ax); bh = fmaxf(bh, ay); }
+    for (int b0 = 0; b0 < m; b0 += 256) {
+      float4 a[4], b[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int ri = min(b0 + k * 64 + lane, m - 1);
+        a[k] = r0[ri].a;
+        b[k] = r0[ri].b;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int ri = b0 + k * 64 + lane;
+        const float dx = cxf - a[k].x, dy = cyf - a[k].y;
+        const float ax = fabsf(dx), ay = fabsf(dy);
+        if (ri < m && ax < thr && ay < thr && angle_pass_exact(b[k].x, b[k].y, b[k].z, dx, dy, inlier)) {
+          bw = fmaxf(bw, ax);
+          bh = fmaxf(bh, ay);
         }
       }
     }
@@ -703,13 +733,61 @@ __global__ __launch_bounds__(256) void hv_select_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// threshold_vote > 0, step 1: the conditions of compute_max_indexes_kernel (:351-367) that need
+// only the votes — v > threshold and no strictly greater cell in the 7x7 neighbourhood — per
+// 32x32 tile with a 3-cell halo staged in LDS; tiles whose maximum (known from hv_vote) is not above
+// the threshold are cleared without reading the Hough space.
+__global__ __launch_bounds__(256) void hv_lmflag_kernel(const int* __restrict__ nslots_g,
+                                                        const int2* __restrict__ tilemax,
+                                                        const float* __restrict__ hs,
+                                                        unsigned char* __restrict__ flags, int H, int W,
+                                                        int C, float vote_thr, int ntx, int ntiles)
+{
+  const int n = blockIdx.z, s = blockIdx.y, tile = blockIdx.x;
+  if (s >= nslots_g[n]) return;
+  constexpr int HALO = 3, TS = HV_TILE + 2 * HALO;
+  __shared__ float s_h[TS][TS + 1];
+  const int tid = threadIdx.x;
+  const int tx0 = (tile % ntx) * HV_TILE, ty0 = (tile / ntx) * HV_TILE;
+  const size_t base = ((size_t)n * (C - 1) + s) * ((size_t)H * W);
+  const bool live = (float)tilemax[((size_t)n * (C - 1) + s) * ntiles + tile].x > vote_thr;
+  if (live) {
+    for (int i = tid; i < TS * TS; i += 256) {
+      const int ly = i / TS, lx = i - ly * TS;
+      const int y = ty0 + ly - HALO, x = tx0 + lx - HALO;
+      s_h[ly][lx] = (x >= 0 && x < W && y >= 0 && y < H) ? hs[base + (size_t)y * W + x] : -1.f;  // votes >= 0
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int lx = tid & 31, ly = (tid >> 5) + 8 * j;
+    const int x = tx0 + lx, y = ty0 + ly;
+    if (x >= W || y >= H) continue;
+    unsigned char f = 0;
+    if (live) {
+      const float v = s_h[ly + HALO][lx + HALO];
+      if (v > vote_thr) {
+        bool greater = false;
+#pragma unroll
+        for (int dy = -HALO; dy <= HALO; dy++)
+#pragma unroll
+          for (int dx = -HALO; dx <= HALO; dx++) greater |= s_h[ly + HALO + dy][lx + HALO + dx] > v;
+        f = greater ? 0 : 1;
+      }
+    }
+    flags[base + (size_t)y * W + x] = f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // threshold_vote > 0: compute_max_indexes_kernel (:335-383), one thread per Hough cell.
 __global__ __launch_bounds__(256) void hv_localmax_kernel(
     const HvRec* __restrict__ rec, const int* __restrict__ nslots_g,
     const int* __restrict__ slots_g, const int* __restrict__ tot_g,
     const int* __restrict__ recoff_g, const float* __restrict__ hs,
-    const float* __restrict__ extents, const float* __restrict__ meta,
-    int* __restrict__ chunkcnt, HvMax* __restrict__ chunkcand, int H, int W, int C, int skip,
+    const unsigned char* __restrict__ flags, const float* __restrict__ extents,
+    const float* __restrict__ meta, int* __restrict__ chunkcnt, HvMax* __restrict__ chunkcand, int H, int W, int C, int skip,
     float inlier, float vote_thr, float per_thr, int reccap, int capmax, int cap, int nlm,
     int num_meta)
 {
@@ -721,6 +799,7 @@ __global__ __launch_bounds__(256) void hv_localmax_kernel(
   if (cbase >= ncell) return;
   __shared__ int s_wc[4];
   __shared__ int s_base;
+  __shared__ float s_wcd[4][WCD_CAP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) s_base = 0;
   __syncthreads();
@@ -728,59 +807,68 @@ __global__ __launch_bounds__(256) void hv_localmax_kernel(
   const float fx = md[0], px = md[2], fy = md[4], py = md[5];
   HvMax* out = chunkcand + ((size_t)n * nlm + chunk) * capmax;
 
-  for (int r = 0; r < LM_CHUNK / 256; r++) {
+  __shared__ int s_cs[256], s_ccell[256];
+  __shared__ float s_cv[256];
+  __shared__ HvMax s_res[4];
+  __shared__ int s_acc[4];
+  for (int r = 0; r < LM_CHUNK / 256 && s_base < cap; r++) {
     long long g = cbase + r * 256 + tid;
-    bool cand = false;
-    HvMax e;
     int s = 0, cell = 0;
     float v = 0.f;
-    bool above = false;
+    bool hs_cand = false;  // v > threshold and 7x7 local maximum, from hv_lmflag_kernel
     if (g < ncell) {
       s = (int)(g / HW);
       cell = (int)(g - (long long)s * HW);
-      v = hs[((size_t)n * (C - 1) + s) * HW + cell];
-      above = v > vote_thr;
+      const size_t gi = ((size_t)n * (C - 1) + s) * HW + cell;
+      hs_cand = flags[gi] != 0;
+      if (hs_cand) v = hs[gi];
     }
-    // most 256-cell rounds hold no cell above the threshold: one coalesced read, then out
-    if (!__syncthreads_or(above ? 1 : 0)) continue;
-    bool hs_cand = false;  // the conditions of compute_max_indexes_kernel that need only the votes
-    if (above) {
-      const float* hsl = hs + ((size_t)n * (C - 1) + s) * HW;
-      int cx = cell % W, cy = cell / W;
-      bool greater = false;
-      for (int x = cx - 3; x <= cx + 3; x++)
-        for (int y = cy - 3; y <= cy + 3; y++)
-          if (x >= 0 && x < W && y >= 0 && y < H && hsl[y * W + x] > v) greater = true;
-      hs_cand = !greater;
-    }
-    // hough_data of each surviving cell, evaluated by the whole wave (the per-thread serial form
-    // kept 63 lanes idle per candidate); depth sum in canonical pixel order (wave_cell_data)
-    unsigned long long cm = __ballot(hs_cand);
-    while (cm) {
-      const int src = __ffsll((long long)cm) - 1;
-      cm &= cm - 1;
-      const int cs = __shfl(s, src), ccell = __shfl(cell, src);
-      const float cv = __shfl(v, src);
-      const int cls = slots_g[n * C + cs];
-      const int m = (tot_g[n * C + cls] + skip - 1) / skip;
-      const HvRec* r0 = rec + (size_t)n * reccap + recoff_g[n * C + cls];
-      float votes, dist, bh2, bw2;
-      wave_cell_data(r0, m, ccell % W, ccell / W, cls, extents, fx, fy, px, py, inlier, votes, dist, bh2, bw2);
-      if (lane == src && bh2 > 0 && bw2 > 0 && !(div_rn(cv, bh2 * bw2) < per_thr)) {
-        cand = true;
-        e.cls = cls; e.idx = ccell; e.votes = cv; e.dist = dist; e.bh2 = bh2; e.bw2 = bw2;
-        e.pad0 = e.pad1 = 0;
-      }
-    }
-    unsigned long long mask = __ballot(cand);
+    // most 256-cell rounds hold no candidate: one coalesced byte read, then out
+    if (!__syncthreads_or(hs_cand ? 1 : 0)) continue;
+    // compact the round's candidates (ascending cell order) into LDS
+    const unsigned long long mask = __ballot(hs_cand);
     if (lane == 0) s_wc[wave] = __popcll(mask);
     __syncthreads();
-    int pos = s_base + __popcll(mask & lanemask_lt());
+    int pos = __popcll(mask & lanemask_lt());
     for (int w2 = 0; w2 < wave; w2++) pos += s_wc[w2];
-    if (cand && pos < cap) out[pos] = e;
+    const int nc = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+    if (hs_cand) { s_cs[pos] = s; s_ccell[pos] = cell; s_cv[pos] = v; }
     __syncthreads();
-    if (tid == 0) s_base += s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
-    __syncthreads();
+    // hough_data of the candidates, 4 at a time (one wave each, depth sums in canonical order),
+    // accepted in ascending order. Only the first `cap` accepted maxima of an image can ever be
+    // emitted (index_size, .cu.cc:377-379,773-774), so a chunk stops as soon as it holds `cap`: a
+    // plateau of equal votes (every cell a "no strictly greater neighbour" maximum) would otherwise
+    // cost one full pass over the class' pixels per plateau cell.
+    for (int i0 = 0; i0 < nc && s_base < cap; i0 += 4) {
+      const int ci = i0 + wave;
+      if (ci < nc) {
+        const int cs = s_cs[ci], ccell = s_ccell[ci];
+        const float cv = s_cv[ci];
+        const int cls = slots_g[n * C + cs];
+        const int m = (tot_g[n * C + cls] + skip - 1) / skip;
+        const HvRec* r0 = rec + (size_t)n * reccap + recoff_g[n * C + cls];
+        float votes, dist, bh2, bw2;
+        wave_cell_data(r0, m, ccell % W, ccell / W, cls, extents, fx, fy, px, py, inlier, s_wcd[wave], votes, dist, bh2, bw2);
+        if (lane == 0) {
+          const bool ok = bh2 > 0 && bw2 > 0 && !(div_rn(cv, bh2 * bw2) < per_thr);
+          s_acc[wave] = ok ? 1 : 0;
+          HvMax e;
+          e.cls = cls; e.idx = ccell; e.votes = cv; e.dist = dist; e.bh2 = bh2; e.bw2 = bw2;
+          e.pad0 = e.pad1 = 0;
+          s_res[wave] = e;
+        }
+      } else if (lane == 0) {
+        s_acc[wave] = 0;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int b = s_base;
+        for (int w2 = 0; w2 < 4; w2++)
+          if (s_acc[w2]) { if (b < cap) out[b] = s_res[w2]; b++; }
+        s_base = b;
+      }
+      __syncthreads();
+    }
   }
   if (tid == 0) chunkcnt[(size_t)n * nlm + chunk] = s_base;
 }
@@ -1064,8 +1152,11 @@ extern "C" int pcnn_hough_voting_fwd(const int32_t* label, const float* vertex,
                        tot, recoff, tilemax, extents, meta, maxima, nmax, W, C, skip, inlier,
                        L.ntiles, L.reccap, L.cap, L.capmax, num_meta);
   } else {
+    unsigned char* flags = (unsigned char*)(ws + L.off_flags);
+    PCNN_LAUNCH(hv_lmflag_kernel, dim3(L.ntiles, C - 1, B), dim3(256), 0, stream, nslots, tilemax, hs,
+                flags, H, W, C, vote_thr, L.ntx, L.ntiles);
     PCNN_LAUNCH(hv_localmax_kernel, dim3(L.nlm, B), dim3(256), 0, stream, rec, nslots,
-                       slots, tot, recoff, hs, extents, meta, chunkcnt, chunkcand, H, W, C, skip,
+                       slots, tot, recoff, hs, flags, extents, meta, chunkcnt, chunkcand, H, W, C, skip,
                        inlier, vote_thr, per_thr, L.reccap, L.capmax, L.cap, L.nlm, num_meta);
     PCNN_LAUNCH(hv_gather_kernel, dim3(B), dim3(256), 0, stream, nslots, chunkcnt,
                        chunkcand, maxima, nmax, HW, L.nlm, L.cap, L.capmax);

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--thr", type=float, default=50.0)
     ap.add_argument("--ops", default="hough,hough_thr,hard_label,softmax,roi_pool,adl,backproject")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -78,7 +79,13 @@ def main():
             res["hough"]["kernels_us"] = {k: round(v["avg_us"], 2) for k, v in _lib.profile_report().items()}
             _lib.profile_enable(False)
         if "hough_thr" in which:
-            r = timeit(lambda: ops.hough_voting_gpu_padded(label, vertex, ext, meta, None, 0, 50.0, 0.002, 10), a.iters)
+            r = timeit(lambda: ops.hough_voting_gpu_padded(label, vertex, ext, meta, None, 0, a.thr, 0.002, 10), a.iters)
+            _lib.profile_enable(True)
+            for _ in range(3):
+                ops.hough_voting_gpu_padded(label, vertex, ext, meta, None, 0, a.thr, 0.002, 10)
+            torch.cuda.synchronize()
+            r["kernels_us"] = {k: round(v["avg_us"], 2) for k, v in _lib.profile_report().items()}
+            _lib.profile_enable(False)
             res["hough_vote_threshold_50"] = r
         if "roi_pool" in which:
             g = torch.Generator(device=dev).manual_seed(1)
