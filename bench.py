@@ -115,30 +115,50 @@ def main():
     feed_cache = None
     last = {}
 
-    def step(i):
+    drain = pdist.HostDrain(depth=2)
+
+    def launch(i):
+        """Enqueue one batch: backbone + heads + Hough voting + RoI/pose branch + all-gather + async D2H.
+        No host synchronisation in here."""
         nonlocal feed_cache
         data, data_p, planted, _ = bufs[i % len(bufs)]
         if feed_cache is None:
             feed_cache = fcn._feed(net, data, data_p, K, config.LOV_EXTENTS, pts, config.LOV_SYMMETRY, 22, dev)
         det = fcn.im_segment_batch(net, data, K, config.LOV_EXTENTS, pts, config.LOV_SYMMETRY, data_p=data_p,
                                    planted=planted, feed_cache=feed_cache, with_losses=not a.no_losses)
-        rows, counts = pdist.all_gather_detections(det.rows, det.count, frame_offset=rank * B)
-        flat = pdist.flatten_gathered(rows, counts)          # device -> host (the only sync of the step)
-        rois, poses = fcn.finalize_batch(flat, flat.shape[0])  # class-aware NMS + pose rows, host
-        last["rois"], last["det"] = rois, det
+        packed = pdist.all_gather_packed(det.rows, det.count, frame_offset=rank * B)
+        last["det"] = det
+        return drain.submit(packed)
+
+    def finish(ticket):
+        """Wait for THAT batch's detections and post-process them on the host (class-aware NMS, pose rows)."""
+        flat = drain.collect(ticket)
+        rois, poses = fcn.finalize_batch(flat, flat.shape[0])
+        last["rois"] = rois
         return rois.shape[0]
 
+    def run(first, n):
+        """n batches, software-pipelined by one: batch i+1 is enqueued before batch i is collected, so
+        the D2H latency and the host NMS of batch i overlap the kernels of batch i+1. Every batch is
+        launched AND finished inside the call."""
+        ndet, pending = 0, None
+        for i in range(n):
+            t = launch(first + i)
+            if pending is not None:
+                ndet += finish(pending)
+            pending = t
+        if pending is not None:
+            ndet += finish(pending)
+        return ndet
+
     with torch.no_grad():
-        for i in range(a.warmup):
-            step(i)
+        run(0, a.warmup)
         torch.cuda.synchronize()
         _lib.profile_enable(True)   # HIP events around every library kernel, on the launch stream
         pdist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ndet = 0
-        for i in range(a.steps):
-            ndet += step(a.warmup + i)
+        ndet = run(a.warmup, a.steps)
         torch.cuda.synchronize()
         pdist.barrier()
         t1 = time.perf_counter()

@@ -100,6 +100,28 @@ int pcnn_hough_voting_fwd(const int32_t* label, const float* vertex, const float
                           int32_t* top_domain, int32_t* num_rois,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* Fused vertex head -> Hough voting (replaces the pair
+ * `deconv(16,16,128,8,8,'upscore_vertex') -> conv(1,1,3C,'vertex_pred')` + Houghvotinggpu of
+ * lib/networks/vgg16_convs.py:152-163 without materialising `vertex_pred`).
+ *   z     f32 [B, H/stride, W/stride, 3*C]   the 1x1 `vertex_pred` conv applied at low resolution
+ *                                            (it commutes with the fixed bilinear deconv), no bias
+ *   bias  f32 [3*C]                          `vertex_pred/biases`
+ * The op behaves exactly like pcnn_hough_voting_fwd on
+ * vertex = pcnn_deconv_bilinear_fwd(z, kernel, stride, bias): only the own-class (u, v, log d) of
+ * the sampled foreground pixels are interpolated (same arithmetic, same bits), so the
+ * [B,H,W,3C] tensor (81 MB/frame at 640x480, C=22) never exists. Everything else (outputs,
+ * workspace, canonical order, attrs) as above. */
+int pcnn_hough_voting_lowres_fwd(const int32_t* label, const float* z, const float* bias,
+                                 int kernel, int stride, const float* extents,
+                                 const float* meta, const float* gt,
+                                 int batch, int height, int width, int num_classes,
+                                 int num_meta, int num_gt,
+                                 int is_train, float threshold_vote, float threshold_percentage,
+                                 int skip_pixels, float inlier_threshold, int label_threshold,
+                                 float* top_box, float* top_pose, float* top_target,
+                                 float* top_weight, int32_t* top_domain, int32_t* num_rois,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
 /* Diagnostics for tests: byte offsets of intermediate buffers inside the workspace.
  * offsets[8] = { hough space f32 [B][C-1][H*W] (SIZE_MAX unless threshold_vote > 0), pixel records
  * (32 B each), class totals i32 [B][C], slot classes i32 [B][C], slot counts i32 [B], record

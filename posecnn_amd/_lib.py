@@ -37,6 +37,11 @@ SIGNATURES = {
                                       c_int, c_float, c_float, c_int, c_float, c_int,
                                       _P, _P, _P, _P, _P, _P,
                                       _P, c_size_t, _P]),
+    "pcnn_hough_voting_lowres_fwd": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P,
+                                             c_int, c_int, c_int, c_int, c_int, c_int,
+                                             c_int, c_float, c_float, c_int, c_float, c_int,
+                                             _P, _P, _P, _P, _P, _P,
+                                             _P, c_size_t, _P]),
     "pcnn_hough_voting_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "pcnn_roi_pool_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_float, c_int, _P, _P, _P]),

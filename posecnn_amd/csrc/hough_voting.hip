@@ -29,7 +29,7 @@
 // Exactness: the vote predicate is evaluated either by a filter that provably agrees with the
 // exact expression (|q~ - q| << 2e-5) or by the exact expression itself (IEEE div/sqrt, no
 // contraction), so outputs equal the CPU oracle bit for bit.
-#include "pcnn_device.h"
+#include "bilinear.h"
 
 namespace {
 
@@ -227,8 +227,20 @@ __global__ __launch_bounds__(256) void hv_hist_kernel(const int* __restrict__ la
 }
 
 // ---------------------------------------------------------------------------------------------
+// Where the (u, v, log d) triple of a sampled pixel comes from: the full-resolution `vertex_pred`
+// [B,H,W,3C] of the reference op, or (fused head) the 1/s-resolution field
+// z [B,Hl,Wl,3C] + bias [3C] that `vertex_pred = deconv_k,s(z) + bias` would have been built from;
+// then only the sampled pixels' own-class channels are ever interpolated (bilinear.h arithmetic,
+// bit-identical to deconv_bilinear_kernel) and the 81 MB/frame tensor is never written or read.
+struct HvVertexSrc {
+  const float* full;
+  const float* z;
+  const float* bias;
+  int Hl, Wl, k, s;
+};
+
 __global__ __launch_bounds__(256) void hv_scatter_kernel(
-    const int* __restrict__ label, const float* __restrict__ vertex,
+    const int* __restrict__ label, const HvVertexSrc vs,
     const float* __restrict__ extents, const float* __restrict__ meta,
     const int* __restrict__ hist, int* __restrict__ tot_g, int* __restrict__ slots_g,
     int* __restrict__ nslots_g, int* __restrict__ recoff_g, HvRec* __restrict__ rec, int HW, int W,
@@ -323,10 +335,22 @@ __global__ __launch_bounds__(256) void hv_scatter_kernel(
       if (ro >= 0 && (my_rank % skip) == 0) {
         int i = wbase + r * 64 + lane;
         int x = i % W, y = i / W;
-        const float* vp = vertex + ((size_t)n * HW + i) * (PCNN_VERTEX_CHANNELS * C) +
-                          PCNN_VERTEX_CHANNELS * l;
-        float u = vp[0], v = vp[1];
-        float d = exp_f32(vp[2]);
+        float u, v, logd;
+        if (vs.full) {
+          const float* vp = vs.full + ((size_t)n * HW + i) * (PCNN_VERTEX_CHANNELS * C) +
+                            PCNN_VERTEX_CHANNELS * l;
+          u = vp[0]; v = vp[1]; logd = vp[2];
+        } else {
+          const int VC = PCNN_VERTEX_CHANNELS * C, pad = (vs.k - vs.s) / 2;
+          const Taps ty = make_taps(y, vs.k, vs.s, pad, vs.Hl);
+          const Taps tx = make_taps(x, vs.k, vs.s, pad, vs.Wl);
+          const float* zb = vs.z + (size_t)n * vs.Hl * vs.Wl * VC;
+          const int c0 = PCNN_VERTEX_CHANNELS * l;
+          u = bilinear_at(zb, ty, tx, vs.Wl, VC, c0) + vs.bias[c0];
+          v = bilinear_at(zb, ty, tx, vs.Wl, VC, c0 + 1) + vs.bias[c0 + 1];
+          logd = bilinear_at(zb, ty, tx, vs.Wl, VC, c0 + 2) + vs.bias[c0 + 2];
+        }
+        float d = exp_f32(logd);
         float n1 = sqrt_rn(u * u + v * v);
         float thr = project_box(extents, l, fx, fy, px, py, d);
         float rn1 = (n1 >= 1e-15f && n1 <= 1e15f) ? div_rn(1.0f, n1) : __builtin_nanf("");
@@ -1091,7 +1115,8 @@ extern "C" int pcnn_hough_voting_debug_layout(int batch, int height, int width, 
   return PCNN_OK;
 }
 
-extern "C" int pcnn_hough_voting_fwd(const int32_t* label, const float* vertex,
+namespace {
+int hough_fwd_impl(const int32_t* label, const HvVertexSrc vs,
                                      const float* extents, const float* meta, const float* gt,
                                      int B, int H, int W, int C, int num_meta, int num_gt,
                                      int is_train, float vote_thr, float per_thr, int skip,
@@ -1105,7 +1130,7 @@ extern "C" int pcnn_hough_voting_fwd(const int32_t* label, const float* vertex,
   PCNN_REQUIRE(is_train >= 0, PCNN_EINVAL, "hough_voting: Need is_train >= 0, got %d", is_train);
   PCNN_REQUIRE(num_meta >= 6, PCNN_EINVAL, "hough_voting: meta_data needs >= 6 values per image (got %d)", num_meta);
   PCNN_REQUIRE(num_gt >= 0, PCNN_EINVAL, "hough_voting: num_gt < 0");
-  PCNN_REQUIRE(label && vertex && extents && meta, PCNN_ENULL, "hough_voting: NULL input");
+  PCNN_REQUIRE(label && (vs.full || (vs.z && vs.bias)) && extents && meta, PCNN_ENULL, "hough_voting: NULL input");
   PCNN_REQUIRE(gt || num_gt == 0, PCNN_ENULL, "hough_voting: gt is NULL but num_gt = %d", num_gt);
   PCNN_REQUIRE(top_box && top_pose && top_target && top_weight && top_domain && num_rois,
                PCNN_ENULL, "hough_voting: NULL output");
@@ -1141,7 +1166,7 @@ extern "C" int pcnn_hough_voting_fwd(const int32_t* label, const float* vertex,
 
   PCNN_LAUNCH(hv_hist_kernel, dim3(L.nchunk, B), dim3(256), 0, stream, label, hist, HW, C,
                      L.nchunk, zj);
-  PCNN_LAUNCH(hv_scatter_kernel, dim3(L.nchunk, B), dim3(256), 0, stream, label, vertex,
+  PCNN_LAUNCH(hv_scatter_kernel, dim3(L.nchunk, B), dim3(256), 0, stream, label, vs,
                      extents, meta, hist, tot, slots, nslots, recoff, rec, HW, W, C, L.nchunk,
                      skip, label_thr, num_meta, L.reccap, inlier);
   PCNN_LAUNCH(hv_vote_kernel, dim3(L.ntiles, C - 1, B), dim3(256), 0, stream, rec, nslots,
@@ -1165,6 +1190,45 @@ extern "C" int pcnn_hough_voting_fwd(const int32_t* label, const float* vertex,
                      gt, top_box, top_pose, top_target, top_weight, top_domain, num_rois, B, W, C,
                      L.cap, L.capmax, num_meta, num_gt, is_train);
   return check_launch("hough_voting_fwd");
+}
+}  // namespace
+
+extern "C" int pcnn_hough_voting_fwd(const int32_t* label, const float* vertex,
+                                     const float* extents, const float* meta, const float* gt,
+                                     int B, int H, int W, int C, int num_meta, int num_gt,
+                                     int is_train, float vote_thr, float per_thr, int skip,
+                                     float inlier, int label_thr, float* top_box, float* top_pose,
+                                     float* top_target, float* top_weight, int32_t* top_domain,
+                                     int32_t* num_rois, void* workspace, size_t workspace_bytes,
+                                     void* stream_)
+{
+  HvVertexSrc vs = {vertex, nullptr, nullptr, 0, 0, 0, 0};
+  return hough_fwd_impl(label, vs, extents, meta, gt, B, H, W, C, num_meta, num_gt, is_train,
+                        vote_thr, per_thr, skip, inlier, label_thr, top_box, top_pose, top_target,
+                        top_weight, top_domain, num_rois, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int pcnn_hough_voting_lowres_fwd(const int32_t* label, const float* z, const float* bias,
+                                            int kernel, int stride, const float* extents,
+                                            const float* meta, const float* gt, int B, int H, int W,
+                                            int C, int num_meta, int num_gt, int is_train,
+                                            float vote_thr, float per_thr, int skip, float inlier,
+                                            int label_thr, float* top_box, float* top_pose,
+                                            float* top_target, float* top_weight,
+                                            int32_t* top_domain, int32_t* num_rois, void* workspace,
+                                            size_t workspace_bytes, void* stream_)
+{
+  PCNN_REQUIRE(z && bias, PCNN_ENULL, "hough_voting_lowres: NULL vertex field or bias");
+  PCNN_REQUIRE(stride >= 1 && kernel >= stride && (kernel - stride) % 2 == 0 && kernel <= 4 * stride,
+               PCNN_EINVAL,
+               "hough_voting_lowres: need stride >= 1, stride <= kernel <= 4*stride and (kernel - stride) even (got k=%d s=%d)",
+               kernel, stride);
+  PCNN_REQUIRE(H >= 1 && W >= 1 && H % stride == 0 && W % stride == 0, PCNN_EINVAL,
+               "hough_voting_lowres: label map %dx%d is not a multiple of the stride %d", H, W, stride);
+  HvVertexSrc vs = {nullptr, z, bias, H / stride, W / stride, kernel, stride};
+  return hough_fwd_impl(label, vs, extents, meta, gt, B, H, W, C, num_meta, num_gt, is_train,
+                        vote_thr, per_thr, skip, inlier, label_thr, top_box, top_pose, top_target,
+                        top_weight, top_domain, num_rois, workspace, workspace_bytes, stream_);
 }
 
 extern "C" int pcnn_hough_voting_bwd(float* grad_label, float* grad_vertex, int B, int H, int W,

@@ -17,43 +17,11 @@
 // acc = 0; for input rows ascending, input cols ascending: acc += (fy*fx) * in — products of the
 // bilinear taps are exact in f32 (multiples of 1/f^2), one rounding per multiply and per add,
 // then + add1, + add2, + bias in that order (the CPU checker restates it).
-#include "pcnn_device.h"
+#include "bilinear.h"
 
 namespace {
 
 using namespace pcnn;
-
-// network.py:144-150: f = ceil(k/2), c = (2f - 1 - f%2) / (2f), w[t] = 1 - |t/f - c|
-// (evaluated in double like the numpy code, then stored as f32 like tf.constant_initializer)
-__host__ __device__ inline float bilinear_tap(int t, int k)
-{
-  const int f = (k + 1) / 2;
-  const double c = (double)(2 * f - 1 - f % 2) / (2.0 * (double)f);
-  return (float)(1.0 - fabs((double)t / (double)f - c));
-}
-
-struct Taps {
-  int i0, n;       // first contributing input index and count (<= 2 when k == 2s); may be clipped
-  float w[4];      // tap weights for i0, i0+1, ...
-};
-
-// output index o of a SAME conv2d_transpose (pad = (k - s) / 2): o = s*i + t - pad, 0 <= t < k
-__device__ __forceinline__ Taps make_taps(int o, int k, int s, int pad, int n_in)
-{
-  Taps T;
-  const int a = o + pad;
-  int lo = (a - k + 1 + s - 1) / s;  // ceil((a - k + 1) / s) for a - k + 1 possibly negative
-  if (a - k + 1 < 0) lo = -((k - 1 - a) / s);
-  int hi = a / s;
-  if (lo < 0) lo = 0;
-  if (hi > n_in - 1) hi = n_in - 1;
-  T.i0 = lo;
-  T.n = hi - lo + 1;
-  if (T.n < 0) T.n = 0;
-#pragma unroll
-  for (int j = 0; j < 4; j++) T.w[j] = j < T.n ? bilinear_tap(a - s * (lo + j), k) : 0.f;
-  return T;
-}
 
 template <int V>
 struct Vec;

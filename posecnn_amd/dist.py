@@ -57,19 +57,31 @@ def pack_detections(rows, count, frame_offset=0):
     return buf
 
 
-def all_gather_detections(rows, count, frame_offset=0, group=None):
-    """Every rank ends up with all ranks' detections: returns (rows [W, cap, 14], counts [W] int64).
-    A no-op (plus reshape) at world size 1."""
+def all_gather_packed(rows, count, frame_offset=0, group=None):
+    """The collective itself: returns the packed buffer of every rank, [W, cap+1, 14] (count of
+    rank r in [r, cap, 0]). Asynchronous with respect to the host on RCCL."""
     buf = pack_detections(rows, count, frame_offset)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
-        gathered = buf.unsqueeze(0)
-    else:
-        flat = torch.empty((world * buf.shape[0], buf.shape[1]), dtype=buf.dtype, device=buf.device)
-        dist.all_gather_into_tensor(flat, buf, group=group)  # rank-major concatenation (RCCL and gloo)
-        gathered = flat.view(world, buf.shape[0], buf.shape[1])
+        return buf.unsqueeze(0)
+    flat = torch.empty((world * buf.shape[0], buf.shape[1]), dtype=buf.dtype, device=buf.device)
+    dist.all_gather_into_tensor(flat, buf, group=group)  # rank-major concatenation (RCCL and gloo)
+    return flat.view(world, buf.shape[0], buf.shape[1])
+
+
+def all_gather_detections(rows, count, frame_offset=0, group=None):
+    """Every rank ends up with all ranks' detections: returns (rows [W, cap, 14], counts [W] int64).
+    A no-op (plus reshape) at world size 1."""
+    gathered = all_gather_packed(rows, count, frame_offset, group)
     cap = rows.shape[0]
     return gathered[:, :cap], gathered[:, cap, 0].round().to(torch.int64)
+
+
+def _flatten_host(packed):
+    import numpy as np
+    cap = packed.shape[1] - 1
+    parts = [packed[r, :int(round(float(packed[r, cap, 0])))] for r in range(packed.shape[0])]
+    return np.concatenate(parts) if parts else np.zeros((0, DET_COLS), np.float32)
 
 
 def flatten_gathered(rows, counts):
@@ -79,6 +91,39 @@ def flatten_gathered(rows, counts):
     import numpy as np
     parts = [rows[r, :int(counts[r])] for r in range(rows.shape[0])]
     return np.concatenate(parts) if parts else np.zeros((0, DET_COLS), np.float32)
+
+
+class HostDrain:
+    """Device -> host drain of the gathered detection buffer without stalling the launch thread.
+
+    `submit` enqueues an asynchronous copy of the packed [W, cap+1, 14] buffer into one of `depth`
+    pinned host buffers and records an event; `collect` waits for THAT event only and returns the
+    flattened [sum(counts), 14] rows. With depth 2 the host can launch batch i+1 before it collects
+    batch i, so the D2H latency and the host-side NMS overlap the next batch's kernels (on CPU
+    tensors the copy is synchronous and the event is skipped)."""
+
+    def __init__(self, depth=2):
+        self.depth = depth
+        self.slots = [None] * depth
+        self.events = [None] * depth
+        self.n = 0
+
+    def submit(self, packed):
+        k = self.n % self.depth
+        self.n += 1
+        on_gpu = packed.is_cuda
+        if self.slots[k] is None or self.slots[k].shape != packed.shape:
+            self.slots[k] = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=on_gpu)
+            self.events[k] = torch.cuda.Event() if on_gpu else None
+        self.slots[k].copy_(packed, non_blocking=True)
+        if on_gpu:
+            self.events[k].record()
+        return k
+
+    def collect(self, ticket):
+        if self.events[ticket] is not None:
+            self.events[ticket].synchronize()
+        return _flatten_host(self.slots[ticket].numpy())
 
 
 def barrier():

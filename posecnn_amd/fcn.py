@@ -169,10 +169,18 @@ def im_segment_batch(net, data, K, extents, points, symmetry, data_p=None, plant
         net.run(feed, planted=planted)
     finally:
         net.vertex_reg_2d = saved[0]
-    label_2d, vertex_pred = net.get_output("label_2d"), net.get_output("vertex_pred")
-    top_box, top_pose, top_target, top_weight, top_domain, num_rois = ops.hough_voting_gpu_padded(
-        label_2d, vertex_pred, feed["extents"], feed["meta_data"], None, 0, net.vote_threshold,
-        net.vote_percentage, net.skip_pixels)
+    label_2d = net.get_output("label_2d")
+    if "vertex_pred_lowres" in net.layers:
+        # fused heads: the Hough kernel interpolates the 1/8-resolution field itself; `vertex_pred`
+        # stays a lazy layer that nobody fetches on this path
+        top_box, top_pose, top_target, top_weight, top_domain, num_rois = ops.hough_voting_gpu_lowres_padded(
+            label_2d, net.get_output("vertex_pred_lowres"), net.get_output("vertex_pred_bias"),
+            int(16 * net.scale), int(8 * net.scale), feed["extents"], feed["meta_data"], None, 0,
+            net.vote_threshold, net.vote_percentage, net.skip_pixels)
+    else:
+        top_box, top_pose, top_target, top_weight, top_domain, num_rois = ops.hough_voting_gpu_padded(
+            label_2d, net.get_output("vertex_pred"), feed["extents"], feed["meta_data"], None, 0,
+            net.vote_threshold, net.vote_percentage, net.skip_pixels)
     cap = min(top_box.shape[0], ops.MAX_ROI)  # is_train = 0: at most MAX_ROI rows
     rois = top_box[:cap]
     pool = ops.roi_pool_add2(net.get_output("conv5_3"), 1.0 / 16.0, net.get_output("conv4_3"), 1.0 / 8.0, rois)

@@ -62,6 +62,14 @@ def _nhwc(x):  # channels-last NCHW -> NHWC contiguous view (no copy when channe
     return x.permute(0, 2, 3, 1).contiguous()
 
 
+class _Lazy(object):
+    """A layer output that is only evaluated when somebody fetches or feeds it (TF evaluates only
+    fetched tensors; eager code needs to be told)."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+
 class Network(object):
     """Eager re-statement of the reference's graph-building `Network` (network.py:61-137).
 
@@ -88,18 +96,18 @@ class Network(object):
         self.inputs = []
         for l in args:
             if isinstance(l, str):
-                try:
-                    l = self.layers[l]
-                except KeyError:
-                    raise KeyError("Unknown layer name fed: %s" % l)
+                l = self.get_output(l)
             self.inputs.append(l)
         return self
 
     def get_output(self, name):
         try:
-            return self.layers[name]
+            out = self.layers[name]
         except KeyError:
             raise KeyError("Unknown layer name fed: %s" % name)
+        if isinstance(out, _Lazy):
+            out = self.layers[name] = out.fn()
+        return out
 
     def get_unique_name(self, prefix):
         ident = sum(t.startswith(prefix) for t in self.layers) + 1
@@ -287,6 +295,15 @@ class Network(object):
     def hough_voting_gpu(self, input, is_train, threshold, per_threshold, skip_pixels, name):
         return ops.hough_voting_gpu(input[0], input[1], input[2], input[3], input[4], is_train, threshold,
                                     per_threshold, skip_pixels, name=name)
+
+    @layer
+    def hough_voting_gpu_lowres(self, input, kernel, stride, is_train, threshold, per_threshold, skip_pixels, name):
+        """Hough layer fed by the 1/stride-resolution vertex field (+ bias) instead of `vertex_pred`;
+        same outputs as hough_voting_gpu on deconv(z) + bias (include/posecnn_hip.h)."""
+        out = ops.hough_voting_gpu_lowres_padded(input[0], input[1], input[2], kernel, stride, input[3], input[4],
+                                                 input[5], is_train, threshold, per_threshold, skip_pixels)
+        r = int(out[5][0].item())
+        return tuple(o[:r] for o in out[:5])
 
     @layer
     def roi_pool(self, input, pooled_height, pooled_width, spatial_scale, pool_channel, name):
@@ -484,16 +501,26 @@ class vgg16_convs(Network):
             if self.fused_heads:
                 # same commutation as the label head: 128->3C at 1/8 resolution, then one
                 # interpolation pass writes vertex_pred (+ bias); `upscore_vertex` is never built
+                # and the Hough layer interpolates just the pixels it samples, so `vertex_pred`
+                # itself (81 MB/frame) is only materialised if somebody fetches it.
                 zv, bv = self._conv1x1_lowres(self.get_output('dropout_vertex'), 'vertex_pred', 3 * self.num_classes, 128)
-                self.layers['vertex_pred'] = self._deconv_bilinear(zv, int(16 * self.scale), int(8 * self.scale), bias=bv)
+                kv, sv = int(16 * self.scale), int(8 * self.scale)
+                self.layers['vertex_pred_lowres'] = zv
+                self.layers['vertex_pred_bias'] = bv
+                self.layers['vertex_pred'] = _Lazy(lambda: self._deconv_bilinear(zv, kv, sv, bias=bv))
             else:
                 (self.feed('dropout_vertex')
                      .deconv(int(16 * self.scale), int(16 * self.scale), 128, int(8 * self.scale), int(8 * self.scale), name='upscore_vertex', trainable=False)
                      .conv(1, 1, 3 * self.num_classes, 1, 1, name='vertex_pred', relu=False, c_i=128))
 
             if self.vertex_reg_2d:
-                (self.feed('label_2d', 'vertex_pred', 'extents', 'meta_data', 'poses')
-                     .hough_voting_gpu(self.is_train, self.vote_threshold, self.vote_percentage, self.skip_pixels, name='hough'))
+                if self.fused_heads:
+                    (self.feed('label_2d', 'vertex_pred_lowres', 'vertex_pred_bias', 'extents', 'meta_data', 'poses')
+                         .hough_voting_gpu_lowres(kv, sv, self.is_train, self.vote_threshold, self.vote_percentage,
+                                                  self.skip_pixels, name='hough'))
+                else:
+                    (self.feed('label_2d', 'vertex_pred', 'extents', 'meta_data', 'poses')
+                         .hough_voting_gpu(self.is_train, self.vote_threshold, self.vote_percentage, self.skip_pixels, name='hough'))
 
                 self.layers['rois'] = self.get_output('hough')[0]
                 self.layers['poses_init'] = self.get_output('hough')[1]

@@ -67,27 +67,26 @@ def _ws(device, key):
 
 
 # ------------------------------------------------------------------------------------------------
-def hough_voting_gpu_padded(label_2d, vertex_pred, extents, meta_data, poses, is_train, threshold,
-                            per_threshold, skip_pixels, workspace=None, out=None,
-                            inlier_threshold=INLIER_THRESHOLD, label_threshold=LABEL_THRESHOLD):
-    """Sync-free form: returns capacity-sized buffers and the device-side row counts.
-
-    Returns (top_box[1152,7], top_pose[1152,7], top_target[1152,4C], top_weight[1152,4C],
-    top_domain[1152] int32, num_rois[2] int32) where num_rois[0] is the number of rows the
-    reference op returns (>= 1) and num_rois[1] the true detection row count.
-    """
+def _hough_common(label_2d, field, extents, meta_data, poses, threshold, skip_pixels, workspace, out, lowres):
     label_2d = _dev(label_2d, "label_2d", torch.int32)
-    vertex_pred = _dev(vertex_pred, "vertex_pred", torch.float32)
+    field = _dev(field, "vertex_pred", torch.float32)
     extents = _dev(extents, "extents", torch.float32)
     meta_data = _dev(meta_data, "meta_data", torch.float32)
     if label_2d.dim() != 3:
         raise ValueError("label must be 3-dimensional")  # hough_voting_gpu_op.cc:328-329
-    if vertex_pred.dim() != 4:
+    if field.dim() != 4:
         raise ValueError("vertex must be 4-dimensional")  # :331-332
     B, H, W = label_2d.shape
-    if tuple(vertex_pred.shape[:3]) != (B, H, W) or vertex_pred.shape[3] % VERTEX_CHANNELS:
-        raise ValueError("vertex must be [B,H,W,3*num_classes] matching label")
-    C = vertex_pred.shape[3] // VERTEX_CHANNELS
+    if lowres is None:
+        want = (B, H, W)
+    else:
+        stride = int(lowres)
+        if stride < 1 or H % stride or W % stride:
+            raise ValueError("label map %dx%d is not a multiple of the stride %d" % (H, W, stride))
+        want = (B, H // stride, W // stride)
+    if tuple(field.shape[:3]) != want or field.shape[3] % VERTEX_CHANNELS:
+        raise ValueError("vertex must be [B,%d,%d,3*num_classes] matching label" % want[1:])
+    C = field.shape[3] // VERTEX_CHANNELS
     if extents.numel() != C * 3:
         raise ValueError("extents must be [num_classes,3]")
     num_meta = meta_data.shape[-1]
@@ -101,10 +100,9 @@ def hough_voting_gpu_padded(label_2d, vertex_pred, extents, meta_data, poses, is
             raise ValueError("poses (gt) must be [N,13]")
         num_gt = gt.shape[0]
     dev = label_2d.device
-    L = lib()
     nbytes = c_size_t(0)
     check("pcnn_hough_voting_workspace_bytes",
-          L.pcnn_hough_voting_workspace_bytes(B, H, W, C, float(threshold), int(skip_pixels), ctypes.byref(nbytes)))
+          lib().pcnn_hough_voting_workspace_bytes(B, H, W, C, float(threshold), int(skip_pixels), ctypes.byref(nbytes)))
     ws = (workspace or _ws(dev, "hough")).get(nbytes.value, dev)
     if out is None:
         cap = HOUGH_ROWS_CAPACITY
@@ -114,15 +112,54 @@ def hough_voting_gpu_padded(label_2d, vertex_pred, extents, meta_data, poses, is
                torch.empty((cap, POSE_CHANNELS * C), dtype=torch.float32, device=dev),
                torch.empty((cap,), dtype=torch.int32, device=dev),
                torch.empty((2,), dtype=torch.int32, device=dev))
+    return label_2d, field, extents, meta_data, gt, num_gt, (B, H, W, C, num_meta), ws, out
+
+
+def hough_voting_gpu_padded(label_2d, vertex_pred, extents, meta_data, poses, is_train, threshold,
+                            per_threshold, skip_pixels, workspace=None, out=None,
+                            inlier_threshold=INLIER_THRESHOLD, label_threshold=LABEL_THRESHOLD):
+    """Sync-free form: returns capacity-sized buffers and the device-side row counts.
+
+    Returns (top_box[1152,7], top_pose[1152,7], top_target[1152,4C], top_weight[1152,4C],
+    top_domain[1152] int32, num_rois[2] int32) where num_rois[0] is the number of rows the
+    reference op returns (>= 1) and num_rois[1] the true detection row count.
+    """
+    label_2d, vertex_pred, extents, meta_data, gt, num_gt, (B, H, W, C, num_meta), ws, out = _hough_common(
+        label_2d, vertex_pred, extents, meta_data, poses, threshold, skip_pixels, workspace, out, None)
     top_box, top_pose, top_target, top_weight, top_domain, num_rois = out
     check("pcnn_hough_voting_fwd",
-          L.pcnn_hough_voting_fwd(_ptr(label_2d), _ptr(vertex_pred), _ptr(extents), _ptr(meta_data), _ptr(gt),
-                                  B, H, W, C, num_meta, num_gt,
-                                  int(is_train), float(threshold), float(per_threshold), int(skip_pixels),
-                                  float(inlier_threshold), int(label_threshold),
-                                  _ptr(top_box), _ptr(top_pose), _ptr(top_target), _ptr(top_weight),
-                                  _ptr(top_domain), _ptr(num_rois),
-                                  _ptr(ws), ws.numel(), _stream(label_2d)))
+          lib().pcnn_hough_voting_fwd(_ptr(label_2d), _ptr(vertex_pred), _ptr(extents), _ptr(meta_data), _ptr(gt),
+                                      B, H, W, C, num_meta, num_gt,
+                                      int(is_train), float(threshold), float(per_threshold), int(skip_pixels),
+                                      float(inlier_threshold), int(label_threshold),
+                                      _ptr(top_box), _ptr(top_pose), _ptr(top_target), _ptr(top_weight),
+                                      _ptr(top_domain), _ptr(num_rois),
+                                      _ptr(ws), ws.numel(), _stream(label_2d)))
+    return out
+
+
+def hough_voting_gpu_lowres_padded(label_2d, z, bias, kernel, stride, extents, meta_data, poses, is_train,
+                                   threshold, per_threshold, skip_pixels, workspace=None, out=None,
+                                   inlier_threshold=INLIER_THRESHOLD, label_threshold=LABEL_THRESHOLD):
+    """Fused vertex head -> Hough voting: identical results to
+    `hough_voting_gpu_padded(label_2d, deconv_bilinear(z, kernel, stride, bias=bias), ...)` without
+    ever building the [B,H,W,3C] `vertex_pred` (vgg16_convs.py:152-163).
+    z is the 1x1 `vertex_pred` conv evaluated at 1/stride resolution, [B,H/stride,W/stride,3C]."""
+    label_2d, z, extents, meta_data, gt, num_gt, (B, H, W, C, num_meta), ws, out = _hough_common(
+        label_2d, z, extents, meta_data, poses, threshold, skip_pixels, workspace, out, stride)
+    bias = _dev(bias, "bias", torch.float32)
+    if bias.numel() != VERTEX_CHANNELS * C:
+        raise ValueError("bias must be [3*num_classes]")
+    top_box, top_pose, top_target, top_weight, top_domain, num_rois = out
+    check("pcnn_hough_voting_lowres_fwd",
+          lib().pcnn_hough_voting_lowres_fwd(_ptr(label_2d), _ptr(z), _ptr(bias), int(kernel), int(stride),
+                                             _ptr(extents), _ptr(meta_data), _ptr(gt),
+                                             B, H, W, C, num_meta, num_gt,
+                                             int(is_train), float(threshold), float(per_threshold), int(skip_pixels),
+                                             float(inlier_threshold), int(label_threshold),
+                                             _ptr(top_box), _ptr(top_pose), _ptr(top_target), _ptr(top_weight),
+                                             _ptr(top_domain), _ptr(num_rois),
+                                             _ptr(ws), ws.numel(), _stream(label_2d)))
     return out
 
 

@@ -48,6 +48,15 @@ class vgg16_convs_cpu(vgg16_convs):
         return tuple(torch.from_numpy(np.ascontiguousarray(o)) for o in out)
 
     @layer
+    def hough_voting_gpu_lowres(self, input, kernel, stride, is_train, threshold, per_threshold, skip_pixels, name):
+        # the checker takes the long way round: materialise vertex_pred, then the plain op
+        vertex = oracle.deconv_bilinear(input[1].numpy(), kernel, stride, None, None, input[2].numpy(), False)
+        gt = None if input[5] is None else input[5].numpy()
+        out = oracle.hough_voting(input[0].numpy(), vertex, input[3].numpy(), input[4].numpy(),
+                                  gt, is_train, threshold, per_threshold, skip_pixels)
+        return tuple(torch.from_numpy(np.ascontiguousarray(o)) for o in out)
+
+    @layer
     def roi_pool(self, input, pooled_height, pooled_width, spatial_scale, pool_channel, name):
         t, a = oracle.roi_pool(input[0].numpy(), input[1].numpy(), pooled_height, pooled_width, spatial_scale, pool_channel)
         return torch.from_numpy(t), torch.from_numpy(a)

@@ -339,3 +339,60 @@ def test_linemod_stress_size_960x1280(gpu):
     assert int(got[5][1]) == 4
     # Hough windows at this size exceed 600 px: also exercise the local-maximum path once
     both(gpu, label, vertex, ext, meta, vote_thr=200.0, per_thr=0.002)
+
+
+# ---- fused vertex head -> Hough voting (pcnn_hough_voting_lowres_fwd) -----------
+def lowres_case(first, B, H, W, C, n_obj, stride):
+    """A 1/stride-resolution vertex field whose bilinear upsampling still looks like a scene:
+    subsample the synthetic full-resolution field at the cell centres."""
+    label, vertex, meta, _ = frames(first, B, H=H, W=W, C=C, n_obj=n_obj)
+    z = np.ascontiguousarray(vertex[:, stride // 2::stride, stride // 2::stride, :])
+    bias = (np.random.default_rng(first).standard_normal(3 * C) * 0.01).astype(F)
+    return label, z, bias, meta
+
+
+@pytest.mark.parametrize("shape,k,s,vote_thr,per_thr", [
+    ((2, 480, 640, 22, 5), 16, 8, -1.0, 0.02),      # the network's configuration
+    ((1, 240, 320, 22, 4), 16, 8, 20.0, 0.002),     # threshold path
+    ((3, 120, 160, 8, 3), 4, 2, -1.0, 0.02),        # the other (k, s) pair the graph uses
+    ((1, 96, 128, 6, 2), 4, 4, -1.0, 0.02),         # k == s: one tap per axis
+])
+def test_lowres_vertex_source_equals_materialised_field(gpu, shape, k, s, vote_thr, per_thr):
+    """Interpolating only the sampled pixels inside the Hough kernel must give the same bits as
+    deconv_bilinear -> hough_voting (both HIP), and as the oracle fed the oracle's deconv."""
+    import torch
+    from posecnn_amd import ops
+    B, H, W, C, n_obj = shape
+    label, z, bias, meta = lowres_case(500 + H, B, H, W, C, n_obj, s)
+    ext = config.LOV_EXTENTS[:C]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    lt = 500 if H >= 480 else 60
+    got = ops.hough_voting_gpu_lowres_padded(t(label), t(z), t(bias), k, s, t(ext), t(meta), None, 0, vote_thr, per_thr, 10,
+                                             label_threshold=lt)
+    full = ops.deconv_bilinear(t(z), k, s, bias=t(bias))
+    ref = ops.hough_voting_gpu_padded(t(label), full, t(ext), t(meta), None, 0, vote_thr, per_thr, 10, label_threshold=lt)
+    torch.cuda.synchronize()
+    got = [o.cpu().numpy() for o in got]
+    compare(got, [o.cpu().numpy() for o in ref])
+    want = oracle.hough_voting(label, oracle.deconv_bilinear(z, k, s, None, None, bias, False), ext, meta, None, 0,
+                               vote_thr, per_thr, 10, label_thr=lt, padded=True)
+    compare(got, want)
+    assert int(got[5][1]) >= 1
+
+
+def test_lowres_argument_checks(gpu):
+    import torch
+    from posecnn_amd import ops
+    label = torch.zeros((1, 60, 80), dtype=torch.int32, device=gpu)
+    ext = torch.from_numpy(config.LOV_EXTENTS[:4]).to(gpu)
+    meta = torch.from_numpy(config.make_meta_data(config.DEMO_INTRINSICS)[None]).to(gpu)
+    z = torch.zeros((1, 15, 20, 12), device=gpu)
+    bias = torch.zeros(12, device=gpu)
+    out = ops.hough_voting_gpu_lowres_padded(label, z, bias, 8, 4, ext, meta, None, 0, -1.0, 0.02, 10)
+    assert out[5].tolist() == [1, 0]                      # empty scene: the single dummy row
+    with pytest.raises(ValueError):                       # field does not match label / stride
+        ops.hough_voting_gpu_lowres_padded(label, z[:, :14], bias, 8, 4, ext, meta, None, 0, -1.0, 0.02, 10)
+    with pytest.raises(ValueError):
+        ops.hough_voting_gpu_lowres_padded(label, z, bias[:11], 8, 4, ext, meta, None, 0, -1.0, 0.02, 10)
+    with pytest.raises(ValueError):                       # (kernel - stride) odd: rejected by the C-ABI (EINVAL)
+        ops.hough_voting_gpu_lowres_padded(label, z, bias, 7, 4, ext, meta, None, 0, -1.0, 0.02, 10)

@@ -94,6 +94,11 @@ def _worker(rank, world, port, q):
     count = torch.tensor([n], dtype=torch.int32)
     g_rows, g_counts = pdist.all_gather_detections(rows, count, frame_offset=rank * B)
     flat = pdist.flatten_gathered(g_rows, g_counts)
+    # the pipelined drain used by bench.py must deliver the same rows, in submit order
+    drain = pdist.HostDrain(depth=2)
+    t0 = drain.submit(pdist.all_gather_packed(rows, count, frame_offset=rank * B))
+    t1 = drain.submit(pdist.all_gather_packed(rows * 0, count * 0, frame_offset=rank * B))
+    assert np.array_equal(drain.collect(t0), flat) and drain.collect(t1).shape == (0, 14)
     t = pdist.max_over_ranks(1.0 + rank, torch.device("cpu"))
     pdist.barrier()
     q.put((rank, g_counts.tolist(), flat[:, :2].tolist(), t))
