@@ -233,6 +233,22 @@ int pcnn_deconv_bilinear_fwd(const float* in, int batch, int height, int width, 
 int pcnn_bias_act_fwd(const float* x, const float* bias, int64_t num_pixels, int channels, int relu,
                       float* y, void* stream);
 
+/* First layer of a VGG tower (conv1_1 / conv1_1_p, vgg16_convs.py:36,53): 3x3, stride 1, SAME,
+ * 3 input channels, with bias_add + ReLU (network.py:181-187) fused.
+ *   x f32 [B,H,W,3];  weights f32 [3,3,3,Cout] = (ky, kx, ci, co), the layout of the TF variable
+ *   `conv1_1/weights` (network.py:169-180);  bias f32 [Cout];  Cout % 64 == 0
+ *   y f32 [B,H,W,Cout] = [ReLU](conv(x) + bias); acc = fma(w, x, acc) over (ky, kx, ci) ascending.
+ * Bound by writing y once (HBM); the library GEMM path + separate bias pass is 3.5x slower here. */
+int pcnn_conv3x3_c3_fwd(const float* x, const float* weights, const float* bias, int batch,
+                        int height, int width, int out_channels, int relu, float* y, void* stream);
+
+/* y[b,oy,ox,c] = max over the 2x2 window of [ReLU](x + bias[c]): the `conv -> max_pool(2,2,2,2)`
+ * pairs of the VGG trunk (vgg16_convs.py:36-49; network.py:181-187 + :189-196) from the raw
+ * convolution output x f32 [B,H,W,C] (H, W even) to y f32 [B,H/2,W/2,C], same bits as
+ * max_pool(bias_act(x)) without the intermediate tensor. */
+int pcnn_bias_relu_pool2_fwd(const float* x, const float* bias, int batch, int height, int width,
+                             int channels, int relu, float* y, void* stream);
+
 int pcnn_upscore_softmax_argmax_fwd(const float* z, const float* bias, int batch, int height,
                                     int width, int num_classes, int kernel, int stride, int relu,
                                     float* score_out, float* prob, int32_t* label, void* stream);

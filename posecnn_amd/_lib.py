@@ -42,6 +42,8 @@ SIGNATURES = {
                                              c_int, c_float, c_float, c_int, c_float, c_int,
                                              _P, _P, _P, _P, _P, _P,
                                              _P, c_size_t, _P]),
+    "pcnn_conv3x3_c3_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "pcnn_bias_relu_pool2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pcnn_hough_voting_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "pcnn_roi_pool_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_float, c_int, _P, _P, _P]),

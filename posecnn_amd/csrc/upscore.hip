@@ -155,6 +155,46 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const float* __restrict__
   }
 }
 
+// pool = max_pool_2x2(ReLU(x + bias)) straight from the raw convolution output: the conv -> pool
+// pairs of the VGG trunk (vgg16_convs.py:36-49) without writing and re-reading the activated
+// full-resolution tensor. max and (+bias, ReLU) commute exactly — x1 >= x2 implies
+// fl(x1 + b) >= fl(x2 + b) — so the four raw values are reduced first and one add + ReLU follows;
+// the bits equal max_pool(bias_act(x)) for finite inputs. Window order (y, x), (y, x+1), (y+1, x),
+// (y+1, x+1).
+template <int V>
+__global__ __launch_bounds__(256) void bias_relu_pool2_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ bias,
+                                                              float* __restrict__ y, long long total,
+                                                              int Ho, int Wo, int C, int relu)
+{
+  const int cv = C / V;
+  const long long rowstride = (long long)2 * Wo * C;  // one input row
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % cv) * V;
+    const long long p = idx / cv;           // pooled pixel (b, oy, ox)
+    const int ox = (int)(p % Wo);
+    const long long bo = p / Wo;            // b * Ho + oy
+    const float* s0 = x + (bo * 2) * rowstride + (long long)(2 * ox) * C + c;
+    float a[V], t[V];
+    load_v<V>(s0, a);
+    load_v<V>(s0 + C, t);
+#pragma unroll
+    for (int i = 0; i < V; i++) a[i] = t[i] > a[i] ? t[i] : a[i];
+    load_v<V>(s0 + rowstride, t);
+#pragma unroll
+    for (int i = 0; i < V; i++) a[i] = t[i] > a[i] ? t[i] : a[i];
+    load_v<V>(s0 + rowstride + C, t);
+#pragma unroll
+    for (int i = 0; i < V; i++) {
+      float m = t[i] > a[i] ? t[i] : a[i];
+      m = m + bias[c + i];
+      a[i] = relu ? (m > 0.f ? m : 0.f) : m;
+    }
+    store_v<V>(y + idx * V, a);
+  }
+}
+
 // Label head epilogue. A workgroup owns SEG consecutive output pixels of one output row; the
 // (<= 2) x (SEG/s + 2) low-resolution cells it needs sit in LDS; every thread owns one pixel:
 // C interpolated scores in registers -> softmax -> argmax; prob / score rows are parked in LDS and
@@ -302,6 +342,23 @@ extern "C" int pcnn_bias_act_fwd(const float* x, const float* bias, int64_t num_
   else
     PCNN_LAUNCH(bias_act_kernel<1>, dim3(grid(n)), dim3(256), 0, stream, x, bias, y, n, channels, relu);
   return check_launch("bias_act_fwd");
+}
+
+extern "C" int pcnn_bias_relu_pool2_fwd(const float* x, const float* bias, int B, int H, int W, int C,
+                                       int relu, float* y, void* stream_)
+{
+  PCNN_REQUIRE(B >= 1 && H >= 2 && W >= 2 && C >= 1 && H % 2 == 0 && W % 2 == 0, PCNN_EINVAL,
+               "bias_relu_pool2: need even height/width (got %dx%dx%dx%d)", B, H, W, C);
+  PCNN_REQUIRE(x && bias && y, PCNN_ENULL, "bias_relu_pool2: NULL pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int Ho = H / 2, Wo = W / 2;
+  auto grid = [](long long total) { long long b = (total + 255) / 256; return (unsigned)(b < 256 * 32 ? b : 256 * 32); };
+  const long long n = (long long)B * Ho * Wo * C;
+  if (C % 4 == 0 && aligned16(x) && aligned16(y))
+    PCNN_LAUNCH(bias_relu_pool2_kernel<4>, dim3(grid(n / 4)), dim3(256), 0, stream, x, bias, y, n / 4, Ho, Wo, C, relu);
+  else
+    PCNN_LAUNCH(bias_relu_pool2_kernel<1>, dim3(grid(n)), dim3(256), 0, stream, x, bias, y, n, Ho, Wo, C, relu);
+  return check_launch("bias_relu_pool2_fwd");
 }
 
 extern "C" int pcnn_upscore_softmax_argmax_fwd(const float* z, const float* bias, int B, int H,

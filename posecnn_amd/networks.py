@@ -70,6 +70,14 @@ class _Lazy(object):
         self.fn = fn
 
 
+class _RawConv(object):
+    """A convolution output before bias + ReLU, handed to a consumer that fuses them (max_pool).
+    Fetching the layer by name materialises the activated tensor (in place) like any other."""
+
+    def __init__(self, y, bias, relu):
+        self.y, self.bias, self.relu, self.out = y, bias, relu, None
+
+
 class Network(object):
     """Eager re-statement of the reference's graph-building `Network` (network.py:61-137).
 
@@ -86,6 +94,8 @@ class Network(object):
         self.init = init
         self._gen = torch.Generator(device="cpu").manual_seed(seed)  # cfg.RNG_SEED = 3 (config.py)
         self.keep_prob_queue = 1.0
+        self.fused_first_conv = True  # 3-channel 3x3 convs go to the fused conv + bias + ReLU kernel
+        self.defer_act = frozenset()  # conv layers whose bias + ReLU is left to the following max_pool
 
     # ---- plumbing ------------------------------------------------------------------------------
     def setup(self):
@@ -107,7 +117,14 @@ class Network(object):
             raise KeyError("Unknown layer name fed: %s" % name)
         if isinstance(out, _Lazy):
             out = self.layers[name] = out.fn()
+        if isinstance(out, _RawConv):
+            out = self.layers[name] = self._activate(out)
         return out
+
+    def _activate(self, raw):
+        if raw.out is None:
+            raw.out = self._bias_act(raw.y, raw.bias, raw.relu)
+        return raw.out
 
     def get_unique_name(self, prefix):
         ident = sum(t.startswith(prefix) for t in self.layers) + 1
@@ -164,7 +181,13 @@ class Network(object):
         b = self.make_var(name + "/biases", (c_o,), lambda s: torch.zeros(s)) if biased else None
         assert s_h == 1 and s_w == 1 or padding == "VALID" or (k_h == 1 and k_w == 1), "strided SAME conv not on this path"
         pad = (k_h // 2, k_w // 2) if padding == "SAME" else 0
+        if (self.fused_first_conv and b is not None and (k_h, k_w, c_i, group) == (3, 3, 3, 1) and padding == "SAME"
+                and c_o % 64 == 0 and not (torch.is_grad_enabled() and (w.requires_grad or input.requires_grad))):
+            # conv1_1: K = 27 is no GEMM; one HBM-bound kernel does conv + bias + ReLU
+            return self._conv_first(input, w, b, relu)
         y = _nhwc(F.conv2d(_nchw(input), w, None, stride=(s_h, s_w), padding=pad, groups=group))
+        if b is not None and name in self.defer_act and not (torch.is_grad_enabled() and y.requires_grad):
+            return _RawConv(y, b, relu)
         if b is None and not relu:
             return y
         if b is None:
@@ -174,6 +197,11 @@ class Network(object):
     @layer
     def max_pool(self, input, k_h, k_w, s_h, s_w, name, padding=DEFAULT_PADDING):
         assert padding in ("SAME", "VALID")
+        if isinstance(input, _RawConv):
+            if (input.out is None and (k_h, k_w, s_h, s_w) == (2, 2, 2, 2)
+                    and input.y.shape[1] % 2 == 0 and input.y.shape[2] % 2 == 0):
+                return self._bias_relu_pool2(input.y, input.bias, input.relu)
+            input = self._activate(input)
         H, W = input.shape[1], input.shape[2]
         if padding == "SAME" and (H % s_h or W % s_w):
             # TF 'SAME' pads at the bottom/right with -inf; not reached after pad_im(., 16)
@@ -202,6 +230,13 @@ class Network(object):
     # hooks the CPU checker overrides (tests/cpu_reference.py)
     def _bias_act(self, y, bias, relu):
         return ops.bias_act_(y, bias, relu)
+
+    def _bias_relu_pool2(self, y, bias, relu):
+        return ops.bias_relu_pool2(y, bias, relu)
+
+    def _conv_first(self, x, w, bias, relu):
+        # torch filter [c_o, c_i, kh, kw] -> the TF variable layout [kh, kw, c_i, c_o] the kernel reads
+        return ops.conv3x3_c3(x.contiguous(), w.permute(2, 3, 1, 0).contiguous(), bias, relu)
 
     def _deconv_bilinear(self, x, k, s, add1=None, add2=None, bias=None, relu=False):
         return ops.deconv_bilinear(x, k, s, add1=add1, add2=add2, bias=bias, relu=relu)
@@ -336,8 +371,13 @@ class vgg16_convs(Network):
     def __init__(self, input_format, num_classes, num_units, scales, threshold_label, vote_threshold,
                  vertex_reg_2d=False, vertex_reg_3d=False, pose_reg=False, adaptation=False, trainable=True,
                  is_train=True, device="cuda", seed=3, init="he", with_losses=None, fused_heads=True,
-                 want_prob=True):
+                 want_prob=True, fused_pool=True):
         Network.__init__(self, device=device, seed=seed, init=init, trainable=trainable)
+        # conv -> max_pool pairs whose un-pooled activation nobody else consumes: one kernel does
+        # bias + ReLU + 2x2 max from the raw convolution output (conv4_3 feeds score_conv4 and
+        # roi_pool, so pool4 stays a plain max_pool)
+        if fused_pool:
+            self.defer_act = frozenset(n + sfx for n in ("conv1_2", "conv2_2", "conv3_3") for sfx in ("", "_p"))
         # fused_heads=False evaluates the heads in the reference's literal op order
         # (deconv -> 1x1 conv -> softmax -> argmax); True (default) uses the algebraically
         # identical low-resolution form + fused gfx950 epilogue (see setup()).

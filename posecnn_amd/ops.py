@@ -278,6 +278,37 @@ def bias_act_(x, bias, relu=True):
     return x
 
 
+def conv3x3_c3(x, weights, bias, relu=True):
+    """[ReLU](conv3x3_SAME(x) + bias) for a 3-channel NHWC input: x [B,H,W,3], weights [3,3,3,Cout]
+    laid out (ky, kx, ci, co) like the TF variable, Cout a multiple of 64. Returns [B,H,W,Cout]."""
+    x = _dev(x, "x", torch.float32)
+    weights = _dev(weights, "weights", torch.float32)
+    bias = _dev(bias, "bias", torch.float32)
+    if x.dim() != 4 or x.shape[3] != 3:
+        raise ValueError("x must be [B,H,W,3]")
+    B, H, W, _ = x.shape
+    Cout = weights.shape[-1]
+    if tuple(weights.shape) != (3, 3, 3, Cout) or bias.numel() != Cout:
+        raise ValueError("weights must be [3,3,3,Cout] (ky,kx,ci,co) and bias [Cout]")
+    y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+    check("pcnn_conv3x3_c3_fwd",
+          lib().pcnn_conv3x3_c3_fwd(_ptr(x), _ptr(weights), _ptr(bias), B, H, W, Cout, 1 if relu else 0, _ptr(y), _stream(x)))
+    return y
+
+
+def bias_relu_pool2(x, bias, relu=True):
+    """max_pool_2x2(ReLU(x + bias)) from the raw convolution output [B,H,W,C] (H, W even)."""
+    x = _dev(x, "x", torch.float32)
+    bias = _dev(bias, "bias", torch.float32)
+    B, H, W, C = x.shape
+    if bias.numel() != C:
+        raise ValueError("bias must have one entry per channel")
+    y = torch.empty((B, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
+    check("pcnn_bias_relu_pool2_fwd",
+          lib().pcnn_bias_relu_pool2_fwd(_ptr(x), _ptr(bias), B, H, W, C, 1 if relu else 0, _ptr(y), _stream(x)))
+    return y
+
+
 def deconv_bilinear(input, kernel, stride, add1=None, add2=None, bias=None, relu=False):
     """The fixed bilinear `deconv` layer (network.py:207-222 with make_deconv_filter :141-157) as a
     per-channel interpolation: [B,H,W,C] -> [B,H*s,W*s,C], optionally fused with up to two addends

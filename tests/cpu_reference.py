@@ -23,6 +23,14 @@ class vgg16_convs_cpu(vgg16_convs):
         y = y + bias
         return torch.relu(y) if relu else y
 
+    def _conv_first(self, x, w, bias, relu):
+        y = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, None, padding=1).permute(0, 2, 3, 1).contiguous()
+        return self._bias_act(y, bias, relu)
+
+    def _bias_relu_pool2(self, y, bias, relu):
+        a = self._bias_act(y, bias, relu)
+        return torch.nn.functional.max_pool2d(a.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).contiguous()
+
     def _deconv_bilinear(self, x, k, s, add1=None, add2=None, bias=None, relu=False):
         n = lambda t: None if t is None else t.numpy()
         return torch.from_numpy(oracle.deconv_bilinear(x.numpy(), k, s, n(add1), n(add2), n(bias), relu))

@@ -329,3 +329,52 @@ def test_bias_act_inplace(gpu, shape):
         if relu:
             want = np.maximum(want, 0)
         same(N(out), want.astype(F), "bias_act relu=%s" % relu)
+
+
+@pytest.mark.parametrize("shape", [(2, 48, 64, 64), (1, 6, 10, 3), (3, 2, 2, 128), (1, 30, 40, 256)])
+def test_bias_relu_pool2_equals_pool_of_bias_act(gpu, shape):
+    """conv -> max_pool pairs of the VGG trunk: one pass from the raw conv output, same bits as
+    max_pool_2x2(ReLU(x + b)) (numpy restatement; network.py:181-187 + :189-196)."""
+    from posecnn_amd import ops
+    rng = np.random.default_rng(31)
+    x = (rng.standard_normal(shape) * 3).astype(F)
+    b = rng.standard_normal(shape[-1]).astype(F)
+    B, H, W, C = shape
+    for relu in (True, False):
+        act = x + b
+        if relu:
+            act = np.maximum(act, 0)
+        want = act.reshape(B, H // 2, 2, W // 2, 2, C).max(axis=(2, 4)).astype(F)
+        got = ops.bias_relu_pool2(T(gpu, x), T(gpu, b), relu)
+        assert got.shape == (B, H // 2, W // 2, C)
+        same(N(got), want, "bias_relu_pool2 relu=%s" % relu)
+    with pytest.raises(ValueError):
+        ops.bias_relu_pool2(T(gpu, x[:, :H - 1]), T(gpu, b))
+
+
+@pytest.mark.parametrize("shape,cout", [((2, 48, 64), 64), ((1, 5, 131), 64), ((1, 33, 7), 128), ((1, 1, 1), 64), ((1, 17, 300), 64)])
+def test_conv3x3_c3_bias_relu(gpu, shape, cout):
+    """conv1_1 fused kernel against a float64 restatement (tolerance: f32 accumulation of 27 products)
+    and against the library convolution the unfused path uses."""
+    import torch
+    from posecnn_amd import ops
+    rng = np.random.default_rng(41)
+    B, H, W = shape
+    x = (rng.standard_normal((B, H, W, 3)) * 50).astype(F)          # mean-subtracted pixels: O(100)
+    w = (rng.standard_normal((3, 3, 3, cout)) * 0.3).astype(F)      # (ky, kx, ci, co)
+    b = rng.standard_normal(cout).astype(F)
+    xp = np.zeros((B, H + 2, W + 2, 3), np.float64); xp[:, 1:-1, 1:-1] = x
+    want = np.zeros((B, H, W, cout), np.float64)
+    for ky in range(3):
+        for kx in range(3):
+            want += np.einsum("bhwc,oc->bhwo", xp[:, ky:ky + H, kx:kx + W], w[ky, kx].T.astype(np.float64))
+    want += b
+    for relu in (True, False):
+        ref = np.maximum(want, 0) if relu else want
+        got = N(ops.conv3x3_c3(T(gpu, x), T(gpu, w), T(gpu, b), relu))
+        assert got.shape == (B, H, W, cout)
+        assert np.abs(got - ref).max() <= 2e-5 * np.abs(want).max()
+    lib_y = torch.nn.functional.conv2d(T(gpu, x).permute(0, 3, 1, 2), T(gpu, w).permute(3, 2, 0, 1), T(gpu, b), padding=1)
+    assert np.abs(N(lib_y.permute(0, 2, 3, 1)) - want).max() <= 2e-5 * np.abs(want).max()
+    with pytest.raises(ValueError):
+        ops.conv3x3_c3(T(gpu, x), T(gpu, w[..., :48]), T(gpu, b[:48]))
