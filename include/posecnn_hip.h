@@ -228,6 +228,12 @@ int pcnn_deconv_bilinear_fwd(const float* in, int batch, int height, int width, 
                              int kernel, int stride, const float* add1, const float* add2,
                              const float* bias, int relu, float* out, void* stream);
 
+/* Gradient of pcnn_deconv_bilinear_fwd w.r.t. `in` (the transposed interpolation; TF's
+ * conv2d_transpose gradient for the fixed filter): grad_out f32 [B,H*s,W*s,C] -> grad_in f32
+ * [B,H,W,C]; sum order: output rows ascending, output columns ascending. */
+int pcnn_deconv_bilinear_bwd(const float* grad_out, int batch, int height, int width, int channels,
+                             int kernel, int stride, float* grad_in, void* stream);
+
 /* y = [ReLU](x + bias[c]) over [num_pixels, channels] NHWC rows; y may alias x. The bias_add + relu
  * of Network.conv (network.py:181-187) in one pass. */
 int pcnn_bias_act_fwd(const float* x, const float* bias, int64_t num_pixels, int channels, int relu,
@@ -252,6 +258,23 @@ int pcnn_bias_relu_pool2_fwd(const float* x, const float* bias, int batch, int h
 int pcnn_upscore_softmax_argmax_fwd(const float* z, const float* bias, int batch, int height,
                                     int width, int num_classes, int kernel, int stride, int relu,
                                     float* score_out, float* prob, int32_t* label, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * smooth_l1_loss_vertex (lib/fcn/train.py:564-573), the vertex regression loss of the training
+ * graph, over n = B*H*W*3C elements of pred / target / weight (f32):
+ *   diff = w*(pred - target);  in = |diff| < 1/sigma^2 ? diff^2*sigma^2/2 : |diff| - 0.5/sigma^2
+ *   out[0] = loss = sum(in) / (sum(w) + 1e-10),  out[1] = sum(in),  out[2] = sum(w)   (f32 [3])
+ * bwd: grad_pred = upstream[0] * w * (|diff| < 1/sigma^2 ? sigma^2*diff : sign(diff)) / (sum(w) + 1e-10)
+ *   (`out` is the forward's; upstream f32 [1] on the device, NULL = 1). The reduction order is
+ *   fixed so the loss is reproducible bit for bit.
+ * ------------------------------------------------------------------------------------------ */
+int pcnn_smooth_l1_vertex_workspace_bytes(size_t* bytes);
+int pcnn_smooth_l1_vertex_fwd(const float* pred, const float* target, const float* weight, int64_t n,
+                              float sigma, float* out, void* workspace, size_t workspace_bytes,
+                              void* stream);
+int pcnn_smooth_l1_vertex_bwd(const float* pred, const float* target, const float* weight,
+                              const float* out, const float* upstream, int64_t n, float sigma,
+                              float* grad_pred, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Kernel timing diagnostics (off by default; the reference's only instrumentation is the

@@ -875,3 +875,100 @@ int oracle_deconv_bilinear(const float* in, int B, int H, int W, int C, int k, i
   }
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Gradient of the fixed bilinear deconv (the transpose of oracle_deconv_bilinear; what TF's
+ * Conv2DBackpropInput gradient computes for network.py:207-222 with the make_deconv_filter
+ * weights): grad_in[b,i,j,c] = sum_{oy,ox} tap(oy+pad-s*i) * tap(ox+pad-s*j) * grad_out[b,oy,ox,c].
+ * Canonical order: oy ascending, ox ascending, acc = acc + (wy*wx)*g.
+ * ---------------------------------------------------------------------------------------------- */
+int oracle_deconv_bilinear_bwd(const float* grad_out, int B, int H, int W, int C, int k, int s,
+                               float* grad_in)
+{
+  const int pad = (k - s) / 2, Ho = H * s, Wo = W * s;
+#pragma omp parallel for schedule(static)
+  for (long row = 0; row < (long)B * H; row++) {
+    const int b = (int)(row / H), i = (int)(row % H);
+    for (int j = 0; j < W; j++) {
+      float* gi = grad_in + ((size_t)row * W + j) * C;
+      for (int c = 0; c < C; c++) gi[c] = 0.f;
+      for (int ty = 0; ty < k; ty++) {
+        const int oy = s * i + ty - pad;
+        if (oy < 0 || oy >= Ho) continue;
+        for (int tx = 0; tx < k; tx++) {
+          const int ox = s * j + tx - pad;
+          if (ox < 0 || ox >= Wo) continue;
+          const float w = bilinear_tap(ty, k) * bilinear_tap(tx, k);
+          const float* g = grad_out + (((size_t)b * Ho + oy) * Wo + ox) * C;
+          for (int c = 0; c < C; c++) gi[c] = gi[c] + w * g[c];
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * smooth_l1_loss_vertex (lib/fcn/train.py:564-573):
+ *   diff = w * (pred - target); in = |diff| < 1/sigma^2 ? diff^2 * sigma^2/2 : |diff| - 0.5/sigma^2
+ *   loss = sum(in) / (sum(w) + 1e-10)
+ * TF's reduce_sum order is unspecified; canonical order = the HIP kernel's: SL1_BLOCKS x 256
+ * virtual threads, thread (blk, t) adds elements (blk*256 + t) + m*SL1_BLOCKS*256, m ascending,
+ * into f32 accumulators; a 256-leaf then a SL1_BLOCKS-leaf halving tree (x[t] += x[t + stride],
+ * stride = n/2 .. 1) combines them. out[0] = loss, out[1] = sum(in), out[2] = sum(w).
+ * grad (d loss / d pred) = w * (|diff| < 1/sigma^2 ? sigma^2 * diff : sign(diff)) / (sum(w) + 1e-10).
+ * ---------------------------------------------------------------------------------------------- */
+#define SL1_BLOCKS 1024
+
+static void sl1_elem(float p, float t, float w, float sigma2, float* in_loss, float* dpred)
+{
+  const float diff = w * (p - t);
+  const float ad = fabsf(diff);
+  const float inv = 1.0f / sigma2;
+  if (ad < inv) {
+    *in_loss = (diff * diff) * (sigma2 / 2.0f);
+    *dpred = w * (sigma2 * diff);
+  } else {
+    *in_loss = ad - 0.5f / sigma2;
+    *dpred = w * (diff > 0.f ? 1.0f : (diff < 0.f ? -1.0f : 0.0f));
+  }
+}
+
+int oracle_smooth_l1_vertex(const float* pred, const float* target, const float* weight, long n,
+                            float sigma, float* out, float* grad)
+{
+  const float sigma2 = sigma * sigma;
+  float* pl = (float*)malloc(sizeof(float) * SL1_BLOCKS * 2);
+  float* pw = pl + SL1_BLOCKS;
+#pragma omp parallel for schedule(static)
+  for (int blk = 0; blk < SL1_BLOCKS; blk++) {
+    float sl[256], sw[256];
+    for (int t = 0; t < 256; t++) {
+      float al = 0.f, aw = 0.f;
+      for (long i = (long)blk * 256 + t; i < n; i += (long)SL1_BLOCKS * 256) {
+        float il, dp;
+        sl1_elem(pred[i], target[i], weight[i], sigma2, &il, &dp);
+        al = al + il;
+        aw = aw + weight[i];
+      }
+      sl[t] = al; sw[t] = aw;
+    }
+    for (int st = 128; st >= 1; st >>= 1)
+      for (int t = 0; t < st; t++) { sl[t] = sl[t] + sl[t + st]; sw[t] = sw[t] + sw[t + st]; }
+    pl[blk] = sl[0]; pw[blk] = sw[0];
+  }
+  for (int st = SL1_BLOCKS / 2; st >= 1; st >>= 1)
+    for (int t = 0; t < st; t++) { pl[t] = pl[t] + pl[t + st]; pw[t] = pw[t] + pw[t + st]; }
+  const float denom = pw[0] + 1e-10f;
+  out[0] = pl[0] / denom; out[1] = pl[0]; out[2] = pw[0];
+  free(pl);
+  if (grad) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; i++) {
+      float il, dp;
+      sl1_elem(pred[i], target[i], weight[i], sigma2, &il, &dp);
+      grad[i] = dp / denom;
+    }
+  }
+  return 0;
+}

@@ -132,6 +132,50 @@ __global__ __launch_bounds__(256) void deconv_bilinear_kernel(
   }
 }
 
+// Gradient of the fixed bilinear deconv w.r.t. its input (what TF's conv2d_transpose gradient
+// returns for the make_deconv_filter weights): the transposed interpolation, as a gather so that
+// the sum order is fixed — output rows ascending, output columns ascending, acc = acc + (wy*wx)*g.
+// One thread owns V channels of one input cell and reads its k x k output footprint (each output
+// element is shared by <= ceil(k/s)^2 neighbouring cells, served by L2).
+template <int V>
+__global__ __launch_bounds__(256) void deconv_bilinear_bwd_kernel(const float* __restrict__ g,
+                                                                  float* __restrict__ gin, int H,
+                                                                  int W, int C, int k, int s,
+                                                                  long long total)
+{
+  const int pad = (k - s) / 2;
+  const int cv = C / V;
+  const int Ho = H * s, Wo = W * s;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % cv) * V;
+    long long p = idx / cv;
+    const int j = (int)(p % W);
+    p /= W;
+    const int i = (int)(p % H);
+    const int b = (int)(p / H);
+    float acc[V];
+#pragma unroll
+    for (int q = 0; q < V; q++) acc[q] = 0.f;
+    for (int ty = 0; ty < k; ty++) {
+      const int oy = s * i + ty - pad;
+      if (oy < 0 || oy >= Ho) continue;
+      const float wy = bilinear_tap(ty, k);
+      const float* grow = g + (((size_t)b * Ho + oy) * Wo) * C + c;
+      for (int tx = 0; tx < k; tx++) {
+        const int ox = s * j + tx - pad;
+        if (ox < 0 || ox >= Wo) continue;
+        const float w = wy * bilinear_tap(tx, k);
+        float v[V];
+        load_v<V>(grow + (size_t)ox * C, v);
+#pragma unroll
+        for (int q = 0; q < V; q++) acc[q] = acc[q] + w * v[q];
+      }
+    }
+    store_v<V>(gin + idx * V, acc);
+  }
+}
+
 // y = [ReLU](x + bias[c]) over NHWC rows, in place or out of place: the bias_add + relu pair of
 // Network.conv (network.py:181-187) as one pass instead of two framework kernels.
 template <int V>
@@ -326,6 +370,22 @@ extern "C" int pcnn_deconv_bilinear_fwd(const float* in, int B, int H, int W, in
   else
     PCNN_LAUNCH(deconv_bilinear_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, in, add1, add2, bias, out, H, W, C, k, s, relu, nseg);
   return check_launch("deconv_bilinear_fwd");
+}
+
+extern "C" int pcnn_deconv_bilinear_bwd(const float* grad_out, int B, int H, int W, int C, int k,
+                                        int s, float* grad_in, void* stream_)
+{
+  int st = validate(B, H, W, C, k, s);
+  if (st != PCNN_OK) return st;
+  PCNN_REQUIRE(grad_out && grad_in, PCNN_ENULL, "deconv_bwd: NULL pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  auto grid = [](long long total) { long long b = (total + 255) / 256; return (unsigned)(b < 256 * 64 ? b : 256 * 64); };
+  const long long n = (long long)B * H * W * C;
+  if (C % 4 == 0 && aligned16(grad_out) && aligned16(grad_in))
+    PCNN_LAUNCH(deconv_bilinear_bwd_kernel<4>, dim3(grid(n / 4)), dim3(256), 0, stream, grad_out, grad_in, H, W, C, k, s, n / 4);
+  else
+    PCNN_LAUNCH(deconv_bilinear_bwd_kernel<1>, dim3(grid(n)), dim3(256), 0, stream, grad_out, grad_in, H, W, C, k, s, n);
+  return check_launch("deconv_bilinear_bwd");
 }
 
 extern "C" int pcnn_bias_act_fwd(const float* x, const float* bias, int64_t num_pixels, int channels,

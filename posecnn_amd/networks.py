@@ -130,10 +130,14 @@ class Network(object):
         ident = sum(t.startswith(prefix) for t in self.layers) + 1
         return "%s_%d" % (prefix, ident)
 
-    def make_var(self, name, shape, initializer):
+    def make_var(self, name, shape, initializer, trainable=False):
+        """network.py:108-110. A variable asks for gradients when both the network and the layer are
+        trainable (the reference passes `trainable` to tf.get_variable the same way)."""
         if name not in self.vars:
             self.vars[name] = initializer(shape).to(self.device)
         v = self.vars[name]
+        if self.trainable and trainable and not v.requires_grad and v.is_leaf:
+            v.requires_grad_(True)
         if tuple(v.shape) != tuple(shape):
             raise ValueError("variable %s has shape %s, layer wants %s" % (name, tuple(v.shape), tuple(shape)))
         return v
@@ -177,8 +181,9 @@ class Network(object):
             c_i = input.shape[-1]
         assert c_i % group == 0 and c_o % group == 0
         w = self.make_var(name + "/weights", (c_o, c_i // group, k_h, k_w),
-                          lambda s: self._weight_init(c_i // group * k_h * k_w)(s).contiguous(memory_format=torch.channels_last))
-        b = self.make_var(name + "/biases", (c_o,), lambda s: torch.zeros(s)) if biased else None
+                          lambda s: self._weight_init(c_i // group * k_h * k_w)(s).contiguous(memory_format=torch.channels_last),
+                          trainable)
+        b = self.make_var(name + "/biases", (c_o,), lambda s: torch.zeros(s), trainable) if biased else None
         assert s_h == 1 and s_w == 1 or padding == "VALID" or (k_h == 1 and k_w == 1), "strided SAME conv not on this path"
         pad = (k_h // 2, k_w // 2) if padding == "SAME" else 0
         if (self.fused_first_conv and b is not None and (k_h, k_w, c_i, group) == (3, 3, 3, 1) and padding == "SAME"
@@ -229,6 +234,9 @@ class Network(object):
 
     # hooks the CPU checker overrides (tests/cpu_reference.py)
     def _bias_act(self, y, bias, relu):
+        if torch.is_grad_enabled() and (y.requires_grad or bias.requires_grad):
+            y = y + bias   # training: leave bias_add / relu to autograd
+            return F.relu(y) if relu else y
         return ops.bias_act_(y, bias, relu)
 
     def _bias_relu_pool2(self, y, bias, relu):
@@ -256,10 +264,10 @@ class Network(object):
         else:
             dim = int(input.shape[-1]) if num_in == -1 else int(num_in)
             feed_in = input
-        w = self.make_var(name + "/weights", (dim, num_out), self._weight_init(dim))
-        b = self.make_var(name + "/biases", (num_out,), lambda s: torch.zeros(s))
+        w = self.make_var(name + "/weights", (dim, num_out), self._weight_init(dim), trainable)
+        b = self.make_var(name + "/biases", (num_out,), lambda s: torch.zeros(s), trainable)
         y = torch.addmm(b, feed_in, w)
-        return F.relu_(y) if relu else y
+        return F.relu(y) if relu else y
 
     # ---- element-wise -----------------------------------------------------------------------------
     @layer
@@ -381,7 +389,8 @@ class vgg16_convs(Network):
         # fused_heads=False evaluates the heads in the reference's literal op order
         # (deconv -> 1x1 conv -> softmax -> argmax); True (default) uses the algebraically
         # identical low-resolution form + fused gfx950 epilogue (see setup()).
-        self.fused_heads = fused_heads
+        # (the fused epilogues have no backward: a trainable training graph keeps the literal order)
+        self.fused_heads = fused_heads and not (is_train and trainable)
         self.want_prob = want_prob  # prob_normalized is a fetched output in lib/fcn/test.py:193-195
         self.input_format = input_format
         self.num_classes = num_classes

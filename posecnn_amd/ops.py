@@ -309,10 +309,7 @@ def bias_relu_pool2(x, bias, relu=True):
     return y
 
 
-def deconv_bilinear(input, kernel, stride, add1=None, add2=None, bias=None, relu=False):
-    """The fixed bilinear `deconv` layer (network.py:207-222 with make_deconv_filter :141-157) as a
-    per-channel interpolation: [B,H,W,C] -> [B,H*s,W*s,C], optionally fused with up to two addends
-    (same shape as the output), a per-channel bias and ReLU."""
+def _deconv_bilinear_raw(input, kernel, stride, add1=None, add2=None, bias=None, relu=False):
     input = _dev(input, "input", torch.float32)
     if input.dim() != 4:
         raise ValueError("deconv input must be 4-dimensional")
@@ -328,6 +325,84 @@ def deconv_bilinear(input, kernel, stride, add1=None, add2=None, bias=None, relu
           lib().pcnn_deconv_bilinear_fwd(_ptr(input), B, H, W, C, int(kernel), int(stride), _ptr(a1), _ptr(a2),
                                          _ptr(bs), 1 if relu else 0, _ptr(out), _stream(input)))
     return out
+
+
+def deconv_bilinear_grad(grad_out, kernel, stride):
+    """Gradient of `deconv_bilinear` w.r.t. its input: [B,H*s,W*s,C] -> [B,H,W,C]."""
+    grad_out = _dev(grad_out, "grad_out", torch.float32)
+    B, Ho, Wo, C = grad_out.shape
+    if Ho % stride or Wo % stride:
+        raise ValueError("grad_out is not a multiple of the stride")
+    gin = torch.empty((B, Ho // stride, Wo // stride, C), dtype=torch.float32, device=grad_out.device)
+    check("pcnn_deconv_bilinear_bwd",
+          lib().pcnn_deconv_bilinear_bwd(_ptr(grad_out), B, Ho // stride, Wo // stride, C, int(kernel), int(stride),
+                                         _ptr(gin), _stream(grad_out)))
+    return gin
+
+
+class _DeconvBilinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, kernel, stride):
+        ctx.ks = (kernel, stride)
+        return _deconv_bilinear_raw(input, kernel, stride)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return deconv_bilinear_grad(grad_out.contiguous(), *ctx.ks), None, None
+
+
+def deconv_bilinear(input, kernel, stride, add1=None, add2=None, bias=None, relu=False):
+    """The fixed bilinear `deconv` layer (network.py:207-222 with make_deconv_filter :141-157) as a
+    per-channel interpolation: [B,H,W,C] -> [B,H*s,W*s,C], optionally fused with up to two addends
+    (same shape as the output), a per-channel bias and ReLU. Differentiable w.r.t. `input` (the
+    filter is not trainable in the reference: deconv(..., trainable=False)); when a gradient is
+    needed the extras are applied as separate framework ops."""
+    needs_grad = torch.is_grad_enabled() and any(
+        isinstance(t, torch.Tensor) and t.requires_grad for t in (input, add1, add2, bias))
+    if not needs_grad:
+        return _deconv_bilinear_raw(input, kernel, stride, add1, add2, bias, relu)
+    out = _DeconvBilinearFn.apply(_dev(input, "input", torch.float32), int(kernel), int(stride))
+    for t in (add1, add2, bias):
+        if t is not None:
+            out = out + t
+    return torch.relu(out) if relu else out
+
+
+class _SmoothL1VertexFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, weight, sigma):
+        n = pred.numel()
+        out = torch.empty(3, dtype=torch.float32, device=pred.device)
+        nbytes = c_size_t(0)
+        check("pcnn_smooth_l1_vertex_workspace_bytes", lib().pcnn_smooth_l1_vertex_workspace_bytes(ctypes.byref(nbytes)))
+        ws = _ws(pred.device, "smooth_l1").get(nbytes.value, pred.device)
+        check("pcnn_smooth_l1_vertex_fwd",
+              lib().pcnn_smooth_l1_vertex_fwd(_ptr(pred), _ptr(target), _ptr(weight), n, float(sigma), _ptr(out),
+                                              _ptr(ws), ws.numel(), _stream(pred)))
+        ctx.save_for_backward(pred, target, weight, out)
+        ctx.sigma = float(sigma)
+        return out[0], out[1:].clone()
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_sums):
+        pred, target, weight, out = ctx.saved_tensors
+        grad = torch.empty_like(pred)
+        up = grad_loss.reshape(1).to(torch.float32).contiguous()
+        check("pcnn_smooth_l1_vertex_bwd",
+              lib().pcnn_smooth_l1_vertex_bwd(_ptr(pred), _ptr(target), _ptr(weight), _ptr(out), _ptr(up), pred.numel(),
+                                              ctx.sigma, _ptr(grad), _stream(pred)))
+        return grad, None, None, None
+
+
+def smooth_l1_loss_vertex(vertex_pred, vertex_targets, vertex_weights, sigma=1.0):
+    """lib/fcn/train.py:564-573 as two streaming kernels (forward, backward w.r.t. vertex_pred).
+    Returns the scalar loss = sum(in_loss) / (sum(weights) + 1e-10)."""
+    pred = _dev(vertex_pred, "vertex_pred", torch.float32)
+    target = _dev(vertex_targets, "vertex_targets", torch.float32)
+    weight = _dev(vertex_weights, "vertex_weights", torch.float32)
+    if pred.shape != target.shape or pred.shape != weight.shape:
+        raise ValueError("vertex_pred, vertex_targets and vertex_weights must have the same shape")
+    return _SmoothL1VertexFn.apply(pred, target, weight, float(sigma))[0]
 
 
 def upscore_softmax_argmax(z, bias, kernel, stride, relu=True, want_score=False, want_prob=True):

@@ -189,6 +189,26 @@ def deconv_bilinear(x, k, s, add1=None, add2=None, bias=None, relu=False):
     return out
 
 
+def deconv_bilinear_bwd(grad_out, k, s):
+    g = _f32(grad_out)
+    B, Ho, Wo, C = g.shape
+    gin = np.empty((B, Ho // s, Wo // s, C), np.float32)
+    lib().oracle_deconv_bilinear_bwd(_p(g), B, Ho // s, Wo // s, C, int(k), int(s), _p(gin))
+    return gin
+
+
+def smooth_l1_vertex(pred, target, weight, sigma=1.0, want_grad=True):
+    """-> (out[3] = loss, sum(in_loss), sum(weight); grad d loss / d pred or None)"""
+    import ctypes
+    pred, target, weight = _f32(pred), _f32(target), _f32(weight)
+    out = np.empty(3, np.float32)
+    grad = np.empty_like(pred) if want_grad else None
+    f = lib().oracle_smooth_l1_vertex
+    f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_long, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]
+    f(_p(pred), _p(target), _p(weight), pred.size, float(sigma), _p(out), _p(grad))
+    return out, grad
+
+
 def upscore_softmax_argmax(z, bias, k, s, relu=True):
     score = deconv_bilinear(z, k, s, bias=bias, relu=relu)
     prob, label = softmax_argmax(score)
