@@ -15,6 +15,7 @@ class vgg16_convs_cpu(vgg16_convs):
     def __init__(self, *args, **kw):
         kw["device"] = "cpu"
         vgg16_convs.__init__(self, *args, **kw)
+        self.trainable = False  # a checker: its custom layers are numpy, nothing to differentiate
 
     def share_weights(self, other):
         self.vars = {k: v.detach().cpu() for k, v in other.vars.items()}

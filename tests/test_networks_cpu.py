@@ -89,7 +89,7 @@ def test_deconv_matches_dense_conv2d_transpose(k, s):
 
 def test_max_pool_and_fc_flatten_order():
     rng = np.random.default_rng(2)
-    net = Tiny(device="cpu")
+    net = Tiny(device="cpu", trainable=False)
     x = rng.standard_normal((2, 4, 6, 3)).astype(F)
     net.layers = {"x": torch.from_numpy(x)}
     y = net.feed("x").max_pool(2, 2, 2, 2, name="p").get_output("p").numpy()
