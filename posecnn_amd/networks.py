@@ -170,6 +170,36 @@ class Network(object):
                     if suffix == "" or key in self.vars:
                         self.vars[key] = t.to(self.device)
 
+    def load_file(self, path, ignore_missing=False):
+        """Checkpoint ingestion. Accepts
+          - `vgg16.npy`-style pickled dicts {layer: {'weights', 'biases'}} (network.py:71-107), and
+          - `.npz` archives keyed by TF variable name ('conv1_1/weights', 'fc6/biases', ...) in TF
+            layouts ([kh,kw,cin,cout] / [in,out]) — what three lines of TF dump from a checkpoint:
+            `np.savez(out, **{v.name[:-2]: sess.run(v) for v in tf.global_variables()})`
+            (INTEGRATION.md). Optimizer slots ('.../Momentum') are skipped."""
+        if str(path).endswith(".npz"):
+            arch = np.load(path)
+            data = {}
+            for key in arch.files:
+                if key.count("/") != 1 or key.rsplit("/", 1)[1] not in ("weights", "biases"):
+                    continue
+                layer_name, pname = key.rsplit("/", 1)
+                data.setdefault(layer_name, {})[pname] = arch[key]
+        else:
+            data = np.load(path, allow_pickle=True, encoding="latin1").item()
+        self.load(data, ignore_missing)
+        return sorted(data)
+
+    def save_npz(self, path):
+        """Writes every variable under its TF name in TF layout (the inverse of load_file)."""
+        out = {}
+        for key, v in self.vars.items():
+            t = v.detach().cpu()
+            if key.endswith("/weights") and t.dim() == 4:
+                t = t.permute(2, 3, 1, 0)  # [cout,cin,kh,kw] -> [kh,kw,cin,cout]
+            out[key] = np.ascontiguousarray(t.numpy())
+        np.savez(path, **out)
+
     # ---- dense layers (MIOpen / hipBLASLt) -------------------------------------------------------
     @layer
     def conv(self, input, k_h, k_w, c_o, s_h, s_w, name, reuse=None, relu=True, padding=DEFAULT_PADDING,

@@ -133,3 +133,28 @@ def test_vgg16_convs_graph_runs_on_cpu_reference():
     assert net2.vars["score_conv5/weights"].shape == (64, 1024, 1, 1)
     assert net2.vars["score_conv5_vertex/weights"].shape == (128, 512, 1, 1)
     assert "conv5_3_p" in net2.layers and net2.get_output("concat_conv5").shape[-1] == 1024
+
+
+def test_checkpoint_round_trip_npz_and_npy(tmp_path):
+    """save_npz writes TF-named / TF-layout variables; load_file reads them back (and the vgg16.npy
+    dict format, network.py:71-107) into a second network that then computes the same outputs."""
+    rng = np.random.default_rng(7)
+    a = vgg16_convs_cpu("COLOR", 22, 64, (1.0,), 1.0, -1.0)
+    x = torch.from_numpy(rng.standard_normal((1, 6, 8, 3)).astype(F))
+    a.layers = {"x": x}
+    a.feed("x").conv(3, 3, 4, 1, 1, name="c1", c_i=3).fc(5, height=6, width=8, channel=4, name="f1", relu=False)
+    path = str(tmp_path / "w.npz")
+    a.save_npz(path)
+    arch = np.load(path)
+    assert arch["c1/weights"].shape == (3, 3, 3, 4) and arch["f1/weights"].shape == (6 * 8 * 4, 5)
+    b = vgg16_convs_cpu("COLOR", 22, 64, (1.0,), 1.0, -1.0)
+    assert b.load_file(path) == ["c1", "f1"]
+    b.layers = {"x": x}
+    b.feed("x").conv(3, 3, 4, 1, 1, name="c1", c_i=3).fc(5, height=6, width=8, channel=4, name="f1", relu=False)
+    assert torch.equal(a.get_output("f1"), b.get_output("f1"))
+    npy = str(tmp_path / "vgg.npy")
+    np.save(npy, {"c1": {"weights": arch["c1/weights"], "biases": arch["c1/biases"]}}, allow_pickle=True)
+    c = vgg16_convs_cpu("COLOR", 22, 64, (1.0,), 1.0, -1.0)
+    assert c.load_file(npy) == ["c1"]
+    c.layers = {"x": x}
+    assert torch.equal(c.feed("x").conv(3, 3, 4, 1, 1, name="c1", c_i=3).get_output("c1"), a.get_output("c1"))
