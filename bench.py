@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 from posecnn_amd import _lib, config, dist as pdist, fcn, synth  # noqa: E402
 from posecnn_amd.networks import vgg16_convs  # noqa: E402
 
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -155,6 +156,7 @@ def main():
         run(0, a.warmup)
         torch.cuda.synchronize()
         _lib.profile_enable(True)   # HIP events around every library kernel, on the launch stream
+        net.conv_timing = []        # ... and around every MIOpen convolution of the trunk
         pdist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -164,6 +166,9 @@ def main():
         t1 = time.perf_counter()
         kern = _lib.profile_report()
         _lib.profile_enable(False)
+        conv_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in net.conv_timing)
+        conv_flops = sum(f for _, f, _, _ in net.conv_timing)
+        net.conv_timing = None
     elapsed = pdist.max_over_ranks(t1 - t0, dev)
 
     if rank != 0:
@@ -189,6 +194,32 @@ def main():
             traffic = int((2.0 * pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024)
     except Exception:
         pass
+    # brute-force-equivalent pair predicates of the reference kernel: sum_c ceil(N_c/skip)*H*W
+    per_class = torch.bincount((lab.reshape(B, -1).long() + 22 * torch.arange(B, device=dev).unsqueeze(1)).flatten(),
+                               minlength=22 * B).reshape(B, 22)[:, 1:]
+    pairs = float(((per_class + net.skip_pixels - 1) // net.skip_pixels * (per_class > 500)).sum().item()) * H * W
+    # HBM-bound kernels of the library: algorithmic bytes per step / live event time per step
+    def us(k):
+        return kern[k]["avg_us"] * kern[k]["calls"] / a.steps if k in kern else None
+    act = lambda div, ch: 4.0 * B * (H // div) * (W // div) * ch
+    hbm = {
+        "conv3x3_c3_bias_relu_kernel": act(1, 3) + act(1, 64),
+        "bias_relu_pool2_kernel": 1.25 * (act(1, 64) + act(2, 128) + act(4, 256)),
+        "bias_act_kernel": 2.0 * (act(2, 128) + 2 * act(4, 256) + 3 * act(8, 512) + 3 * act(16, 512)),
+        "hard_label_fwd_kernel": 4.0 * B * H * W * (2 + 22),
+        "upscore_softmax_argmax_kernel": 4.0 * B * H * W * (22 + 1) + act(8, 22),
+    }
+    if a.input == "RGBD":
+        for k in ("conv3x3_c3_bias_relu_kernel", "bias_relu_pool2_kernel"):
+            hbm[k] *= 2
+        hbm["bias_act_kernel"] = None
+    others = []
+    for k, byt in hbm.items():
+        t = us(k)
+        if t and byt:
+            others.append({"kernel": k, "bound": "hbm", "achieved": byt / (t * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": byt / (t * 1e-6) / 1e9 / HBM_PEAK_GBPS, "us_per_step": round(t, 1)})
+    conv_tflops = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else None
     out = {
         "metric": "RGB-D frames/sec (640x480, 21 YCB classes)",
         "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -205,7 +236,14 @@ def main():
                      "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) from separate rocprofv3 --pmc passes (profiles/r01_hough_pmc.json)",
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": hv["avg_us"], "launches": hv["calls"],
                      "note": "Hough voting is VALU/LDS bound, not HBM bound (SURVEY.md §8d): compulsory traffic is ~2 MB/frame",
-                     "hough_sequence_us": hough_us, "hough_GBps_whole_sequence": alg_bytes / (hough_us * 1e-6) / 1e9 if hough_us else None},
+                     "hough_sequence_us": hough_us, "hough_GBps_whole_sequence": alg_bytes / (hough_us * 1e-6) / 1e9 if hough_us else None,
+                     "pair_predicates_equiv_per_launch": pairs,
+                     "pair_predicates_equiv_per_s": pairs / (hv["avg_us"] * 1e-6) if hv["calls"] else None},
+        "roofline_other": others,
+        "backbone": {"what": "the library fp32 convolutions of the VGG16 trunk + heads (MIOpen/CK, not hand-written)", "bound": "mfma",
+                     "achieved": conv_tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": conv_tflops / FP32_MFMA_PEAK_TFLOPS if conv_tflops else None,
+                     "ms_per_step": conv_ms / a.steps, "share_of_step": conv_ms / a.steps / ms_per_step},
         "kernels_us": {k: round(v["avg_us"], 2) for k, v in sorted(kern.items())},
     }
     if world == 1 and not a.no_cpu_baseline:

@@ -94,6 +94,7 @@ class Network(object):
         self.init = init
         self._gen = torch.Generator(device="cpu").manual_seed(seed)  # cfg.RNG_SEED = 3 (config.py)
         self.keep_prob_queue = 1.0
+        self.conv_timing = None       # a list -> (name, flops, start_event, end_event) per library conv
         self.fused_first_conv = True  # 3-channel 3x3 convs go to the fused conv + bias + ReLU kernel
         self.defer_act = frozenset()  # conv layers whose bias + ReLU is left to the following max_pool
 
@@ -220,7 +221,15 @@ class Network(object):
                 and c_o % 64 == 0 and not (torch.is_grad_enabled() and (w.requires_grad or input.requires_grad))):
             # conv1_1: K = 27 is no GEMM; one HBM-bound kernel does conv + bias + ReLU
             return self._conv_first(input, w, b, relu)
-        y = _nhwc(F.conv2d(_nchw(input), w, None, stride=(s_h, s_w), padding=pad, groups=group))
+        if self.conv_timing is not None and input.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = _nhwc(F.conv2d(_nchw(input), w, None, stride=(s_h, s_w), padding=pad, groups=group))
+            e1.record()
+            flops = 2.0 * y.numel() * (c_i // group) * k_h * k_w
+            self.conv_timing.append((name, flops, e0, e1))
+        else:
+            y = _nhwc(F.conv2d(_nchw(input), w, None, stride=(s_h, s_w), padding=pad, groups=group))
         if b is not None and name in self.defer_act and not (torch.is_grad_enabled() and y.requires_grad):
             return _RawConv(y, b, relu)
         if b is None and not relu:
