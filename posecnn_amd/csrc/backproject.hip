@@ -141,6 +141,110 @@ __global__ __launch_bounds__(256) void backproject_label_kernel(
   }
 }
 
+// Fused forward for windows of at most 64 pixels ((2k+1)^2 <= 64, i.e. k <= 3 — the reference's
+// k = 3, vgg16.py:131-132). A wave owns 64 consecutive voxels:
+//   A  lane = voxel: ONE projection + ONE window scan per voxel, kept as a 64-bit mask of the
+//      matching window pixels (bit = column-major position inside the unclipped window, which is
+//      the reference's summation order) — the kernels above redo this in every channel's thread;
+//   B  lane = (voxel of a group of 64/LPV, channel quad): masks travel by shuffle, the set bits are
+//      walked in ascending order (`acc += v`, same order as the nested loops) and every store
+//      instruction writes 64/LPV voxels x Cd floats contiguously (data and flag);
+//   C  lane = flattened (voxel, class) of the wave's 64 x Cl contiguous label outputs.
+template <int LPV>  // lanes per voxel in phase B = min(Cd, 64) / 4
+__global__ __launch_bounds__(256) void backproject_fused_kernel(
+    const float* __restrict__ data, const float* __restrict__ label, const float* __restrict__ depth,
+    const float* __restrict__ meta, const float* __restrict__ label_3d, float* __restrict__ top_data,
+    float* __restrict__ top_label, float* __restrict__ top_flag, long long nvox, int H, int W, int Cd,
+    int Cl, int num_meta, int G, int ksize, float threshold)
+{
+  const int lane = threadIdx.x & 63;
+  const long long nwave = (nvox + 63) / 64;
+  const int S = 2 * ksize + 1;
+  const long long G3 = (long long)G * G * G;
+  for (long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); wv < nwave; wv += (long long)gridDim.x * 4) {
+    const long long vbase = wv * 64;
+    // ---- A: one voxel per lane
+    unsigned long long mask = 0;
+    int px = 0, py = 0;  // window origin (column, row) of this lane's voxel
+    {
+      const long long vox = vbase + lane;
+      if (vox < nvox) {
+        long long t = vox;
+        const int w = (int)(t % G); t /= G;
+        const int h = (int)(t % G); t /= G;
+        const int d = (int)(t % G); t /= G;
+        const int n = (int)t;
+        const float* md = meta + (size_t)n * num_meta;
+        const Proj p = project_voxel(md, d, h, w);
+        const Window win = clip_window(p, ksize, H, W);
+        // window origin; clamped so that garbage projections (saturated to INT_MIN/MAX, empty
+        // window, never dereferenced) cannot overflow the subtraction
+        px = (int)max(-(1ll << 30), min(1ll << 30, (long long)p.px - ksize));
+        py = (int)max(-(1ll << 30), min(1ll << 30, (long long)p.py - ksize));
+        const float* dn = depth + (long long)n * H * W;
+        for (int x = win.xlo; x <= win.xhi; x++)
+          for (int y = win.ylo; y <= win.yhi; y++)
+            if (fabsf(dn[(long long)y * W + x] - p.Z1) < threshold)
+              mask |= 1ull << ((x - px) * S + (y - py));
+      }
+    }
+    const unsigned mlo = (unsigned)mask, mhi = (unsigned)(mask >> 32);
+    // ---- B: data + flag
+    constexpr int VPI = 64 / LPV;  // voxels per iteration
+    const int sub = lane / LPV, cq = lane % LPV;
+    for (int it = 0; it < 64 / VPI; it++) {
+      const int vl = it * VPI + sub;
+      const long long vox = vbase + vl;
+      unsigned long long m = ((unsigned long long)(unsigned)__shfl((int)mhi, vl) << 32) | (unsigned)__shfl((int)mlo, vl);
+      const int vx = __shfl(px, vl), vy = __shfl(py, vl);
+      if (vox >= nvox) continue;
+      const long long n = vox / G3;
+      const float* dbase = data + n * H * W * (long long)Cd;
+      const float cnt = (float)__popcll(m);
+      for (int c = cq * 4; c < Cd; c += LPV * 4) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned long long mm = m;
+        while (mm) {
+          const int b = __ffsll((long long)mm) - 1;
+          mm &= mm - 1;
+          const int x = vx + b / S, y = vy + b % S;
+          const float4 v = *reinterpret_cast<const float4*>(dbase + ((long long)y * W + x) * Cd + c);
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        float flag = 0.f;
+        if (m) {
+          acc.x = div_rn(acc.x, cnt); acc.y = div_rn(acc.y, cnt); acc.z = div_rn(acc.z, cnt); acc.w = div_rn(acc.w, cnt);
+          flag = 1.f;
+        }
+        *reinterpret_cast<float4*>(top_data + vox * Cd + c) = acc;
+        *reinterpret_cast<float4*>(top_flag + vox * Cd + c) = make_float4(flag, flag, flag, flag);
+      }
+    }
+    // ---- C: labels, 64 * Cl contiguous outputs of this wave
+    const long long lbase = vbase * Cl;
+    for (int i = lane; i < 64 * Cl; i += 64) {
+      const int vl = i / Cl, cl = i - vl * Cl;
+      // (every lane reaches the shuffles: 64 * Cl is a multiple of 64)
+      unsigned long long m = ((unsigned long long)(unsigned)__shfl((int)mhi, vl) << 32) | (unsigned)__shfl((int)mlo, vl);
+      const int vx = __shfl(px, vl), vy = __shfl(py, vl);
+      const long long vox = vbase + vl;
+      if (vox >= nvox) continue;
+      const long long n = vox / G3;
+      const float* lb = label + n * H * W * (long long)Cl;
+      float acc = 0.f;
+      const float cnt = (float)__popcll(m);
+      unsigned long long mm = m;
+      while (mm) {
+        const int b = __ffsll((long long)mm) - 1;
+        mm &= mm - 1;
+        const int x = vx + b / S, y = vy + b % S;
+        acc += lb[((long long)y * W + x) * Cl + cl];
+      }
+      top_label[lbase + i] = m ? div_rn(acc, cnt) : label_3d[lbase + i];
+    }
+  }
+}
+
 // BackprojectBackward, backprojecting_op_gpu.cu.cc:159-217
 __global__ __launch_bounds__(256) void backproject_bwd_kernel(
     const float* __restrict__ top_diff, const float* __restrict__ depth,
@@ -207,6 +311,18 @@ extern "C" int pcnn_backproject_fwd(const float* data, const float* label, const
   hipStream_t stream = (hipStream_t)stream_;
   const long long nvox = (long long)B * G * G * G;
   const bool vec = (Cd % 4 == 0) && aligned16(data) && aligned16(top_data) && aligned16(top_flag);
+  const int lpv = Cd >= 64 ? 16 : Cd / 4;
+  const bool fused = vec && (2 * ksize + 1) * (2 * ksize + 1) <= 64 && (Cd % 64 == 0 || Cd == 32 || Cd == 16 || Cd == 8 || Cd == 4);
+  if (fused) {
+    const long long nwave = (nvox + 63) / 64;
+    const long long blocks = (nwave + 3) / 4;
+    const dim3 grid((unsigned)(blocks < 256 * 64 ? blocks : 256 * 64));
+#define BP_GO(L) PCNN_LAUNCH(backproject_fused_kernel<L>, grid, dim3(256), 0, stream, data, label, depth, meta, label_3d, \
+                             top_data, top_label, top_flag, nvox, H, W, Cd, Cl, num_meta, G, ksize, threshold)
+    if (lpv == 16) BP_GO(16); else if (lpv == 8) BP_GO(8); else if (lpv == 4) BP_GO(4); else if (lpv == 2) BP_GO(2); else BP_GO(1);
+#undef BP_GO
+    return pcnn::check_launch("backproject_fwd");
+  }
   if (vec) {
     const long long total = nvox * (Cd / 4);
     PCNN_LAUNCH(backproject_data_kernel<4>, dim3(grid_for(total)), dim3(256), 0, stream, data,

@@ -225,7 +225,12 @@ def backproject_case(rng, B, H, W, Cd, Cl, G):
     return data, label, depth[..., None], meta, label3d
 
 
-@pytest.mark.parametrize("B,H,W,Cd,Cl,G,k", [(1, 48, 64, 64, 22, 24, 3), (2, 20, 28, 6, 3, 9, 1), (1, 16, 16, 5, 2, 8, 0)])
+@pytest.mark.parametrize("B,H,W,Cd,Cl,G,k", [(1, 48, 64, 64, 22, 24, 3), (2, 20, 28, 6, 3, 9, 1), (1, 16, 16, 5, 2, 8, 0),
+                                            # fused one-scan-per-voxel kernel: every lanes-per-voxel variant, a voxel
+                                            # count that is no multiple of 64, two images; and k = 4 (81-pixel window
+                                            # > 64 bits) which must take the per-channel kernels
+                                            (2, 24, 32, 128, 5, 7, 3), (1, 24, 32, 32, 22, 9, 2), (1, 20, 24, 16, 4, 6, 3),
+                                            (2, 20, 24, 8, 3, 5, 1), (1, 20, 24, 4, 3, 5, 3), (1, 24, 32, 64, 22, 10, 4)])
 def test_backproject_forward(gpu, B, H, W, Cd, Cl, G, k):
     from posecnn_amd import ops
     rng = np.random.default_rng(19)
