@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--thr", type=float, default=50.0)
-    ap.add_argument("--ops", default="hough,hough_thr,hard_label,softmax,roi_pool,adl,backproject")
+    ap.add_argument("--ops", default="hough,hough_lowres,hough_thr,hard_label,softmax,roi_pool,adl,backproject,trunk,upscore,smooth_l1")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     B, H, W, C = a.batch, a.height, a.width, 22
@@ -48,7 +48,7 @@ def main():
     meta = T(np.stack([config.make_meta_data(K)] * B))
     ext = T(config.LOV_EXTENTS)
 
-    if which & {"hough", "hough_thr", "roi_pool"}:
+    if which & {"hough", "hough_thr", "roi_pool", "hough_lowres"}:
         label_np, vertex_np, _ = synth.make_batch(0, B, H=H, W=W, C=C, K=K)
         label, vertex = T(label_np), T(vertex_np)
         nfg = int((label_np > 0).sum())
@@ -78,6 +78,14 @@ def main():
             torch.cuda.synchronize()
             res["hough"]["kernels_us"] = {k: round(v["avg_us"], 2) for k, v in _lib.profile_report().items()}
             _lib.profile_enable(False)
+        if "hough_lowres" in which:
+            # the fused vertex head path: 1/8-resolution field, interpolated for the sampled pixels only
+            z = vertex[:, 4::8, 4::8, :].contiguous()
+            zb = torch.zeros(3 * C, device=dev)
+            r = timeit(lambda: ops.hough_voting_gpu_lowres_padded(label, z, zb, 16, 8, ext, meta, None, 0, -1.0, 0.02, 10), a.iters)
+            r["note"] = "vs materialising vertex_pred first: + deconv_bilinear below"
+            r["deconv_vertex_pred"] = timeit(lambda: ops.deconv_bilinear(z, 16, 8, bias=zb), a.iters)
+            res["hough_lowres"] = r
         if "hough_thr" in which:
             r = timeit(lambda: ops.hough_voting_gpu_padded(label, vertex, ext, meta, None, 0, a.thr, 0.002, 10), a.iters)
             _lib.profile_enable(True)
@@ -111,6 +119,59 @@ def main():
             byt = B * H * W * (4 + 4 + 4 * C)
             r.update({"algorithmic_bytes": byt, "GBps": byt / r["ms_median"] / 1e6})
             res["hard_label"] = r
+    if "trunk" in which:
+        g = torch.Generator(device=dev).manual_seed(5)
+        x = torch.randn((B, H, W, 3), device=dev, generator=g) * 50
+        w = torch.randn((3, 3, 3, 64), device=dev, generator=g) * 0.1
+        bias = torch.randn(64, device=dev, generator=g)
+        r = timeit(lambda: ops.conv3x3_c3(x, w, bias, True), a.iters)
+        byt = B * H * W * (3 + 64) * 4
+        r.update({"algorithmic_bytes": byt, "GBps": byt / r["ms_median"] / 1e6})
+        res["conv3x3_c3_bias_relu"] = r
+        y = torch.randn((B, H, W, 64), device=dev, generator=g)
+        r = timeit(lambda: ops.bias_relu_pool2(y, bias, True), a.iters)
+        byt = int(B * H * W * 64 * 4 * 1.25)
+        r.update({"algorithmic_bytes": byt, "GBps": byt / r["ms_median"] / 1e6})
+        res["bias_relu_pool2_conv1_2"] = r
+        r = timeit(lambda: ops.bias_act_(y, bias, True), a.iters)
+        byt = B * H * W * 64 * 4 * 2
+        r.update({"algorithmic_bytes": byt, "GBps": byt / r["ms_median"] / 1e6})
+        res["bias_act_conv1"] = r
+    if "upscore" in which:
+        g = torch.Generator(device=dev).manual_seed(6)
+        z = torch.randn((B, H // 8, W // 8, C), device=dev, generator=g)
+        zb = torch.randn(C, device=dev, generator=g)
+        r = timeit(lambda: ops.upscore_softmax_argmax(z, zb, 16, 8), a.iters)
+        byt = B * H * W * (C + 1) * 4
+        r.update({"algorithmic_bytes": byt, "GBps": byt / r["ms_median"] / 1e6})
+        res["upscore_softmax_argmax"] = r
+        z64 = torch.randn((B, H // 8, W // 8, 64), device=dev, generator=g)
+        r = timeit(lambda: ops.deconv_bilinear(z64, 16, 8), max(3, a.iters // 2))
+        byt = B * H * W * 64 * 4
+        r.update({"algorithmic_bytes": byt, "GBps": byt / r["ms_median"] / 1e6})
+        res["deconv_bilinear_64ch_x8"] = r
+        gout = torch.randn((B, H, W, 64), device=dev, generator=g)
+        r = timeit(lambda: ops.deconv_bilinear_grad(gout, 16, 8), max(3, a.iters // 2))
+        r.update({"algorithmic_bytes": byt, "GBps": byt / r["ms_median"] / 1e6})
+        res["deconv_bilinear_bwd_64ch_x8"] = r
+    if "smooth_l1" in which:
+        g = torch.Generator(device=dev).manual_seed(7)
+        n = (B, H, W, 3 * C)
+        p = torch.randn(n, device=dev, generator=g).requires_grad_(True)
+        t = torch.randn(n, device=dev, generator=g)
+        wt = (torch.rand(n, device=dev, generator=g) < 0.1).float()
+        r = timeit(lambda: ops.smooth_l1_loss_vertex(p.detach(), t, wt), max(3, a.iters // 2))
+        byt = p.numel() * 4 * 3
+        r.update({"algorithmic_bytes": byt, "GBps": byt / r["ms_median"] / 1e6})
+        res["smooth_l1_vertex_fwd"] = r
+
+        def fb():
+            p.grad = None
+            ops.smooth_l1_loss_vertex(p, t, wt).backward()
+        r = timeit(fb, max(3, a.iters // 2))
+        byt = p.numel() * 4 * 7
+        r.update({"algorithmic_bytes": byt, "GBps": byt / r["ms_median"] / 1e6})
+        res["smooth_l1_vertex_fwd_bwd"] = r
     if "adl" in which:
         rng = np.random.default_rng(3)
         P = config.NUM_MODEL_POINTS
