@@ -106,11 +106,15 @@ class HostDrain:
         self.depth = depth
         self.slots = [None] * depth
         self.events = [None] * depth
+        self.busy = [False] * depth
         self.n = 0
 
     def submit(self, packed):
         k = self.n % self.depth
+        if self.busy[k]:
+            raise RuntimeError("HostDrain: %d batches in flight, collect() one before submitting more" % self.depth)
         self.n += 1
+        self.busy[k] = True
         on_gpu = packed.is_cuda
         if self.slots[k] is None or self.slots[k].shape != packed.shape:
             self.slots[k] = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=on_gpu)
@@ -121,9 +125,13 @@ class HostDrain:
         return k
 
     def collect(self, ticket):
+        if not self.busy[ticket]:
+            raise RuntimeError("HostDrain: ticket %d was already collected" % ticket)
         if self.events[ticket] is not None:
             self.events[ticket].synchronize()
-        return _flatten_host(self.slots[ticket].numpy())
+        out = _flatten_host(self.slots[ticket].numpy())  # concatenation copies out of the pinned slot
+        self.busy[ticket] = False
+        return out
 
 
 def barrier():

@@ -38,6 +38,12 @@ def layer(op):
             layer_input = self.inputs[0]
         else:
             layer_input = list(self.inputs)
+        if op.__name__ != "max_pool":
+            # only max_pool fuses a deferred bias + ReLU; everybody else sees the activated tensor
+            if isinstance(layer_input, list):
+                layer_input = [self._activate(i) if isinstance(i, _RawConv) else i for i in layer_input]
+            elif isinstance(layer_input, _RawConv):
+                layer_input = self._activate(layer_input)
         layer_output = op(self, layer_input, *args, **kwargs)
         self.layers[name] = layer_output
         self.feed(layer_output)

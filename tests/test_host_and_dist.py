@@ -124,6 +124,21 @@ def test_all_gather_detections_world2_gloo():
         assert tmax == 2.0            # MAX over ranks (bench.py timing contract)
 
 
+def test_host_drain_refuses_to_overwrite_an_uncollected_batch():
+    import pytest
+    rows = torch.zeros((4, 14)); rows[0, 1] = 5
+    packed = pdist.all_gather_packed(rows, torch.tensor([1], dtype=torch.int32))
+    drain = pdist.HostDrain(depth=2)
+    t0, t1 = drain.submit(packed), drain.submit(packed)
+    with pytest.raises(RuntimeError):
+        drain.submit(packed)
+    assert drain.collect(t0).shape == (1, 14)
+    with pytest.raises(RuntimeError):
+        drain.collect(t0)
+    t2 = drain.submit(packed)
+    assert drain.collect(t1).shape == (1, 14) and drain.collect(t2).shape == (1, 14)
+
+
 def test_all_gather_detections_world1_is_local():
     rows = torch.zeros((4, 14)); rows[0, 1] = 5
     g, c = pdist.all_gather_detections(rows, torch.tensor([1], dtype=torch.int32))

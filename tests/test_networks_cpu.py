@@ -158,3 +158,25 @@ def test_checkpoint_round_trip_npz_and_npy(tmp_path):
     assert c.load_file(npy) == ["c1"]
     c.layers = {"x": x}
     assert torch.equal(c.feed("x").conv(3, 3, 4, 1, 1, name="c1", c_i=3).get_output("c1"), a.get_output("c1"))
+
+
+def test_deferred_bias_relu_is_fused_only_into_max_pool():
+    """A conv listed in `defer_act` hands its raw output to the next layer: max_pool fuses bias + ReLU,
+    every other consumer (and a fetch by name) sees the activated tensor."""
+    rng = np.random.default_rng(9)
+    x = torch.from_numpy(rng.standard_normal((1, 6, 8, 5)).astype(F))
+    w = rng.standard_normal((3, 3, 5, 4)).astype(F); b = rng.standard_normal(4).astype(F)
+    outs = {}
+    for defer in (False, True):
+        net = vgg16_convs_cpu("COLOR", 22, 64, (1.0,), 1.0, -1.0)
+        net.defer_act = frozenset(["c"]) if defer else frozenset()
+        net.load({"c": {"weights": w, "biases": b}})
+        net.layers = {"x": x}
+        with torch.no_grad():
+            net.feed("x").conv(3, 3, 4, 1, 1, name="c", c_i=5).max_pool(2, 2, 2, 2, name="p")
+            pooled = net.get_output("p").clone()
+            net.feed("x").conv(3, 3, 4, 1, 1, name="c", c_i=5).relu(name="r")
+            outs[defer] = (pooled, net.get_output("r").clone(), net.get_output("c").clone())
+    for a, b_ in zip(outs[False], outs[True]):
+        assert torch.equal(a, b_)
+    assert float(outs[True][2].min()) >= 0  # fetched by name: activated
