@@ -248,6 +248,20 @@ int pcnn_bias_act_fwd(const float* x, const float* bias, int64_t num_pixels, int
 int pcnn_conv3x3_c3_fwd(const float* x, const float* weights, const float* bias, int batch,
                         int height, int width, int out_channels, int relu, float* y, void* stream);
 
+/* Data transforms of a Winograd F(2x2,3x3) evaluation of `Network.conv` for the deep 3x3 / stride 1 /
+ * SAME layers of the trunk (network.py:159-187; vgg16_convs.py:42-52). All f32.
+ *   pcnn_winograd_input_fwd : x f32 [B,H,W,C] (H, W even, C % 4 == 0) -> v f32 [16][T][C],
+ *       T = B*(H/2)*(W/2) tiles in (b, ty, tx) order, v[4i+j] = (B^T d B)[i][j] of the 4x4 input
+ *       patch at (2ty-1, 2tx-1) (zero outside the image).
+ *   (caller) m[k] = v[k] (T x Cin) * u[k] (Cin x Cout) for k = 0..15 with u[4i+j] = (G g G^T)[i][j].
+ *   pcnn_winograd_output_fwd: m f32 [16][T][C] -> y = [ReLU](A^T m A + bias) as f32 [B,H,W,C], or with
+ *       pool != 0 its 2x2 max-pool f32 [B,H/2,W/2,C] (an output tile is one pooling window).
+ * Transform order: rows, then columns, sums left to right, bias last. */
+int pcnn_winograd_input_fwd(const float* x, int batch, int height, int width, int channels, float* v,
+                            void* stream);
+int pcnn_winograd_output_fwd(const float* m, const float* bias, int batch, int height, int width,
+                             int channels, int relu, int pool, float* y, void* stream);
+
 /* y[b,oy,ox,c] = max over the 2x2 window of [ReLU](x + bias[c]): the `conv -> max_pool(2,2,2,2)`
  * pairs of the VGG trunk (vgg16_convs.py:36-49; network.py:181-187 + :189-196) from the raw
  * convolution output x f32 [B,H,W,C] (H, W even) to y f32 [B,H/2,W/2,C], same bits as

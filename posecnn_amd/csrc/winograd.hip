@@ -1,0 +1,188 @@
+// winograd.hip — the data transforms of a Winograd F(2x2, 3x3) evaluation of the VGG trunk's deep
+// 3x3 convolutions (`Network.conv`, lib/networks/network.py:159-187; vgg16_convs.py:42-52).
+//
+// The trunk is 85 % of a frame and runs at 83 % of the fp32 MFMA peak as a direct convolution:
+// the only way to make an fp32 3x3 convolution cheaper is to do fewer multiplies. F(2x2, 3x3)
+// computes a 2x2 output tile from a 4x4 input tile with 16 multiplies per (cin, cout) instead of
+// 36 — exact in real arithmetic, all-f32 here (what cuDNN itself picks for these layers):
+//
+//   V[k][t][ci] = (B^T d B)[k]          pcnn_winograd_input_fwd    (this file, HBM stream)
+//   M[k] = V[k] (T x Cin) * U[k]        16 fp32 GEMMs              (library batched GEMM, MFMA)
+//   Y tile = A^T M A + bias, ReLU       pcnn_winograd_output_fwd   (this file, HBM stream;
+//                                                                   optional fused 2x2 max-pool)
+//   U[k][ci][co] = (G g G^T)[k]         once per filter            (host, float64 -> f32)
+//
+// with t = (b, ty, tx) over the (H/2) x (W/2) output tiles, k = 4*i + j over the 4x4 transform
+// domain. It pays where the 4x larger V / M tensors are cheap against the saved MACs: C >= 256.
+//
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]      A^T = [1 1 1 0; 0 1 -1 -1]
+// Canonical order: rows first, then columns; sums left to right; + bias last.
+#include "pcnn_device.h"
+
+namespace {
+
+using namespace pcnn;
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x,
+                                                         float* __restrict__ v, int H, int W, int C,
+                                                         long long total, long long plane)
+{
+  const int cv = C / 4;
+  const int Ht = H / 2, Wt = W / 2;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % cv) * 4;
+    const long long t = idx / cv;
+    const int tx = (int)(t % Wt);
+    const int ty = (int)((t / Wt) % Ht);
+    const long long b = t / ((long long)Wt * Ht);
+    const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+    const float* xb = x + b * H * W * (long long)C + c;
+    f4 d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int yy = y0 + r;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const int xx = x0 + s;
+        f4 val = {0.f, 0.f, 0.f, 0.f};
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+          val = *reinterpret_cast<const f4*>(xb + ((long long)yy * W + xx) * C);
+        d[r][s] = val;
+      }
+    }
+    f4 tmp[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      tmp[0][s] = d[0][s] - d[2][s];
+      tmp[1][s] = d[1][s] + d[2][s];
+      tmp[2][s] = d[2][s] - d[1][s];
+      tmp[3][s] = d[1][s] - d[3][s];
+    }
+    float* vo = v + t * C + c;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      *reinterpret_cast<f4*>(vo + (4 * i + 0) * plane) = tmp[i][0] - tmp[i][2];
+      *reinterpret_cast<f4*>(vo + (4 * i + 1) * plane) = tmp[i][1] + tmp[i][2];
+      *reinterpret_cast<f4*>(vo + (4 * i + 2) * plane) = tmp[i][2] - tmp[i][1];
+      *reinterpret_cast<f4*>(vo + (4 * i + 3) * plane) = tmp[i][1] - tmp[i][3];
+    }
+  }
+}
+
+__device__ __forceinline__ f4 relu4(f4 a)
+{
+  f4 r;
+  r.x = a.x > 0.f ? a.x : 0.f;
+  r.y = a.y > 0.f ? a.y : 0.f;
+  r.z = a.z > 0.f ? a.z : 0.f;
+  r.w = a.w > 0.f ? a.w : 0.f;
+  return r;
+}
+
+__device__ __forceinline__ f4 max4(f4 a, f4 b)
+{
+  f4 r;
+  r.x = b.x > a.x ? b.x : a.x;
+  r.y = b.y > a.y ? b.y : a.y;
+  r.z = b.z > a.z ? b.z : a.z;
+  r.w = b.w > a.w ? b.w : a.w;
+  return r;
+}
+
+template <bool POOL>
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ m,
+                                                          const float* __restrict__ bias,
+                                                          float* __restrict__ y, int H, int W, int C,
+                                                          int relu, long long total, long long plane)
+{
+  const int cv = C / 4;
+  const int Ht = H / 2, Wt = W / 2;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % cv) * 4;
+    const long long t = idx / cv;
+    const int tx = (int)(t % Wt);
+    const int ty = (int)((t / Wt) % Ht);
+    const long long b = t / ((long long)Wt * Ht);
+    const float* mi = m + t * C + c;
+    f4 q[4][4];
+#pragma unroll
+    for (int k = 0; k < 16; k++) q[k >> 2][k & 3] = *reinterpret_cast<const f4*>(mi + k * plane);
+    f4 tmp[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      tmp[0][j] = q[0][j] + q[1][j] + q[2][j];
+      tmp[1][j] = q[1][j] - q[2][j] - q[3][j];
+    }
+    const f4 bq = *reinterpret_cast<const f4*>(bias + c);
+    f4 o[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+      o[a][0] = tmp[a][0] + tmp[a][1] + tmp[a][2] + bq;
+      o[a][1] = tmp[a][1] - tmp[a][2] - tmp[a][3] + bq;
+      if (relu) { o[a][0] = relu4(o[a][0]); o[a][1] = relu4(o[a][1]); }
+    }
+    if (POOL) {
+      // the 2x2 output tile is exactly one max_pool(2,2,2,2) window (same window order as
+      // bias_relu_pool2_kernel: (y,x), (y,x+1), (y+1,x), (y+1,x+1))
+      const f4 p = max4(max4(max4(o[0][0], o[0][1]), o[1][0]), o[1][1]);
+      *reinterpret_cast<f4*>(y + ((b * Ht + ty) * Wt + tx) * C + c) = p;
+    } else {
+      float* yo = y + ((b * H + 2 * ty) * W + 2 * tx) * C + c;
+      *reinterpret_cast<f4*>(yo) = o[0][0];
+      *reinterpret_cast<f4*>(yo + C) = o[0][1];
+      *reinterpret_cast<f4*>(yo + (long long)W * C) = o[1][0];
+      *reinterpret_cast<f4*>(yo + (long long)W * C + C) = o[1][1];
+    }
+  }
+}
+
+int validate(int B, int H, int W, int C)
+{
+  PCNN_REQUIRE(B >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, PCNN_EINVAL,
+               "winograd: need even height/width (got %dx%dx%d)", B, H, W);
+  PCNN_REQUIRE(C >= 4 && C % 4 == 0, PCNN_EINVAL, "winograd: channels must be a multiple of 4 (got %d)", C);
+  return PCNN_OK;
+}
+
+inline unsigned grid_for(long long total)
+{
+  long long b = (total + 255) / 256;
+  return (unsigned)(b < 256 * 64 ? b : 256 * 64);
+}
+
+}  // namespace
+
+extern "C" int pcnn_winograd_input_fwd(const float* x, int B, int H, int W, int C, float* v,
+                                       void* stream_)
+{
+  int st = validate(B, H, W, C);
+  if (st != PCNN_OK) return st;
+  PCNN_REQUIRE(x && v, PCNN_ENULL, "winograd_input: NULL pointer");
+  PCNN_REQUIRE(aligned16(x) && aligned16(v), PCNN_EINVAL, "winograd_input: pointers must be 16-byte aligned");
+  hipStream_t stream = (hipStream_t)stream_;
+  const long long T = (long long)B * (H / 2) * (W / 2);
+  const long long total = T * (C / 4);
+  PCNN_LAUNCH(wino_input_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, v, H, W, C, total, T * C);
+  return check_launch("winograd_input_fwd");
+}
+
+extern "C" int pcnn_winograd_output_fwd(const float* m, const float* bias, int B, int H, int W, int C,
+                                        int relu, int pool, float* y, void* stream_)
+{
+  int st = validate(B, H, W, C);
+  if (st != PCNN_OK) return st;
+  PCNN_REQUIRE(m && bias && y, PCNN_ENULL, "winograd_output: NULL pointer");
+  PCNN_REQUIRE(aligned16(m) && aligned16(y) && aligned16(bias), PCNN_EINVAL, "winograd_output: pointers must be 16-byte aligned");
+  hipStream_t stream = (hipStream_t)stream_;
+  const long long T = (long long)B * (H / 2) * (W / 2);
+  const long long total = T * (C / 4);
+  if (pool)
+    PCNN_LAUNCH(wino_output_kernel<true>, dim3(grid_for(total)), dim3(256), 0, stream, m, bias, y, H, W, C, relu, total, T * C);
+  else
+    PCNN_LAUNCH(wino_output_kernel<false>, dim3(grid_for(total)), dim3(256), 0, stream, m, bias, y, H, W, C, relu, total, T * C);
+  return check_launch("winograd_output_fwd");
+}

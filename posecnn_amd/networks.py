@@ -80,8 +80,16 @@ class _RawConv(object):
     """A convolution output before bias + ReLU, handed to a consumer that fuses them (max_pool).
     Fetching the layer by name materialises the activated tensor (in place) like any other."""
 
-    def __init__(self, y, bias, relu):
-        self.y, self.bias, self.relu, self.out = y, bias, relu, None
+    def __init__(self, y, bias, relu, wino=None):
+        # y: raw NHWC conv output, or None when the conv is pending in the Winograd domain:
+        # wino = (M [16,T,C], B, H, W) still waiting for its output transform
+        self.y, self.bias, self.relu, self.out, self.wino = y, bias, relu, None, wino
+
+    @property
+    def shape(self):
+        if self.wino is not None:
+            return (self.wino[1], self.wino[2], self.wino[3], self.wino[0].shape[2])
+        return tuple(self.y.shape)
 
 
 class Network(object):
@@ -100,7 +108,11 @@ class Network(object):
         self.init = init
         self._gen = torch.Generator(device="cpu").manual_seed(seed)  # cfg.RNG_SEED = 3 (config.py)
         self.keep_prob_queue = 1.0
-        self.conv_timing = None       # a list -> (name, flops, start_event, end_event) per library conv
+        self.conv_timing = None       # a list -> (name, executed flops, direct-conv flops, start, end) per conv
+        # 3x3 convs with at least this many input channels are evaluated as Winograd F(2x2,3x3)
+        # (2.25x fewer multiplies; the 4x larger transform-domain tensors stop paying below ~256)
+        self.winograd_min_channels = 256
+        self._wino_u = {}
         self.fused_first_conv = True  # 3-channel 3x3 convs go to the fused conv + bias + ReLU kernel
         self.defer_act = frozenset()  # conv layers whose bias + ReLU is left to the following max_pool
 
@@ -130,8 +142,21 @@ class Network(object):
 
     def _activate(self, raw):
         if raw.out is None:
-            raw.out = self._bias_act(raw.y, raw.bias, raw.relu)
+            if raw.wino is not None:
+                m, B, H, W = raw.wino
+                raw.out = ops.winograd_output(m, raw.bias, B, H, W, raw.relu, pool=False)
+            else:
+                raw.out = self._bias_act(raw.y, raw.bias, raw.relu)
         return raw.out
+
+    def _winograd_filter(self, name, w):
+        """U = G g G^T of a conv filter, cached until the variable changes."""
+        key = (w.data_ptr(), w._version)
+        hit = self._wino_u.get(name)
+        if hit is None or hit[0] != key:
+            hit = (key, ops.winograd_filter(w))
+            self._wino_u[name] = hit
+        return hit[1]
 
     def get_unique_name(self, prefix):
         ident = sum(t.startswith(prefix) for t in self.layers) + 1
@@ -227,13 +252,31 @@ class Network(object):
                 and c_o % 64 == 0 and not (torch.is_grad_enabled() and (w.requires_grad or input.requires_grad))):
             # conv1_1: K = 27 is no GEMM; one HBM-bound kernel does conv + bias + ReLU
             return self._conv_first(input, w, b, relu)
+        if (b is not None and (k_h, k_w, s_h, s_w, group) == (3, 3, 1, 1, 1) and padding == "SAME" and input.is_cuda
+                and self.winograd_min_channels and c_i >= self.winograd_min_channels and c_i % 4 == 0 and c_o % 4 == 0
+                and input.shape[1] % 2 == 0 and input.shape[2] % 2 == 0
+                and not (torch.is_grad_enabled() and (w.requires_grad or input.requires_grad))):
+            B_, H_, W_, _ = input.shape
+            u = self._winograd_filter(name, w)
+            timed = self.conv_timing is not None
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            v = ops.winograd_input(input)
+            m = torch.bmm(v, u)
+            if timed:
+                e1.record()   # input transform + the 16 GEMMs; the output transform is timed by the library
+                self.conv_timing.append((name, 2.0 * m.numel() * c_i, 2.25 * 2.0 * m.numel() * c_i, e0, e1))
+            if name in self.defer_act:
+                return _RawConv(None, b, relu, wino=(m, B_, H_, W_))
+            return ops.winograd_output(m, b, B_, H_, W_, relu, pool=False)
         if self.conv_timing is not None and input.is_cuda:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             y = _nhwc(F.conv2d(_nchw(input), w, None, stride=(s_h, s_w), padding=pad, groups=group))
             e1.record()
             flops = 2.0 * y.numel() * (c_i // group) * k_h * k_w
-            self.conv_timing.append((name, flops, e0, e1))
+            self.conv_timing.append((name, flops, flops, e0, e1))
         else:
             y = _nhwc(F.conv2d(_nchw(input), w, None, stride=(s_h, s_w), padding=pad, groups=group))
         if b is not None and name in self.defer_act and not (torch.is_grad_enabled() and y.requires_grad):
@@ -249,7 +292,10 @@ class Network(object):
         assert padding in ("SAME", "VALID")
         if isinstance(input, _RawConv):
             if (input.out is None and (k_h, k_w, s_h, s_w) == (2, 2, 2, 2)
-                    and input.y.shape[1] % 2 == 0 and input.y.shape[2] % 2 == 0):
+                    and input.shape[1] % 2 == 0 and input.shape[2] % 2 == 0):
+                if input.wino is not None:  # a Winograd output tile is exactly one pooling window
+                    m, B_, H_, W_ = input.wino
+                    return ops.winograd_output(m, input.bias, B_, H_, W_, input.relu, pool=True)
                 return self._bias_relu_pool2(input.y, input.bias, input.relu)
             input = self._activate(input)
         H, W = input.shape[1], input.shape[2]

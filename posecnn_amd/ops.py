@@ -296,6 +296,48 @@ def conv3x3_c3(x, weights, bias, relu=True):
     return y
 
 
+def winograd_filter(weights):
+    """torch filter [Cout, Cin, 3, 3] -> U f32 [16, Cin, Cout], U[4i+j] = (G g G^T)[i][j] (float64
+    arithmetic, one rounding). Host-side plumbing, done once per filter."""
+    g = weights.detach().to(torch.float64)
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=g.device)
+    u = torch.einsum("ir,ocrs,js->ijco", G, g, G)   # [4,4,Cin,Cout]
+    return u.reshape(16, g.shape[1], g.shape[0]).to(torch.float32).contiguous()
+
+
+def winograd_input(x):
+    """x [B,H,W,C] -> V [16, T, C] (T = B*H/2*W/2): the input transform B^T d B of every 4x4 patch."""
+    x = _dev(x, "x", torch.float32)
+    B, H, W, C = x.shape
+    v = torch.empty((16, B * (H // 2) * (W // 2), C), dtype=torch.float32, device=x.device)
+    check("pcnn_winograd_input_fwd", lib().pcnn_winograd_input_fwd(_ptr(x), B, H, W, C, _ptr(v), _stream(x)))
+    return v
+
+
+def winograd_output(m, bias, B, H, W, relu=True, pool=False):
+    """M [16, T, C] -> [ReLU](A^T M A + bias) as [B,H,W,C], or its 2x2 max-pool [B,H/2,W/2,C]."""
+    m = _dev(m, "m", torch.float32)
+    bias = _dev(bias, "bias", torch.float32)
+    C = m.shape[2]
+    if m.shape[0] != 16 or m.shape[1] != B * (H // 2) * (W // 2) or bias.numel() != C:
+        raise ValueError("m must be [16, B*H/2*W/2, C] and bias [C]")
+    shape = (B, H // 2, W // 2, C) if pool else (B, H, W, C)
+    y = torch.empty(shape, dtype=torch.float32, device=m.device)
+    check("pcnn_winograd_output_fwd",
+          lib().pcnn_winograd_output_fwd(_ptr(m), _ptr(bias), B, H, W, C, 1 if relu else 0, 1 if pool else 0, _ptr(y), _stream(m)))
+    return y
+
+
+def conv3x3_winograd(x, u, bias, relu=True, pool=False):
+    """3x3 / stride 1 / SAME convolution + bias [+ ReLU] [+ 2x2 max-pool] as Winograd F(2x2,3x3):
+    input transform (gfx950 kernel) -> 16 fp32 GEMMs (library, MFMA) -> output transform (gfx950
+    kernel). `u` comes from `winograd_filter`."""
+    B, H, W, _ = x.shape
+    v = winograd_input(x)
+    m = torch.bmm(v, u)
+    return winograd_output(m, bias, B, H, W, relu, pool)
+
+
 def bias_relu_pool2(x, bias, relu=True):
     """max_pool_2x2(ReLU(x + bias)) from the raw convolution output [B,H,W,C] (H, W even)."""
     x = _dev(x, "x", torch.float32)

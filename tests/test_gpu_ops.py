@@ -383,3 +383,87 @@ def test_conv3x3_c3_bias_relu(gpu, shape, cout):
     assert np.abs(N(lib_y.permute(0, 2, 3, 1)) - want).max() <= 2e-5 * np.abs(want).max()
     with pytest.raises(ValueError):
         ops.conv3x3_c3(T(gpu, x), T(gpu, w[..., :48]), T(gpu, b[:48]))
+
+
+# ---- Winograd F(2x2,3x3) transforms (csrc/winograd.hip) -----------------------------------------------
+BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
+AT = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], np.float64)
+GM = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
+
+
+def np_wino_input(x):
+    """f32 restatement of wino_input_kernel: rows first, then columns (every entry of B^T is 0 / +-1 and
+    every row has two non-zeros, so each output is ONE f32 add or subtract — no order ambiguity)."""
+    B, H, W, C = x.shape
+    xp = np.zeros((B, H + 2, W + 2, C), F); xp[:, 1:-1, 1:-1] = x
+    Ht, Wt = H // 2, W // 2
+    d = np.empty((4, 4, B, Ht, Wt, C), F)
+    for r in range(4):
+        for s in range(4):
+            d[r, s] = xp[:, r:r + H:2, s:s + W:2][:, :Ht, :Wt]
+    t = np.stack([d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]])            # [4(i), 4(s), ...]
+    v = np.stack([t[:, 0] - t[:, 2], t[:, 1] + t[:, 2], t[:, 2] - t[:, 1], t[:, 1] - t[:, 3]], axis=1)  # [i, j, ...]
+    return v.reshape(16, B * Ht * Wt, C)
+
+
+def np_wino_output(m, bias, B, H, W, relu):
+    C = m.shape[2]
+    q = m.reshape(4, 4, B, H // 2, W // 2, C)
+    t0 = q[0] + q[1] + q[2]; t1 = q[1] - q[2] - q[3]                               # [j, ...]
+    o = np.empty((2, 2, B, H // 2, W // 2, C), F)
+    for a, t in enumerate((t0, t1)):
+        o[a, 0] = t[0] + t[1] + t[2] + bias
+        o[a, 1] = t[1] - t[2] - t[3] + bias
+    if relu:
+        o = np.maximum(o, 0)
+    y = np.empty((B, H, W, C), F)
+    for a in range(2):
+        for b_ in range(2):
+            y[:, a::2, b_::2] = o[a, b_]
+    return y
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 12, 16), (1, 30, 40, 512), (1, 2, 2, 4), (3, 6, 4, 260)])
+def test_winograd_transforms_bit_exact(gpu, shape):
+    from posecnn_amd import ops
+    rng = np.random.default_rng(61)
+    B, H, W, C = shape
+    x = rng.standard_normal(shape).astype(F)
+    same(N(ops.winograd_input(T(gpu, x))), np_wino_input(x), "winograd input transform")
+    m = rng.standard_normal((16, B * (H // 2) * (W // 2), C)).astype(F)
+    bias = rng.standard_normal(C).astype(F)
+    for relu in (True, False):
+        want = np_wino_output(m, bias, B, H, W, relu)
+        same(N(ops.winograd_output(T(gpu, m), T(gpu, bias), B, H, W, relu, pool=False)), want, "winograd output transform")
+        pooled = want.reshape(B, H // 2, 2, W // 2, 2, C).max(axis=(2, 4))
+        same(N(ops.winograd_output(T(gpu, m), T(gpu, bias), B, H, W, relu, pool=True)), pooled, "winograd output + pool")
+    with pytest.raises(ValueError):
+        ops.winograd_input(T(gpu, x[:, :H - 1])) if H > 2 else ops.winograd_input(T(gpu, x[:, :1]))
+
+
+@pytest.mark.parametrize("shape,cout", [((2, 12, 16, 64), 32), ((1, 30, 40, 256), 512), ((1, 6, 6, 512), 512)])
+def test_winograd_convolution_matches_direct(gpu, shape, cout):
+    """F(2x2,3x3) end to end (transform kernels + library batched GEMM) against a float64 direct
+    convolution: all-f32 arithmetic, error of the order of the direct f32 convolution's own."""
+    import torch
+    from posecnn_amd import ops
+    torch.backends.cuda.matmul.allow_tf32 = False
+    rng = np.random.default_rng(62)
+    B, H, W, C = shape
+    x = np.maximum(rng.standard_normal(shape), 0).astype(F)                  # post-ReLU activations
+    w = (rng.standard_normal((cout, C, 3, 3)) * np.sqrt(2.0 / (9 * C))).astype(F)
+    b = rng.standard_normal(cout).astype(F)
+    xt, wt, bt = T(gpu, x), T(gpu, w), T(gpu, b)
+    u = ops.winograd_filter(wt)
+    # G g G^T of the filter, float64 (the filter transform is host-side plumbing)
+    assert np.allclose(N(u).reshape(4, 4, C, cout)[1, 2], np.einsum("r,ocrs,s->co", GM[1], w.astype(np.float64), GM[2]), atol=1e-6)
+    y = N(ops.conv3x3_winograd(xt, u, bt, relu=True))
+    ref = torch.nn.functional.conv2d(xt.double().permute(0, 3, 1, 2), wt.double(), bt.double(), padding=1).permute(0, 2, 3, 1)
+    ref = np.maximum(ref.cpu().numpy(), 0)
+    lib = np.maximum(N(torch.nn.functional.conv2d(xt.permute(0, 3, 1, 2), wt, bt, padding=1).permute(0, 2, 3, 1)), 0)
+    scale = np.abs(ref).max()
+    err_w, err_l = np.abs(y - ref).max() / scale, np.abs(lib - ref).max() / scale
+    assert err_w < 2e-5, (err_w, err_l)
+    assert err_w < 20 * max(err_l, 1e-7), (err_w, err_l)
+    yp = N(ops.conv3x3_winograd(xt, u, bt, relu=True, pool=True))
+    same(yp, y.reshape(B, H // 2, 2, W // 2, 2, cout).max(axis=(2, 4)), "pooled winograd conv")
