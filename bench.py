@@ -244,9 +244,10 @@ def main():
                      "pair_predicates_equiv_per_launch": pairs,
                      "pair_predicates_equiv_per_s": pairs / (hv["avg_us"] * 1e-6) if hv["calls"] else None},
         "roofline_other": others,
-        "backbone": {"what": "the fp32 convolutions of the VGG16 trunk + heads: MIOpen/CK direct convolutions, and for the 3x3 layers with "
-                             ">= 256 input channels Winograd F(2x2,3x3) = gfx950 transform kernels + library fp32 batched GEMM; "
-                             "achieved counts EXECUTED flops", "bound": "mfma",
+        "backbone": {"what": "the fp32 convolutions of the VGG16 trunk + heads: 3x3 layers with >= %d input channels as Winograd F(%dx%d,3x3) "
+                             "(gfx950 transform kernels + library fp32 batched GEMM on MFMA), the rest as MIOpen/CK direct convolutions; "
+                             "achieved = EXECUTED flops / (transforms + GEMMs + direct convs) time" % (
+                                 net.winograd_min_channels, net.winograd_tile, net.winograd_tile), "bound": "mfma",
                      "direct_conv_equivalent_TFLOPs": conv_direct_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else None,
                      "achieved": conv_tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": conv_tflops / FP32_MFMA_PEAK_TFLOPS if conv_tflops else None,

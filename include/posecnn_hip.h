@@ -262,6 +262,14 @@ int pcnn_winograd_input_fwd(const float* x, int batch, int height, int width, in
 int pcnn_winograd_output_fwd(const float* m, const float* bias, int batch, int height, int width,
                              int channels, int relu, int pool, float* y, void* stream);
 
+/* The same with F(4x4,3x3) (36 multiplies per 16 outputs; interpolation points 0, +-1, +-2, inf):
+ * T = B*ceil(H/4)*ceil(W/4) tiles, v / m are f32 [36][T][C] with index 6i+j; any H, W >= 1 (partial
+ * tiles read zeros and store only inside the image); pool needs even H, W. */
+int pcnn_winograd43_input_fwd(const float* x, int batch, int height, int width, int channels, float* v,
+                              void* stream);
+int pcnn_winograd43_output_fwd(const float* m, const float* bias, int batch, int height, int width,
+                               int channels, int relu, int pool, float* y, void* stream);
+
 /* y[b,oy,ox,c] = max over the 2x2 window of [ReLU](x + bias[c]): the `conv -> max_pool(2,2,2,2)`
  * pairs of the VGG trunk (vgg16_convs.py:36-49; network.py:181-187 + :189-196) from the raw
  * convolution output x f32 [B,H,W,C] (H, W even) to y f32 [B,H/2,W/2,C], same bits as

@@ -48,6 +48,8 @@ SIGNATURES = {
     "pcnn_smooth_l1_vertex_bwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_float, _P, _P]),
     "pcnn_winograd_input_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "pcnn_winograd_output_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "pcnn_winograd43_input_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "pcnn_winograd43_output_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pcnn_conv3x3_c3_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pcnn_bias_relu_pool2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pcnn_hough_voting_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -140,6 +140,144 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
   }
 }
 
+// ---- F(4x4, 3x3): 36 multiplies per 16 outputs (4x fewer than direct), transform-domain tensors
+// only 2.25x the activation. Interpolation points 0, +-1, +-2, inf (Lavin & Gray 2015):
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// Tiles are 4x4 outputs; the tile grid is ceil(H/4) x ceil(W/4), partial tiles read zeros and skip
+// the stores outside the image. Canonical expressions (one f32 rounding per written operation):
+//   in : r0 = (4 d0 - 5 d2) + d4;  a = d4 - 4 d2, b = d3 - 4 d1: r1 = a + b, r2 = a - b;
+//        c = d4 - d2, e = 2 (d3 - d1): r3 = c + e, r4 = c - e;  r5 = (4 d1 - 5 d3) + d5
+//   out: s = m1 + m2, d = m1 - m2, S = m3 + m4, D = m3 - m4:
+//        y0 = (m0 + s) + S;  y1 = d + 2 D;  y2 = s + 4 S;  y3 = (d + 8 D) + m5
+__device__ __forceinline__ void bt6(const f4* d, f4* r)
+{
+  r[0] = (4.f * d[0] - 5.f * d[2]) + d[4];
+  const f4 a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1];
+  r[1] = a + b;
+  r[2] = a - b;
+  const f4 c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
+  r[3] = c + e;
+  r[4] = c - e;
+  r[5] = (4.f * d[1] - 5.f * d[3]) + d[5];
+}
+
+__device__ __forceinline__ void at6(const f4* m, f4* y)
+{
+  const f4 s = m[1] + m[2], d = m[1] - m[2], S = m[3] + m[4], D = m[3] - m[4];
+  y[0] = (m[0] + s) + S;
+  y[1] = d + 2.f * D;
+  y[2] = s + 4.f * S;
+  y[3] = (d + 8.f * D) + m[5];
+}
+
+__global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restrict__ x,
+                                                           float* __restrict__ v, int H, int W, int C,
+                                                           int Ht, int Wt, long long total,
+                                                           long long plane)
+{
+  const int cv = C / 4;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % cv) * 4;
+    const long long t = idx / cv;
+    const int tx = (int)(t % Wt);
+    const int ty = (int)((t / Wt) % Ht);
+    const long long b = t / ((long long)Wt * Ht);
+    const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+    const float* xb = x + b * H * W * (long long)C + c;
+    f4 tmp[6][6];  // tmp[i][s] = (B^T d)[i][s]
+#pragma unroll
+    for (int s2 = 0; s2 < 6; s2++) {
+      const int xx = x0 + s2;
+      f4 col[6];
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        const int yy = y0 + r;
+        f4 val = {0.f, 0.f, 0.f, 0.f};
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+          val = *reinterpret_cast<const f4*>(xb + ((long long)yy * W + xx) * C);
+        col[r] = val;
+      }
+      f4 o[6];
+      bt6(col, o);
+#pragma unroll
+      for (int i = 0; i < 6; i++) tmp[i][s2] = o[i];
+    }
+    float* vo = v + t * C + c;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      f4 o[6];
+      bt6(tmp[i], o);
+#pragma unroll
+      for (int j = 0; j < 6; j++) *reinterpret_cast<f4*>(vo + (6 * i + j) * plane) = o[j];
+    }
+  }
+}
+
+template <bool POOL>
+__global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restrict__ m,
+                                                            const float* __restrict__ bias,
+                                                            float* __restrict__ y, int H, int W, int C,
+                                                            int Ht, int Wt, int relu, long long total,
+                                                            long long plane)
+{
+  const int cv = C / 4;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % cv) * 4;
+    const long long t = idx / cv;
+    const int tx = (int)(t % Wt);
+    const int ty = (int)((t / Wt) % Ht);
+    const long long b = t / ((long long)Wt * Ht);
+    const float* mi = m + t * C + c;
+    f4 tmp[4][6];  // tmp[a][j] = (A^T m)[a][j]
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      f4 col[6];
+#pragma unroll
+      for (int i = 0; i < 6; i++) col[i] = *reinterpret_cast<const f4*>(mi + (6 * i + j) * plane);
+      f4 o[4];
+      at6(col, o);
+#pragma unroll
+      for (int a = 0; a < 4; a++) tmp[a][j] = o[a];
+    }
+    const f4 bq = *reinterpret_cast<const f4*>(bias + c);
+    f4 out[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+      at6(tmp[a], out[a]);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        out[a][e] = out[a][e] + bq;
+        if (relu) out[a][e] = relu4(out[a][e]);
+      }
+    }
+    const int oy0 = 4 * ty, ox0 = 4 * tx;
+    if (POOL) {
+      // a 4x4 output tile holds 2x2 pooling windows (H, W even)
+      const int Hp = H / 2, Wp = W / 2;
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const int py = 2 * ty + a, px = 2 * tx + e;
+          if (py < Hp && px < Wp) {
+            const f4 p = max4(max4(max4(out[2 * a][2 * e], out[2 * a][2 * e + 1]), out[2 * a + 1][2 * e]), out[2 * a + 1][2 * e + 1]);
+            *reinterpret_cast<f4*>(y + ((b * Hp + py) * Wp + px) * C + c) = p;
+          }
+        }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          if (oy0 + a < H && ox0 + e < W)
+            *reinterpret_cast<f4*>(y + ((b * H + oy0 + a) * W + ox0 + e) * C + c) = out[a][e];
+    }
+  }
+}
+
 int validate(int B, int H, int W, int C)
 {
   PCNN_REQUIRE(B >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, PCNN_EINVAL,
@@ -155,6 +293,40 @@ inline unsigned grid_for(long long total)
 }
 
 }  // namespace
+
+extern "C" int pcnn_winograd43_input_fwd(const float* x, int B, int H, int W, int C, float* v,
+                                         void* stream_)
+{
+  PCNN_REQUIRE(B >= 1 && H >= 1 && W >= 1, PCNN_EINVAL, "winograd43: bad shape %dx%dx%d", B, H, W);
+  PCNN_REQUIRE(C >= 4 && C % 4 == 0, PCNN_EINVAL, "winograd43: channels must be a multiple of 4 (got %d)", C);
+  PCNN_REQUIRE(x && v, PCNN_ENULL, "winograd43_input: NULL pointer");
+  PCNN_REQUIRE(aligned16(x) && aligned16(v), PCNN_EINVAL, "winograd43_input: pointers must be 16-byte aligned");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int Ht = (H + 3) / 4, Wt = (W + 3) / 4;
+  const long long T = (long long)B * Ht * Wt;
+  const long long total = T * (C / 4);
+  PCNN_LAUNCH(wino43_input_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, v, H, W, C, Ht, Wt, total, T * C);
+  return check_launch("winograd43_input_fwd");
+}
+
+extern "C" int pcnn_winograd43_output_fwd(const float* m, const float* bias, int B, int H, int W, int C,
+                                          int relu, int pool, float* y, void* stream_)
+{
+  PCNN_REQUIRE(B >= 1 && H >= 1 && W >= 1, PCNN_EINVAL, "winograd43: bad shape %dx%dx%d", B, H, W);
+  PCNN_REQUIRE(C >= 4 && C % 4 == 0, PCNN_EINVAL, "winograd43: channels must be a multiple of 4 (got %d)", C);
+  PCNN_REQUIRE(!pool || (H % 2 == 0 && W % 2 == 0), PCNN_EINVAL, "winograd43_output: pooling needs even height/width");
+  PCNN_REQUIRE(m && bias && y, PCNN_ENULL, "winograd43_output: NULL pointer");
+  PCNN_REQUIRE(aligned16(m) && aligned16(y) && aligned16(bias), PCNN_EINVAL, "winograd43_output: pointers must be 16-byte aligned");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int Ht = (H + 3) / 4, Wt = (W + 3) / 4;
+  const long long T = (long long)B * Ht * Wt;
+  const long long total = T * (C / 4);
+  if (pool)
+    PCNN_LAUNCH(wino43_output_kernel<true>, dim3(grid_for(total)), dim3(256), 0, stream, m, bias, y, H, W, C, Ht, Wt, relu, total, T * C);
+  else
+    PCNN_LAUNCH(wino43_output_kernel<false>, dim3(grid_for(total)), dim3(256), 0, stream, m, bias, y, H, W, C, Ht, Wt, relu, total, T * C);
+  return check_launch("winograd43_output_fwd");
+}
 
 extern "C" int pcnn_winograd_input_fwd(const float* x, int B, int H, int W, int C, float* v,
                                        void* stream_)

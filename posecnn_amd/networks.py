@@ -109,9 +109,15 @@ class Network(object):
         self._gen = torch.Generator(device="cpu").manual_seed(seed)  # cfg.RNG_SEED = 3 (config.py)
         self.keep_prob_queue = 1.0
         self.conv_timing = None       # a list -> (name, executed flops, direct-conv flops, start, end) per conv
-        # 3x3 convs with at least this many input channels are evaluated as Winograd F(2x2,3x3)
-        # (2.25x fewer multiplies; the 4x larger transform-domain tensors stop paying below ~256)
-        self.winograd_min_channels = 256
+        # 3x3 / stride 1 / SAME convs with at least this many input channels are evaluated in the
+        # Winograd domain (0 = never). tile 4 = F(4x4,3x3): 4x fewer multiplies, all f32, per-layer
+        # error <= 1e-5 of the output range and end-to-end indistinguishable from the direct path at
+        # the pipeline's tolerances (tests/test_gpu_pipeline.py); it beats the direct library
+        # convolution on every VGG layer from conv1_2 on (tools/bench_layers.py). tile 2 =
+        # F(2x2,3x3): 2.25x fewer multiplies, same error as a direct f32 convolution, wins from 128
+        # input channels.
+        self.winograd_min_channels = 64
+        self.winograd_tile = 4
         self._wino_u = {}
         self.fused_first_conv = True  # 3-channel 3x3 convs go to the fused conv + bias + ReLU kernel
         self.defer_act = frozenset()  # conv layers whose bias + ReLU is left to the following max_pool
@@ -144,17 +150,17 @@ class Network(object):
         if raw.out is None:
             if raw.wino is not None:
                 m, B, H, W = raw.wino
-                raw.out = ops.winograd_output(m, raw.bias, B, H, W, raw.relu, pool=False)
+                raw.out = ops.winograd_output(m, raw.bias, B, H, W, raw.relu, pool=False, tile=self.winograd_tile)
             else:
                 raw.out = self._bias_act(raw.y, raw.bias, raw.relu)
         return raw.out
 
     def _winograd_filter(self, name, w):
         """U = G g G^T of a conv filter, cached until the variable changes."""
-        key = (w.data_ptr(), w._version)
+        key = (w.data_ptr(), w._version, self.winograd_tile)
         hit = self._wino_u.get(name)
         if hit is None or hit[0] != key:
-            hit = (key, ops.winograd_filter(w))
+            hit = (key, ops.winograd_filter(w, self.winograd_tile))
             self._wino_u[name] = hit
         return hit[1]
 
@@ -254,7 +260,7 @@ class Network(object):
             return self._conv_first(input, w, b, relu)
         if (b is not None and (k_h, k_w, s_h, s_w, group) == (3, 3, 1, 1, 1) and padding == "SAME" and input.is_cuda
                 and self.winograd_min_channels and c_i >= self.winograd_min_channels and c_i % 4 == 0 and c_o % 4 == 0
-                and input.shape[1] % 2 == 0 and input.shape[2] % 2 == 0
+                and (self.winograd_tile == 4 or (input.shape[1] % 2 == 0 and input.shape[2] % 2 == 0))
                 and not (torch.is_grad_enabled() and (w.requires_grad or input.requires_grad))):
             B_, H_, W_, _ = input.shape
             u = self._winograd_filter(name, w)
@@ -262,14 +268,15 @@ class Network(object):
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            v = ops.winograd_input(input)
+            tile = self.winograd_tile
+            v = ops.winograd_input(input, tile)
             m = torch.bmm(v, u)
             if timed:
                 e1.record()   # input transform + the 16 GEMMs; the output transform is timed by the library
-                self.conv_timing.append((name, 2.0 * m.numel() * c_i, 2.25 * 2.0 * m.numel() * c_i, e0, e1))
+                self.conv_timing.append((name, 2.0 * m.numel() * c_i, 2.0 * B_ * H_ * W_ * c_o * c_i * 9, e0, e1))
             if name in self.defer_act:
                 return _RawConv(None, b, relu, wino=(m, B_, H_, W_))
-            return ops.winograd_output(m, b, B_, H_, W_, relu, pool=False)
+            return ops.winograd_output(m, b, B_, H_, W_, relu, pool=False, tile=tile)
         if self.conv_timing is not None and input.is_cuda:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -295,7 +302,7 @@ class Network(object):
                     and input.shape[1] % 2 == 0 and input.shape[2] % 2 == 0):
                 if input.wino is not None:  # a Winograd output tile is exactly one pooling window
                     m, B_, H_, W_ = input.wino
-                    return ops.winograd_output(m, input.bias, B_, H_, W_, input.relu, pool=True)
+                    return ops.winograd_output(m, input.bias, B_, H_, W_, input.relu, pool=True, tile=self.winograd_tile)
                 return self._bias_relu_pool2(input.y, input.bias, input.relu)
             input = self._activate(input)
         H, W = input.shape[1], input.shape[2]

@@ -296,46 +296,64 @@ def conv3x3_c3(x, weights, bias, relu=True):
     return y
 
 
-def winograd_filter(weights):
-    """torch filter [Cout, Cin, 3, 3] -> U f32 [16, Cin, Cout], U[4i+j] = (G g G^T)[i][j] (float64
-    arithmetic, one rounding). Host-side plumbing, done once per filter."""
+_WINO_G = {
+    2: [[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]],
+    4: [[1 / 4, 0.0, 0.0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+        [1 / 24, -1 / 12, 1 / 6], [0.0, 0.0, 1.0]],
+}
+
+
+def _wino_tiles(B, H, W, tile):
+    if tile == 2:
+        return B * (H // 2) * (W // 2)
+    return B * ((H + 3) // 4) * ((W + 3) // 4)
+
+
+def winograd_filter(weights, tile=2):
+    """torch filter [Cout, Cin, 3, 3] -> U f32 [(tile+2)^2, Cin, Cout], U[n*i+j] = (G g G^T)[i][j]
+    (float64 arithmetic, one rounding). Host-side plumbing, done once per filter."""
     g = weights.detach().to(torch.float64)
-    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=g.device)
-    u = torch.einsum("ir,ocrs,js->ijco", G, g, G)   # [4,4,Cin,Cout]
-    return u.reshape(16, g.shape[1], g.shape[0]).to(torch.float32).contiguous()
+    G = torch.tensor(_WINO_G[tile], dtype=torch.float64, device=g.device)
+    u = torch.einsum("ir,ocrs,js->ijco", G, g, G)   # [n,n,Cin,Cout]
+    n = tile + 2
+    return u.reshape(n * n, g.shape[1], g.shape[0]).to(torch.float32).contiguous()
 
 
-def winograd_input(x):
-    """x [B,H,W,C] -> V [16, T, C] (T = B*H/2*W/2): the input transform B^T d B of every 4x4 patch."""
+def winograd_input(x, tile=2):
+    """x [B,H,W,C] -> V [(tile+2)^2, T, C]: the input transform B^T d B of every input patch
+    (tile = 2: F(2x2,3x3), T = B*H/2*W/2; tile = 4: F(4x4,3x3), T = B*ceil(H/4)*ceil(W/4))."""
     x = _dev(x, "x", torch.float32)
     B, H, W, C = x.shape
-    v = torch.empty((16, B * (H // 2) * (W // 2), C), dtype=torch.float32, device=x.device)
-    check("pcnn_winograd_input_fwd", lib().pcnn_winograd_input_fwd(_ptr(x), B, H, W, C, _ptr(v), _stream(x)))
+    n = tile + 2
+    v = torch.empty((n * n, _wino_tiles(B, H, W, tile), C), dtype=torch.float32, device=x.device)
+    fn = "pcnn_winograd_input_fwd" if tile == 2 else "pcnn_winograd43_input_fwd"
+    check(fn, getattr(lib(), fn)(_ptr(x), B, H, W, C, _ptr(v), _stream(x)))
     return v
 
 
-def winograd_output(m, bias, B, H, W, relu=True, pool=False):
-    """M [16, T, C] -> [ReLU](A^T M A + bias) as [B,H,W,C], or its 2x2 max-pool [B,H/2,W/2,C]."""
+def winograd_output(m, bias, B, H, W, relu=True, pool=False, tile=2):
+    """M [(tile+2)^2, T, C] -> [ReLU](A^T M A + bias) as [B,H,W,C], or its 2x2 max-pool [B,H/2,W/2,C]."""
     m = _dev(m, "m", torch.float32)
     bias = _dev(bias, "bias", torch.float32)
     C = m.shape[2]
-    if m.shape[0] != 16 or m.shape[1] != B * (H // 2) * (W // 2) or bias.numel() != C:
-        raise ValueError("m must be [16, B*H/2*W/2, C] and bias [C]")
+    n = tile + 2
+    if m.shape[0] != n * n or m.shape[1] != _wino_tiles(B, H, W, tile) or bias.numel() != C:
+        raise ValueError("m must be [%d, tiles, C] and bias [C]" % (n * n))
     shape = (B, H // 2, W // 2, C) if pool else (B, H, W, C)
     y = torch.empty(shape, dtype=torch.float32, device=m.device)
-    check("pcnn_winograd_output_fwd",
-          lib().pcnn_winograd_output_fwd(_ptr(m), _ptr(bias), B, H, W, C, 1 if relu else 0, 1 if pool else 0, _ptr(y), _stream(m)))
+    fn = "pcnn_winograd_output_fwd" if tile == 2 else "pcnn_winograd43_output_fwd"
+    check(fn, getattr(lib(), fn)(_ptr(m), _ptr(bias), B, H, W, C, 1 if relu else 0, 1 if pool else 0, _ptr(y), _stream(m)))
     return y
 
 
-def conv3x3_winograd(x, u, bias, relu=True, pool=False):
-    """3x3 / stride 1 / SAME convolution + bias [+ ReLU] [+ 2x2 max-pool] as Winograd F(2x2,3x3):
-    input transform (gfx950 kernel) -> 16 fp32 GEMMs (library, MFMA) -> output transform (gfx950
-    kernel). `u` comes from `winograd_filter`."""
+def conv3x3_winograd(x, u, bias, relu=True, pool=False, tile=2):
+    """3x3 / stride 1 / SAME convolution + bias [+ ReLU] [+ 2x2 max-pool] as Winograd F(tile x tile, 3x3):
+    input transform (gfx950 kernel) -> (tile+2)^2 fp32 GEMMs (library, MFMA) -> output transform
+    (gfx950 kernel). `u` comes from `winograd_filter(weights, tile)`."""
     B, H, W, _ = x.shape
-    v = winograd_input(x)
+    v = winograd_input(x, tile)
     m = torch.bmm(v, u)
-    return winograd_output(m, bias, B, H, W, relu, pool)
+    return winograd_output(m, bias, B, H, W, relu, pool, tile)
 
 
 def bias_relu_pool2(x, bias, relu=True):

@@ -467,3 +467,94 @@ def test_winograd_convolution_matches_direct(gpu, shape, cout):
     assert err_w < 20 * max(err_l, 1e-7), (err_w, err_l)
     yp = N(ops.conv3x3_winograd(xt, u, bt, relu=True, pool=True))
     same(yp, y.reshape(B, H // 2, 2, W // 2, 2, cout).max(axis=(2, 4)), "pooled winograd conv")
+
+
+# ---- F(4x4,3x3) ---------------------------------------------------------------------------------------
+def np_bt6(d):
+    f4, f5, f2 = F(4), F(5), F(2)
+    a = d[4] - f4 * d[2]; b = d[3] - f4 * d[1]
+    c = d[4] - d[2]; e = f2 * (d[3] - d[1])
+    return [(f4 * d[0] - f5 * d[2]) + d[4], a + b, a - b, c + e, c - e, (f4 * d[1] - f5 * d[3]) + d[5]]
+
+
+def np_at6(m):
+    s = m[1] + m[2]; d = m[1] - m[2]; S = m[3] + m[4]; D = m[3] - m[4]
+    return [(m[0] + s) + S, d + F(2) * D, s + F(4) * S, (d + F(8) * D) + m[5]]
+
+
+def np_wino43_input(x):
+    B, H, W, C = x.shape
+    Ht, Wt = (H + 3) // 4, (W + 3) // 4
+    xp = np.zeros((B, 4 * Ht + 2, 4 * Wt + 2, C), F); xp[:, 1:H + 1, 1:W + 1] = x
+    d = [[xp[:, r:r + 4 * Ht:4, s:s + 4 * Wt:4] for s in range(6)] for r in range(6)]       # d[r][s]: [B,Ht,Wt,C]
+    tmp = [np_bt6([d[r][s] for r in range(6)]) for s in range(6)]                           # tmp[s][i]
+    v = [[None] * 6 for _ in range(6)]
+    for i in range(6):
+        row = np_bt6([tmp[s][i] for s in range(6)])
+        for j in range(6):
+            v[i][j] = row[j]
+    return np.stack([v[i][j] for i in range(6) for j in range(6)]).reshape(36, B * Ht * Wt, C)
+
+
+def np_wino43_output(m, bias, B, H, W, relu):
+    C = m.shape[2]
+    Ht, Wt = (H + 3) // 4, (W + 3) // 4
+    q = m.reshape(6, 6, B, Ht, Wt, C)
+    tmp = [np_at6([q[i, j] for i in range(6)]) for j in range(6)]                           # tmp[j][a]
+    y = np.zeros((B, 4 * Ht, 4 * Wt, C), F)
+    for a in range(4):
+        row = np_at6([tmp[j][a] for j in range(6)])
+        for e in range(4):
+            o = row[e] + bias
+            y[:, a::4, e::4] = np.maximum(o, 0) if relu else o
+    return y[:, :H, :W]
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 12, 16), (1, 30, 40, 512), (1, 6, 10, 4), (2, 5, 7, 36), (1, 1, 1, 8)])
+def test_winograd43_transforms_bit_exact(gpu, shape):
+    from posecnn_amd import ops
+    rng = np.random.default_rng(63)
+    B, H, W, C = shape
+    x = rng.standard_normal(shape).astype(F)
+    same(N(ops.winograd_input(T(gpu, x), tile=4)), np_wino43_input(x), "F(4,3) input transform")
+    Tn = B * ((H + 3) // 4) * ((W + 3) // 4)
+    m = rng.standard_normal((36, Tn, C)).astype(F)
+    bias = rng.standard_normal(C).astype(F)
+    for relu in (True, False):
+        want = np_wino43_output(m, bias, B, H, W, relu)
+        same(N(ops.winograd_output(T(gpu, m), T(gpu, bias), B, H, W, relu, pool=False, tile=4)), want, "F(4,3) output transform")
+        if H % 2 == 0 and W % 2 == 0:
+            pooled = want.reshape(B, H // 2, 2, W // 2, 2, C).max(axis=(2, 4))
+            same(N(ops.winograd_output(T(gpu, m), T(gpu, bias), B, H, W, relu, pool=True, tile=4)), pooled, "F(4,3) output + pool")
+    if H % 2:
+        with pytest.raises(ValueError):
+            ops.winograd_output(T(gpu, m), T(gpu, bias), B, H, W, True, pool=True, tile=4)
+
+
+@pytest.mark.parametrize("shape,cout", [((2, 12, 16, 64), 32), ((1, 30, 40, 256), 512), ((1, 6, 6, 512), 512), ((1, 60, 80, 128), 128)])
+def test_winograd43_convolution_accuracy(gpu, shape, cout):
+    """F(4x4,3x3) end to end against a float64 direct convolution; its f32 error is reported next to
+    F(2x2,3x3)'s and the library direct convolution's, and bounded."""
+    import torch
+    from posecnn_amd import ops
+    torch.backends.cuda.matmul.allow_tf32 = False
+    rng = np.random.default_rng(64)
+    B, H, W, C = shape
+    x = np.maximum(rng.standard_normal(shape), 0).astype(F)
+    w = (rng.standard_normal((cout, C, 3, 3)) * np.sqrt(2.0 / (9 * C))).astype(F)
+    b = rng.standard_normal(cout).astype(F)
+    xt, wt, bt = T(gpu, x), T(gpu, w), T(gpu, b)
+    ref = torch.nn.functional.conv2d(xt.double().permute(0, 3, 1, 2), wt.double(), bt.double(), padding=1).permute(0, 2, 3, 1)
+    ref = np.maximum(ref.cpu().numpy(), 0)
+    scale = np.abs(ref).max()
+    errs = {}
+    for tile in (2, 4):
+        y = N(ops.conv3x3_winograd(xt, ops.winograd_filter(wt, tile), bt, relu=True, tile=tile))
+        errs[tile] = np.abs(y - ref).max() / scale
+    lib = np.maximum(N(torch.nn.functional.conv2d(xt.permute(0, 3, 1, 2), wt, bt, padding=1).permute(0, 2, 3, 1)), 0)
+    errs["direct"] = np.abs(lib - ref).max() / scale
+    print("relative max error vs float64:", errs)
+    assert errs[4] < 5e-5, errs
+    yp = N(ops.conv3x3_winograd(xt, ops.winograd_filter(wt, 4), bt, relu=True, pool=True, tile=4))
+    y4 = N(ops.conv3x3_winograd(xt, ops.winograd_filter(wt, 4), bt, relu=True, tile=4))
+    same(yp, y4.reshape(B, H // 2, 2, W // 2, 2, cout).max(axis=(2, 4)), "pooled F(4,3) conv")

@@ -141,3 +141,46 @@ def test_fused_heads_equal_literal_op_order(gpu):
     assert a["rois"].shape == b["rois"].shape and np.array_equal(a["rois"][:, :2], b["rois"][:, :2])
     assert np.abs(a["rois"][:, 2:6] - b["rois"][:, 2:6]).max() < 2.0
     assert "upscore" not in nets[0].layers and "upscore" in nets[1].layers
+
+
+def test_winograd_trunk_end_to_end_against_direct_convolutions(gpu, capsys):
+    """The whole network with the 3x3 layers as direct library convolutions, F(2x2,3x3) and F(4x4,3x3):
+    same weights, same frames. All three are f32; the outputs must agree within the path's tolerances
+    (labels: only near-tie pixels may differ; poses 1e-4)."""
+    import torch
+    from posecnn_amd import fcn
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    B, H, W = 2, 240, 320
+    K = config.DEMO_INTRINSICS.copy(); K[:2] *= W / 640.0
+    rng = np.random.default_rng(9)
+    data = torch.from_numpy((rng.integers(0, 256, (B, H, W, 3)).astype(F) - config.PIXEL_MEANS).astype(F)).to(gpu)
+    planted_np, _ = synth.make_planted_batch(31, B, H=H, W=W, K=K, n_obj=3)
+    planted = {k: torch.from_numpy(v).to(gpu) for k, v in planted_np.items()}
+    pts = synth.make_model_points(22, 64)
+    net, _ = build(gpu)
+    outs = {}
+    for mode, (minch, tile) in {"direct": (0, 2), "F(2,3)": (128, 2), "F(4,3)": (64, 4)}.items():
+        net.winograd_min_channels, net.winograd_tile = minch, tile
+        with torch.no_grad():
+            det = fcn.im_segment_batch(net, data, K, config.LOV_EXTENTS, pts, config.LOV_SYMMETRY, planted=planted)
+            n = int(det.count.item())
+            outs[mode] = (det.label_2d.cpu().numpy(), net.get_output("prob_normalized").cpu().numpy(),
+                          det.rows[:n].cpu().numpy(), net.get_output("conv5_3").cpu().numpy())
+    ref = outs["direct"]
+    report = {}
+    for mode in ("F(2,3)", "F(4,3)"):
+        lab, prob, rows, c5 = outs[mode]
+        flips = int((lab != ref[0]).sum())
+        report[mode] = {"label_flips": flips, "of": lab.size, "max_prob_diff": float(np.abs(prob - ref[1]).max()),
+                        "conv5_3_rel_err": float(np.abs(c5 - ref[3]).max() / np.abs(ref[3]).max())}
+        assert flips <= 1e-4 * lab.size, report
+        assert report[mode]["max_prob_diff"] < 1e-3, report
+        assert rows.shape == ref[2].shape and np.array_equal(rows[:, :2], ref[2][:, :2]), report
+        if flips == 0:
+            assert np.abs(rows[:, 2:6] - ref[2][:, 2:6]).max() < 1e-3
+        report[mode]["max_quat_diff"] = float(np.abs(rows[:, 7:11] - ref[2][:, 7:11]).max())
+        report[mode]["max_trans_diff"] = float(np.abs(rows[:, 11:] - ref[2][:, 11:]).max())
+        assert report[mode]["max_quat_diff"] < 1e-4, report
+    with capsys.disabled():
+        print("\nwinograd vs direct:", report)

@@ -58,6 +58,26 @@ def main():
             fl = 2.0 * B * H * W * ci * co * 9
             res["layers"][name] = {"conv_ms": round(ms, 4), "TFLOPs": round(fl / ms / 1e9, 1), "bias_act_ms": round(ms_b, 4),
                                    "act_GBps": round(2 * y.numel() * 4 / ms_b / 1e6, 0)}
+            if ci >= 64 and ci % 4 == 0:
+                xh = x.permute(0, 2, 3, 1).contiguous()
+                u = ops.winograd_filter(w)
+                ms_w = timeit(lambda: ops.conv3x3_winograd(xh, u, b, True))
+                ms_in = timeit(lambda: ops.winograd_input(xh))
+                v = ops.winograd_input(xh)
+                ms_mm = timeit(lambda: torch.bmm(v, u))
+                res["layers"][name].update({"winograd_total_ms": round(ms_w, 4), "winograd_input_ms": round(ms_in, 4),
+                                            "winograd_gemm_ms": round(ms_mm, 4), "winograd_gemm_TFLOPs": round(fl / 2.25 / ms_mm / 1e9, 1),
+                                            "direct_plus_bias_ms": round(ms + ms_b, 4)})
+                del v
+                u4 = ops.winograd_filter(w, 4)
+                ms_w4 = timeit(lambda: ops.conv3x3_winograd(xh, u4, b, True, tile=4))
+                ms_in4 = timeit(lambda: ops.winograd_input(xh, 4))
+                v4 = ops.winograd_input(xh, 4)
+                ms_mm4 = timeit(lambda: torch.bmm(v4, u4))
+                res["layers"][name].update({"winograd43_total_ms": round(ms_w4, 4), "winograd43_input_ms": round(ms_in4, 4),
+                                            "winograd43_gemm_ms": round(ms_mm4, 4),
+                                            "winograd43_gemm_TFLOPs": round(2.0 * v4.numel() * co / ms_mm4 / 1e9, 1)})
+                del v4
             if ci == 3:
                 xh = x.permute(0, 2, 3, 1).contiguous()
                 wh = w.permute(2, 3, 1, 0).contiguous()
