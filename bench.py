@@ -144,7 +144,9 @@ def main():
         launched AND finished inside the call."""
         ndet, pending = 0, None
         for i in range(n):
+            h0 = time.perf_counter()
             t = launch(first + i)
+            last["host_launch_s"] = last.get("host_launch_s", 0.0) + time.perf_counter() - h0
             if pending is not None:
                 ndet += finish(pending)
             pending = t
@@ -159,6 +161,7 @@ def main():
         net.conv_timing = []        # ... and around every MIOpen convolution of the trunk
         pdist.barrier()
         torch.cuda.synchronize()
+        last["host_launch_s"] = 0.0
         t0 = time.perf_counter()
         ndet = run(a.warmup, a.steps)
         torch.cuda.synchronize()
@@ -252,6 +255,7 @@ def main():
                      "achieved": conv_tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": conv_tflops / FP32_MFMA_PEAK_TFLOPS if conv_tflops else None,
                      "ms_per_step": conv_ms / a.steps, "share_of_step": conv_ms / a.steps / ms_per_step},
+        "host_launch_ms_per_step": 1000.0 * last["host_launch_s"] / a.steps,
         "kernels_us": {k: round(v["avg_us"], 2) for k, v in sorted(kern.items())},
     }
     if world == 1 and not a.no_cpu_baseline:

@@ -256,7 +256,7 @@ int pcnn_conv3x3_c3_fwd(const float* x, const float* weights, const float* bias,
  *   (caller) m[k] = v[k] (T x Cin) * u[k] (Cin x Cout) for k = 0..15 with u[4i+j] = (G g G^T)[i][j].
  *   pcnn_winograd_output_fwd: m f32 [16][T][C] -> y = [ReLU](A^T m A + bias) as f32 [B,H,W,C], or with
  *       pool != 0 its 2x2 max-pool f32 [B,H/2,W/2,C] (an output tile is one pooling window).
- * Transform order: rows, then columns, sums left to right, bias last (DESIGN.md §3.2d). */
+ * Transform order: rows, then columns, sums left to right, bias last (DESIGN.md §3.2c). */
 int pcnn_winograd_input_fwd(const float* x, int batch, int height, int width, int channels, float* v,
                             void* stream);
 int pcnn_winograd_output_fwd(const float* m, const float* bias, int batch, int height, int width,

@@ -43,6 +43,9 @@ def main():
     ap.add_argument("path")
     ap.add_argument("--tail-ms", type=float, default=0.0)
     ap.add_argument("--top", type=int, default=60)
+    ap.add_argument("--marker", default="", help="kernel launched once per step (e.g. hv_emit_kernel): with --steps, "
+                                                  "the window is exactly the last N steps")
+    ap.add_argument("--steps", type=int, default=0)
     a = ap.parse_args()
     path = a.path
     if os.path.isdir(path):
@@ -54,7 +57,31 @@ def main():
     if not rows:
         sys.exit("empty trace")
     tmax = max(e for _, _, e in rows)
-    if a.tail_ms > 0:
+    span_note = ""
+    if a.marker and a.steps > 0:
+        marks = sorted(e for n, _, e in rows if a.marker in n)
+        if len(marks) > a.steps:
+            t0, t1 = marks[-a.steps - 1], marks[-1]
+            rows = sorted((r for r in rows if r[1] >= t0 and r[2] <= t1), key=lambda r: r[1])
+            # GPU busy time = union of kernel intervals; the largest idle gaps and what ran before them
+            busy, cur_s, cur_e, gaps = 0, None, None, []
+            for n, s_, e_ in rows:
+                if cur_e is None:
+                    cur_s, cur_e = s_, e_
+                elif s_ > cur_e:
+                    busy += cur_e - cur_s
+                    gaps.append((s_ - cur_e, prev))
+                    cur_s, cur_e = s_, e_
+                else:
+                    cur_e = max(cur_e, e_)
+                prev = short(n)[:40]
+            busy += cur_e - cur_s
+            span = t1 - t0
+            gaps.sort(reverse=True)
+            span_note = " steps=%d span_ms=%.3f ms_per_step=%.3f gpu_busy=%.3f idle_ms_per_step=%.3f gaps>20us=%d largest_gaps_us=%s" % (
+                a.steps, span / 1e6, span / 1e6 / a.steps, busy / span, (span - busy) / 1e6 / a.steps,
+                sum(1 for g, _ in gaps if g > 20000), ";".join("%.0f after %s" % (g / 1e3, p) for g, p in gaps[:6]))
+    elif a.tail_ms > 0:
         t0 = tmax - int(a.tail_ms * 1e6)
         rows = [r for r in rows if r[1] >= t0]
     agg = {}
@@ -68,7 +95,7 @@ def main():
     w.writerow(["kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "percent"])
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:a.top]:
         w.writerow([k, v[0], "%.1f" % v[1], "%.2f" % (v[1] / v[0]), "%.2f" % v[2], "%.2f" % v[3], "%.2f" % (100 * v[1] / total)])
-    w.writerow(["# window_ms=%s kernels_total_us=%.1f source=%s" % (a.tail_ms or "all", total, os.path.basename(path))])
+    w.writerow(["# window_ms=%s kernels_total_us=%.1f source=%s%s" % (a.tail_ms or "all", total, os.path.basename(path), span_note)])
 
 
 if __name__ == "__main__":
