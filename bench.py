@@ -203,20 +203,26 @@ def main():
                                minlength=22 * B).reshape(B, 22)[:, 1:]
     pairs = float(((per_class + net.skip_pixels - 1) // net.skip_pixels * (per_class > 500)).sum().item()) * H * W
     # HBM-bound kernels of the library: algorithmic bytes per step / live event time per step
-    def us(k):
-        return kern[k]["avg_us"] * kern[k]["calls"] / a.steps if k in kern else None
     act = lambda div, ch: 4.0 * B * (H // div) * (W // div) * ch
+    towers = 2 if a.input == "RGBD" else 1
     hbm = {
-        "conv3x3_c3_bias_relu_kernel": act(1, 3) + act(1, 64),
-        "bias_relu_pool2_kernel": 1.25 * (act(1, 64) + act(2, 128) + act(4, 256)),
-        "bias_act_kernel": 2.0 * (act(2, 128) + 2 * act(4, 256) + 3 * act(8, 512) + 3 * act(16, 512)),
+        "conv3x3_c3_bias_relu_kernel": towers * (act(1, 3) + act(1, 64)),
         "hard_label_fwd_kernel": 4.0 * B * H * W * (2 + 22),
         "upscore_softmax_argmax_kernel": 4.0 * B * H * W * (22 + 1) + act(8, 22),
     }
-    if a.input == "RGBD":
-        for k in ("conv3x3_c3_bias_relu_kernel", "bias_relu_pool2_kernel"):
-            hbm[k] *= 2
-        hbm["bias_act_kernel"] = None
+    if net.winograd_tile == 4 and net.winograd_min_channels == 64:
+        # F(4x4,3x3) transforms of conv1_2 ... conv5_3: the input transform reads X and writes 2.25 X,
+        # the output transform reads 2.25 Y and writes Y (or Y/4 where the max-pool is fused)
+        x_in = (act(1, 64) + act(2, 64) + act(2, 128) + act(4, 128) + 2 * act(4, 256) + act(8, 256) + 2 * act(8, 512)
+                + 3 * act(16, 512))
+        y_all = (act(1, 64) + 2 * act(2, 128) + 3 * act(4, 256) + 3 * act(8, 512) + 3 * act(16, 512))
+        y_written = y_all - 0.75 * (act(1, 64) + act(2, 128) + act(4, 256))
+        hbm["wino43_input_kernel"] = towers * 3.25 * x_in
+        hbm["wino43_output_kernel"] = towers * (2.25 * y_all + y_written)
+
+    def us(k):  # per step, all template instances of a kernel together
+        t = sum(v["avg_us"] * v["calls"] for n, v in kern.items() if n == k or n.startswith(k + "<"))
+        return t / a.steps if t else None
     others = []
     for k, byt in hbm.items():
         t = us(k)
@@ -224,7 +230,7 @@ def main():
             others.append({"kernel": k, "bound": "hbm", "achieved": byt / (t * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": byt / (t * 1e-6) / 1e9 / HBM_PEAK_GBPS, "us_per_step": round(t, 1)})
     # the Winograd output transforms (library kernels) belong to the convolutions' time
-    wino_out_ms = sum(v["avg_us"] * v["calls"] for k, v in kern.items() if k.startswith("wino_output")) / 1e3
+    wino_out_ms = sum(v["avg_us"] * v["calls"] for k, v in kern.items() if k.startswith("wino") and "_output" in k) / 1e3
     conv_ms += wino_out_ms
     conv_tflops = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else None
     out = {
