@@ -79,7 +79,20 @@ def cpu_baseline(K, H, W, input_format, net_gpu, max_seconds=25.0, max_frames=6)
         t_total += dt
         if t_total > max_seconds:
             break
+    # the Hough layer alone on the last frame's label / vertex maps: the GPU-kernel semantics (the parity
+    # target, OpenMP) and the reference's own CPU kernel semantics (H7: ray marching, what demo.sh runs
+    # without a GPU; single-threaded like the original, a different algorithm — not a parity target)
+    import oracle
+    meta1 = config.make_meta_data(K)[None]
+    lab, ver = out["label_2d"], out["vertex_pred"]
+    t0 = time.perf_counter(); oracle.hough_voting(lab, ver, config.LOV_EXTENTS, meta1, None, 0, -1.0, 0.02, 10)
+    hough_port_ms = 1000 * (time.perf_counter() - t0)
+    t0 = time.perf_counter(); rows_h7 = oracle.hough_cpu_kernel(lab, ver, config.LOV_EXTENTS, meta1)
+    hough_h7_ms = 1000 * (time.perf_counter() - t0)
     return {"value": done / t_total, "unit": "frames/s", "cores": int(threads), "kind": "port",
+            "hough_ms_per_frame": {"gpu_kernel_semantics_openmp": hough_port_ms,
+                                   "reference_cpu_kernel_semantics_1_thread": hough_h7_ms,
+                                   "reference_cpu_kernel_detections": int(rows_h7.shape[0])},
             "sample": "%d synthetic 640x480 frames, batch 1, same graph/weights: PyTorch-CPU fp32 (%d threads) "
                       "+ C oracle (OpenMP) for hough/roi_pool/softmax; %d detections on the last frame"
                       % (done, threads, out["final_rois"].shape[0]),

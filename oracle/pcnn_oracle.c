@@ -972,3 +972,121 @@ int oracle_smooth_l1_vertex(const float* pred, const float* target, const float*
   }
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * H7 — the reference's CPU kernel of the same op (HoughvotinggpuOp<CPUDevice>,
+ * hough_voting_gpu_op.cc:132-297; hough_voting :486-672; compute_width_height :679-758). It is a
+ * DIFFERENT algorithm from the GPU kernels (every foreground pixel marches a ray along its
+ * predicted direction and increments the cells it crosses; one maximum per class, >= 50 votes)
+ * and therefore NOT a parity target — it is restated only because it is what `demo.sh` executes on a
+ * machine without a GPU (BASELINE configs[0]); bench.py times it beside the GPU path.
+ * The OpenCV types of the original (cv::Mat, projectPoints with zero rotation) are written out:
+ * a corner (X,Y,Z) of the extents box at distance d projects to fx*X/(Z+d)+px, fy*Y/(Z+d)+py.
+ * out rows: (batch, cls, x1, y1, x2, y2, votes, 1,0,0,0, tx, ty, tz); returns the row count.
+ * ---------------------------------------------------------------------------------------------- */
+#define PCNN_MAX_CLASSES_ORACLE 256
+
+static int cmp_float(const void* a, const void* b)
+{
+  const float x = *(const float*)a, y = *(const float*)b;
+  return (x > y) - (x < y);
+}
+
+int oracle_hough_cpu_kernel(const int* label, const float* vertex, const float* extents,
+                            const float* meta, int B, int H, int W, int C, int num_meta, float* out,
+                            int max_rows)
+{
+  const float inlier = 0.9f;
+  const int voting_threshold = 50;
+  int rows = 0;
+  if (C < 1 || C > PCNN_MAX_CLASSES_ORACLE) return -1;
+  int* hs = (int*)malloc(sizeof(int) * (size_t)H * W * C);
+  float* dxs = (float*)malloc(sizeof(float) * (size_t)H * W);
+  float* dys = (float*)malloc(sizeof(float) * (size_t)H * W);
+  for (int n = 0; n < B; n++) {
+    const int* lab = label + (size_t)n * H * W;
+    const float* vm = vertex + (size_t)n * H * W * 3 * C;
+    const float fx = meta[n * num_meta + 0], px = meta[n * num_meta + 2];
+    const float fy = meta[n * num_meta + 4], py = meta[n * num_meta + 5];
+    memset(hs, 0, sizeof(int) * (size_t)H * W * C);  /* (:501-502 clears a quarter; fresh pages are zero) */
+    char flags[PCNN_MAX_CLASSES_ORACLE];
+    memset(flags, 0, sizeof flags);
+    for (int x = 0; x < W; x++)
+      for (int y = 0; y < H; y++) {                                            /* :507-545 */
+        const int c = lab[y * W + x];
+        if (c <= 0 || c >= C) continue;
+        flags[c] = 1;
+        const float* vp = vm + (size_t)(y * W + x) * 3 * C + 3 * c;
+        float u = vp[0], v = vp[1];
+        const float nrm = sqrtf(u * u + v * v);
+        u /= nrm; v /= nrm;
+        const float delta = 1.0f / fabsf(u);
+        if (!(delta < 1e30f)) continue;      /* u == 0 or NaN: the original never terminates / is undefined */
+        float cx = (float)x, cy = (float)y;
+        for (;;) {
+          cx += delta * u; cy += delta * v;
+          if (!(fabsf(cy) < 1e9f)) break;    /* int(cy) would overflow (undefined in the original) */
+          const int ix = (int)cx, iy = (int)cy;   /* truncation: (-1, 0) counts as cell 0, as in the original */
+          if (ix >= 0 && ix < W && iy >= 0 && iy < H) hs[c + C * (iy * W + ix)] += 1;
+          else break;
+        }
+      }
+    for (int c = 1; c < C; c++) {                                              /* :548-566 */
+      if (!flags[c]) continue;
+      int max_vote = 0, max_x = 0, max_y = 0;
+      for (int x = 0; x < W; x++)
+        for (int y = 0; y < H; y++) {
+          const int v = hs[c + C * (y * W + x)];
+          if (v > max_vote) { max_vote = v; max_x = x; max_y = y; }
+        }
+      if (max_vote < voting_threshold) continue;
+      /* compute_width_height :679-758 */
+      float dsum = 0.f;
+      int cnt = 0;
+      for (int x = 0; x < W; x++)
+        for (int y = 0; y < H; y++) {
+          if (lab[y * W + x] != c) continue;
+          const float* vp = vm + (size_t)(y * W + x) * 3 * C + 3 * c;
+          float u = vp[0], v = vp[1];
+          const float dist = oracle_expf(vp[2]);
+          const float nrm = sqrtf(u * u + v * v);
+          u /= nrm; v /= nrm;
+          const float ddx = (float)max_x - x, ddy = (float)max_y - y;
+          const float ang = (u * ddx + v * ddy) / (sqrtf(u * u + v * v) * sqrtf(ddx * ddx + ddy * ddy));
+          if (ang > inlier) { dxs[cnt] = fabsf(ddx); dys[cnt] = fabsf(ddy); dsum += dist; cnt++; }
+        }
+      if (cnt == 0) continue;                /* the original divides by zero and indexes an empty vector */
+      const float bb_distance = dsum / cnt;
+      int minX = 100000000, maxX = -100000000, minY = 100000000, maxY = -100000000;
+      for (int i = 0; i < 8; i++) {
+        const float X = (i & 1 ? 0.5f : -0.5f) * extents[3 * c + 0];
+        const float Y = (i & 2 ? 0.5f : -0.5f) * extents[3 * c + 1];
+        const float Z = (i & 4 ? 0.5f : -0.5f) * extents[3 * c + 2] + bb_distance;
+        const float qx = fx * X / Z + px, qy = fy * Y / Z + py;
+        minX = (int)fminf((float)minX, qx); maxX = (int)fmaxf((float)maxX, qx);
+        minY = (int)fminf((float)minY, qy); maxY = (int)fmaxf((float)maxY, qy);
+      }
+      const float lim = (float)((maxX - minX + 1) > (maxY - minY + 1) ? (maxX - minX + 1) : (maxY - minY + 1));
+      int nx = 0, ny = 0;
+      for (int i = 0; i < cnt; i++) if (!(dxs[i] > lim)) dxs[nx++] = dxs[i];
+      for (int i = 0; i < cnt; i++) if (!(dys[i] > lim)) dys[ny++] = dys[i];
+      if (nx == 0 || ny == 0) continue;
+      qsort(dxs, nx, sizeof(float), cmp_float);
+      qsort(dys, ny, sizeof(float), cmp_float);
+      const int bb_w = (int)(2 * dxs[(int)(nx * 0.95)]), bb_h = (int)(2 * dys[(int)(ny * 0.95)]);
+      if (rows < max_rows) {                                                   /* :575-603 */
+        float* r = out + 14 * rows;
+        const float scale = 0.05f;
+        r[0] = (float)n; r[1] = (float)c;
+        r[2] = max_x - bb_w * (0.5f + scale); r[3] = max_y - bb_h * (0.5f + scale);
+        r[4] = max_x + bb_w * (0.5f + scale); r[5] = max_y + bb_h * (0.5f + scale);
+        r[6] = (float)max_vote;
+        r[7] = 1; r[8] = 0; r[9] = 0; r[10] = 0;
+        r[11] = (max_x - px) / fx * bb_distance; r[12] = (max_y - py) / fy * bb_distance; r[13] = bb_distance;
+        rows++;
+      }
+    }
+  }
+  free(hs); free(dxs); free(dys);
+  return rows;
+}

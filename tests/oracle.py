@@ -189,6 +189,17 @@ def deconv_bilinear(x, k, s, add1=None, add2=None, bias=None, relu=False):
     return out
 
 
+def hough_cpu_kernel(label, vertex, extents, meta, max_rows=1024):
+    """H7: the reference's CPU kernel semantics (ray marching) — a different algorithm, timing only."""
+    label = np.ascontiguousarray(label, dtype=np.int32)
+    vertex, extents, meta = _f32(vertex), _f32(extents), _f32(meta)
+    B, H, W = label.shape
+    C = vertex.shape[3] // 3
+    out = np.zeros((max_rows, 14), np.float32)
+    n = lib().oracle_hough_cpu_kernel(_p(label), _p(vertex), _p(extents), _p(meta), B, H, W, C, meta.shape[-1], _p(out), max_rows)
+    return out[:max(n, 0)]
+
+
 def deconv_bilinear_bwd(grad_out, k, s):
     g = _f32(grad_out)
     B, Ho, Wo, C = g.shape
