@@ -92,7 +92,9 @@ def profile_report(reset=True):
     L.pcnn_profile_report(buf, len(buf))
     if reset:
         L.pcnn_profile_reset()
-    return json.loads(buf.value.decode())
+    rep = json.loads(buf.value.decode())
+    # template instances are launched as `(kernel<a, b>)`: drop the macro's parentheses
+    return {k.strip("()"): v for k, v in rep.items()}
 
 _lib = None
 

@@ -150,56 +150,80 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 //        c = d4 - d2, e = 2 (d3 - d1): r3 = c + e, r4 = c - e;  r5 = (4 d1 - 5 d3) + d5
 //   out: s = m1 + m2, d = m1 - m2, S = m3 + m4, D = m3 - m4:
 //        y0 = (m0 + s) + S;  y1 = d + 2 D;  y2 = s + 4 S;  y3 = (d + 8 D) + m5
-__device__ __forceinline__ void bt6(const f4* d, f4* r)
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <typename VT>
+__device__ __forceinline__ VT vrelu(VT a)
+{
+  VT r;
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(VT) / 4); i++) r[i] = a[i] > 0.f ? a[i] : 0.f;
+  return r;
+}
+
+template <typename VT>
+__device__ __forceinline__ VT vmax(VT a, VT b)
+{
+  VT r;
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(VT) / 4); i++) r[i] = b[i] > a[i] ? b[i] : a[i];
+  return r;
+}
+
+template <typename VT>
+__device__ __forceinline__ void bt6(const VT* d, VT* r)
 {
   r[0] = (4.f * d[0] - 5.f * d[2]) + d[4];
-  const f4 a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1];
+  const VT a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1];
   r[1] = a + b;
   r[2] = a - b;
-  const f4 c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
+  const VT c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
   r[3] = c + e;
   r[4] = c - e;
   r[5] = (4.f * d[1] - 5.f * d[3]) + d[5];
 }
 
-__device__ __forceinline__ void at6(const f4* m, f4* y)
+template <typename VT>
+__device__ __forceinline__ void at6(const VT* m, VT* y)
 {
-  const f4 s = m[1] + m[2], d = m[1] - m[2], S = m[3] + m[4], D = m[3] - m[4];
+  const VT s = m[1] + m[2], d = m[1] - m[2], S = m[3] + m[4], D = m[3] - m[4];
   y[0] = (m[0] + s) + S;
   y[1] = d + 2.f * D;
   y[2] = s + 4.f * S;
   y[3] = (d + 8.f * D) + m[5];
 }
 
+template <typename VT>
 __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restrict__ x,
                                                            float* __restrict__ v, int H, int W, int C,
                                                            int Ht, int Wt, long long total,
                                                            long long plane)
 {
-  const int cv = C / 4;
+  constexpr int VW = sizeof(VT) / 4;
+  const int cv = C / VW;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * 256) {
-    const int c = (int)(idx % cv) * 4;
+    const int c = (int)(idx % cv) * VW;
     const long long t = idx / cv;
     const int tx = (int)(t % Wt);
     const int ty = (int)((t / Wt) % Ht);
     const long long b = t / ((long long)Wt * Ht);
     const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
     const float* xb = x + b * H * W * (long long)C + c;
-    f4 tmp[6][6];  // tmp[i][s] = (B^T d)[i][s]
+    VT tmp[6][6];  // tmp[i][s] = (B^T d)[i][s]
 #pragma unroll
     for (int s2 = 0; s2 < 6; s2++) {
       const int xx = x0 + s2;
-      f4 col[6];
+      VT col[6];
 #pragma unroll
       for (int r = 0; r < 6; r++) {
         const int yy = y0 + r;
-        f4 val = {0.f, 0.f, 0.f, 0.f};
+        VT val = {};
         if (yy >= 0 && yy < H && xx >= 0 && xx < W)
-          val = *reinterpret_cast<const f4*>(xb + ((long long)yy * W + xx) * C);
+          val = *reinterpret_cast<const VT*>(xb + ((long long)yy * W + xx) * C);
         col[r] = val;
       }
-      f4 o[6];
+      VT o[6];
       bt6(col, o);
 #pragma unroll
       for (int i = 0; i < 6; i++) tmp[i][s2] = o[i];
@@ -207,50 +231,51 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restri
     float* vo = v + t * C + c;
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-      f4 o[6];
+      VT o[6];
       bt6(tmp[i], o);
 #pragma unroll
-      for (int j = 0; j < 6; j++) *reinterpret_cast<f4*>(vo + (6 * i + j) * plane) = o[j];
+      for (int j = 0; j < 6; j++) *reinterpret_cast<VT*>(vo + (6 * i + j) * plane) = o[j];
     }
   }
 }
 
-template <bool POOL>
+template <bool POOL, typename VT>
 __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restrict__ m,
                                                             const float* __restrict__ bias,
                                                             float* __restrict__ y, int H, int W, int C,
                                                             int Ht, int Wt, int relu, long long total,
                                                             long long plane)
 {
-  const int cv = C / 4;
+  constexpr int VW = sizeof(VT) / 4;
+  const int cv = C / VW;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * 256) {
-    const int c = (int)(idx % cv) * 4;
+    const int c = (int)(idx % cv) * VW;
     const long long t = idx / cv;
     const int tx = (int)(t % Wt);
     const int ty = (int)((t / Wt) % Ht);
     const long long b = t / ((long long)Wt * Ht);
     const float* mi = m + t * C + c;
-    f4 tmp[4][6];  // tmp[a][j] = (A^T m)[a][j]
+    VT tmp[4][6];  // tmp[a][j] = (A^T m)[a][j]
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-      f4 col[6];
+      VT col[6];
 #pragma unroll
-      for (int i = 0; i < 6; i++) col[i] = *reinterpret_cast<const f4*>(mi + (6 * i + j) * plane);
-      f4 o[4];
+      for (int i = 0; i < 6; i++) col[i] = *reinterpret_cast<const VT*>(mi + (6 * i + j) * plane);
+      VT o[4];
       at6(col, o);
 #pragma unroll
       for (int a = 0; a < 4; a++) tmp[a][j] = o[a];
     }
-    const f4 bq = *reinterpret_cast<const f4*>(bias + c);
-    f4 out[4][4];
+    const VT bq = *reinterpret_cast<const VT*>(bias + c);
+    VT out[4][4];
 #pragma unroll
     for (int a = 0; a < 4; a++) {
       at6(tmp[a], out[a]);
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         out[a][e] = out[a][e] + bq;
-        if (relu) out[a][e] = relu4(out[a][e]);
+        if (relu) out[a][e] = vrelu(out[a][e]);
       }
     }
     const int oy0 = 4 * ty, ox0 = 4 * tx;
@@ -263,8 +288,8 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restr
         for (int e = 0; e < 2; e++) {
           const int py = 2 * ty + a, px = 2 * tx + e;
           if (py < Hp && px < Wp) {
-            const f4 p = max4(max4(max4(out[2 * a][2 * e], out[2 * a][2 * e + 1]), out[2 * a + 1][2 * e]), out[2 * a + 1][2 * e + 1]);
-            *reinterpret_cast<f4*>(y + ((b * Hp + py) * Wp + px) * C + c) = p;
+            const VT p = vmax(vmax(vmax(out[2 * a][2 * e], out[2 * a][2 * e + 1]), out[2 * a + 1][2 * e]), out[2 * a + 1][2 * e + 1]);
+            *reinterpret_cast<VT*>(y + ((b * Hp + py) * Wp + px) * C + c) = p;
           }
         }
     } else {
@@ -273,7 +298,7 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restr
 #pragma unroll
         for (int e = 0; e < 4; e++)
           if (oy0 + a < H && ox0 + e < W)
-            *reinterpret_cast<f4*>(y + ((b * H + oy0 + a) * W + ox0 + e) * C + c) = out[a][e];
+            *reinterpret_cast<VT*>(y + ((b * H + oy0 + a) * W + ox0 + e) * C + c) = out[a][e];
     }
   }
 }
@@ -305,7 +330,9 @@ extern "C" int pcnn_winograd43_input_fwd(const float* x, int B, int H, int W, in
   const int Ht = (H + 3) / 4, Wt = (W + 3) / 4;
   const long long T = (long long)B * Ht * Wt;
   const long long total = T * (C / 4);
-  PCNN_LAUNCH(wino43_input_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, v, H, W, C, Ht, Wt, total, T * C);
+  // (a float2-per-thread instance — half the registers, twice the waves — measures the same: the
+  // transforms sit at the HBM streaming rate, not at an occupancy limit)
+  PCNN_LAUNCH(wino43_input_kernel<f4>, dim3(grid_for(total)), dim3(256), 0, stream, x, v, H, W, C, Ht, Wt, total, T * C);
   return check_launch("winograd43_input_fwd");
 }
 
@@ -322,9 +349,9 @@ extern "C" int pcnn_winograd43_output_fwd(const float* m, const float* bias, int
   const long long T = (long long)B * Ht * Wt;
   const long long total = T * (C / 4);
   if (pool)
-    PCNN_LAUNCH(wino43_output_kernel<true>, dim3(grid_for(total)), dim3(256), 0, stream, m, bias, y, H, W, C, Ht, Wt, relu, total, T * C);
+    PCNN_LAUNCH((wino43_output_kernel<true, f4>), dim3(grid_for(total)), dim3(256), 0, stream, m, bias, y, H, W, C, Ht, Wt, relu, total, T * C);
   else
-    PCNN_LAUNCH(wino43_output_kernel<false>, dim3(grid_for(total)), dim3(256), 0, stream, m, bias, y, H, W, C, Ht, Wt, relu, total, T * C);
+    PCNN_LAUNCH((wino43_output_kernel<false, f4>), dim3(grid_for(total)), dim3(256), 0, stream, m, bias, y, H, W, C, Ht, Wt, relu, total, T * C);
   return check_launch("winograd43_output_fwd");
 }
 
