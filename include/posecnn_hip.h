@@ -248,6 +248,13 @@ int pcnn_bias_act_fwd(const float* x, const float* bias, int64_t num_pixels, int
 int pcnn_conv3x3_c3_fwd(const float* x, const float* weights, const float* bias, int batch,
                         int height, int width, int out_channels, int relu, float* y, void* stream);
 
+/* pcnn_conv3x3_c3_fwd fused with the F(4x4,3x3) input transform of the NEXT 3x3 layer (conv1_1 ->
+ * conv1_2, vgg16_convs.py:36-37): v f32 [36][T][Cout] = pcnn_winograd43_input_fwd(pcnn_conv3x3_c3_fwd(x)),
+ * bit for bit, without the [B,H,W,Cout] activation in between. */
+int pcnn_conv3x3_c3_winograd43_fwd(const float* x, const float* weights, const float* bias, int batch,
+                                   int height, int width, int out_channels, int relu, float* v,
+                                   void* stream);
+
 /* Data transforms of a Winograd F(2x2,3x3) evaluation of `Network.conv` for the deep 3x3 / stride 1 /
  * SAME layers of the trunk (network.py:159-187; vgg16_convs.py:42-52). All f32.
  *   pcnn_winograd_input_fwd : x f32 [B,H,W,C] (H, W even, C % 4 == 0) -> v f32 [16][T][C],

@@ -90,7 +90,142 @@ __global__ __launch_bounds__(256) void conv3x3_c3_bias_relu_kernel(
   }
 }
 
+// conv1_1 + bias + ReLU feeding conv1_2's Winograd F(4x4,3x3) input transform directly: the
+// 78.6 MB/frame activation between the two layers is neither written nor read back. A workgroup owns
+// one row of FW_TILES 4x4 output tiles: phase 1 computes the (4+2) x (4*FW_TILES+2) pixel patch of
+// relu(conv1_1) those tiles need into LDS (zeros outside the image: conv1_2's SAME padding), phase 2
+// applies B^T d B to each tile's 6x6 patch with exactly the expressions of wino43_input_kernel
+// (csrc/winograd.hip), so V is bit-identical to the unfused pair.
+constexpr int FW_TILES = 8;
+constexpr int FW_COLS = 4 * FW_TILES + 2;   // 34 patch columns
+constexpr int FW_INF = (FW_COLS + 2) * CF_CIN;
+
+__device__ __forceinline__ void fw_bt6(const f4* d, f4* r)
+{
+  r[0] = (4.f * d[0] - 5.f * d[2]) + d[4];
+  const f4 a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1];
+  r[1] = a + b;
+  r[2] = a - b;
+  const f4 c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
+  r[3] = c + e;
+  r[4] = c - e;
+  r[5] = (4.f * d[1] - 5.f * d[3]) + d[5];
+}
+
+__global__ __launch_bounds__(256) void conv3x3_c3_wino43_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ v, int H, int W, int Cout, int relu, int Ht, int Wt, int nseg,
+    long long plane)
+{
+  __shared__ float s_in[8][FW_INF];
+  __shared__ __attribute__((aligned(16))) float s_y[6][FW_COLS][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int seg = blockIdx.x % nseg;
+  const int ty = (blockIdx.x / nseg) % Ht;
+  const int b = blockIdx.x / (nseg * Ht);
+  const int cg = blockIdx.y;
+  const int tx0 = seg * FW_TILES;
+  const int py0 = 4 * ty - 1, px0 = 4 * tx0 - 1;   // image coordinates of patch pixel (0, 0)
+
+  // input window: rows py0-1 .. py0+6, columns px0-1 .. px0+34
+  for (int i = tid; i < 8 * FW_INF; i += 256) {
+    const int r = i / FW_INF, j = i - r * FW_INF;
+    const int iy = py0 - 1 + r, ix = px0 - 1 + j / CF_CIN;
+    float val = 0.f;
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+      val = x[(((size_t)b * H + iy) * W + ix) * CF_CIN + (j % CF_CIN)];
+    s_in[r][j] = val;
+  }
+  const int quad = lane & 15, slot = lane >> 4;
+  const int c0 = cg * 64 + quad * 4;
+  {
+    f4 wq[27];
+#pragma unroll
+    for (int t = 0; t < 27; t++) wq[t] = *reinterpret_cast<const f4*>(w + (size_t)t * Cout + c0);
+    const f4 bq = *reinterpret_cast<const f4*>(bias + c0);
+    __syncthreads();
+    // phase 1: 6 x 34 patch pixels, 16 per iteration (4 waves x 4 slots)
+    for (int it = 0; it < (6 * FW_COLS + 15) / 16; it++) {
+      const int p = it * 16 + wave * 4 + slot;
+      if (p < 6 * FW_COLS) {
+        const int r = p / FW_COLS, cx = p - r * FW_COLS;
+        const int yy = py0 + r, xx = px0 + cx;
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+#pragma unroll
+          for (int ky = 0; ky < 3; ky++) {
+            const float* win = &s_in[r + ky][cx * CF_CIN];
+#pragma unroll
+            for (int j = 0; j < 9; j++) {
+              const float val = win[j];
+              const f4 vv = {val, val, val, val};
+              acc = __builtin_elementwise_fma(wq[ky * 9 + j], vv, acc);
+            }
+          }
+          acc = acc + bq;
+          if (relu) {
+            acc.x = acc.x > 0.f ? acc.x : 0.f;
+            acc.y = acc.y > 0.f ? acc.y : 0.f;
+            acc.z = acc.z > 0.f ? acc.z : 0.f;
+            acc.w = acc.w > 0.f ? acc.w : 0.f;
+          }
+        }
+        *reinterpret_cast<f4*>(&s_y[r][cx][quad * 4]) = acc;
+      }
+    }
+  }
+  __syncthreads();
+  // phase 2: thread = (tile, channel quad)
+  if (tid < FW_TILES * 16) {
+    const int t = tid >> 4, q = tid & 15;
+    const int tx = tx0 + t;
+    if (tx < Wt) {
+      f4 tmp[6][6];
+#pragma unroll
+      for (int s2 = 0; s2 < 6; s2++) {
+        f4 col[6];
+#pragma unroll
+        for (int r = 0; r < 6; r++) col[r] = *reinterpret_cast<const f4*>(&s_y[r][4 * t + s2][q * 4]);
+        f4 o[6];
+        fw_bt6(col, o);
+#pragma unroll
+        for (int i = 0; i < 6; i++) tmp[i][s2] = o[i];
+      }
+      const long long tile = ((long long)b * Ht + ty) * Wt + tx;
+      float* vo = v + tile * Cout + cg * 64 + q * 4;
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        f4 o[6];
+        fw_bt6(tmp[i], o);
+#pragma unroll
+        for (int j = 0; j < 6; j++) *reinterpret_cast<f4*>(vo + (6 * i + j) * plane) = o[j];
+      }
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int pcnn_conv3x3_c3_winograd43_fwd(const float* x, const float* weights, const float* bias,
+                                              int B, int H, int W, int Cout, int relu, float* v,
+                                              void* stream_)
+{
+  PCNN_REQUIRE(B >= 1 && H >= 1 && W >= 1, PCNN_EINVAL, "conv3x3_c3_winograd43: bad shape %dx%dx%d", B, H, W);
+  PCNN_REQUIRE(Cout >= 64 && Cout % 64 == 0, PCNN_EINVAL,
+               "conv3x3_c3_winograd43: output channels must be a multiple of 64 (got %d)", Cout);
+  PCNN_REQUIRE(x && weights && bias && v, PCNN_ENULL, "conv3x3_c3_winograd43: NULL pointer");
+  PCNN_REQUIRE(aligned16(v) && aligned16(weights) && aligned16(bias), PCNN_EINVAL,
+               "conv3x3_c3_winograd43: weights, bias and output must be 16-byte aligned");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int Ht = (H + 3) / 4, Wt = (W + 3) / 4;
+  const int nseg = (Wt + FW_TILES - 1) / FW_TILES;
+  const long long blocks = (long long)B * Ht * nseg;
+  PCNN_REQUIRE(blocks < (1ll << 31), PCNN_EINVAL, "conv3x3_c3_winograd43: grid too large");
+  const long long plane = (long long)B * Ht * Wt * Cout;
+  PCNN_LAUNCH(conv3x3_c3_wino43_kernel, dim3((unsigned)blocks, Cout / 64), dim3(256), 0, stream, x,
+              weights, bias, v, H, W, Cout, relu, Ht, Wt, nseg, plane);
+  return check_launch("conv3x3_c3_winograd43_fwd");
+}
 
 extern "C" int pcnn_conv3x3_c3_fwd(const float* x, const float* weights, const float* bias, int B,
                                    int H, int W, int Cout, int relu, float* y, void* stream_)

@@ -38,7 +38,9 @@ def layer(op):
             layer_input = self.inputs[0]
         else:
             layer_input = list(self.inputs)
-        if op.__name__ != "max_pool":
+        if op.__name__ == "conv" and isinstance(layer_input, _RawConv) and layer_input.first is not None:
+            pass  # a Winograd conv can take a pending first conv as it is (conv() decides)
+        elif op.__name__ != "max_pool":
             # only max_pool fuses a deferred bias + ReLU; everybody else sees the activated tensor
             if isinstance(layer_input, list):
                 layer_input = [self._activate(i) if isinstance(i, _RawConv) else i for i in layer_input]
@@ -80,15 +82,19 @@ class _RawConv(object):
     """A convolution output before bias + ReLU, handed to a consumer that fuses them (max_pool).
     Fetching the layer by name materialises the activated tensor (in place) like any other."""
 
-    def __init__(self, y, bias, relu, wino=None):
-        # y: raw NHWC conv output, or None when the conv is pending in the Winograd domain:
-        # wino = (M [16,T,C], B, H, W) still waiting for its output transform
-        self.y, self.bias, self.relu, self.out, self.wino = y, bias, relu, None, wino
+    def __init__(self, y, bias, relu, wino=None, first=None):
+        # y: raw NHWC conv output, or None when the conv is still pending:
+        # wino  = (M [n*n,T,C], B, H, W): in the Winograd domain, waiting for its output transform
+        # first = (x [B,H,W,3], w [3,3,3,C]): a 3-channel first conv not evaluated yet — a following
+        #         Winograd conv computes it fused with its own input transform
+        self.y, self.bias, self.relu, self.out, self.wino, self.first = y, bias, relu, None, wino, first
 
     @property
     def shape(self):
         if self.wino is not None:
             return (self.wino[1], self.wino[2], self.wino[3], self.wino[0].shape[2])
+        if self.first is not None:
+            return tuple(self.first[0].shape[:3]) + (self.first[1].shape[3],)
         return tuple(self.y.shape)
 
 
@@ -119,6 +125,7 @@ class Network(object):
         self.winograd_min_channels = 64
         self.winograd_tile = 4
         self._wino_u = {}
+        self.fuse_first_conv_into_winograd = True
         self.fused_first_conv = True  # 3-channel 3x3 convs go to the fused conv + bias + ReLU kernel
         self.defer_act = frozenset()  # conv layers whose bias + ReLU is left to the following max_pool
 
@@ -151,6 +158,8 @@ class Network(object):
             if raw.wino is not None:
                 m, B, H, W = raw.wino
                 raw.out = ops.winograd_output(m, raw.bias, B, H, W, raw.relu, pool=False, tile=self.winograd_tile)
+            elif raw.first is not None:
+                raw.out = ops.conv3x3_c3(raw.first[0], raw.first[1], raw.bias, raw.relu)
             else:
                 raw.out = self._bias_act(raw.y, raw.bias, raw.relu)
         return raw.out
@@ -248,6 +257,7 @@ class Network(object):
         if c_i == -1:
             c_i = input.shape[-1]
         assert c_i % group == 0 and c_o % group == 0
+        pending_first = input if isinstance(input, _RawConv) else None
         w = self.make_var(name + "/weights", (c_o, c_i // group, k_h, k_w),
                           lambda s: self._weight_init(c_i // group * k_h * k_w)(s).contiguous(memory_format=torch.channels_last),
                           trainable)
@@ -256,9 +266,35 @@ class Network(object):
         pad = (k_h // 2, k_w // 2) if padding == "SAME" else 0
         if (self.fused_first_conv and b is not None and (k_h, k_w, c_i, group) == (3, 3, 3, 1) and padding == "SAME"
                 and c_o % 64 == 0 and not (torch.is_grad_enabled() and (w.requires_grad or input.requires_grad))):
-            # conv1_1: K = 27 is no GEMM; one HBM-bound kernel does conv + bias + ReLU
+            # conv1_1: K = 27 is no GEMM; one HBM-bound kernel does conv + bias + ReLU — or, when a
+            # Winograd conv follows, that layer's input transform kernel does it on the fly
+            if self.fuse_first_conv_into_winograd and self.winograd_tile == 4 and self.winograd_min_channels and input.is_cuda:
+                return _RawConv(None, b, relu, first=(input.contiguous(), w.permute(2, 3, 1, 0).contiguous()))
             return self._conv_first(input, w, b, relu)
-        if (b is not None and (k_h, k_w, s_h, s_w, group) == (3, 3, 1, 1, 1) and padding == "SAME" and input.is_cuda
+        wino_ok = (b is not None and (k_h, k_w, s_h, s_w, group) == (3, 3, 1, 1, 1) and padding == "SAME")
+        if pending_first is not None:
+            if (wino_ok and self.winograd_tile == 4 and self.winograd_min_channels
+                    and c_i >= self.winograd_min_channels and c_i % 64 == 0 and c_o % 4 == 0
+                    and not (torch.is_grad_enabled() and w.requires_grad)):
+                # conv1_1 -> conv1_2: the first conv is evaluated inside this layer's input transform
+                B_, H_, W_ = pending_first.shape[:3]
+                u = self._winograd_filter(name, w)
+                timed = self.conv_timing is not None
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                v = ops.conv3x3_c3_winograd43(pending_first.first[0], pending_first.first[1], pending_first.bias, pending_first.relu)
+                m = torch.bmm(v, u)
+                if timed:
+                    e1.record()
+                    first_flops = 2.0 * B_ * H_ * W_ * c_i * 27
+                    self.conv_timing.append((name, 2.0 * m.numel() * c_i + first_flops,
+                                             2.0 * B_ * H_ * W_ * c_o * c_i * 9 + first_flops, e0, e1))
+                if name in self.defer_act:
+                    return _RawConv(None, b, relu, wino=(m, B_, H_, W_))
+                return ops.winograd_output(m, b, B_, H_, W_, relu, pool=False, tile=4)
+            input = self._activate(pending_first)
+        if (wino_ok and input.is_cuda
                 and self.winograd_min_channels and c_i >= self.winograd_min_channels and c_i % 4 == 0 and c_o % 4 == 0
                 and (self.winograd_tile == 4 or (input.shape[1] % 2 == 0 and input.shape[2] % 2 == 0))
                 and not (torch.is_grad_enabled() and (w.requires_grad or input.requires_grad))):
@@ -300,6 +336,8 @@ class Network(object):
         if isinstance(input, _RawConv):
             if (input.out is None and (k_h, k_w, s_h, s_w) == (2, 2, 2, 2)
                     and input.shape[1] % 2 == 0 and input.shape[2] % 2 == 0):
+                if input.first is not None:
+                    return F.max_pool2d(_nchw(self._activate(input)), 2, 2).permute(0, 2, 3, 1).contiguous()
                 if input.wino is not None:  # a Winograd output tile is exactly one pooling window
                     m, B_, H_, W_ = input.wino
                     return ops.winograd_output(m, input.bias, B_, H_, W_, input.relu, pool=True, tile=self.winograd_tile)

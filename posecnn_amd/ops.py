@@ -296,6 +296,23 @@ def conv3x3_c3(x, weights, bias, relu=True):
     return y
 
 
+def conv3x3_c3_winograd43(x, weights, bias, relu=True):
+    """winograd_input(conv3x3_c3(x, weights, bias, relu), tile=4) in one kernel: V [36, T, Cout]."""
+    x = _dev(x, "x", torch.float32)
+    weights = _dev(weights, "weights", torch.float32)
+    bias = _dev(bias, "bias", torch.float32)
+    if x.dim() != 4 or x.shape[3] != 3:
+        raise ValueError("x must be [B,H,W,3]")
+    B, H, W, _ = x.shape
+    Cout = weights.shape[-1]
+    if tuple(weights.shape) != (3, 3, 3, Cout) or bias.numel() != Cout:
+        raise ValueError("weights must be [3,3,3,Cout] (ky,kx,ci,co) and bias [Cout]")
+    v = torch.empty((36, B * ((H + 3) // 4) * ((W + 3) // 4), Cout), dtype=torch.float32, device=x.device)
+    check("pcnn_conv3x3_c3_winograd43_fwd",
+          lib().pcnn_conv3x3_c3_winograd43_fwd(_ptr(x), _ptr(weights), _ptr(bias), B, H, W, Cout, 1 if relu else 0, _ptr(v), _stream(x)))
+    return v
+
+
 _WINO_G = {
     2: [[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]],
     4: [[1 / 4, 0.0, 0.0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],

@@ -558,3 +558,45 @@ def test_winograd43_convolution_accuracy(gpu, shape, cout):
     yp = N(ops.conv3x3_winograd(xt, ops.winograd_filter(wt, 4), bt, relu=True, pool=True, tile=4))
     y4 = N(ops.conv3x3_winograd(xt, ops.winograd_filter(wt, 4), bt, relu=True, tile=4))
     same(yp, y4.reshape(B, H // 2, 2, W // 2, 2, cout).max(axis=(2, 4)), "pooled F(4,3) conv")
+
+
+@pytest.mark.parametrize("shape,cout", [((2, 16, 32), 64), ((1, 30, 50), 64), ((1, 5, 7), 128), ((1, 480, 640), 64)])
+def test_first_conv_fused_into_winograd_input_transform(gpu, shape, cout):
+    """conv1_1 + bias + ReLU evaluated inside conv1_2's F(4x4,3x3) input transform: V must equal
+    winograd_input(conv3x3_c3(x)) bit for bit (same fma order, same transform expressions)."""
+    from posecnn_amd import ops
+    rng = np.random.default_rng(71)
+    B, H, W = shape
+    x = (rng.standard_normal((B, H, W, 3)) * 50).astype(F)
+    w = (rng.standard_normal((3, 3, 3, cout)) * 0.1).astype(F)
+    b = rng.standard_normal(cout).astype(F)
+    for relu in (True, False):
+        want = ops.winograd_input(ops.conv3x3_c3(T(gpu, x), T(gpu, w), T(gpu, b), relu), tile=4)
+        got = ops.conv3x3_c3_winograd43(T(gpu, x), T(gpu, w), T(gpu, b), relu)
+        same(N(got), N(want), "fused conv1_1 -> V (relu=%s)" % relu)
+    with pytest.raises(ValueError):
+        ops.conv3x3_c3_winograd43(T(gpu, x), T(gpu, w[..., :48]), T(gpu, b[:48]))
+
+
+def test_network_first_conv_fusion_is_transparent(gpu):
+    """The DSL path: conv1_1 stays a pending layer that conv1_2 consumes; the outputs of conv1_2 and a
+    fetch of conv1_1 by name are the same bits as without the fusion."""
+    import torch
+    from posecnn_amd.networks import vgg16_convs
+    rng = np.random.default_rng(72)
+    x = T(gpu, (rng.standard_normal((1, 32, 48, 3)) * 50).astype(F))
+    outs = []
+    nets = []
+    for fuse in (True, False):
+        net = vgg16_convs("COLOR", 22, 64, (1.0,), 1.0, -1.0, trainable=False, is_train=False, device=gpu)
+        net.fuse_first_conv_into_winograd = fuse
+        if nets:
+            net.vars = nets[0].vars
+        nets.append(net)
+        net.layers = {"data": x}
+        with torch.no_grad():
+            (net.feed("data").conv(3, 3, 64, 1, 1, name="conv1_1", c_i=3).conv(3, 3, 64, 1, 1, name="conv1_2", c_i=64)
+                .max_pool(2, 2, 2, 2, name="pool1"))
+            outs.append((N(net.get_output("pool1")), N(net.get_output("conv1_1")), N(net.get_output("conv1_2"))))
+    for a, b_ in zip(outs[0], outs[1]):
+        same(a, b_, "fused vs unfused first conv")
