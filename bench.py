@@ -230,6 +230,10 @@ def main():
                 + 3 * act(16, 512))
         y_all = (act(1, 64) + 2 * act(2, 128) + 3 * act(4, 256) + 3 * act(8, 512) + 3 * act(16, 512))
         y_written = y_all - 0.75 * (act(1, 64) + act(2, 128) + act(4, 256))
+        if net.fuse_first_conv_into_winograd and net.fused_first_conv:
+            # conv1_1 runs inside conv1_2's input transform: reads the frame, writes V (2.25 x [H,W,64])
+            x_in -= act(1, 64)
+            hbm["conv3x3_c3_wino43_kernel"] = towers * (act(1, 3) + 2.25 * act(1, 64))
         hbm["wino43_input_kernel"] = towers * 3.25 * x_in
         hbm["wino43_output_kernel"] = towers * (2.25 * y_all + y_written)
 
