@@ -197,17 +197,38 @@ template <typename VT>
 __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restrict__ x,
                                                            float* __restrict__ v, int H, int W, int C,
                                                            int Ht, int Wt, long long total,
-                                                           long long plane)
+                                                           long long plane, int blocked)
 {
   constexpr int VW = sizeof(VT) / 4;
   const int cv = C / VW;
+  // `blocked` (C % 64 == 0, float4): a workgroup = 4x4 neighbouring tiles x 64 channels, so the
+  // overlapping halves of neighbouring 6x6 patches are re-read by the same CU (L1 / its XCD's L2)
+  // instead of by workgroups the dispatcher has scattered over all 8 XCDs (PMC: 2.16x -> the
+  // fetched bytes of X with the linear map). total then counts workgroups * 256.
+  const int nbx = (Wt + 3) / 4, nby = (Ht + 3) / 4, ncg = C / 64;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * 256) {
-    const int c = (int)(idx % cv) * VW;
-    const long long t = idx / cv;
-    const int tx = (int)(t % Wt);
-    const int ty = (int)((t / Wt) % Ht);
-    const long long b = t / ((long long)Wt * Ht);
+    int c, tx, ty;
+    long long b, t;
+    if (blocked) {
+      long long wg = idx >> 8;
+      const int l = (int)(idx & 255);
+      const int cgi = (int)(wg % ncg); wg /= ncg;
+      const int bx = (int)(wg % nbx); wg /= nbx;
+      const int by = (int)(wg % nby);
+      b = wg / nby;
+      c = cgi * 64 + (l & 15) * 4;
+      tx = bx * 4 + ((l >> 4) & 3);
+      ty = by * 4 + (l >> 6);
+      if (tx >= Wt || ty >= Ht) continue;
+      t = (b * Ht + ty) * Wt + tx;
+    } else {
+      c = (int)(idx % cv) * VW;
+      t = idx / cv;
+      tx = (int)(t % Wt);
+      ty = (int)((t / Wt) % Ht);
+      b = t / ((long long)Wt * Ht);
+    }
     const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
     const float* xb = x + b * H * W * (long long)C + c;
     VT tmp[6][6];  // tmp[i][s] = (B^T d)[i][s]
@@ -332,7 +353,12 @@ extern "C" int pcnn_winograd43_input_fwd(const float* x, int B, int H, int W, in
   const long long total = T * (C / 4);
   // (a float2-per-thread instance — half the registers, twice the waves — measures the same: the
   // transforms sit at the HBM streaming rate, not at an occupancy limit)
-  PCNN_LAUNCH(wino43_input_kernel<f4>, dim3(grid_for(total)), dim3(256), 0, stream, x, v, H, W, C, Ht, Wt, total, T * C);
+  if (C % 64 == 0) {
+    const long long wgs = (long long)B * ((Ht + 3) / 4) * ((Wt + 3) / 4) * (C / 64);
+    PCNN_LAUNCH(wino43_input_kernel<f4>, dim3(grid_for(wgs * 256)), dim3(256), 0, stream, x, v, H, W, C, Ht, Wt, wgs * 256, T * C, 1);
+  } else {
+    PCNN_LAUNCH(wino43_input_kernel<f4>, dim3(grid_for(total)), dim3(256), 0, stream, x, v, H, W, C, Ht, Wt, total, T * C, 0);
+  }
   return check_launch("winograd43_input_fwd");
 }
 

@@ -510,7 +510,8 @@ def np_wino43_output(m, bias, B, H, W, relu):
     return y[:, :H, :W]
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 12, 16), (1, 30, 40, 512), (1, 6, 10, 4), (2, 5, 7, 36), (1, 1, 1, 8)])
+@pytest.mark.parametrize("shape", [(2, 8, 12, 16), (1, 30, 40, 512), (1, 6, 10, 4), (2, 5, 7, 36), (1, 1, 1, 8),
+                                   (2, 22, 38, 64), (1, 17, 9, 128)])   # C % 64 == 0: the blocked tile map
 def test_winograd43_transforms_bit_exact(gpu, shape):
     from posecnn_amd import ops
     rng = np.random.default_rng(63)
