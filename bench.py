@@ -247,7 +247,7 @@ def main():
             others.append({"kernel": k, "bound": "hbm", "achieved": byt / (t * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": byt / (t * 1e-6) / 1e9 / HBM_PEAK_GBPS, "us_per_step": round(t, 1)})
     # the Winograd output transforms (library kernels) belong to the convolutions' time
-    wino_out_ms = sum(v["avg_us"] * v["calls"] for k, v in kern.items() if k.startswith("wino") and "_output" in k) / 1e3
+    wino_out_ms = sum(v["avg_us"] * v["calls"] for k, v in kern.items() if k.startswith("wino") and "_output" in k) / 1e3   # incl. wino43_gemm_output_kernel
     conv_ms += wino_out_ms
     conv_tflops = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else None
     out = {

@@ -277,6 +277,16 @@ int pcnn_winograd43_input_fwd(const float* x, int batch, int height, int width, 
 int pcnn_winograd43_output_fwd(const float* m, const float* bias, int batch, int height, int width,
                                int channels, int relu, int pool, float* y, void* stream);
 
+/* F(4x4,3x3) GEMMs + output transform in one kernel for the small-channel layers (Cin = 64 or 128;
+ * conv1_2 ... conv3_1): y = [ReLU](A^T (v[k] * u[k]) A + bias) [max-pooled 2x2 when pool != 0] without
+ * the transform-domain product m ever reaching HBM (fp32 MFMA, accumulators stay in registers).
+ *   v  f32 [36][T][Cin]  from pcnn_winograd43_input_fwd / pcnn_conv3x3_c3_winograd43_fwd
+ *   ut f32 [36][Cout][Cin]  the filter transform TRANSPOSED: ut[6i+j][co][ci] = (G g G^T)[i][j]
+ *   y  f32 [B,H,W,Cout] or [B,H/2,W/2,Cout];  Cout % 64 == 0 */
+int pcnn_winograd43_gemm_output_fwd(const float* v, const float* ut, const float* bias, int batch,
+                                    int height, int width, int in_channels, int out_channels, int relu,
+                                    int pool, float* y, void* stream);
+
 /* y[b,oy,ox,c] = max over the 2x2 window of [ReLU](x + bias[c]): the `conv -> max_pool(2,2,2,2)`
  * pairs of the VGG trunk (vgg16_convs.py:36-49; network.py:181-187 + :189-196) from the raw
  * convolution output x f32 [B,H,W,C] (H, W even) to y f32 [B,H/2,W/2,C], same bits as

@@ -82,12 +82,14 @@ class _RawConv(object):
     """A convolution output before bias + ReLU, handed to a consumer that fuses them (max_pool).
     Fetching the layer by name materialises the activated tensor (in place) like any other."""
 
-    def __init__(self, y, bias, relu, wino=None, first=None):
+    def __init__(self, y, bias, relu, wino=None, first=None, gemm=None):
         # y: raw NHWC conv output, or None when the conv is still pending:
         # wino  = (M [n*n,T,C], B, H, W): in the Winograd domain, waiting for its output transform
         # first = (x [B,H,W,3], w [3,3,3,C]): a 3-channel first conv not evaluated yet — a following
         #         Winograd conv computes it fused with its own input transform
-        self.y, self.bias, self.relu, self.out, self.wino, self.first = y, bias, relu, None, wino, first
+        # gemm  = (V [36,T,Cin], Ut [36,Cout,Cin], B, H, W): F(4x4,3x3) input transform done, the fused
+        #         GEMM + output transform kernel still to run (with or without the max-pool)
+        self.y, self.bias, self.relu, self.out, self.wino, self.first, self.gemm = y, bias, relu, None, wino, first, gemm
 
     @property
     def shape(self):
@@ -95,6 +97,8 @@ class _RawConv(object):
             return (self.wino[1], self.wino[2], self.wino[3], self.wino[0].shape[2])
         if self.first is not None:
             return tuple(self.first[0].shape[:3]) + (self.first[1].shape[3],)
+        if self.gemm is not None:
+            return (self.gemm[2], self.gemm[3], self.gemm[4], self.gemm[1].shape[1])
         return tuple(self.y.shape)
 
 
@@ -125,6 +129,7 @@ class Network(object):
         self.winograd_min_channels = 64
         self.winograd_tile = 4
         self._wino_u = {}
+        self.winograd_fused_gemm = True      # F(4x4,3x3), Cin 64/128: GEMMs + output transform in one MFMA kernel
         self.fuse_first_conv_into_winograd = True
         self.fused_first_conv = True  # 3-channel 3x3 convs go to the fused conv + bias + ReLU kernel
         self.defer_act = frozenset()  # conv layers whose bias + ReLU is left to the following max_pool
@@ -160,18 +165,48 @@ class Network(object):
                 raw.out = ops.winograd_output(m, raw.bias, B, H, W, raw.relu, pool=False, tile=self.winograd_tile)
             elif raw.first is not None:
                 raw.out = ops.conv3x3_c3(raw.first[0], raw.first[1], raw.bias, raw.relu)
+            elif raw.gemm is not None:
+                v, ut, B, H, W = raw.gemm
+                raw.out = ops.winograd43_gemm_output(v, ut, raw.bias, B, H, W, raw.relu, pool=False)
             else:
                 raw.out = self._bias_act(raw.y, raw.bias, raw.relu)
         return raw.out
 
-    def _winograd_filter(self, name, w):
-        """U = G g G^T of a conv filter, cached until the variable changes."""
-        key = (w.data_ptr(), w._version, self.winograd_tile)
-        hit = self._wino_u.get(name)
+    def _winograd_filter(self, name, w, transposed=False):
+        """U = G g G^T of a conv filter ([n*n, Cin, Cout]; transposed: [n*n, Cout, Cin] for the fused
+        GEMM + output kernel), cached until the variable changes."""
+        key = (w.data_ptr(), w._version, self.winograd_tile, transposed)
+        hit = self._wino_u.get((name, transposed))
         if hit is None or hit[0] != key:
-            hit = (key, ops.winograd_filter(w, self.winograd_tile))
-            self._wino_u[name] = hit
+            u = ops.winograd_filter(w, self.winograd_tile)
+            hit = (key, u.transpose(1, 2).contiguous() if transposed else u)
+            self._wino_u[(name, transposed)] = hit
         return hit[1]
+
+    def _winograd43_tail(self, name, v, w, b, relu, B_, H_, W_, c_i, c_o, timing):
+        """Everything after the F(4x4,3x3) input transform: fused MFMA kernel for the small-channel
+        layers, library batched GEMM + output transform kernel otherwise."""
+        # (measured, tools/bench_layers.py: the fused kernel wins for Cin = 64 — conv1_2 2.02 -> 1.48 ms,
+        # conv2_1 1.03 -> 0.86 ms — and loses to the library GEMM from Cin = 128 on)
+        fused = self.winograd_fused_gemm and c_i == 64 and c_o % 64 == 0
+        if fused:
+            ut = self._winograd_filter(name, w, transposed=True)
+            executed = 2.0 * 36 * v.shape[1] * c_i * c_o
+            if timing is not None:
+                timing[1].record()   # the fused GEMM + output kernel is timed by the library's own events
+            out = (_RawConv(None, b, relu, gemm=(v, ut, B_, H_, W_)) if name in self.defer_act
+                   else ops.winograd43_gemm_output(v, ut, b, B_, H_, W_, relu, pool=False))
+        else:
+            m = torch.bmm(v, self._winograd_filter(name, w))
+            executed = 2.0 * m.numel() * c_i
+            if timing is not None:
+                timing[1].record()   # transform + GEMMs; the output transform is timed by the library
+            out = (_RawConv(None, b, relu, wino=(m, B_, H_, W_)) if name in self.defer_act
+                   else ops.winograd_output(m, b, B_, H_, W_, relu, pool=False, tile=4))
+        if timing is not None:
+            e0, e1, extra = timing
+            self.conv_timing.append((name, executed + extra, 2.0 * B_ * H_ * W_ * c_o * c_i * 9 + extra, e0, e1))
+        return out
 
     def get_unique_name(self, prefix):
         ident = sum(t.startswith(prefix) for t in self.layers) + 1
@@ -278,38 +313,30 @@ class Network(object):
                     and not (torch.is_grad_enabled() and w.requires_grad)):
                 # conv1_1 -> conv1_2: the first conv is evaluated inside this layer's input transform
                 B_, H_, W_ = pending_first.shape[:3]
-                u = self._winograd_filter(name, w)
-                timed = self.conv_timing is not None
-                if timed:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
+                timing = None
+                if self.conv_timing is not None:
+                    timing = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), 2.0 * B_ * H_ * W_ * c_i * 27)
+                    timing[0].record()
                 v = ops.conv3x3_c3_winograd43(pending_first.first[0], pending_first.first[1], pending_first.bias, pending_first.relu)
-                m = torch.bmm(v, u)
-                if timed:
-                    e1.record()
-                    first_flops = 2.0 * B_ * H_ * W_ * c_i * 27
-                    self.conv_timing.append((name, 2.0 * m.numel() * c_i + first_flops,
-                                             2.0 * B_ * H_ * W_ * c_o * c_i * 9 + first_flops, e0, e1))
-                if name in self.defer_act:
-                    return _RawConv(None, b, relu, wino=(m, B_, H_, W_))
-                return ops.winograd_output(m, b, B_, H_, W_, relu, pool=False, tile=4)
+                return self._winograd43_tail(name, v, w, b, relu, B_, H_, W_, c_i, c_o, timing)
             input = self._activate(pending_first)
         if (wino_ok and input.is_cuda
                 and self.winograd_min_channels and c_i >= self.winograd_min_channels and c_i % 4 == 0 and c_o % 4 == 0
                 and (self.winograd_tile == 4 or (input.shape[1] % 2 == 0 and input.shape[2] % 2 == 0))
                 and not (torch.is_grad_enabled() and (w.requires_grad or input.requires_grad))):
             B_, H_, W_, _ = input.shape
-            u = self._winograd_filter(name, w)
-            timed = self.conv_timing is not None
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
             tile = self.winograd_tile
+            timing = None
+            if self.conv_timing is not None:
+                timing = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), 0.0)
+                timing[0].record()
             v = ops.winograd_input(input, tile)
-            m = torch.bmm(v, u)
-            if timed:
-                e1.record()   # input transform + the 16 GEMMs; the output transform is timed by the library
-                self.conv_timing.append((name, 2.0 * m.numel() * c_i, 2.0 * B_ * H_ * W_ * c_o * c_i * 9, e0, e1))
+            if tile == 4:
+                return self._winograd43_tail(name, v, w, b, relu, B_, H_, W_, c_i, c_o, timing)
+            m = torch.bmm(v, self._winograd_filter(name, w))
+            if timing is not None:
+                timing[1].record()
+                self.conv_timing.append((name, 2.0 * m.numel() * c_i, 2.0 * B_ * H_ * W_ * c_o * c_i * 9, timing[0], timing[1]))
             if name in self.defer_act:
                 return _RawConv(None, b, relu, wino=(m, B_, H_, W_))
             return ops.winograd_output(m, b, B_, H_, W_, relu, pool=False, tile=tile)
@@ -338,6 +365,9 @@ class Network(object):
                     and input.shape[1] % 2 == 0 and input.shape[2] % 2 == 0):
                 if input.first is not None:
                     return F.max_pool2d(_nchw(self._activate(input)), 2, 2).permute(0, 2, 3, 1).contiguous()
+                if input.gemm is not None:
+                    v, ut, B_, H_, W_ = input.gemm
+                    return ops.winograd43_gemm_output(v, ut, input.bias, B_, H_, W_, input.relu, pool=True)
                 if input.wino is not None:  # a Winograd output tile is exactly one pooling window
                     m, B_, H_, W_ = input.wino
                     return ops.winograd_output(m, input.bias, B_, H_, W_, input.relu, pool=True, tile=self.winograd_tile)

@@ -363,6 +363,23 @@ def winograd_output(m, bias, B, H, W, relu=True, pool=False, tile=2):
     return y
 
 
+def winograd43_gemm_output(v, ut, bias, B, H, W, relu=True, pool=False):
+    """The 36 GEMMs + output transform of F(4x4,3x3) in one fp32-MFMA kernel (Cin 64 / 128):
+    v [36,T,Cin], ut [36,Cout,Cin] (= winograd_filter(w, 4).transpose(1, 2)) -> y [B,H,W,Cout] or pooled."""
+    v = _dev(v, "v", torch.float32)
+    ut = _dev(ut, "ut", torch.float32)
+    bias = _dev(bias, "bias", torch.float32)
+    Cin, Cout = v.shape[2], ut.shape[1]
+    if v.shape[0] != 36 or v.shape[1] != _wino_tiles(B, H, W, 4) or tuple(ut.shape) != (36, Cout, Cin) or bias.numel() != Cout:
+        raise ValueError("v must be [36, tiles, Cin], ut [36, Cout, Cin], bias [Cout]")
+    shape = (B, H // 2, W // 2, Cout) if pool else (B, H, W, Cout)
+    y = torch.empty(shape, dtype=torch.float32, device=v.device)
+    check("pcnn_winograd43_gemm_output_fwd",
+          lib().pcnn_winograd43_gemm_output_fwd(_ptr(v), _ptr(ut), _ptr(bias), B, H, W, Cin, Cout, 1 if relu else 0,
+                                                1 if pool else 0, _ptr(y), _stream(v)))
+    return y
+
+
 def conv3x3_winograd(x, u, bias, relu=True, pool=False, tile=2):
     """3x3 / stride 1 / SAME convolution + bias [+ ReLU] [+ 2x2 max-pool] as Winograd F(tile x tile, 3x3):
     input transform (gfx950 kernel) -> (tile+2)^2 fp32 GEMMs (library, MFMA) -> output transform

@@ -601,3 +601,37 @@ def test_network_first_conv_fusion_is_transparent(gpu):
             outs.append((N(net.get_output("pool1")), N(net.get_output("conv1_1")), N(net.get_output("conv1_2"))))
     for a, b_ in zip(outs[0], outs[1]):
         same(a, b_, "fused vs unfused first conv")
+
+
+@pytest.mark.parametrize("shape,cout,pool", [((1, 8, 16, 64), 64, False), ((2, 12, 20, 64), 128, True), ((1, 30, 44, 128), 128, False),
+                                             ((1, 10, 6, 128), 256, True), ((3, 5, 7, 64), 64, False), ((1, 120, 160, 64), 64, True)])
+def test_winograd43_fused_gemm_output_kernel(gpu, shape, cout, pool):
+    """GEMMs + output transform in one MFMA kernel against the unfused pair (library batched GEMM +
+    wino43_output_kernel) and a float64 direct convolution. Only the K summation order differs from the
+    library GEMM; A^T . A amplifies that rounding difference by up to 8 x 8, so the two f32 paths agree to
+    ~1e-5 of the output range — each is within F(4x4,3x3)'s usual error of the float64 reference."""
+    import torch
+    from posecnn_amd import ops
+    torch.backends.cuda.matmul.allow_tf32 = False
+    rng = np.random.default_rng(81)
+    B, H, W, C = shape
+    if pool and (H % 2 or W % 2):
+        pytest.skip("pooling needs even sizes")
+    x = np.maximum(rng.standard_normal(shape), 0).astype(F)
+    w = (rng.standard_normal((cout, C, 3, 3)) * np.sqrt(2.0 / (9 * C))).astype(F)
+    b = rng.standard_normal(cout).astype(F)
+    xt, wt, bt = T(gpu, x), T(gpu, w), T(gpu, b)
+    u = ops.winograd_filter(wt, 4)
+    v = ops.winograd_input(xt, 4)
+    want = N(ops.winograd_output(torch.bmm(v, u), bt, B, H, W, True, pool, 4))
+    got = N(ops.winograd43_gemm_output(v, u.transpose(1, 2).contiguous(), bt, B, H, W, True, pool))
+    assert got.shape == want.shape
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 3e-5 * scale, np.abs(got - want).max() / scale
+    ref = torch.nn.functional.conv2d(xt.double().permute(0, 3, 1, 2), wt.double(), bt.double(), padding=1).permute(0, 2, 3, 1)
+    ref = np.maximum(ref.cpu().numpy(), 0)
+    if pool:
+        ref = ref.reshape(B, H // 2, 2, W // 2, 2, cout).max(axis=(2, 4))
+    assert np.abs(got - ref).max() <= 5e-5 * np.abs(ref).max()
+    with pytest.raises(ValueError):
+        ops.winograd43_gemm_output(v[:, :, :32].contiguous(), u.transpose(1, 2)[:, :, :32].contiguous(), bt, B, H, W)
