@@ -277,8 +277,7 @@ int pcnn_winograd43_input_fwd(const float* x, int batch, int height, int width, 
 int pcnn_winograd43_output_fwd(const float* m, const float* bias, int batch, int height, int width,
                                int channels, int relu, int pool, float* y, void* stream);
 
-/* F(4x4,3x3) GEMMs + output transform in one kernel for the small-channel layers (Cin = 64 or 128;
- * conv1_2 ... conv3_1): y = [ReLU](A^T (v[k] * u[k]) A + bias) [max-pooled 2x2 when pool != 0] without
+/* F(4x4,3x3) GEMMs + output transform in one kernel for the Cin = 64 layers (conv1_2, conv2_1): y = [ReLU](A^T (v[k] * u[k]) A + bias) [max-pooled 2x2 when pool != 0] without
  * the transform-domain product m ever reaching HBM (fp32 MFMA, accumulators stay in registers).
  *   v  f32 [36][T][Cin]  from pcnn_winograd43_input_fwd / pcnn_conv3x3_c3_winograd43_fwd
  *   ut f32 [36][Cout][Cin]  the filter transform TRANSPOSED: ut[6i+j][co][ci] = (G g G^T)[i][j]

@@ -348,8 +348,8 @@ struct wg_int { static constexpr int value = V; };
 // compute, stash moves the next stage from registers into the other LDS buffer.
 template <int CIN, int ST, int NST, int PF>
 struct wg_pipeline {
-  template <typename F, typename S, typename C>
-  static __device__ __forceinline__ void run(F&& fetch, S&& stash, C&& compute)
+  template <typename F, typename S, typename L, typename C>
+  static __device__ __forceinline__ void run(F&& fetch, S&& stash, L&& lds_read, C&& compute)
   {
     if constexpr (ST == 0) {
       fetch(wg_int<0>{});
@@ -358,11 +358,12 @@ struct wg_pipeline {
       __syncthreads();
     }
     if constexpr (ST < NST) {
-      compute(wg_int<ST>{});
+      lds_read(wg_int<ST>{});
       if constexpr (ST + 1 < NST) stash(wg_int<ST + 1>{});
-      if constexpr (ST + 1 + PF < NST + 0 && true) fetch(wg_int<(ST + 1 + PF < NST ? ST + 1 + PF : 0)>{});
+      if constexpr (ST + 1 + PF < NST) fetch(wg_int<(ST + 1 + PF < NST ? ST + 1 + PF : 0)>{});
+      compute(wg_int<ST>{});
       __syncthreads();
-      wg_pipeline<CIN, ST + 1, NST, PF>::run(fetch, stash, compute);
+      wg_pipeline<CIN, ST + 1, NST, PF>::run(fetch, stash, lds_read, compute);
     }
   }
   template <int A, int N, int LIM, typename F>
@@ -375,7 +376,7 @@ struct wg_pipeline {
   }
 };
 
-template <int CIN, bool POOL>
+template <int CIN, bool POOL, int WG_PF = 2>
 __global__ __launch_bounds__(256) void wino43_gemm_output_kernel(
     const float* __restrict__ v, const float* __restrict__ ut, const float* __restrict__ bias,
     float* __restrict__ y, int H, int W, int Cout, int Ht, int Wt, long long T, int relu)
@@ -394,10 +395,9 @@ __global__ __launch_bounds__(256) void wino43_gemm_output_kernel(
   for (int k = 0; k < 36; k++) { acc[k][0] = (v4f){0.f, 0.f, 0.f, 0.f}; acc[k][1] = (v4f){0.f, 0.f, 0.f, 0.f}; }
 
   // global -> registers -> LDS. One workgroup per CU (the accumulators take the whole register
-  // file), so nobody else hides memory latency: loads run WG_PF stages ahead of the MFMAs (a stage =
-  // 1024 MFMA cycles per wave, an HBM round trip = several thousand), each stage parked in its own
-  // register set (2 float4 of A + 4 float4 of B per thread) until its turn to enter the LDS ring.
-  constexpr int WG_PF = 4;
+  // file): loads run WG_PF stages ahead of the MFMAs, each stage parked in its own register set
+  // (2 float4 of A + 4 float4 of B per thread) until its turn to enter the LDS ring. (Measured: depth
+  // 2, 4 and 6 give the same time — the kernel is not bound by load latency.)
   v4f ga[WG_PF][2], gb[WG_PF][4];
 #define WG_FETCH(ST)                                                                                   \
   do {                                                                                                 \
@@ -428,83 +428,98 @@ __global__ __launch_bounds__(256) void wino43_gemm_output_kernel(
     }                                                                                                  \
   } while (0)
 
+  // program order per stage: LDS reads of this stage -> stash of the next -> global fetch of stage
+  // +WG_PF -> the 32 MFMAs -> barrier. The memory instructions are all in flight before the MFMA
+  // burst starts, and the barrier does not wait for the matrix pipe, so MFMAs issue nearly back to back.
+  v4f fa0[4], fa1[4], fb[4];
   wg_pipeline<CIN, 0, NST, WG_PF>::run(
       [&](auto st_c) { constexpr int ST = decltype(st_c)::value; WG_FETCH(ST); },
       [&](auto st_c) { constexpr int ST = decltype(st_c)::value; WG_STASH(ST); },
       [&](auto st_c) {
         constexpr int ST = decltype(st_c)::value;
-        constexpr int buf = ST & 1, k = ST / NH;
+        constexpr int buf = ST & 1;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const v4f b4 = *reinterpret_cast<const v4f*>(&sB[buf][16 * wave + lr][16 * j + 4 * lk]);
-          const v4f a0 = *reinterpret_cast<const v4f*>(&sA[buf][lr][16 * j + 4 * lk]);
-          const v4f a1 = *reinterpret_cast<const v4f*>(&sA[buf][16 + lr][16 * j + 4 * lk]);
+          fb[j] = *reinterpret_cast<const v4f*>(&sB[buf][16 * wave + lr][16 * j + 4 * lk]);
+          fa0[j] = *reinterpret_cast<const v4f*>(&sA[buf][lr][16 * j + 4 * lk]);
+          fa1[j] = *reinterpret_cast<const v4f*>(&sA[buf][16 + lr][16 * j + 4 * lk]);
+        }
+      },
+      [&](auto st_c) {
+        constexpr int ST = decltype(st_c)::value;
+        constexpr int k = ST / NH;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
 #pragma unroll
           for (int i = 0; i < 4; i++) {
-            acc[k][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], b4[i], acc[k][0], 0, 0, 0);
-            acc[k][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i], b4[i], acc[k][1], 0, 0, 0);
+            acc[k][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[j][i], fb[j][i], acc[k][0], 0, 0, 0);
+            acc[k][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[j][i], fb[j][i], acc[k][1], 0, 0, 0);
           }
-        }
       });
 #undef WG_FETCH
 #undef WG_STASH
 
-  // epilogue: this lane's 8 (tile, channel) elements
+  // epilogue: this lane's 8 (tile, channel) elements. Tile coordinates advance incrementally (one
+  // 32-bit division pair per row block, not three 64-bit divisions per element — those cost more
+  // instructions than the whole MFMA loop) and the stores of an element share one base pointer.
   const int co = cg * 64 + 16 * wave + lr;
   const float bv = bias[co];
+  const int Hp = H / 2, Wp = W / 2;
 #pragma unroll
   for (int rb = 0; rb < 2; rb++) {
+    const long long tf = t0 + 16 * rb + 4 * lk;
+    unsigned rem = (unsigned)(tf % ((long long)Wt * Ht));   // tile inside its image (one 64-bit op pair per rb)
+    int b = (int)(tf / ((long long)Wt * Ht));
+    int ty = (int)(rem / (unsigned)Wt), tx = (int)(rem - (unsigned)ty * (unsigned)Wt);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const long long t = t0 + 16 * rb + 4 * lk + i;
-      if (t >= T) continue;
-      const int tx = (int)(t % Wt);
-      const int ty = (int)((t / Wt) % Ht);
-      const long long b = t / ((long long)Wt * Ht);
-      float tmp[4][6];
+      if (tf + i < T) {
+        float tmp[4][6];
 #pragma unroll
-      for (int jj = 0; jj < 6; jj++) {
-        float col[6], o[4];
+        for (int jj = 0; jj < 6; jj++) {
+          float col[6], o[4];
 #pragma unroll
-        for (int ii = 0; ii < 6; ii++) col[ii] = acc[6 * ii + jj][rb][i];
-        at6(col, o);
+          for (int ii = 0; ii < 6; ii++) col[ii] = acc[6 * ii + jj][rb][i];
+          at6(col, o);
 #pragma unroll
-        for (int a = 0; a < 4; a++) tmp[a][jj] = o[a];
-      }
-      float out[4][4];
+          for (int a = 0; a < 4; a++) tmp[a][jj] = o[a];
+        }
+        float out[4][4];
 #pragma unroll
-      for (int a = 0; a < 4; a++) {
-        at6(tmp[a], out[a]);
+        for (int a = 0; a < 4; a++) {
+          at6(tmp[a], out[a]);
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-          float val = out[a][e] + bv;
-          if (relu) val = val > 0.f ? val : 0.f;
-          out[a][e] = val;
+          for (int e = 0; e < 4; e++) {
+            float val = out[a][e] + bv;
+            if (relu) val = val > 0.f ? val : 0.f;
+            out[a][e] = val;
+          }
+        }
+        if (POOL) {
+          float* yp = y + (((long long)b * Hp + 2 * ty) * Wp + 2 * tx) * Cout + co;
+          const int rs = Wp * Cout;
+#pragma unroll
+          for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int e = 0; e < 2; e++)
+              if (2 * ty + a < Hp && 2 * tx + e < Wp) {
+                float p = out[2 * a][2 * e];
+                p = out[2 * a][2 * e + 1] > p ? out[2 * a][2 * e + 1] : p;
+                p = out[2 * a + 1][2 * e] > p ? out[2 * a + 1][2 * e] : p;
+                p = out[2 * a + 1][2 * e + 1] > p ? out[2 * a + 1][2 * e + 1] : p;
+                yp[a * rs + e * Cout] = p;
+              }
+        } else {
+          float* yp = y + (((long long)b * H + 4 * ty) * W + 4 * tx) * Cout + co;
+          const int rs = W * Cout;
+#pragma unroll
+          for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+              if (4 * ty + a < H && 4 * tx + e < W) yp[a * rs + e * Cout] = out[a][e];
         }
       }
-      if (POOL) {
-        const int Hp = H / 2, Wp = W / 2;
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-          for (int e = 0; e < 2; e++) {
-            const int py = 2 * ty + a, px = 2 * tx + e;
-            if (py < Hp && px < Wp) {
-              float p = out[2 * a][2 * e];
-              p = out[2 * a][2 * e + 1] > p ? out[2 * a][2 * e + 1] : p;
-              p = out[2 * a + 1][2 * e] > p ? out[2 * a + 1][2 * e] : p;
-              p = out[2 * a + 1][2 * e + 1] > p ? out[2 * a + 1][2 * e + 1] : p;
-              y[((b * Hp + py) * Wp + px) * Cout + co] = p;
-            }
-          }
-      } else {
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-          for (int e = 0; e < 4; e++)
-            if (4 * ty + a < H && 4 * tx + e < W)
-              y[((b * H + 4 * ty + a) * W + 4 * tx + e) * Cout + co] = out[a][e];
-      }
+      if (++tx == Wt) { tx = 0; if (++ty == Ht) { ty = 0; b++; } }
     }
   }
 }
@@ -571,7 +586,9 @@ extern "C" int pcnn_winograd43_gemm_output_fwd(const float* v, const float* ut, 
                                                float* y, void* stream_)
 {
   PCNN_REQUIRE(B >= 1 && H >= 1 && W >= 1, PCNN_EINVAL, "winograd43_gemm_output: bad shape %dx%dx%d", B, H, W);
-  PCNN_REQUIRE(Cin == 64 || Cin == 128, PCNN_EINVAL, "winograd43_gemm_output: input channels must be 64 or 128 (got %d)", Cin);
+  // (Cin = 128 is implemented by the template but loses to the library GEMM + output transform, and
+  // one of its instances is miscompiled under the accumulator-register pressure — not offered)
+  PCNN_REQUIRE(Cin == 64, PCNN_EINVAL, "winograd43_gemm_output: input channels must be 64 (got %d)", Cin);
   PCNN_REQUIRE(Cout >= 64 && Cout % 64 == 0, PCNN_EINVAL, "winograd43_gemm_output: output channels must be a multiple of 64 (got %d)", Cout);
   PCNN_REQUIRE(!pool || (H % 2 == 0 && W % 2 == 0), PCNN_EINVAL, "winograd43_gemm_output: pooling needs even height/width");
   PCNN_REQUIRE(v && ut && bias && y, PCNN_ENULL, "winograd43_gemm_output: NULL pointer");
@@ -583,8 +600,7 @@ extern "C" int pcnn_winograd43_gemm_output_fwd(const float* v, const float* ut, 
   PCNN_REQUIRE(blocks < (1ll << 31), PCNN_EINVAL, "winograd43_gemm_output: grid too large");
   const dim3 grid((unsigned)blocks, Cout / 64);
 #define WG_GO(CI, P) PCNN_LAUNCH((wino43_gemm_output_kernel<CI, P>), grid, dim3(256), 0, stream, v, ut, bias, y, H, W, Cout, Ht, Wt, T, relu)
-  if (Cin == 64) { if (pool) WG_GO(64, true); else WG_GO(64, false); }
-  else { if (pool) WG_GO(128, true); else WG_GO(128, false); }
+  if (pool) WG_GO(64, true); else WG_GO(64, false);
 #undef WG_GO
   return check_launch("winograd43_gemm_output_fwd");
 }

@@ -364,7 +364,7 @@ def winograd_output(m, bias, B, H, W, relu=True, pool=False, tile=2):
 
 
 def winograd43_gemm_output(v, ut, bias, B, H, W, relu=True, pool=False):
-    """The 36 GEMMs + output transform of F(4x4,3x3) in one fp32-MFMA kernel (Cin 64 / 128):
+    """The 36 GEMMs + output transform of F(4x4,3x3) in one fp32-MFMA kernel (Cin = 64):
     v [36,T,Cin], ut [36,Cout,Cin] (= winograd_filter(w, 4).transpose(1, 2)) -> y [B,H,W,Cout] or pooled."""
     v = _dev(v, "v", torch.float32)
     ut = _dev(ut, "ut", torch.float32)
