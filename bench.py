@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-losses", action="store_true")
     ap.add_argument("--nbuf", type=int, default=2)
+    ap.add_argument("--blas", default="hipblas", choices=["default", "hipblas", "hipblaslt"],
+                    help="library behind the fp32 GEMMs (Winograd planes, fc6-8); see tools/probe_bmm.py")
     a = ap.parse_args()
 
     rank, world, local = pdist.init_from_env()
@@ -123,6 +125,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if a.blas != "default":
+        torch.backends.cuda.preferred_blas_library(a.blas)
     torch.backends.cudnn.benchmark = True          # MIOpen find: pick the fastest fp32 conv kernels
     torch.backends.cuda.matmul.allow_tf32 = False  # fp32 like the reference; no reduced precision
     torch.backends.cudnn.allow_tf32 = False
