@@ -16,6 +16,7 @@ TF1 -> PyTorch semantics (SURVEY.md §8a "Semantics ..."):
   softmax_high_dimension / argmax_2d  -> fused gfx950 kernel                     (:474-488,432-434)
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -255,11 +256,16 @@ class Network(object):
     def load_file(self, path, ignore_missing=False):
         """Checkpoint ingestion. Accepts
           - `vgg16.npy`-style pickled dicts {layer: {'weights', 'biases'}} (network.py:71-107), and
+          - TF checkpoint prefixes (`<prefix>.index` + `<prefix>.data-*`; `posecnn_amd/tf_checkpoint.py`),
           - `.npz` archives keyed by TF variable name ('conv1_1/weights', 'fc6/biases', ...) in TF
             layouts ([kh,kw,cin,cout] / [in,out]) — what three lines of TF dump from a checkpoint:
             `np.savez(out, **{v.name[:-2]: sess.run(v) for v in tf.global_variables()})`
             (INTEGRATION.md). Optimizer slots ('.../Momentum') are skipped."""
-        if str(path).endswith(".npz"):
+        if os.path.exists(str(path) + ".index"):
+            # a TF checkpoint prefix (saver.restore, lib/fcn/test.py:1809-1811): read the tensor bundle
+            from . import tf_checkpoint
+            data = tf_checkpoint.to_layer_dict(tf_checkpoint.read_checkpoint(str(path)))
+        elif str(path).endswith(".npz"):
             arch = np.load(path)
             data = {}
             for key in arch.files:
