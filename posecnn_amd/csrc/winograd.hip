@@ -333,12 +333,12 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restr
 // rows padded to 68 floats = conflict-free ds_read_b128) into v_mfma_f32_16x16x4_f32:
 // lane l feeds A[row l&15][k l>>4], B[k l>>4][col l&15] and holds D[4(l>>4)+i][l&15] — so after
 // the last plane a lane has, for each of its 8 (tile, channel) elements, all 36 transform-domain
-// values in registers (288 accumulator VGPRs) and applies A^T m A, bias, ReLU and the optional
-// 2x2 max-pool itself. K runs in the order 16j + 4(l>>4) + i (one b128 read = 4 MFMAs), the same
+// values in registers (144 accumulator VGPRs per 16-tile row block) and applies A^T m A, bias, ReLU
+// and the optional 2x2 max-pool itself. K runs in the order 16j + 4(l>>4) + i (one b128 read = 4 MFMAs), the same
 // for A and B.
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int WG_TILES = 32;
+// RB row blocks of 16 tiles per workgroup: RB = 2 (32 tiles, one workgroup per CU) or RB = 1 (two per CU)
 constexpr int WG_LD = 68;   // padded LDS row (floats)
 
 template <int V>
@@ -376,34 +376,36 @@ struct wg_pipeline {
   }
 };
 
-template <int CIN, bool POOL, int WG_PF = 2>
-__global__ __launch_bounds__(256) void wino43_gemm_output_kernel(
+template <int CIN, bool POOL, int RB, int WG_PF = 2>
+__global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void wino43_gemm_output_kernel(
     const float* __restrict__ v, const float* __restrict__ ut, const float* __restrict__ bias,
     float* __restrict__ y, int H, int W, int Cout, int Ht, int Wt, long long T, int relu)
 {
-  __shared__ __attribute__((aligned(16))) float sA[2][WG_TILES][WG_LD];
+  __shared__ __attribute__((aligned(16))) float sA[2][16 * RB][WG_LD];
   __shared__ __attribute__((aligned(16))) float sB[2][64][WG_LD];
   constexpr int NH = CIN / 64;          // 64-wide K slices per plane
   constexpr int NST = 36 * NH;          // pipeline stages
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const long long t0 = (long long)blockIdx.x * WG_TILES;
+  const long long t0 = (long long)blockIdx.x * (16 * RB);
   const int cg = blockIdx.y;
   const int lr = lane & 15, lk = lane >> 4;
 
-  v4f acc[36][2];
+  v4f acc[36][RB];
 #pragma unroll
-  for (int k = 0; k < 36; k++) { acc[k][0] = (v4f){0.f, 0.f, 0.f, 0.f}; acc[k][1] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+  for (int k = 0; k < 36; k++)
+#pragma unroll
+    for (int r = 0; r < RB; r++) acc[k][r] = (v4f){0.f, 0.f, 0.f, 0.f};
 
   // global -> registers -> LDS. One workgroup per CU (the accumulators take the whole register
   // file): loads run WG_PF stages ahead of the MFMAs, each stage parked in its own register set
   // (2 float4 of A + 4 float4 of B per thread) until its turn to enter the LDS ring. (Measured: depth
   // 2, 4 and 6 give the same time — the kernel is not bound by load latency.)
-  v4f ga[WG_PF][2], gb[WG_PF][4];
+  v4f ga[WG_PF][RB], gb[WG_PF][4];
 #define WG_FETCH(ST)                                                                                   \
   do {                                                                                                 \
     constexpr int st_ = (ST);                                                                          \
     constexpr int set_ = st_ % WG_PF, k_ = st_ / NH, h_ = st_ % NH;                                    \
-    _Pragma("unroll") for (int r = 0; r < 2; r++) {                                                    \
+    _Pragma("unroll") for (int r = 0; r < RB; r++) {                                                   \
       const int q = tid + 256 * r, row = q >> 4, c4 = q & 15;                                          \
       const long long t = t0 + row;                                                                    \
       ga[set_][r] = t < T ? *reinterpret_cast<const v4f*>(v + ((long long)k_ * T + t) * CIN + h_ * 64 + c4 * 4) \
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(256) void wino43_gemm_output_kernel(
   do {                                                                                                 \
     constexpr int st_ = (ST);                                                                          \
     constexpr int set_ = st_ % WG_PF, buf_ = st_ & 1;                                                  \
-    _Pragma("unroll") for (int r = 0; r < 2; r++) {                                                    \
+    _Pragma("unroll") for (int r = 0; r < RB; r++) {                                                   \
       const int q = tid + 256 * r;                                                                     \
       *reinterpret_cast<v4f*>(&sA[buf_][q >> 4][(q & 15) * 4]) = ga[set_][r];                          \
     }                                                                                                  \
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(256) void wino43_gemm_output_kernel(
   // program order per stage: LDS reads of this stage -> stash of the next -> global fetch of stage
   // +WG_PF -> the 32 MFMAs -> barrier. The memory instructions are all in flight before the MFMA
   // burst starts, and the barrier does not wait for the matrix pipe, so MFMAs issue nearly back to back.
-  v4f fa0[4], fa1[4], fb[4];
+  v4f fa[RB][4], fb[4];
   wg_pipeline<CIN, 0, NST, WG_PF>::run(
       [&](auto st_c) { constexpr int ST = decltype(st_c)::value; WG_FETCH(ST); },
       [&](auto st_c) { constexpr int ST = decltype(st_c)::value; WG_STASH(ST); },
@@ -441,8 +443,8 @@ __global__ __launch_bounds__(256) void wino43_gemm_output_kernel(
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           fb[j] = *reinterpret_cast<const v4f*>(&sB[buf][16 * wave + lr][16 * j + 4 * lk]);
-          fa0[j] = *reinterpret_cast<const v4f*>(&sA[buf][lr][16 * j + 4 * lk]);
-          fa1[j] = *reinterpret_cast<const v4f*>(&sA[buf][16 + lr][16 * j + 4 * lk]);
+#pragma unroll
+          for (int r = 0; r < RB; r++) fa[r][j] = *reinterpret_cast<const v4f*>(&sA[buf][16 * r + lr][16 * j + 4 * lk]);
         }
       },
       [&](auto st_c) {
@@ -452,8 +454,9 @@ __global__ __launch_bounds__(256) void wino43_gemm_output_kernel(
         for (int j = 0; j < 4; j++)
 #pragma unroll
           for (int i = 0; i < 4; i++) {
-            acc[k][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[j][i], fb[j][i], acc[k][0], 0, 0, 0);
-            acc[k][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[j][i], fb[j][i], acc[k][1], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < RB; r++)
+              acc[k][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[r][j][i], fb[j][i], acc[k][r], 0, 0, 0);
           }
       });
 #undef WG_FETCH
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(256) void wino43_gemm_output_kernel(
   const float bv = bias[co];
   const int Hp = H / 2, Wp = W / 2;
 #pragma unroll
-  for (int rb = 0; rb < 2; rb++) {
+  for (int rb = 0; rb < RB; rb++) {
     const long long tf = t0 + 16 * rb + 4 * lk;
     unsigned rem = (unsigned)(tf % ((long long)Wt * Ht));   // tile inside its image (one 64-bit op pair per rb)
     int b = (int)(tf / ((long long)Wt * Ht));
@@ -596,11 +599,16 @@ extern "C" int pcnn_winograd43_gemm_output_fwd(const float* v, const float* ut, 
   hipStream_t stream = (hipStream_t)stream_;
   const int Ht = (H + 3) / 4, Wt = (W + 3) / 4;
   const long long T = (long long)B * Ht * Wt;
-  const long long blocks = (T + WG_TILES - 1) / WG_TILES;
+  // RB = 1 (16 tiles, 236 VGPRs, two workgroups per CU so that one's epilogue overlaps the other's MFMAs)
+  // measures 4-10 % faster than RB = 2 (32 tiles, one workgroup per CU, half the filter traffic)
+  const int rb = 1;
+  const int wg_tiles = 16 * rb;
+  const long long blocks = (T + wg_tiles - 1) / wg_tiles;
   PCNN_REQUIRE(blocks < (1ll << 31), PCNN_EINVAL, "winograd43_gemm_output: grid too large");
   const dim3 grid((unsigned)blocks, Cout / 64);
-#define WG_GO(CI, P) PCNN_LAUNCH((wino43_gemm_output_kernel<CI, P>), grid, dim3(256), 0, stream, v, ut, bias, y, H, W, Cout, Ht, Wt, T, relu)
-  if (pool) WG_GO(64, true); else WG_GO(64, false);
+#define WG_GO(CI, P, R) PCNN_LAUNCH((wino43_gemm_output_kernel<CI, P, R>), grid, dim3(256), 0, stream, v, ut, bias, y, H, W, Cout, Ht, Wt, T, relu)
+  if (rb == 1) { if (pool) WG_GO(64, true, 1); else WG_GO(64, false, 1); }
+  else { if (pool) WG_GO(64, true, 2); else WG_GO(64, false, 2); }
 #undef WG_GO
   return check_launch("winograd43_gemm_output_fwd");
 }
