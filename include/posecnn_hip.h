@@ -286,6 +286,11 @@ int pcnn_winograd43_gemm_output_fwd(const float* v, const float* ut, const float
                                     int height, int width, int in_channels, int out_channels, int relu,
                                     int pool, float* y, void* stream);
 
+/* pcnn_winograd43_output_fwd writing BOTH the activation y f32 [B,H,W,C] and its 2x2 max-pool y_pool f32
+ * [B,H/2,W/2,C] in one pass (conv4_3 -> pool4, whose un-pooled output score_conv4 and roi_pool read too). */
+int pcnn_winograd43_output_both_fwd(const float* m, const float* bias, int batch, int height, int width,
+                                    int channels, int relu, float* y, float* y_pool, void* stream);
+
 /* y[b,oy,ox,c] = max over the 2x2 window of [ReLU](x + bias[c]): the `conv -> max_pool(2,2,2,2)`
  * pairs of the VGG trunk (vgg16_convs.py:36-49; network.py:181-187 + :189-196) from the raw
  * convolution output x f32 [B,H,W,C] (H, W even) to y f32 [B,H/2,W/2,C], same bits as

@@ -260,10 +260,13 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restri
   }
 }
 
-template <bool POOL, typename VT>
+// POOL: 0 = y [B,H,W,C]; 1 = only the 2x2 max-pooled tensor (into y); 2 = both (y and ypool) — for a
+// layer like conv4_3 whose un-pooled activation other layers read as well
+template <int POOL, typename VT>
 __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restrict__ m,
                                                             const float* __restrict__ bias,
-                                                            float* __restrict__ y, int H, int W, int C,
+                                                            float* __restrict__ y, float* __restrict__ ypool,
+                                                            int H, int W, int C,
                                                             int Ht, int Wt, int relu, long long total,
                                                             long long plane)
 {
@@ -300,8 +303,9 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restr
       }
     }
     const int oy0 = 4 * ty, ox0 = 4 * tx;
-    if (POOL) {
+    if (POOL != 0) {
       // a 4x4 output tile holds 2x2 pooling windows (H, W even)
+      float* yp = POOL == 1 ? y : ypool;
       const int Hp = H / 2, Wp = W / 2;
 #pragma unroll
       for (int a = 0; a < 2; a++)
@@ -310,10 +314,11 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restr
           const int py = 2 * ty + a, px = 2 * tx + e;
           if (py < Hp && px < Wp) {
             const VT p = vmax(vmax(vmax(out[2 * a][2 * e], out[2 * a][2 * e + 1]), out[2 * a + 1][2 * e]), out[2 * a + 1][2 * e + 1]);
-            *reinterpret_cast<VT*>(y + ((b * Hp + py) * Wp + px) * C + c) = p;
+            *reinterpret_cast<VT*>(yp + ((b * Hp + py) * Wp + px) * C + c) = p;
           }
         }
-    } else {
+    }
+    if (POOL != 1) {
 #pragma unroll
       for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -578,10 +583,27 @@ extern "C" int pcnn_winograd43_output_fwd(const float* m, const float* bias, int
   const long long T = (long long)B * Ht * Wt;
   const long long total = T * (C / 4);
   if (pool)
-    PCNN_LAUNCH((wino43_output_kernel<true, f4>), dim3(grid_for(total)), dim3(256), 0, stream, m, bias, y, H, W, C, Ht, Wt, relu, total, T * C);
+    PCNN_LAUNCH((wino43_output_kernel<1, f4>), dim3(grid_for(total)), dim3(256), 0, stream, m, bias, y, (float*)nullptr, H, W, C, Ht, Wt, relu, total, T * C);
   else
-    PCNN_LAUNCH((wino43_output_kernel<false, f4>), dim3(grid_for(total)), dim3(256), 0, stream, m, bias, y, H, W, C, Ht, Wt, relu, total, T * C);
+    PCNN_LAUNCH((wino43_output_kernel<0, f4>), dim3(grid_for(total)), dim3(256), 0, stream, m, bias, y, (float*)nullptr, H, W, C, Ht, Wt, relu, total, T * C);
   return check_launch("winograd43_output_fwd");
+}
+
+extern "C" int pcnn_winograd43_output_both_fwd(const float* m, const float* bias, int B, int H, int W,
+                                               int C, int relu, float* y, float* y_pool, void* stream_)
+{
+  PCNN_REQUIRE(B >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, PCNN_EINVAL,
+               "winograd43_output_both: need even height/width (got %dx%dx%d)", B, H, W);
+  PCNN_REQUIRE(C >= 4 && C % 4 == 0, PCNN_EINVAL, "winograd43: channels must be a multiple of 4 (got %d)", C);
+  PCNN_REQUIRE(m && bias && y && y_pool, PCNN_ENULL, "winograd43_output_both: NULL pointer");
+  PCNN_REQUIRE(aligned16(m) && aligned16(y) && aligned16(y_pool) && aligned16(bias), PCNN_EINVAL,
+               "winograd43_output_both: pointers must be 16-byte aligned");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int Ht = (H + 3) / 4, Wt = (W + 3) / 4;
+  const long long T = (long long)B * Ht * Wt;
+  const long long total = T * (C / 4);
+  PCNN_LAUNCH((wino43_output_kernel<2, f4>), dim3(grid_for(total)), dim3(256), 0, stream, m, bias, y, y_pool, H, W, C, Ht, Wt, relu, total, T * C);
+  return check_launch("winograd43_output_both_fwd");
 }
 
 extern "C" int pcnn_winograd43_gemm_output_fwd(const float* v, const float* ut, const float* bias, int B,

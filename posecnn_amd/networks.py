@@ -91,6 +91,7 @@ class _RawConv(object):
         # gemm  = (V [36,T,Cin], Ut [36,Cout,Cin], B, H, W): F(4x4,3x3) input transform done, the fused
         #         GEMM + output transform kernel still to run (with or without the max-pool)
         self.y, self.bias, self.relu, self.out, self.wino, self.first, self.gemm = y, bias, relu, None, wino, first, gemm
+        self.dual = False
 
     @property
     def shape(self):
@@ -134,6 +135,7 @@ class Network(object):
         self.fuse_first_conv_into_winograd = True
         self.fused_first_conv = True  # 3-channel 3x3 convs go to the fused conv + bias + ReLU kernel
         self.defer_act = frozenset()  # conv layers whose bias + ReLU is left to the following max_pool
+        self.dual_pool = frozenset()  # ... and those whose un-pooled output other layers read too (Winograd only)
 
     # ---- plumbing ------------------------------------------------------------------------------
     def setup(self):
@@ -202,8 +204,13 @@ class Network(object):
             executed = 2.0 * m.numel() * c_i
             if timing is not None:
                 timing[1].record()   # transform + GEMMs; the output transform is timed by the library
-            out = (_RawConv(None, b, relu, wino=(m, B_, H_, W_)) if name in self.defer_act
-                   else ops.winograd_output(m, b, B_, H_, W_, relu, pool=False, tile=4))
+            if name in self.defer_act:
+                out = _RawConv(None, b, relu, wino=(m, B_, H_, W_))
+            elif name in self.dual_pool and H_ % 2 == 0 and W_ % 2 == 0:
+                out = _RawConv(None, b, relu, wino=(m, B_, H_, W_))
+                out.dual = True   # the following max_pool produces both tensors in one pass
+            else:
+                out = ops.winograd_output(m, b, B_, H_, W_, relu, pool=False, tile=4)
         if timing is not None:
             e0, e1, extra = timing
             self.conv_timing.append((name, executed + extra, 2.0 * B_ * H_ * W_ * c_o * c_i * 9 + extra, e0, e1))
@@ -374,6 +381,10 @@ class Network(object):
                 if input.gemm is not None:
                     v, ut, B_, H_, W_ = input.gemm
                     return ops.winograd43_gemm_output(v, ut, input.bias, B_, H_, W_, input.relu, pool=True)
+                if input.wino is not None and input.dual and self.winograd_tile == 4:
+                    m, B_, H_, W_ = input.wino
+                    input.out, pooled = ops.winograd43_output_both(m, input.bias, B_, H_, W_, input.relu)
+                    return pooled
                 if input.wino is not None:  # a Winograd output tile is exactly one pooling window
                     m, B_, H_, W_ = input.wino
                     return ops.winograd_output(m, input.bias, B_, H_, W_, input.relu, pool=True, tile=self.winograd_tile)
@@ -558,6 +569,10 @@ class vgg16_convs(Network):
         # roi_pool, so pool4 stays a plain max_pool)
         if fused_pool:
             self.defer_act = frozenset(n + sfx for n in ("conv1_2", "conv2_2", "conv3_3") for sfx in ("", "_p"))
+            # (conv4_3 -> pool4 could come out of one dual-output transform pass — opt in with
+            # net.dual_pool = {"conv4_3"}; on MI355X it measures 1.4 % slower end to end than the
+            # transform + a separate max_pool, so it is off)
+            self.dual_pool = frozenset()
         # fused_heads=False evaluates the heads in the reference's literal op order
         # (deconv -> 1x1 conv -> softmax -> argmax); True (default) uses the algebraically
         # identical low-resolution form + fused gfx950 epilogue (see setup()).

@@ -363,6 +363,20 @@ def winograd_output(m, bias, B, H, W, relu=True, pool=False, tile=2):
     return y
 
 
+def winograd43_output_both(m, bias, B, H, W, relu=True):
+    """F(4x4,3x3) output transform returning (y [B,H,W,C], max_pool_2x2(y) [B,H/2,W/2,C]) from one pass."""
+    m = _dev(m, "m", torch.float32)
+    bias = _dev(bias, "bias", torch.float32)
+    C = m.shape[2]
+    if m.shape[0] != 36 or m.shape[1] != _wino_tiles(B, H, W, 4) or bias.numel() != C:
+        raise ValueError("m must be [36, tiles, C] and bias [C]")
+    y = torch.empty((B, H, W, C), dtype=torch.float32, device=m.device)
+    yp = torch.empty((B, H // 2, W // 2, C), dtype=torch.float32, device=m.device)
+    check("pcnn_winograd43_output_both_fwd",
+          lib().pcnn_winograd43_output_both_fwd(_ptr(m), _ptr(bias), B, H, W, C, 1 if relu else 0, _ptr(y), _ptr(yp), _stream(m)))
+    return y, yp
+
+
 def winograd43_gemm_output(v, ut, bias, B, H, W, relu=True, pool=False):
     """The 36 GEMMs + output transform of F(4x4,3x3) in one fp32-MFMA kernel (Cin = 64):
     v [36,T,Cin], ut [36,Cout,Cin] (= winograd_filter(w, 4).transpose(1, 2)) -> y [B,H,W,Cout] or pooled."""

@@ -527,9 +527,13 @@ def test_winograd43_transforms_bit_exact(gpu, shape):
         if H % 2 == 0 and W % 2 == 0:
             pooled = want.reshape(B, H // 2, 2, W // 2, 2, C).max(axis=(2, 4))
             same(N(ops.winograd_output(T(gpu, m), T(gpu, bias), B, H, W, relu, pool=True, tile=4)), pooled, "F(4,3) output + pool")
+            y2, yp2 = ops.winograd43_output_both(T(gpu, m), T(gpu, bias), B, H, W, relu)
+            same(N(y2), want, "F(4,3) output (both)"); same(N(yp2), pooled, "F(4,3) pooled (both)")
     if H % 2:
         with pytest.raises(ValueError):
             ops.winograd_output(T(gpu, m), T(gpu, bias), B, H, W, True, pool=True, tile=4)
+        with pytest.raises(ValueError):
+            ops.winograd43_output_both(T(gpu, m), T(gpu, bias), B, H, W, True)
 
 
 @pytest.mark.parametrize("shape,cout", [((2, 12, 16, 64), 32), ((1, 30, 40, 256), 512), ((1, 6, 6, 512), 512), ((1, 60, 80, 128), 128)])
