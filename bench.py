@@ -304,6 +304,9 @@ def main():
                      "pair_predicates_equiv_per_launch": pairs,
                      "pair_predicates_equiv_per_s": pairs / (hv["avg_us"] * 1e-6) if hv["calls"] else None},
         "roofline_other": others,
+        # the roofline object above is the Hough kernel BASELINE.json asks for; by time per step the
+        # largest hand-written kernel of the library is this one (its own entry is in roofline_other)
+        "dominant_library_kernel": (max(others, key=lambda o: o["us_per_step"])["kernel"] if others else None),
         "backbone": {"what": "the fp32 convolutions of the VGG16 trunk + heads: 3x3 layers with >= %d input channels as Winograd F(%dx%d,3x3) "
                              "(gfx950 transform kernels + library fp32 batched GEMM on MFMA), the rest as MIOpen/CK direct convolutions; "
                              "achieved = EXECUTED flops / (transforms + GEMMs + direct convs) time" % (
