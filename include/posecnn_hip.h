@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define PCNN_ABI_VERSION 1
+#define PCNN_ABI_VERSION 2
 
 /* hough_voting_gpu_op.cc:31-32 */
 #define PCNN_VERTEX_CHANNELS 3
@@ -72,11 +72,11 @@ const char* pcnn_status_string(int status);
  *   meta     f32   [B,num_meta]     bottom_meta_data ([B,1,1,48]); uses fx=0, px=2, fy=4, py=5
  *   gt       f32   [num_gt,13]      bottom_gt = (batch, cls, box4, quat wxyz, trans3); may be NULL iff num_gt==0
  *
- *   top_box    f32   [PCNN_HOUGH_ROWS_CAPACITY,7]   (batch, cls, x1, y1, x2, y2, votes)
- *   top_pose   f32   [PCNN_HOUGH_ROWS_CAPACITY,7]   (1,0,0,0, tx, ty, tz)
- *   top_target f32   [PCNN_HOUGH_ROWS_CAPACITY,4*C]
- *   top_weight f32   [PCNN_HOUGH_ROWS_CAPACITY,4*C]
- *   top_domain int32 [PCNN_HOUGH_ROWS_CAPACITY]
+ *   top_box    f32   [rows_capacity,7]   (batch, cls, x1, y1, x2, y2, votes)
+ *   top_pose   f32   [rows_capacity,7]   (1,0,0,0, tx, ty, tz)
+ *   top_target f32   [rows_capacity,4*C]
+ *   top_weight f32   [rows_capacity,4*C]
+ *   top_domain int32 [rows_capacity]
  *   num_rois   int32 [2]   [0] = rows the reference would return (>=1: a single all-zero dummy
  *                          row when nothing was detected, hough_voting_gpu_op.cc:381-383),
  *                          [1] = true detection row count (may be 0)
@@ -86,9 +86,20 @@ const char* pcnn_status_string(int status);
  * (class slot, cell index) — the reference's order is atomicAdd-dependent.
  * attrs: is_train>=0, threshold_vote, threshold_percentage, skip_pixels>=1; inlier_threshold
  * and label_threshold are the constants 0.9 / 500 of hough_voting_gpu_op.cc:356-357.
+ *
+ * Capacity. The reference keeps at most index_size = MAX_ROI / batch maxima per image
+ * (hough_voting_gpu_op.cu.cc:733,773-774) in scratch outputs of PCNN_HOUGH_ROWS_CAPACITY rows: its
+ * test loop feeds one frame at a time (lib/fcn/test.py:1867), so every frame gets 128. A batched
+ * caller would silently lose detections (batch 16 -> 8 per frame). `rois_per_image`:
+ *   0   the reference rule (MAX_ROI / batch); rows_capacity = PCNN_HOUGH_ROWS_CAPACITY suffices;
+ *   k>0 the first k maxima of EVERY image, whatever the batch: exactly the rows `batch`
+ *       single-frame calls of the reference return when no frame has more than k maxima.
+ * `rows_capacity` = rows allocated in each of the five outputs,
+ * >= batch * capacity * (is_train ? 9 : 1) (and >= 1 for the dummy row).
  * ------------------------------------------------------------------------------------------ */
 int pcnn_hough_voting_workspace_bytes(int batch, int height, int width, int num_classes,
-                                      float threshold_vote, int skip_pixels, size_t* bytes);
+                                      float threshold_vote, int skip_pixels, int rois_per_image,
+                                      size_t* bytes);
 
 int pcnn_hough_voting_fwd(const int32_t* label, const float* vertex, const float* extents,
                           const float* meta, const float* gt,
@@ -96,6 +107,7 @@ int pcnn_hough_voting_fwd(const int32_t* label, const float* vertex, const float
                           int num_meta, int num_gt,
                           int is_train, float threshold_vote, float threshold_percentage,
                           int skip_pixels, float inlier_threshold, int label_threshold,
+                          int rois_per_image, int rows_capacity,
                           float* top_box, float* top_pose, float* top_target, float* top_weight,
                           int32_t* top_domain, int32_t* num_rois,
                           void* workspace, size_t workspace_bytes, void* stream);
@@ -118,6 +130,7 @@ int pcnn_hough_voting_lowres_fwd(const int32_t* label, const float* z, const flo
                                  int num_meta, int num_gt,
                                  int is_train, float threshold_vote, float threshold_percentage,
                                  int skip_pixels, float inlier_threshold, int label_threshold,
+                                 int rois_per_image, int rows_capacity,
                                  float* top_box, float* top_pose, float* top_target,
                                  float* top_weight, int32_t* top_domain, int32_t* num_rois,
                                  void* workspace, size_t workspace_bytes, void* stream);
@@ -127,7 +140,8 @@ int pcnn_hough_voting_lowres_fwd(const int32_t* label, const float* z, const flo
  * (48 B each), class totals i32 [B][C], slot classes i32 [B][C], slot counts i32 [B], record
  * offsets i32 [B][C], tile maxima int2 [B][C-1][tiles], record capacity per image (a count) }. */
 int pcnn_hough_voting_debug_layout(int batch, int height, int width, int num_classes,
-                                   float threshold_vote, int skip_pixels, size_t* offsets);
+                                   float threshold_vote, int skip_pixels, int rois_per_image,
+                                   size_t* offsets);
 
 /* HoughvotinggpuGrad (hough_voting_gpu_op.cc:440-484, set_gradients .cu.cc:608-612): zeros. */
 int pcnn_hough_voting_bwd(float* grad_label, float* grad_vertex,
@@ -154,11 +168,14 @@ int pcnn_roi_pool_bwd(const float* top_diff, const float* rois, const int32_t* a
 
 /* Fused pool5 + pool4 -> add ('pool_score', vgg16_convs.py:177-187): two RoiPool calls with
  * pool_channel=0 and their element-wise sum, without materialising either pooled tensor.
- * out f32 [R,PH,PW,C]; data_a [B,Ha,Wa,C] with scale_a, data_b [B,Hb,Wb,C] with scale_b. */
+ * out f32 [R,PH,PW,C]; data_a [B,Ha,Wa,C] with scale_a, data_b [B,Hb,Wb,C] with scale_b.
+ * num_rows_dev (device int32[1], may be NULL): when `rois` is the capacity-sized buffer of the
+ * sync-free Hough op, the true row count; rows at or past it pool to 0 without touching the maps. */
 int pcnn_roi_pool_add2_fwd(const float* data_a, int height_a, int width_a, float scale_a,
                            const float* data_b, int height_b, int width_b, float scale_b,
                            const float* rois, int batch, int channels, int num_rois, int roi_cols,
-                           int pooled_height, int pooled_width, float* out, void* stream);
+                           int pooled_height, int pooled_width, const int32_t* num_rows_dev,
+                           float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Hard label  (REGISTER_OP("Hardlabel"), hard_label_op.cc:30-35; GPU semantics .cu.cc:17-29)
@@ -175,6 +192,10 @@ int pcnn_hard_label_bwd(float* grad_prob, float* grad_gt, int64_t num_pixels, in
  * Average distance loss  (REGISTER_OP("Averagedistance"), average_distance_loss_op.cc:38-47)
  *   prediction/target/weight f32 [R,4*C]; point f32 [C,P,3]; symmetry f32 [C]; margin >= 0
  *   loss f32 [1]; bottom_diff f32 [R,4*C]
+ *   num_rows_dev (device int32[1], may be NULL): the op's row count when the three inputs are
+ *   capacity-sized buffers of the sync-free Hough op — the loss and gradient are normalised by
+ *   min(R, *num_rows_dev) * P like the reference's exactly-sized call (:190,:203), rows past it
+ *   contribute nothing and get a zero gradient. NULL: R rows.
  * ------------------------------------------------------------------------------------------ */
 int pcnn_average_distance_workspace_bytes(int num_rois, int num_classes, int num_points,
                                           size_t* bytes);
@@ -182,7 +203,7 @@ int pcnn_average_distance_workspace_bytes(int num_rois, int num_classes, int num
 int pcnn_average_distance_fwd(const float* prediction, const float* target, const float* weight,
                               const float* point, const float* symmetry,
                               int num_rois, int num_classes, int num_points, float margin,
-                              float* loss, float* bottom_diff,
+                              const int32_t* num_rows_dev, float* loss, float* bottom_diff,
                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* AveragedistanceGrad (average_distance_loss_op_gpu.cu.cc:347-377): out = grad[0] * bottom_diff. */
@@ -331,6 +352,14 @@ int pcnn_smooth_l1_vertex_bwd(const float* pred, const float* target, const floa
 int pcnn_profile_enable(int on);
 int pcnn_profile_reset(void);
 long pcnn_profile_report(char* buf, long cap);
+
+/* ------------------------------------------------------------------------------------------
+ * Host utility: CRC32C (Castagnoli, reflected polynomial 0x82F63B78) of a HOST buffer, continuing
+ * from `seed` (0 for a fresh checksum) — the checksum TensorFlow's tensor-bundle checkpoints carry
+ * per table block and per tensor (tensorflow/core/lib/hash/crc32c.h); used by the checkpoint reader
+ * behind Network.load_file (lib/fcn/test.py:1809-1811 `saver.restore`). Never touches the GPU.
+ * ------------------------------------------------------------------------------------------ */
+uint32_t pcnn_crc32c(const void* data, size_t num_bytes, uint32_t seed);
 
 #ifdef __cplusplus
 }

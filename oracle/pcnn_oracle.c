@@ -316,6 +316,14 @@ static int collect_pixels(const int* labelmap, const float* vertmap, const float
  * num_rois[0] = rows the op returns (>=1, dummy row), num_rois[1] = true count.
  * hs_debug (optional, may be NULL): [B][C][H*W] votes of every slot class, for cross checks.
  */
+int oracle_hough_voting_ex(const int* label, const float* vertex, const float* extents,
+                           const float* meta, const float* gt, int B, int H, int W, int C,
+                           int num_meta, int num_gt, int is_train, float vote_thr, float per_thr,
+                           int skip, float inlier, int label_thr, int rois_per_image,
+                           int rows_capacity, float* top_box, float* top_pose,
+                           float* top_target, float* top_weight, int* top_domain, int* num_rois,
+                           float* hs_debug);
+
 int oracle_hough_voting(const int* label, const float* vertex, const float* extents,
                         const float* meta, const float* gt, int B, int H, int W, int C,
                         int num_meta, int num_gt, int is_train, float vote_thr, float per_thr,
@@ -323,8 +331,27 @@ int oracle_hough_voting(const int* label, const float* vertex, const float* exte
                         float* top_target, float* top_weight, int* top_domain, int* num_rois,
                         float* hs_debug)
 {
-  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || skip <= 0) return -1;
-  const int cap_rows = MAX_ROI * 9;
+  return oracle_hough_voting_ex(label, vertex, extents, meta, gt, B, H, W, C, num_meta, num_gt,
+                                is_train, vote_thr, per_thr, skip, inlier, label_thr, 0, MAX_ROI * 9,
+                                top_box, top_pose, top_target, top_weight, top_domain, num_rois,
+                                hs_debug);
+}
+
+/* The same op with the per-image capacity lifted off the reference's `index_size = MAX_ROI /
+ * batch_size` (:733): rois_per_image > 0 keeps the first rois_per_image maxima of EVERY image
+ * whatever the batch size (what B single-frame calls of the reference yield, each with
+ * index_size = 128); rois_per_image = 0 is the reference rule. Outputs hold rows_capacity rows
+ * (>= B * capacity * (is_train ? 9 : 1)). */
+int oracle_hough_voting_ex(const int* label, const float* vertex, const float* extents,
+                           const float* meta, const float* gt, int B, int H, int W, int C,
+                           int num_meta, int num_gt, int is_train, float vote_thr, float per_thr,
+                           int skip, float inlier, int label_thr, int rois_per_image,
+                           int rows_capacity, float* top_box, float* top_pose,
+                           float* top_target, float* top_weight, int* top_domain, int* num_rois,
+                           float* hs_debug)
+{
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || skip <= 0 || rois_per_image < 0) return -1;
+  const int cap_rows = rows_capacity;
   memset(top_box, 0, sizeof(float) * cap_rows * 7);
   memset(top_pose, 0, sizeof(float) * cap_rows * 7);
   memset(top_target, 0, sizeof(float) * (size_t)cap_rows * 4 * C);
@@ -332,7 +359,8 @@ int oracle_hough_voting(const int* label, const float* vertex, const float* exte
   memset(top_domain, 0, sizeof(int) * cap_rows);
   int rows = 0;
   const int HW = H * W;
-  const int index_size = MAX_ROI / B; /* :733 */
+  const int index_size = rois_per_image > 0 ? rois_per_image : MAX_ROI / B; /* :733 */
+  if ((long long)B * index_size * (is_train ? 9 : 1) > cap_rows) return -1;
 
   hv_pixel* pix = (hv_pixel*)malloc(sizeof(hv_pixel) * (size_t)(HW / skip + 2));
   float* hs = (float*)malloc(sizeof(float) * (size_t)HW);

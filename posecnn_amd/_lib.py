@@ -30,16 +30,16 @@ SIGNATURES = {
     "pcnn_abi_version": (c_int, []),
     "pcnn_last_error_string": (c_char_p, []),
     "pcnn_status_string": (c_char_p, [c_int]),
-    "pcnn_hough_voting_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_float, c_int, POINTER(c_size_t)]),
-    "pcnn_hough_voting_debug_layout": (c_int, [c_int, c_int, c_int, c_int, c_float, c_int, POINTER(c_size_t)]),
+    "pcnn_hough_voting_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_float, c_int, c_int, POINTER(c_size_t)]),
+    "pcnn_hough_voting_debug_layout": (c_int, [c_int, c_int, c_int, c_int, c_float, c_int, c_int, POINTER(c_size_t)]),
     "pcnn_hough_voting_fwd": (c_int, [_P, _P, _P, _P, _P,
                                       c_int, c_int, c_int, c_int, c_int, c_int,
-                                      c_int, c_float, c_float, c_int, c_float, c_int,
+                                      c_int, c_float, c_float, c_int, c_float, c_int, c_int, c_int,
                                       _P, _P, _P, _P, _P, _P,
                                       _P, c_size_t, _P]),
     "pcnn_hough_voting_lowres_fwd": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P,
                                              c_int, c_int, c_int, c_int, c_int, c_int,
-                                             c_int, c_float, c_float, c_int, c_float, c_int,
+                                             c_int, c_float, c_float, c_int, c_float, c_int, c_int, c_int,
                                              _P, _P, _P, _P, _P, _P,
                                              _P, c_size_t, _P]),
     "pcnn_deconv_bilinear_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
@@ -61,11 +61,11 @@ SIGNATURES = {
     "pcnn_roi_pool_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_float, c_int, _P, _P]),
     "pcnn_roi_pool_add2_fwd": (c_int, [_P, c_int, c_int, c_float, _P, c_int, c_int, c_float,
-                                       _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+                                       _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "pcnn_hard_label_fwd": (c_int, [_P, _P, c_int64, c_int, c_float, _P, _P]),
     "pcnn_hard_label_bwd": (c_int, [_P, _P, c_int64, c_int, _P]),
     "pcnn_average_distance_workspace_bytes": (c_int, [c_int, c_int, c_int, POINTER(c_size_t)]),
-    "pcnn_average_distance_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float,
+    "pcnn_average_distance_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P,
                                           _P, _P, _P, c_size_t, _P]),
     "pcnn_average_distance_bwd": (c_int, [_P, _P, c_int, c_int, _P, _P]),
     "pcnn_backproject_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
@@ -75,6 +75,7 @@ SIGNATURES = {
     "pcnn_deconv_bilinear_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
     "pcnn_bias_act_fwd": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
     "pcnn_upscore_softmax_argmax_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "pcnn_crc32c": (ctypes.c_uint32, [_P, c_size_t, ctypes.c_uint32]),
     "pcnn_profile_enable": (c_int, [c_int]),
     "pcnn_profile_reset": (c_int, []),
     "pcnn_profile_report": (ctypes.c_long, [ctypes.c_char_p, ctypes.c_long]),
@@ -124,7 +125,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the symbol is missing: fail loudly
             fn.restype = res
             fn.argtypes = args
-        if handle.pcnn_abi_version() != 1:
+        if handle.pcnn_abi_version() != 2:
             raise RuntimeError("libposecnn_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -31,6 +31,20 @@ LOV_EXTENTS = np.array([
     [0.140818, 0.174792, 0.040068], [0.210450, 0.185262, 0.036514], [0.052900, 0.077960, 0.067918],
 ], dtype=np.float32)
 
+# data/LINEMOD/extents.txt (metres; 15 objects, lib/datasets/linemod.py:35-37), row 0 = background.
+# BASELINE config 4 ("LINEMOD 13-class") uses the first 13 objects: C = 14.
+LINEMOD_EXTENTS_ALL = np.array([
+    [0.0, 0.0, 0.0],
+    [0.075868, 0.077600, 0.091770], [0.215670, 0.121856, 0.219410], [0.166432, 0.165318, 0.074472],
+    [0.136660, 0.143030, 0.100498], [0.100792, 0.181796, 0.193734], [0.067010, 0.127632, 0.117456],
+    [0.117580, 0.091512, 0.094622], [0.229476, 0.075472, 0.208002], [0.104430, 0.077408, 0.085698],
+    [0.150184, 0.107076, 0.069242], [0.036722, 0.077866, 0.172816], [0.100888, 0.108496, 0.090800],
+    [0.258226, 0.118482, 0.141132], [0.203146, 0.117752, 0.213116], [0.093918, 0.147434, 0.184748],
+], dtype=np.float32)
+LINEMOD_EXTENTS = LINEMOD_EXTENTS_ALL[:14].copy()
+# lib/datasets/linemod.py:45 (eggbox symmetric), cut to the same 13 objects
+LINEMOD_SYMMETRY = np.array([0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0], dtype=np.float32)
+
 # tools/demo.py:100 (YCB-Video camera) and :101
 DEMO_INTRINSICS = np.array([[1066.778, 0.0, 312.9869], [0.0, 1067.487, 241.3109], [0.0, 0.0, 1.0]], dtype=np.float64)
 DEMO_FACTOR_DEPTH = 10000.0

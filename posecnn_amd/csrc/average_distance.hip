@@ -50,13 +50,16 @@ __device__ __forceinline__ int find_class(const float* __restrict__ weight, int 
 __global__ __launch_bounds__(ADL_THREADS) void adl_terms_kernel(
     const float* __restrict__ prediction, const float* __restrict__ target,
     const float* __restrict__ weight, const float* __restrict__ point,
-    const float* __restrict__ symmetry, float* __restrict__ terms, int R, int C, int P,
-    float margin)
+    const float* __restrict__ symmetry, float* __restrict__ terms, int R_cap, int C, int P,
+    float margin, const int* __restrict__ num_rows_dev)
 {
   __shared__ float s_q[ADL_QTILE * 3];
   const int n = blockIdx.y;
   const int p = blockIdx.x * ADL_THREADS + threadIdx.x;
-  const int cls = find_class(weight, n, C);
+  // R = the op's row count: the buffers' row capacity, or (capacity-sized buffers of the sync-free
+  // Hough op) the device-side count; rows past it do not exist for the loss
+  const int R = num_rows_dev ? min(R_cap, num_rows_dev[0]) : R_cap;
+  const int cls = n < R ? find_class(weight, n, C) : -1;
   float* tn = terms + (size_t)n * 5 * P;
   if (cls < 0) {
     if (p < P)
@@ -139,13 +142,15 @@ __global__ __launch_bounds__(ADL_THREADS) void adl_terms_kernel(
 __global__ __launch_bounds__(64) void adl_sum_kernel(const float* __restrict__ terms,
                                                      const float* __restrict__ weight,
                                                      float* __restrict__ loss_batch,
-                                                     float* __restrict__ bottom_diff, int C, int P)
+                                                     float* __restrict__ bottom_diff, int C, int P,
+                                                     int R_cap, const int* __restrict__ num_rows_dev)
 {
   extern __shared__ __attribute__((aligned(16))) float s_t[];  // tile of [5][TILE]
   constexpr int TILE = 2048;
   const int n = blockIdx.x, lane = threadIdx.x;
   const int CH = PCNN_POSE_CHANNELS * C;
-  const int cls = find_class(weight, n, C);
+  const int R = num_rows_dev ? min(R_cap, num_rows_dev[0]) : R_cap;
+  const int cls = n < R ? find_class(weight, n, C) : -1;
   for (int c = lane; c < CH; c += 64) bottom_diff[(size_t)n * CH + c] = 0.f;
   const float* tn = terms + (size_t)n * 5 * P;
   float acc = 0.f;
@@ -198,6 +203,7 @@ extern "C" int pcnn_average_distance_workspace_bytes(int R, int C, int P, size_t
 extern "C" int pcnn_average_distance_fwd(const float* prediction, const float* target,
                                          const float* weight, const float* point,
                                          const float* symmetry, int R, int C, int P, float margin,
+                                         const int32_t* num_rows_dev,
                                          float* loss, float* bottom_diff, void* workspace,
                                          size_t workspace_bytes, void* stream_)
 {
@@ -219,9 +225,9 @@ extern "C" int pcnn_average_distance_fwd(const float* prediction, const float* t
   float* terms = (float*)workspace;
   float* loss_batch = (float*)((char*)workspace + align_up(sizeof(float) * (size_t)R * 5 * P, 256));
   PCNN_LAUNCH(adl_terms_kernel, dim3((P + ADL_THREADS - 1) / ADL_THREADS, R), dim3(ADL_THREADS), 0,
-                     stream, prediction, target, weight, point, symmetry, terms, R, C, P, margin);
+                     stream, prediction, target, weight, point, symmetry, terms, R, C, P, margin, num_rows_dev);
   PCNN_LAUNCH(adl_sum_kernel, dim3(R), dim3(64), sizeof(float) * 5 * 2048, stream, terms, weight,
-                     loss_batch, bottom_diff, C, P);
+                     loss_batch, bottom_diff, C, P, R, num_rows_dev);
   PCNN_LAUNCH(adl_total_kernel, dim3(1), dim3(64), 0, stream, loss_batch, loss, R);
   return pcnn::check_launch("average_distance_fwd");
 }

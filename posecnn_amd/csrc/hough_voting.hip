@@ -64,7 +64,7 @@ struct HvLayout {
       off_nmax, off_hs, off_chunkcnt, off_chunkcand, off_flags, total;
 };
 
-HvLayout hv_layout(int B, int H, int W, int C, bool need_hs, int skip)
+HvLayout hv_layout(int B, int H, int W, int C, bool need_hs, int skip, int rois_per_image)
 {
   HvLayout L;
   const size_t HW = (size_t)H * W;
@@ -73,7 +73,8 @@ HvLayout hv_layout(int B, int H, int W, int C, bool need_hs, int skip)
   L.nty = (H + HV_TILE - 1) / HV_TILE;
   L.ntiles = L.ntx * L.nty;
   L.reccap = (int)(HW / skip) + C + 1;
-  L.cap = PCNN_MAX_ROI / B;  // index_size, hough_voting_gpu_op.cu.cc:733
+  // index_size, hough_voting_gpu_op.cu.cc:733 — or the caller's per-image capacity (posecnn_hip.h)
+  L.cap = rois_per_image > 0 ? rois_per_image : PCNN_MAX_ROI / B;
   L.capmax = L.cap > 0 ? L.cap : 1;
   L.nlm = (int)(((size_t)(C - 1) * HW + LM_CHUNK - 1) / LM_CHUNK);
   size_t o = 0;
@@ -978,7 +979,7 @@ __device__ float compute_box_overlap(int cls, const float* __restrict__ extents,
   return box_iou(box, box_gt);
 }
 
-// compute_rois_kernel (:386-576). One thread per (image, maximum); B * cap <= MAX_ROI.
+// compute_rois_kernel (:386-576). One thread per (image, maximum), B * cap threads in all.
 __global__ __launch_bounds__(128) void hv_emit_kernel(
     const HvMax* __restrict__ maxima, const int* __restrict__ nmax_g,
     const float* __restrict__ extents, const float* __restrict__ meta,
@@ -987,18 +988,20 @@ __global__ __launch_bounds__(128) void hv_emit_kernel(
     int* __restrict__ num_rois, int B, int W, int C, int cap, int capmax, int num_meta, int num_gt,
     int is_train)
 {
-  __shared__ int s_off[PCNN_MAX_ROI + 1];
-  const int tid = threadIdx.x;
-  if (tid == 0) {
-    int acc = 0;  // cap > 0 implies B <= MAX_ROI
+  extern __shared__ int s_off[];  // [B]: rows of the images in front (every block recomputes it)
+  if (threadIdx.x == 0) {
+    int acc = 0;
     if (cap > 0)
       for (int n = 0; n < B; n++) { s_off[n] = acc; acc += nmax_g[n]; }
-    const int rows = acc * (is_train ? 9 : 1);
-    num_rois[0] = rows == 0 ? 1 : rows;  // dummy row, hough_voting_gpu_op.cc:381-383
-    num_rois[1] = rows;
+    if (blockIdx.x == 0) {
+      const int rows = acc * (is_train ? 9 : 1);
+      num_rois[0] = rows == 0 ? 1 : rows;  // dummy row, hough_voting_gpu_op.cc:381-383
+      num_rois[1] = rows;
+    }
   }
   __syncthreads();
   if (cap <= 0) return;
+  const int tid = blockIdx.x * 128 + threadIdx.x;
   const int n = tid / cap, k = tid - n * cap;
   if (n >= B || k >= nmax_g[n]) return;
   const HvMax e = maxima[(size_t)n * capmax + k];
@@ -1082,12 +1085,13 @@ int validate_common(int B, int H, int W, int C, int skip)
 
 extern "C" int pcnn_hough_voting_workspace_bytes(int batch, int height, int width,
                                                  int num_classes, float threshold_vote,
-                                                 int skip_pixels, size_t* bytes)
+                                                 int skip_pixels, int rois_per_image, size_t* bytes)
 {
   PCNN_REQUIRE(bytes != nullptr, PCNN_ENULL, "hough_voting_workspace_bytes: bytes is NULL");
   int st = validate_common(batch, height, width, num_classes, skip_pixels);
   if (st != PCNN_OK) return st;
-  *bytes = hv_layout(batch, height, width, num_classes, threshold_vote > 0, skip_pixels).total;
+  PCNN_REQUIRE(rois_per_image >= 0, PCNN_EINVAL, "hough_voting: rois_per_image < 0");
+  *bytes = hv_layout(batch, height, width, num_classes, threshold_vote > 0, skip_pixels, rois_per_image).total;
   return PCNN_OK;
 }
 
@@ -1097,13 +1101,13 @@ extern "C" int pcnn_hough_voting_workspace_bytes(int batch, int height, int widt
 // slot classes, slot counts, record offsets, tile maxima, record capacity per image (a count).
 extern "C" int pcnn_hough_voting_debug_layout(int batch, int height, int width, int num_classes,
                                               float threshold_vote, int skip_pixels,
-                                              size_t* offsets)
+                                              int rois_per_image, size_t* offsets)
 {
   PCNN_REQUIRE(offsets != nullptr, PCNN_ENULL, "hough_voting_debug_layout: offsets is NULL");
   int st = validate_common(batch, height, width, num_classes, skip_pixels);
   if (st != PCNN_OK) return st;
   const bool need_hs = threshold_vote > 0;
-  const HvLayout L = hv_layout(batch, height, width, num_classes, need_hs, skip_pixels);
+  const HvLayout L = hv_layout(batch, height, width, num_classes, need_hs, skip_pixels, rois_per_image);
   offsets[0] = need_hs ? L.off_hs : (size_t)-1;
   offsets[1] = L.off_rec;
   offsets[2] = L.off_tot;
@@ -1120,13 +1124,15 @@ int hough_fwd_impl(const int32_t* label, const HvVertexSrc vs,
                                      const float* extents, const float* meta, const float* gt,
                                      int B, int H, int W, int C, int num_meta, int num_gt,
                                      int is_train, float vote_thr, float per_thr, int skip,
-                                     float inlier, int label_thr, float* top_box, float* top_pose,
+                                     float inlier, int label_thr, int rois_per_image,
+                                     int rows_capacity, float* top_box, float* top_pose,
                                      float* top_target, float* top_weight, int32_t* top_domain,
                                      int32_t* num_rois, void* workspace, size_t workspace_bytes,
                                      void* stream_)
 {
   int st = validate_common(B, H, W, C, skip);
   if (st != PCNN_OK) return st;
+  PCNN_REQUIRE(rois_per_image >= 0, PCNN_EINVAL, "hough_voting: rois_per_image < 0");
   PCNN_REQUIRE(is_train >= 0, PCNN_EINVAL, "hough_voting: Need is_train >= 0, got %d", is_train);
   PCNN_REQUIRE(num_meta >= 6, PCNN_EINVAL, "hough_voting: meta_data needs >= 6 values per image (got %d)", num_meta);
   PCNN_REQUIRE(num_gt >= 0, PCNN_EINVAL, "hough_voting: num_gt < 0");
@@ -1135,7 +1141,10 @@ int hough_fwd_impl(const int32_t* label, const HvVertexSrc vs,
   PCNN_REQUIRE(top_box && top_pose && top_target && top_weight && top_domain && num_rois,
                PCNN_ENULL, "hough_voting: NULL output");
   const bool need_hs = vote_thr > 0;
-  const HvLayout L = hv_layout(B, H, W, C, need_hs, skip);
+  const HvLayout L = hv_layout(B, H, W, C, need_hs, skip, rois_per_image);
+  PCNN_REQUIRE(rows_capacity >= 1 && (long long)rows_capacity >= (long long)B * L.cap * (is_train ? 9 : 1),
+               PCNN_EINVAL, "hough_voting: outputs hold %d rows, batch %d x %d maxima x %d rows needs %lld",
+               rows_capacity, B, L.cap, is_train ? 9 : 1, (long long)B * L.cap * (is_train ? 9 : 1));
   PCNN_REQUIRE(workspace && aligned16(workspace), PCNN_EWORKSPACE,
                "hough_voting: workspace NULL or not 16-byte aligned");
   PCNN_REQUIRE(workspace_bytes >= L.total, PCNN_EWORKSPACE,
@@ -1158,11 +1167,11 @@ int hough_fwd_impl(const int32_t* label, const HvVertexSrc vs,
   const int HW = H * W;
 
   ZeroJob zj;
-  zj.p[0] = top_box;    zj.words[0] = PCNN_HOUGH_ROWS_CAPACITY * 7;
-  zj.p[1] = top_pose;   zj.words[1] = PCNN_HOUGH_ROWS_CAPACITY * 7;
-  zj.p[2] = top_target; zj.words[2] = PCNN_HOUGH_ROWS_CAPACITY * 4 * C;
-  zj.p[3] = top_weight; zj.words[3] = PCNN_HOUGH_ROWS_CAPACITY * 4 * C;
-  zj.p[4] = (float*)top_domain; zj.words[4] = PCNN_HOUGH_ROWS_CAPACITY;
+  zj.p[0] = top_box;    zj.words[0] = (unsigned)rows_capacity * 7;
+  zj.p[1] = top_pose;   zj.words[1] = (unsigned)rows_capacity * 7;
+  zj.p[2] = top_target; zj.words[2] = (unsigned)rows_capacity * 4 * C;
+  zj.p[3] = top_weight; zj.words[3] = (unsigned)rows_capacity * 4 * C;
+  zj.p[4] = (float*)top_domain; zj.words[4] = (unsigned)rows_capacity;
 
   PCNN_LAUNCH(hv_hist_kernel, dim3(L.nchunk, B), dim3(256), 0, stream, label, hist, HW, C,
                      L.nchunk, zj);
@@ -1186,7 +1195,9 @@ int hough_fwd_impl(const int32_t* label, const HvVertexSrc vs,
     PCNN_LAUNCH(hv_gather_kernel, dim3(B), dim3(256), 0, stream, nslots, chunkcnt,
                        chunkcand, maxima, nmax, HW, L.nlm, L.cap, L.capmax);
   }
-  PCNN_LAUNCH(hv_emit_kernel, dim3(1), dim3(128), 0, stream, maxima, nmax, extents, meta,
+  const int emit_threads = B * (L.cap > 0 ? L.cap : 0);
+  PCNN_LAUNCH(hv_emit_kernel, dim3(emit_threads > 128 ? (emit_threads + 127) / 128 : 1), dim3(128),
+              sizeof(int) * (size_t)B, stream, maxima, nmax, extents, meta,
                      gt, top_box, top_pose, top_target, top_weight, top_domain, num_rois, B, W, C,
                      L.cap, L.capmax, num_meta, num_gt, is_train);
   return check_launch("hough_voting_fwd");
@@ -1197,14 +1208,16 @@ extern "C" int pcnn_hough_voting_fwd(const int32_t* label, const float* vertex,
                                      const float* extents, const float* meta, const float* gt,
                                      int B, int H, int W, int C, int num_meta, int num_gt,
                                      int is_train, float vote_thr, float per_thr, int skip,
-                                     float inlier, int label_thr, float* top_box, float* top_pose,
+                                     float inlier, int label_thr, int rois_per_image,
+                                     int rows_capacity, float* top_box, float* top_pose,
                                      float* top_target, float* top_weight, int32_t* top_domain,
                                      int32_t* num_rois, void* workspace, size_t workspace_bytes,
                                      void* stream_)
 {
   HvVertexSrc vs = {vertex, nullptr, nullptr, 0, 0, 0, 0};
   return hough_fwd_impl(label, vs, extents, meta, gt, B, H, W, C, num_meta, num_gt, is_train,
-                        vote_thr, per_thr, skip, inlier, label_thr, top_box, top_pose, top_target,
+                        vote_thr, per_thr, skip, inlier, label_thr, rois_per_image, rows_capacity,
+                        top_box, top_pose, top_target,
                         top_weight, top_domain, num_rois, workspace, workspace_bytes, stream_);
 }
 
@@ -1213,7 +1226,8 @@ extern "C" int pcnn_hough_voting_lowres_fwd(const int32_t* label, const float* z
                                             const float* meta, const float* gt, int B, int H, int W,
                                             int C, int num_meta, int num_gt, int is_train,
                                             float vote_thr, float per_thr, int skip, float inlier,
-                                            int label_thr, float* top_box, float* top_pose,
+                                            int label_thr, int rois_per_image, int rows_capacity,
+                                            float* top_box, float* top_pose,
                                             float* top_target, float* top_weight,
                                             int32_t* top_domain, int32_t* num_rois, void* workspace,
                                             size_t workspace_bytes, void* stream_)
@@ -1227,7 +1241,8 @@ extern "C" int pcnn_hough_voting_lowres_fwd(const int32_t* label, const float* z
                "hough_voting_lowres: label map %dx%d is not a multiple of the stride %d", H, W, stride);
   HvVertexSrc vs = {nullptr, z, bias, H / stride, W / stride, kernel, stride};
   return hough_fwd_impl(label, vs, extents, meta, gt, B, H, W, C, num_meta, num_gt, is_train,
-                        vote_thr, per_thr, skip, inlier, label_thr, top_box, top_pose, top_target,
+                        vote_thr, per_thr, skip, inlier, label_thr, rois_per_image, rows_capacity,
+                        top_box, top_pose, top_target,
                         top_weight, top_domain, num_rois, workspace, workspace_bytes, stream_);
 }
 

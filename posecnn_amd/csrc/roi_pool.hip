@@ -128,14 +128,15 @@ __global__ __launch_bounds__(128) void roi_pool_add2_vec4(
     const float* __restrict__ data_a, int Ha, int Wa, float scale_a,
     const float* __restrict__ data_b, int Hb, int Wb, float scale_b,
     const float* __restrict__ rois, float* __restrict__ out, int B, int C, int roi_cols, int PH,
-    int PW)
+    int PW, const int* __restrict__ num_rows_dev)
 {
   const int bin = blockIdx.x;
   const int pw = bin % PW, ph = (bin / PW) % PH, n = bin / (PW * PH);
   const float* roi = rois + (size_t)n * roi_cols;
   const Bin ba = make_bin(roi, scale_a, ph, pw, PH, PW, Ha, Wa);
   const Bin bb = make_bin(roi, scale_b, ph, pw, PH, PW, Hb, Wb);
-  const bool ok = ba.batch >= 0 && ba.batch < B;
+  // rows past the device-side count are padding of a capacity-sized ROI buffer: they pool to 0
+  const bool ok = ba.batch >= 0 && ba.batch < B && (num_rows_dev == nullptr || n < num_rows_dev[0]);
   for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {
     float4 ma = make_float4(0, 0, 0, 0), mb = ma;
     if (ok) {
@@ -261,7 +262,7 @@ extern "C" int pcnn_roi_pool_fwd(const float* data, const float* rois, int B, in
 extern "C" int pcnn_roi_pool_add2_fwd(const float* data_a, int Ha, int Wa, float scale_a,
                                       const float* data_b, int Hb, int Wb, float scale_b,
                                       const float* rois, int B, int C, int R, int roi_cols, int PH,
-                                      int PW, float* out, void* stream_)
+                                      int PW, const int32_t* num_rows_dev, float* out, void* stream_)
 {
   int st = validate(B, Ha, Wa, C, R, roi_cols, PH, PW, scale_a, 0);
   if (st != PCNN_OK) return st;
@@ -275,7 +276,7 @@ extern "C" int pcnn_roi_pool_add2_fwd(const float* data_a, int Ha, int Wa, float
   hipStream_t stream = (hipStream_t)stream_;
   const int threads = C >= 512 ? 128 : 64;
   PCNN_LAUNCH(roi_pool_add2_vec4, dim3(R * PH * PW), dim3(threads), 0, stream, data_a, Ha,
-                     Wa, scale_a, data_b, Hb, Wb, scale_b, rois, out, B, C, roi_cols, PH, PW);
+                     Wa, scale_a, data_b, Hb, Wb, scale_b, rois, out, B, C, roi_cols, PH, PW, num_rows_dev);
   return check_launch("roi_pool_add2_fwd");
 }
 

@@ -17,15 +17,27 @@ import torch.distributed as dist
 DET_COLS = 14  # box7 | pose7
 
 
-def init_from_env(backend=None):
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def init_from_env(backend=None, force=False):
     """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (torchrun contract).
-    Returns (rank, world_size, local_rank). world_size 1 needs no process group."""
+    Returns (rank, world_size, local_rank). world_size 1 needs no process group; `force=True`
+    creates one anyway (a 1-rank RCCL communicator), so that the collective path itself runs on
+    a single-GPU box."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(_free_port()) if world == 1 else "29500"
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -61,9 +73,9 @@ def all_gather_packed(rows, count, frame_offset=0, group=None):
     """The collective itself: returns the packed buffer of every rank, [W, cap+1, 14] (count of
     rank r in [r, cap, 0]). Asynchronous with respect to the host on RCCL."""
     buf = pack_detections(rows, count, frame_offset)
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
-        return buf.unsqueeze(0)
+    if not dist.is_initialized():
+        return buf.unsqueeze(0)   # single process, no communicator: nothing to exchange
+    world = dist.get_world_size(group)
     flat = torch.empty((world * buf.shape[0], buf.shape[1]), dtype=buf.dtype, device=buf.device)
     dist.all_gather_into_tensor(flat, buf, group=group)  # rank-major concatenation (RCCL and gloo)
     return flat.view(world, buf.shape[0], buf.shape[1])
@@ -71,7 +83,7 @@ def all_gather_packed(rows, count, frame_offset=0, group=None):
 
 def all_gather_detections(rows, count, frame_offset=0, group=None):
     """Every rank ends up with all ranks' detections: returns (rows [W, cap, 14], counts [W] int64).
-    A no-op (plus reshape) at world size 1."""
+    A no-op (plus reshape) when no process group exists."""
     gathered = all_gather_packed(rows, count, frame_offset, group)
     cap = rows.shape[0]
     return gathered[:, :cap], gathered[:, cap, 0].round().to(torch.int64)

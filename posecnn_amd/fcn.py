@@ -151,12 +151,20 @@ class Detections(object):
 
 
 def im_segment_batch(net, data, K, extents, points, symmetry, data_p=None, planted=None, feed_cache=None,
-                     with_losses=False):
+                     with_losses=False, gt_poses=None, strict_reference=False):
     """B frames, one pass, no host synchronisation. `data` is the mean-subtracted BGR blob
     [B,H,W,3] already on the device. Returns `Detections` (device tensors; rows past count are 0).
-    Differences from B calls of im_segment_single_frame: the Hough layer sees the whole batch, so
-    its per-image capacity is MAX_ROI / B (hough_voting_gpu_op.cu.cc:733) exactly as the reference
-    op behaves when handed a batch; NMS/pose combine happen in `Detections`/`finalize_batch`."""
+
+    Capacity: the reference op keeps MAX_ROI / B maxima per image when handed a batch
+    (hough_voting_gpu_op.cu.cc:733) — but its test loop feeds one frame at a time
+    (lib/fcn/test.py:1867), so every frame gets all its classes. By default this batched driver
+    therefore asks the Hough layer for C-1 maxima per image (threshold_vote <= 0: one per class;
+    > 0: MAX_ROI) whatever B, i.e. the rows B single-frame calls return;
+    `strict_reference=True` keeps the op's own rule (8 per frame at B = 16).
+
+    `net.is_train` selects the Hough layer's training mode (9 jittered rows per maximum + pose
+    targets for the `gt_poses` [N,13] rows, vgg16_convs.py:167-168); with `with_losses` the two loss
+    layers of the graph (hard_label, average_distance_loss) are evaluated on those rows."""
     dev = data.device
     feed = feed_cache if feed_cache is not None else _feed(net, data, data_p, K, extents, points, symmetry, net.num_classes, dev)
     feed["data"] = data
@@ -170,20 +178,25 @@ def im_segment_batch(net, data, K, extents, points, symmetry, data_p=None, plant
     finally:
         net.vertex_reg_2d = saved[0]
     label_2d = net.get_output("label_2d")
+    B = label_2d.shape[0]
+    is_train = int(net.is_train)
+    per_image = 0 if strict_reference else (net.num_classes - 1 if net.vote_threshold <= 0 else ops.MAX_ROI)
     if "vertex_pred_lowres" in net.layers:
         # fused heads: the Hough kernel interpolates the 1/8-resolution field itself; `vertex_pred`
         # stays a lazy layer that nobody fetches on this path
         top_box, top_pose, top_target, top_weight, top_domain, num_rois = ops.hough_voting_gpu_lowres_padded(
             label_2d, net.get_output("vertex_pred_lowres"), net.get_output("vertex_pred_bias"),
-            int(16 * net.scale), int(8 * net.scale), feed["extents"], feed["meta_data"], None, 0,
-            net.vote_threshold, net.vote_percentage, net.skip_pixels)
+            int(16 * net.scale), int(8 * net.scale), feed["extents"], feed["meta_data"], gt_poses, is_train,
+            net.vote_threshold, net.vote_percentage, net.skip_pixels, rois_per_image=per_image)
     else:
         top_box, top_pose, top_target, top_weight, top_domain, num_rois = ops.hough_voting_gpu_padded(
-            label_2d, net.get_output("vertex_pred"), feed["extents"], feed["meta_data"], None, 0,
-            net.vote_threshold, net.vote_percentage, net.skip_pixels)
-    cap = min(top_box.shape[0], ops.MAX_ROI)  # is_train = 0: at most MAX_ROI rows
-    rois = top_box[:cap]
-    pool = ops.roi_pool_add2(net.get_output("conv5_3"), 1.0 / 16.0, net.get_output("conv4_3"), 1.0 / 8.0, rois)
+            label_2d, net.get_output("vertex_pred"), feed["extents"], feed["meta_data"], gt_poses, is_train,
+            net.vote_threshold, net.vote_percentage, net.skip_pixels, rois_per_image=per_image)
+    cap = top_box.shape[0]
+    rois = top_box
+    count = num_rois[1:2]
+    pool = ops.roi_pool_add2(net.get_output("conv5_3"), 1.0 / 16.0, net.get_output("conv4_3"), 1.0 / 8.0, rois,
+                             num_rows=count)
     net.layers["pool_score"] = pool
     (net.feed("pool_score")
         .fc(4096, height=7, width=7, channel=512, name="fc6")
@@ -195,22 +208,28 @@ def im_segment_batch(net, data, K, extents, points, symmetry, data_p=None, plant
     cls = rois[:, 1].long().clamp(min=0)
     idx = (4 * cls).unsqueeze(1) + torch.arange(4, device=dev).unsqueeze(0)
     quat = torch.gather(poses_tanh, 1, idx)
-    valid = (torch.arange(cap, device=dev) < num_rois[1]).unsqueeze(1)
-    rows = torch.cat([rois, torch.where(valid, quat, top_pose[:cap, :4]), top_pose[:cap, 4:]], dim=1)
+    valid = (torch.arange(cap, device=dev) < count).unsqueeze(1)
+    rows = torch.cat([rois, torch.where(valid, quat, top_pose[:, :4]), top_pose[:, 4:]], dim=1)
     rows = torch.where(valid, rows, torch.zeros_like(rows))
-    net.layers.update({"rois": rois, "poses_init": top_pose[:cap], "poses_tanh": poses_tanh})
+    net.layers.update({"rois": rois, "poses_init": top_pose, "poses_tanh": poses_tanh,
+                       "poses_target": top_target, "poses_weight": top_weight})
     if with_losses:
         # the two training-loss layers of the graph (vgg16_convs.py:148-149,195-200). TF prunes them
-        # at test time; BASELINE config 2 lists them, so the bench evaluates them. The loss is
-        # normalised by the padded row capacity here (rows past the count carry zero weight).
-        net.layers["gt_label_weight"] = ops.hard_label(net.get_output("prob_normalized"), feed["gt_label_2d"],
-                                                       net.threshold_label)
-        weight, target = top_weight[:cap], top_target[:cap]
-        mul = poses_tanh * weight
+        # at test time; BASELINE config 2 lists them. Both run on the capacity-sized buffers with
+        # the device-side row count, so the loss is normalised by the true number of rows.
+        if "gt_label_weight" not in net.layers:   # (a with_losses graph has evaluated it in setup())
+            net.layers["gt_label_weight"] = ops.hard_label(net.get_output("prob_normalized"), feed["gt_label_2d"],
+                                                           net.threshold_label)
+        mul = poses_tanh * top_weight
         pred = mul * torch.rsqrt(torch.clamp((mul * mul).sum(dim=1, keepdim=True), min=1e-12))
-        net.layers["loss_pose"] = ops.average_distance_loss(pred, target, weight, feed["points"],
-                                                            feed["symmetry"], 0.01)[0]
-    return Detections(rows, num_rois[1:2].clone(), label_2d)
+        net.layers["poses_pred"] = pred
+        net.layers["loss_pose"] = ops.average_distance_loss(pred, top_target, top_weight, feed["points"],
+                                                            feed["symmetry"], 0.01, num_rows=count)[0]
+    if is_train:
+        # training mode emits 9 rows per maximum (the box + 8 jitters, .cu.cc:440-466); the detection
+        # product is the un-jittered first row of each group
+        return Detections(rows[0::9], count // 9, label_2d)
+    return Detections(rows, count.clone(), label_2d)
 
 
 def finalize_batch(det_rows, count):

@@ -63,6 +63,25 @@ def make_deconv_filter_1d(k):
     return np.array([1 - abs(x / f - c) for x in range(k)], dtype=np.float64)
 
 
+def is_bilinear_deconv_filter(w):
+    """True for a conv_transpose filter in torch layout [c, c, k, k] (TF `[k, k, c_out, c_in]` after
+    Network.load's permute) that equals make_deconv_filter (network.py:141-157):
+    f32(outer(bilinear, bilinear)) on the channel diagonal, exact zeros elsewhere."""
+    w = torch.as_tensor(w)
+    if w.dim() != 4 or w.shape[0] != w.shape[1] or w.shape[2] != w.shape[3]:
+        return False
+    c, k = w.shape[0], w.shape[2]
+    if k % 2 or k < 2:      # PoseCNN's deconvs are k = 4 / 16; 3x3 and 1x1 convs are never candidates
+        return False
+    f = torch.tensor(make_deconv_filter_1d(k), dtype=torch.float64)
+    want = torch.outer(f, f).to(torch.float32)
+    t = w.detach().to("cpu", torch.float32)
+    diag = t[torch.arange(c), torch.arange(c)]                     # [c, k, k]
+    if not torch.equal(diag, want.expand(c, k, k)):
+        return False
+    return float(t.abs().sum(dtype=torch.float64)) == float(diag.abs().sum(dtype=torch.float64))   # nothing off the diagonal
+
+
 def _nchw(x):  # NHWC contiguous -> channels-last NCHW view (no copy)
     return x.permute(0, 3, 1, 2)
 
@@ -245,9 +264,17 @@ class Network(object):
 
     def load(self, data_dict, ignore_missing=False):
         """network.py:71-107: `{layer: {'weights': [kh,kw,cin,cout] | [in,out], 'biases': [cout]}}`
-        (the vgg16.npy / converted-checkpoint layout). Also assigns the dual '<layer>_p' tower."""
+        (the vgg16.npy / converted-checkpoint layout). A layer's weights also initialise its
+        depth-tower twin '<layer>_p' — but only when the dict has no '<layer>_p' entry of its own
+        (vgg16.npy initialisation of an RGBD network); a checkpoint that carries both towers loads
+        each from its own entry whatever the key order. Constant bilinear `deconv` filters
+        (make_deconv_filter, network.py:141-157, trainable=False) are recognised and dropped, so
+        loaded and freshly built networks run the same interpolation kernel; a deconv filter that is
+        NOT the fixed bilinear one is kept and switches the graph to the literal op order."""
         for op_name, params in data_dict.items():
             for suffix in ("", "_p"):
+                if suffix and (op_name + suffix) in data_dict:
+                    continue
                 for pname, data in params.items():
                     key = "%s%s/%s" % (op_name, suffix, pname)
                     t = torch.as_tensor(np.asarray(data), dtype=torch.float32)
@@ -257,8 +284,14 @@ class Network(object):
                         if not ignore_missing:
                             raise ValueError("shape mismatch for %s" % key)
                         continue
+                    if pname == "weights" and t.dim() == 4 and is_bilinear_deconv_filter(t):
+                        self.vars.pop(key, None)   # the constant filter: the interpolation kernels ARE this filter
+                        continue
                     if suffix == "" or key in self.vars:
                         self.vars[key] = t.to(self.device)
+                        if pname == "weights" and t.dim() == 4 and op_name.startswith("upscore") and hasattr(self, "fused_heads"):
+                            # a trained / non-bilinear deconv filter: conv1x1 and deconv no longer commute
+                            self.fused_heads = False
 
     def load_file(self, path, ignore_missing=False):
         """Checkpoint ingestion. Accepts

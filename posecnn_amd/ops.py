@@ -18,6 +18,7 @@ from ._lib import HOUGH_ROWS_CAPACITY, MAX_ROI, POSE_CHANNELS, VERTEX_CHANNELS, 
 __all__ = [
     "hough_voting_gpu", "hough_voting_gpu_padded", "roi_pool", "roi_pool_add2", "hard_label",
     "average_distance_loss", "backproject", "softmax_argmax", "deconv_bilinear", "bias_act_",
+    "hough_voting_grad", "hard_label_grad", "hough_rows_capacity",
     "upscore_softmax_argmax", "Workspace",
 ]
 
@@ -67,7 +68,16 @@ def _ws(device, key):
 
 
 # ------------------------------------------------------------------------------------------------
-def _hough_common(label_2d, field, extents, meta_data, poses, threshold, skip_pixels, workspace, out, lowres):
+def hough_rows_capacity(batch, is_train, rois_per_image=0):
+    """Rows each Hough output needs: the reference's scratch size MAX_ROI * 9
+    (hough_voting_gpu_op.cc:94) under its own capacity rule, batch * k * (9 | 1) for k maxima per image."""
+    if not rois_per_image:
+        return HOUGH_ROWS_CAPACITY
+    return max(1, int(batch) * int(rois_per_image) * (9 if is_train else 1))
+
+
+def _hough_common(label_2d, field, extents, meta_data, poses, threshold, skip_pixels, workspace, out, lowres,
+                  is_train=0, rois_per_image=0):
     label_2d = _dev(label_2d, "label_2d", torch.int32)
     field = _dev(field, "vertex_pred", torch.float32)
     extents = _dev(extents, "extents", torch.float32)
@@ -102,10 +112,11 @@ def _hough_common(label_2d, field, extents, meta_data, poses, threshold, skip_pi
     dev = label_2d.device
     nbytes = c_size_t(0)
     check("pcnn_hough_voting_workspace_bytes",
-          lib().pcnn_hough_voting_workspace_bytes(B, H, W, C, float(threshold), int(skip_pixels), ctypes.byref(nbytes)))
+          lib().pcnn_hough_voting_workspace_bytes(B, H, W, C, float(threshold), int(skip_pixels),
+                                                  int(rois_per_image), ctypes.byref(nbytes)))
     ws = (workspace or _ws(dev, "hough")).get(nbytes.value, dev)
     if out is None:
-        cap = HOUGH_ROWS_CAPACITY
+        cap = hough_rows_capacity(B, is_train, rois_per_image)
         out = (torch.empty((cap, 7), dtype=torch.float32, device=dev),
                torch.empty((cap, 7), dtype=torch.float32, device=dev),
                torch.empty((cap, POSE_CHANNELS * C), dtype=torch.float32, device=dev),
@@ -117,21 +128,27 @@ def _hough_common(label_2d, field, extents, meta_data, poses, threshold, skip_pi
 
 def hough_voting_gpu_padded(label_2d, vertex_pred, extents, meta_data, poses, is_train, threshold,
                             per_threshold, skip_pixels, workspace=None, out=None,
-                            inlier_threshold=INLIER_THRESHOLD, label_threshold=LABEL_THRESHOLD):
+                            inlier_threshold=INLIER_THRESHOLD, label_threshold=LABEL_THRESHOLD,
+                            rois_per_image=0):
     """Sync-free form: returns capacity-sized buffers and the device-side row counts.
 
-    Returns (top_box[1152,7], top_pose[1152,7], top_target[1152,4C], top_weight[1152,4C],
-    top_domain[1152] int32, num_rois[2] int32) where num_rois[0] is the number of rows the
-    reference op returns (>= 1) and num_rois[1] the true detection row count.
+    Returns (top_box[cap,7], top_pose[cap,7], top_target[cap,4C], top_weight[cap,4C],
+    top_domain[cap] int32, num_rois[2] int32) where num_rois[0] is the number of rows the
+    reference op returns (>= 1) and num_rois[1] the true detection row count; cap =
+    `hough_rows_capacity(B, is_train, rois_per_image)` (1152 under the reference's capacity rule).
+    rois_per_image: 0 = the reference's index_size = MAX_ROI / B per image; k > 0 = k maxima per
+    image whatever B (include/posecnn_hip.h, "Capacity").
     """
     label_2d, vertex_pred, extents, meta_data, gt, num_gt, (B, H, W, C, num_meta), ws, out = _hough_common(
-        label_2d, vertex_pred, extents, meta_data, poses, threshold, skip_pixels, workspace, out, None)
+        label_2d, vertex_pred, extents, meta_data, poses, threshold, skip_pixels, workspace, out, None,
+        is_train, rois_per_image)
     top_box, top_pose, top_target, top_weight, top_domain, num_rois = out
     check("pcnn_hough_voting_fwd",
           lib().pcnn_hough_voting_fwd(_ptr(label_2d), _ptr(vertex_pred), _ptr(extents), _ptr(meta_data), _ptr(gt),
                                       B, H, W, C, num_meta, num_gt,
                                       int(is_train), float(threshold), float(per_threshold), int(skip_pixels),
                                       float(inlier_threshold), int(label_threshold),
+                                      int(rois_per_image), int(top_box.shape[0]),
                                       _ptr(top_box), _ptr(top_pose), _ptr(top_target), _ptr(top_weight),
                                       _ptr(top_domain), _ptr(num_rois),
                                       _ptr(ws), ws.numel(), _stream(label_2d)))
@@ -140,13 +157,15 @@ def hough_voting_gpu_padded(label_2d, vertex_pred, extents, meta_data, poses, is
 
 def hough_voting_gpu_lowres_padded(label_2d, z, bias, kernel, stride, extents, meta_data, poses, is_train,
                                    threshold, per_threshold, skip_pixels, workspace=None, out=None,
-                                   inlier_threshold=INLIER_THRESHOLD, label_threshold=LABEL_THRESHOLD):
+                                   inlier_threshold=INLIER_THRESHOLD, label_threshold=LABEL_THRESHOLD,
+                                   rois_per_image=0):
     """Fused vertex head -> Hough voting: identical results to
     `hough_voting_gpu_padded(label_2d, deconv_bilinear(z, kernel, stride, bias=bias), ...)` without
     ever building the [B,H,W,3C] `vertex_pred` (vgg16_convs.py:152-163).
     z is the 1x1 `vertex_pred` conv evaluated at 1/stride resolution, [B,H/stride,W/stride,3C]."""
     label_2d, z, extents, meta_data, gt, num_gt, (B, H, W, C, num_meta), ws, out = _hough_common(
-        label_2d, z, extents, meta_data, poses, threshold, skip_pixels, workspace, out, stride)
+        label_2d, z, extents, meta_data, poses, threshold, skip_pixels, workspace, out, stride,
+        is_train, rois_per_image)
     bias = _dev(bias, "bias", torch.float32)
     if bias.numel() != VERTEX_CHANNELS * C:
         raise ValueError("bias must be [3*num_classes]")
@@ -157,10 +176,44 @@ def hough_voting_gpu_lowres_padded(label_2d, z, bias, kernel, stride, extents, m
                                              B, H, W, C, num_meta, num_gt,
                                              int(is_train), float(threshold), float(per_threshold), int(skip_pixels),
                                              float(inlier_threshold), int(label_threshold),
+                                             int(rois_per_image), int(top_box.shape[0]),
                                              _ptr(top_box), _ptr(top_pose), _ptr(top_target), _ptr(top_weight),
                                              _ptr(top_domain), _ptr(num_rois),
                                              _ptr(ws), ws.numel(), _stream(label_2d)))
     return out
+
+
+def hough_voting_grad(label_2d, vertex_pred):
+    """HoughvotinggpuGrad (hough_voting_gpu_op.cc:440-484 -> set_gradients, .cu.cc:608-612): the op
+    is not differentiable; its registered gradient hands zeros to both inputs. Returns
+    (grad_label f32 [B,H,W], grad_vertex f32 [B,H,W,3C])."""
+    B, H, W = label_2d.shape
+    C = vertex_pred.shape[3] // VERTEX_CHANNELS
+    dev = vertex_pred.device
+    gl = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    gv = torch.empty((B, H, W, VERTEX_CHANNELS * C), dtype=torch.float32, device=dev)
+    check("pcnn_hough_voting_bwd", lib().pcnn_hough_voting_bwd(_ptr(gl), _ptr(gv), B, H, W, C, _stream(gv)))
+    return gl, gv
+
+
+class _HoughVotingFn(torch.autograd.Function):
+    """The op inside an autograd graph (training graph, vgg16_convs.py:167-168): outputs carry no
+    gradient information; backward = the registered zero gradient of the reference."""
+
+    @staticmethod
+    def forward(ctx, label_2d, vertex_pred, extents, meta_data, poses, cfg):
+        is_train, threshold, per_threshold, skip_pixels, workspace, consts = cfg
+        out = hough_voting_gpu_padded(label_2d, vertex_pred, extents, meta_data, poses, is_train, threshold,
+                                      per_threshold, skip_pixels, workspace=workspace, **consts)
+        ctx.save_for_backward(label_2d, vertex_pred)
+        ctx.mark_non_differentiable(out[4], out[5])
+        return out
+
+    @staticmethod
+    def backward(ctx, *_grads):
+        label_2d, vertex_pred = ctx.saved_tensors
+        _, gv = hough_voting_grad(label_2d, vertex_pred)
+        return None, gv, None, None, None, None   # label is int32: no gradient slot
 
 
 def hough_voting_gpu(label_2d, vertex_pred, extents, meta_data, poses, is_train, threshold,
@@ -169,9 +222,14 @@ def hough_voting_gpu(label_2d, vertex_pred, extents, meta_data, poses, is_train,
     (top_box[R,7], top_pose[R,7], top_target[R,4C], top_weight[R,4C], top_domain[R]).
     Like the reference (hough_voting_gpu_op.cc:379-383) this reads the row count back to the host.
     """
-    top_box, top_pose, top_target, top_weight, top_domain, num_rois = hough_voting_gpu_padded(
-        label_2d, vertex_pred, extents, meta_data, poses, is_train, threshold, per_threshold,
-        skip_pixels, workspace=workspace, **consts)
+    if torch.is_grad_enabled() and isinstance(vertex_pred, torch.Tensor) and vertex_pred.requires_grad:
+        top_box, top_pose, top_target, top_weight, top_domain, num_rois = _HoughVotingFn.apply(
+            label_2d, vertex_pred, extents, meta_data, poses,
+            (is_train, threshold, per_threshold, skip_pixels, workspace, consts))
+    else:
+        top_box, top_pose, top_target, top_weight, top_domain, num_rois = hough_voting_gpu_padded(
+            label_2d, vertex_pred, extents, meta_data, poses, is_train, threshold, per_threshold,
+            skip_pixels, workspace=workspace, **consts)
     r = int(num_rois[0].item())
     return top_box[:r], top_pose[:r], top_target[:r], top_weight[:r], top_domain[:r]
 
@@ -218,9 +276,10 @@ def roi_pool(data, rois, pooled_height, pooled_width, spatial_scale, pool_channe
     return _RoiPoolFn.apply(data, rois, pooled_height, pooled_width, spatial_scale, pool_channel)
 
 
-def roi_pool_add2(data_a, scale_a, data_b, scale_b, rois, pooled_height=7, pooled_width=7):
+def roi_pool_add2(data_a, scale_a, data_b, scale_b, rois, pooled_height=7, pooled_width=7, num_rows=None):
     """Fused `pool_score` = roi_pool(conv5_3, 1/16) + roi_pool(conv4_3, 1/8)
-    (vgg16_convs.py:177-187), inference only (no argmax)."""
+    (vgg16_convs.py:177-187), inference only (no argmax). `num_rows` (device int32[1]): true row
+    count of a capacity-sized `rois` buffer; rows past it pool to zero."""
     data_a = _dev(data_a, "data_a", torch.float32)
     data_b = _dev(data_b, "data_b", torch.float32)
     rois = _dev(rois, "rois", torch.float32)
@@ -233,24 +292,57 @@ def roi_pool_add2(data_a, scale_a, data_b, scale_b, rois, pooled_height=7, poole
     check("pcnn_roi_pool_add2_fwd",
           lib().pcnn_roi_pool_add2_fwd(_ptr(data_a), Ha, Wa, float(scale_a), _ptr(data_b), Hb, Wb, float(scale_b),
                                        _ptr(rois), B, C, R, cols, int(pooled_height), int(pooled_width),
+                                       _ptr(_dev(num_rows, "num_rows", torch.int32) if num_rows is not None else None),
                                        _ptr(out), _stream(data_a)))
     return out
 
 
 # ------------------------------------------------------------------------------------------------
+def _hard_label_raw(prob, gt_label, threshold):
+    C = prob.shape[-1]
+    N = prob.numel() // C
+    out = torch.empty_like(prob)
+    check("pcnn_hard_label_fwd",
+          lib().pcnn_hard_label_fwd(_ptr(prob), _ptr(gt_label), N, C, float(threshold), _ptr(out), _stream(prob)))
+    return out
+
+
+def hard_label_grad(prob, gt_label):
+    """HardlabelGrad (hard_label_op_gpu.cu.cc:55-85): zeros for both inputs.
+    Returns (grad_prob f32 like prob, grad_gt f32 [N])."""
+    C = prob.shape[-1]
+    N = prob.numel() // C
+    gp = torch.empty_like(prob)
+    gg = torch.empty(gt_label.shape, dtype=torch.float32, device=prob.device)
+    check("pcnn_hard_label_bwd", lib().pcnn_hard_label_bwd(_ptr(gp), _ptr(gg), N, C, _stream(prob)))
+    return gp, gg
+
+
+class _HardLabelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, prob, gt_label, threshold):
+        ctx.save_for_backward(prob, gt_label)
+        return _hard_label_raw(prob, gt_label, threshold)
+
+    @staticmethod
+    def backward(ctx, _grad):
+        prob, gt_label = ctx.saved_tensors
+        return hard_label_grad(prob, gt_label)[0], None, None
+
+
 def hard_label(prob, gt_label, threshold, name=None):
     """Drop-in for `Network.hard_label` (network.py:338-340); GPU-kernel semantics
-    (hard_label_op_gpu.cu.cc:17-29). prob [B,H,W,C] f32, gt_label [B,H,W] int32 -> [B,H,W,C]."""
+    (hard_label_op_gpu.cu.cc:17-29). prob [B,H,W,C] f32, gt_label [B,H,W] int32 -> [B,H,W,C].
+    Inside an autograd graph the registered zero gradient (HardlabelGrad) is what flows back."""
     prob = _dev(prob, "prob", torch.float32)
     gt_label = _dev(gt_label, "gt_label", torch.int32)
     C = prob.shape[-1]
     N = prob.numel() // C
     if gt_label.numel() != N:
         raise ValueError("gt_label must have one entry per pixel of prob")
-    out = torch.empty_like(prob)
-    check("pcnn_hard_label_fwd",
-          lib().pcnn_hard_label_fwd(_ptr(prob), _ptr(gt_label), N, C, float(threshold), _ptr(out), _stream(prob)))
-    return out
+    if torch.is_grad_enabled() and prob.requires_grad:
+        return _HardLabelFn.apply(prob, gt_label, float(threshold))
+    return _hard_label_raw(prob, gt_label, threshold)
 
 
 def softmax_argmax(score, want_prob=True):
@@ -533,7 +625,7 @@ def upscore_softmax_argmax(z, bias, kernel, stride, relu=True, want_score=False,
 # ------------------------------------------------------------------------------------------------
 class _AverageDistanceFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, prediction, target, weight, point, symmetry, margin):
+    def forward(ctx, prediction, target, weight, point, symmetry, margin, num_rows=None):
         R, CH = prediction.shape
         C, P = point.shape[0], point.shape[1]
         dev = prediction.device
@@ -545,7 +637,7 @@ class _AverageDistanceFn(torch.autograd.Function):
         ws = _ws(dev, "adl").get(nbytes.value, dev)
         check("pcnn_average_distance_fwd",
               lib().pcnn_average_distance_fwd(_ptr(prediction), _ptr(target), _ptr(weight), _ptr(point),
-                                              _ptr(symmetry), R, C, P, float(margin), _ptr(loss),
+                                              _ptr(symmetry), R, C, P, float(margin), _ptr(num_rows), _ptr(loss),
                                               _ptr(bottom_diff), _ptr(ws), ws.numel(), _stream(prediction)))
         ctx.save_for_backward(bottom_diff)
         ctx.mark_non_differentiable(bottom_diff)
@@ -561,12 +653,13 @@ class _AverageDistanceFn(torch.autograd.Function):
             check("pcnn_average_distance_bwd",
                   lib().pcnn_average_distance_bwd(_ptr(grad_loss), _ptr(bottom_diff), R, CH, _ptr(out),
                                                   _stream(bottom_diff)))
-        return out, None, None, None, None, None
+        return out, None, None, None, None, None, None
 
 
-def average_distance_loss(poses_pred, poses_target, poses_weight, points, symmetry, margin, name=None):
+def average_distance_loss(poses_pred, poses_target, poses_weight, points, symmetry, margin, name=None, num_rows=None):
     """Drop-in for `Network.average_distance_loss` (network.py:236-238).
-    Returns (loss[1], bottom_diff[R,4C])."""
+    Returns (loss[1], bottom_diff[R,4C]). `num_rows` (device int32[1]): the op's true row count when
+    the inputs are capacity-sized buffers of the sync-free Hough op (normalisation by that count)."""
     poses_pred = _dev(poses_pred, "prediction", torch.float32)
     poses_target = _dev(poses_target, "target", torch.float32)
     poses_weight = _dev(poses_weight, "weight", torch.float32)
@@ -581,7 +674,9 @@ def average_distance_loss(poses_pred, poses_target, poses_weight, points, symmet
         raise ValueError("symmetry must be 1-dimensional")
     if poses_pred.shape[1] != POSE_CHANNELS * points.shape[0]:
         raise ValueError("prediction must be [R, 4*num_classes]")
-    return _AverageDistanceFn.apply(poses_pred, poses_target, poses_weight, points, symmetry, margin)
+    if num_rows is not None:
+        num_rows = _dev(num_rows, "num_rows", torch.int32)
+    return _AverageDistanceFn.apply(poses_pred, poses_target, poses_weight, points, symmetry, margin, num_rows)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -1,0 +1,73 @@
+"""Host-side frame pipeline of the batched inference driver (the MI355X counterpart of the
+reference's per-frame loop `for i in perm: im_segment_single_frame(...)`, lib/fcn/test.py:1867-1945,
+which builds its blobs on the host and hands them to `sess.run` through `feed_dict`, :151-195).
+
+  FrameUploader  the feed_dict hand-over: image blobs wait in pinned host memory and travel to
+                 HBM on a side HIP stream, `depth` batches ahead of the kernels that consume them,
+                 so the PCIe copy (59 MB per 16 COLOR frames, 118 MB RGB-D) overlaps the previous
+                 batch's backbone instead of sitting in front of it.
+  GraphedStep    (optional) one whole batch captured in a hipGraph and replayed: the ~600 kernel
+                 launches of a step become one host call (lib/fcn/test.py has no equivalent; TF1's
+                 executor plays that role there).
+"""
+import torch
+
+
+class FrameUploader:
+    """Pinned host blobs -> device slots on a side stream.
+
+    `host_batches` is a list of tuples of pinned CPU tensors (one tuple per distinct batch; the
+    bench cycles through them). `get(i)` returns the device tensors of batch i and makes the
+    CURRENT stream wait for their copy; it also enqueues the copy of batch i + depth. A slot is
+    re-used only after the compute stream has passed the point where `release(i)` was called for
+    the batch that last lived in it."""
+
+    def __init__(self, host_batches, device, depth=2):
+        assert depth >= 1
+        self.host = host_batches
+        self.device = torch.device(device)
+        self.depth = depth
+        self.nslots = depth + 1
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.slots = [None] * self.nslots
+        self.ready = [torch.cuda.Event() for _ in range(self.nslots)]
+        self.free = [None] * self.nslots       # event recorded on the compute stream by release()
+        self.loaded = [-1] * self.nslots
+        self.next_to_issue = 0
+        self.bytes_per_batch = sum(t.numel() * t.element_size() for t in host_batches[0] if t is not None)
+
+    def _issue(self, i):
+        k = i % self.nslots
+        src = self.host[i % len(self.host)]
+        if self.slots[k] is None:
+            self.slots[k] = tuple(None if t is None else torch.empty(t.shape, dtype=t.dtype, device=self.device) for t in src)
+        with torch.cuda.stream(self.stream):
+            if self.free[k] is not None:
+                self.stream.wait_event(self.free[k])   # the kernels that read the old contents are done
+            for d, h in zip(self.slots[k], src):
+                if d is not None:
+                    d.copy_(h, non_blocking=True)
+            self.ready[k].record(self.stream)
+        self.loaded[k] = i
+
+    def get(self, i):
+        """Device tensors of batch i (call with i = 0, 1, 2, ... in order)."""
+        while self.next_to_issue <= i + self.depth - 1:
+            self._issue(self.next_to_issue)
+            self.next_to_issue += 1
+        k = i % self.nslots
+        assert self.loaded[k] == i, "FrameUploader.get() must be called in batch order"
+        torch.cuda.current_stream(self.device).wait_event(self.ready[k])
+        return self.slots[k]
+
+    def release(self, i):
+        """The compute stream has enqueued every kernel that reads batch i."""
+        k = i % self.nslots
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.free[k] = ev
+
+
+def pin(t):
+    """Page-locked copy of a CPU tensor (what the feed_dict blobs live in)."""
+    return t.contiguous().pin_memory() if t is not None else None

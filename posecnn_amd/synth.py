@@ -156,3 +156,20 @@ def random_unit_quats(rng, n):
     q = rng.standard_normal((n, 4))
     q /= np.linalg.norm(q, axis=1, keepdims=True)
     return q.astype(np.float32)
+
+
+def make_gt_poses(scenes, K, seed=5, max_tilt=0.15):
+    """`poses` blob [N,13] = (batch, cls, box4, quat wxyz, trans3) (the pose_blob of
+    lib/gt_synthesize_layer/minibatch.py, fed to the Hough layer as bottom_gt) for planted scenes:
+    every object sits at its planted centre and depth with a small random rotation, so the
+    projected 3-D box overlaps the detected box (IoU > 0.2, hough_voting_gpu_op.cu.cc:440-466) and
+    the layer emits pose targets — which is what gives average_distance_loss real rows to work on."""
+    rng = np.random.default_rng(seed)
+    fx, fy, px, py = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    rows = []
+    for b, s in enumerate(scenes):
+        for cls, cx, cy, z in s["objects"]:
+            q = np.concatenate([[1.0], rng.standard_normal(3) * max_tilt])
+            q /= np.linalg.norm(q)
+            rows.append([b, cls, 0, 0, 0, 0, q[0], q[1], q[2], q[3], (cx - px) / fx * z, (cy - py) / fy * z, z])
+    return np.asarray(rows, dtype=np.float32).reshape(-1, 13)

@@ -16,10 +16,17 @@ Format (tensorflow/core/util/tensor_bundle + tensorflow/core/lib/io/table, itsel
     crc32c = 6, slices = 7);
   * tensor bytes sit raw (little endian, row major) at [offset, offset + size) of the named data shard.
 
+Integrity: every table block carries a masked CRC32C of (contents + compression byte) and every
+BundleEntryProto the masked CRC32C of its tensor bytes (tensorflow/core/lib/hash/crc32c.h: Mask(crc) =
+rotr(crc, 15) + 0xa282ead8). Both are verified on read (`verify=True`, the default) through the native
+`pcnn_crc32c` of libposecnn_hip.so; a mismatch raises instead of handing wrong weights to the network.
+
 VALIDATION STATUS: no TensorFlow and no checkpoint file exist in the build environment, so this reader is
 tested against an independent WRITER of the documented format (tests/test_tf_checkpoint.py: prefix-
-compressed keys, several data blocks, restarts, snappy blocks, several shards), not against files written
-by TensorFlow itself. Partitioned variables (`slices`) are reported as an error, not guessed.
+compressed keys, several data blocks, restarts, snappy blocks, several shards, correct and corrupted
+checksums), not against files written by TensorFlow itself: **parity unpinned** for TF-written files.
+The checksum itself is pinned by the published CRC32C known answers (RFC 3720 B.4).
+Partitioned variables (`slices`) are reported as an error, not guessed.
 """
 import os
 import struct
@@ -83,12 +90,40 @@ def _snappy_decompress(data):
     return bytes(out)
 
 
-def _read_block(f, offset, size):
+_CRC_MASK_DELTA = 0xA282EAD8
+
+
+def crc32c(data, seed=0):
+    """CRC32C of a bytes-like object (native, SSE4.2)."""
+    import ctypes
+    from . import _lib
+    buf = bytes(data) if not isinstance(data, (bytes, bytearray)) else data
+    arr = (ctypes.c_char * len(buf)).from_buffer_copy(buf) if len(buf) else None
+    return int(_lib.lib().pcnn_crc32c(ctypes.cast(arr, ctypes.c_void_p) if arr is not None else None, len(buf), seed))
+
+
+def crc32c_array(a):
+    """CRC32C of a numpy array's bytes without a copy."""
+    import ctypes
+    from . import _lib
+    a = np.ascontiguousarray(a)
+    return int(_lib.lib().pcnn_crc32c(ctypes.c_void_p(a.ctypes.data), a.nbytes, 0))
+
+
+def mask_crc(crc):
+    return (((crc >> 15) | (crc << 17)) + _CRC_MASK_DELTA) & 0xFFFFFFFF
+
+
+def _read_block(f, offset, size, verify=True):
     f.seek(offset)
     raw = f.read(size + 5)
     if len(raw) < size + 5:
         raise ValueError("truncated table block")
     body, ctype = raw[:size], raw[size]
+    if verify:
+        stored = struct.unpack_from("<I", raw, size + 1)[0]
+        if mask_crc(crc32c(raw[:size + 1])) != stored:
+            raise ValueError("table block at offset %d: crc32c mismatch (corrupt index file)" % offset)
     if ctype == 1:
         body = _snappy_decompress(body)
     elif ctype != 0:
@@ -151,7 +186,7 @@ def _parse_shape(buf):
 
 
 def _parse_entry(buf):
-    e = {"dtype": 0, "shape": (), "shard_id": 0, "offset": 0, "size": 0, "slices": 0}
+    e = {"dtype": 0, "shape": (), "shard_id": 0, "offset": 0, "size": 0, "slices": 0, "crc32c": None}
     for field, wt, val in _proto_fields(buf):
         if field == 1 and wt == 0:
             e["dtype"] = val
@@ -163,12 +198,14 @@ def _parse_entry(buf):
             e["offset"] = val
         elif field == 5 and wt == 0:
             e["size"] = val
+        elif field == 6 and wt == 5:
+            e["crc32c"] = struct.unpack("<I", val)[0]
         elif field == 7:
             e["slices"] += 1
     return e
 
 
-def read_index(prefix):
+def read_index(prefix, verify=True):
     """-> (header dict, {variable name: entry dict}) from `<prefix>.index`."""
     path = prefix + ".index"
     with open(path, "rb") as f:
@@ -186,10 +223,10 @@ def read_index(prefix):
         idx_off, pos = _varint(footer, pos)
         idx_size, pos = _varint(footer, pos)
         header, entries = {}, {}
-        for _, handle in _block_entries(_read_block(f, idx_off, idx_size)):
+        for _, handle in _block_entries(_read_block(f, idx_off, idx_size, verify)):
             boff, p = _varint(handle, 0)
             bsize, p = _varint(handle, p)
-            for key, value in _block_entries(_read_block(f, boff, bsize)):
+            for key, value in _block_entries(_read_block(f, boff, bsize, verify)):
                 if key == b"":
                     for field, wt, val in _proto_fields(value):
                         if field == 1 and wt == 0:
@@ -203,10 +240,10 @@ def read_index(prefix):
     return header, entries
 
 
-def read_checkpoint(prefix, names=None):
+def read_checkpoint(prefix, names=None, verify=True):
     """Reads variables of a TF checkpoint `prefix` into numpy arrays. `names` restricts the set
-    (default: everything whose dtype is numeric)."""
-    header, entries = read_index(prefix)
+    (default: everything whose dtype is numeric). `verify` checks the block and tensor checksums."""
+    header, entries = read_index(prefix, verify)
     num_shards = max(int(header.get("num_shards", 1)), 1)
     out, files = {}, {}
     try:
@@ -231,7 +268,10 @@ def read_checkpoint(prefix, names=None):
             raw = files[sid].read(e["size"])
             if len(raw) != e["size"]:
                 raise ValueError("variable %s: data shard truncated" % name)
-            out[name] = np.frombuffer(raw, dtype=dt.newbyteorder("<")).reshape(e["shape"]).astype(dt, copy=True)
+            arr = np.frombuffer(raw, dtype=dt.newbyteorder("<")).reshape(e["shape"])
+            if verify and e["crc32c"] is not None and mask_crc(crc32c_array(arr)) != e["crc32c"]:
+                raise ValueError("variable %s: crc32c mismatch (corrupt data shard)" % name)
+            out[name] = arr.astype(dt, copy=True)
     finally:
         for fh in files.values():
             fh.close()

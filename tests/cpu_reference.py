@@ -80,27 +80,39 @@ class vgg16_convs_cpu(vgg16_convs):
         return torch.from_numpy(l), torch.from_numpy(d)
 
 
-def run_cpu_pipeline(net_cpu, data, K, extents, points, symmetry, planted=None):
+def run_cpu_pipeline(net_cpu, data, K, extents, points, symmetry, planted=None, data_p=None, gt_poses=None):
     """B frames through the CPU graph; returns dict of numpy outputs (the fetch list of
-    lib/fcn/test.py:193-195) + NMS'd rois/poses per lib/fcn/test.py:197-211."""
+    lib/fcn/test.py:193-195) + NMS'd rois/poses per lib/fcn/test.py:197-211. `data_p` feeds the
+    depth tower of an RGBD network, `gt_poses` [N,13] the Hough layer's training mode."""
     from posecnn_amd import fcn
     from posecnn_amd.config import make_meta_data
     B, H, W, _ = data.shape
     meta = np.stack([make_meta_data(K)] * B).reshape(B, 1, 1, 48)
     t = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(a), dtype=dt)
     feed = {"data": t(data), "gt_label_2d": torch.ones((B, H, W), dtype=torch.int32), "keep_prob": 1.0,
-            "poses": torch.zeros((1, 13)), "extents": t(extents), "meta_data": t(meta),
-            "points": t(points), "symmetry": t(symmetry)}
+            "poses": torch.zeros((1, 13)) if gt_poses is None else t(gt_poses), "extents": t(extents),
+            "meta_data": t(meta), "points": t(points), "symmetry": t(symmetry)}
+    if data_p is not None:
+        feed["data_p"] = t(data_p)
     pl = None if planted is None else {k: t(v) for k, v in planted.items()}
     with torch.no_grad():
         net_cpu.run(feed, planted=pl)
     g = lambda n: net_cpu.get_output(n)
     out = {"label_2d": g("label_2d").numpy(), "vertex_pred": g("vertex_pred").numpy(),
            "rois": g("rois").numpy(), "poses_init": g("poses_init").numpy(), "poses_tanh": g("poses_tanh").numpy()}
+    for name in ("poses_target", "poses_weight", "poses_pred"):
+        if name in net_cpu.layers:
+            out[name] = g(name).numpy()
+    if "loss_pose" in net_cpu.layers:
+        out["loss_pose"] = g("loss_pose")[0].numpy()
+    rois_all, init_all, tanh_all = out["rois"], out["poses_init"], out["poses_tanh"]
+    if net_cpu.is_train and rois_all.shape[0] % 9 == 0 and out["rois"][:, 6].any():
+        # training mode: 9 rows per maximum (box + 8 jitters); the detection is the first of each group
+        rois_all, init_all, tanh_all = rois_all[0::9], init_all[0::9], tanh_all[0::9]
     rois, poses = [], []
-    for b in np.unique(out["rois"][:, 0]):
-        m = out["rois"][:, 0] == b
-        r, p, _ = fcn.combine_poses(out["rois"][m], out["poses_init"][m], out["poses_tanh"][m])
+    for b in np.unique(rois_all[:, 0]):
+        m = rois_all[:, 0] == b
+        r, p, _ = fcn.combine_poses(rois_all[m], init_all[m], tanh_all[m])
         rois.append(r); poses.append(p)
     out["final_rois"] = np.concatenate(rois) if rois else np.zeros((0, 7), np.float32)
     out["final_poses"] = np.concatenate(poses) if poses else np.zeros((0, 7), np.float32)

@@ -56,7 +56,9 @@ def project_box(cls, extents, meta, distance):
 
 
 def hough_voting(label, vertex, extents, meta, gt, is_train, vote_thr, per_thr, skip,
-                 inlier=0.9, label_thr=500, want_hs=False, padded=False):
+                 inlier=0.9, label_thr=500, want_hs=False, padded=False, rois_per_image=0):
+    """rois_per_image = 0: the reference's capacity rule index_size = MAX_ROI / B (:733);
+    > 0: that many maxima per image whatever B (outputs sized B * rois_per_image * (9 | 1) rows)."""
     label, vertex, extents, meta = _i32(label), _f32(vertex), _f32(extents), _f32(meta)
     B, H, W = label.shape
     C = vertex.shape[3] // 3
@@ -67,18 +69,20 @@ def hough_voting(label, vertex, extents, meta, gt, is_train, vote_thr, per_thr, 
     else:
         gt_a = _f32(gt)
         num_gt = gt_a.shape[0]
-    top_box = np.empty((CAP, 7), np.float32)
-    top_pose = np.empty((CAP, 7), np.float32)
-    top_target = np.empty((CAP, 4 * C), np.float32)
-    top_weight = np.empty((CAP, 4 * C), np.float32)
-    top_domain = np.empty((CAP,), np.int32)
+    cap = CAP if not rois_per_image else max(1, B * int(rois_per_image) * (9 if is_train else 1))
+    top_box = np.empty((cap, 7), np.float32)
+    top_pose = np.empty((cap, 7), np.float32)
+    top_target = np.empty((cap, 4 * C), np.float32)
+    top_weight = np.empty((cap, 4 * C), np.float32)
+    top_domain = np.empty((cap,), np.int32)
     num_rois = np.zeros(2, np.int32)
     hs = np.zeros((B, C, H * W), np.float32) if want_hs else None
-    st = lib().oracle_hough_voting(_p(label), _p(vertex), _p(extents), _p(meta), _p(gt_a),
-                                   B, H, W, C, num_meta, num_gt, int(is_train), c_float(vote_thr),
-                                   c_float(per_thr), int(skip), c_float(inlier), int(label_thr),
-                                   _p(top_box), _p(top_pose), _p(top_target), _p(top_weight),
-                                   _p(top_domain), _p(num_rois), _p(hs))
+    st = lib().oracle_hough_voting_ex(_p(label), _p(vertex), _p(extents), _p(meta), _p(gt_a),
+                                      B, H, W, C, num_meta, num_gt, int(is_train), c_float(vote_thr),
+                                      c_float(per_thr), int(skip), c_float(inlier), int(label_thr),
+                                      int(rois_per_image), cap,
+                                      _p(top_box), _p(top_pose), _p(top_target), _p(top_weight),
+                                      _p(top_domain), _p(num_rois), _p(hs))
     assert st == 0
     if padded:
         res = (top_box, top_pose, top_target, top_weight, top_domain, num_rois)

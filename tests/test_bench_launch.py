@@ -1,0 +1,64 @@
+"""CPU tests of bench.py's launch logic: `python bench.py --gpus N` with no
+WORLD_SIZE must start N ranks by itself, rendezvous on 127.0.0.1, run the detection all-gather and
+print one JSON line from rank 0. `--dry-run` keeps everything except the GPU work and uses gloo."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["OMP_NUM_THREADS"] = "1"
+    return env
+
+
+def _json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_respawn_command_shape():
+    sys.path.insert(0, ROOT)
+    import bench
+    argv = ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+    cmd = bench.respawn_command(bench.parse_args(argv), argv)
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-len(argv) - 1] == BENCH and cmd[-len(argv):] == argv
+
+
+def test_gpus2_self_spawns_two_ranks_and_gathers_on_gloo():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["process_group"] is True
+    assert out["detections_gathered_per_step"] == 6   # 3 rows from each of the 2 ranks
+
+
+def test_under_a_launcher_env_is_respected():
+    # what the driver does for N > 1: torch.distributed.run ... bench.py --gpus N
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "2",
+                        "--warmup", "0", "--dry-run"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert _json_line(r.stdout)["n_gpus"] == 2
+
+
+def test_world1_force_process_group_runs_the_collective():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "2", "--warmup", "0", "--dry-run",
+                        "--force-process-group"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 1 and out["process_group"] is True and out["detections_gathered_per_step"] == 3

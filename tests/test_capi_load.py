@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported_and_bound(L):
 
 
 def test_abi_version_and_status_strings(L):
-    assert L.pcnn_abi_version() == 1
+    assert L.pcnn_abi_version() == 2
     assert L.pcnn_status_string(0) == b"ok"
     assert b"invalid" in L.pcnn_status_string(-1)
 
@@ -46,19 +46,19 @@ def test_argument_validation_happens_on_the_host(L):
     from posecnn_amd import _lib
     n = ctypes.c_size_t(0)
     # hough: skip_pixels >= 1, 2 <= num_classes <= 64
-    assert L.pcnn_hough_voting_workspace_bytes(1, 480, 640, 22, -1.0, 0, ctypes.byref(n)) == _lib.PCNN_EINVAL
+    assert L.pcnn_hough_voting_workspace_bytes(1, 480, 640, 22, -1.0, 0, 0, ctypes.byref(n)) == _lib.PCNN_EINVAL
     assert b"skip_pixels" in L.pcnn_last_error_string()
-    assert L.pcnn_hough_voting_workspace_bytes(1, 480, 640, 1, -1.0, 10, ctypes.byref(n)) == _lib.PCNN_EINVAL
-    assert L.pcnn_hough_voting_workspace_bytes(16, 480, 640, 22, -1.0, 10, ctypes.byref(n)) == 0
+    assert L.pcnn_hough_voting_workspace_bytes(1, 480, 640, 1, -1.0, 10, 0, ctypes.byref(n)) == _lib.PCNN_EINVAL
+    assert L.pcnn_hough_voting_workspace_bytes(16, 480, 640, 22, -1.0, 10, 0, ctypes.byref(n)) == 0
     small = n.value
     assert 0 < small < 64 << 20
-    assert L.pcnn_hough_voting_workspace_bytes(16, 480, 640, 22, 5.0, 10, ctypes.byref(n)) == 0
+    assert L.pcnn_hough_voting_workspace_bytes(16, 480, 640, 22, 5.0, 10, 0, ctypes.byref(n)) == 0
     assert n.value > small  # threshold_vote > 0 keeps the Hough space
     # hard_label: threshold > 0 (hard_label_op.cc:150-155)
     assert L.pcnn_hard_label_fwd(None, None, 10, 22, 0.0, None, None) == _lib.PCNN_EINVAL
     assert b"threshold > 0" in L.pcnn_last_error_string()
     # average distance: margin >= 0 (average_distance_loss_op.cc:262-267)
-    assert L.pcnn_average_distance_fwd(None, None, None, None, None, 1, 22, 10, -1.0, None, None, None, 0, None) == _lib.PCNN_EINVAL
+    assert L.pcnn_average_distance_fwd(None, None, None, None, None, 1, 22, 10, -1.0, None, None, None, None, 0, None) == _lib.PCNN_EINVAL
     assert b"margin >= 0" in L.pcnn_last_error_string()
     # roi_pool: >= 6 ROI columns
     assert L.pcnn_roi_pool_fwd(None, None, 1, 30, 40, 512, 3, 5, 7, 7, 0.0625, 0, None, None, None) == _lib.PCNN_EINVAL
@@ -86,3 +86,17 @@ def test_product_code_never_touches_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "liboracle" not in text and "pcnn_oracle" not in text, f
                 assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
+
+
+def test_plain_c_consumer_of_the_header_links_and_runs(L):
+    """tests/capi_consumer.c includes include/posecnn_hip.h, links libposecnn_hip.so and calls the
+    host-side entry points with the header's prototypes (built by __graft_entry__.build())."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "capi_consumer")
+    src = os.path.join(ROOT, "tests", "capi_consumer.c")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(HEADER)):
+        import __graft_entry__
+        __graft_entry__.build()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "capi_consumer ok" in r.stdout

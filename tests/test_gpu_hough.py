@@ -282,7 +282,7 @@ def gpu_hough_space(gpu, label, vertex, ext, meta, vote_thr, skip, label_thr):
                                       workspace=ws, label_threshold=label_thr)
     torch.cuda.synchronize()
     offs = (ctypes.c_size_t * 8)()
-    _lib.check("debug_layout", _lib.lib().pcnn_hough_voting_debug_layout(B, H, W, C, float(vote_thr), skip, offs))
+    _lib.check("debug_layout", _lib.lib().pcnn_hough_voting_debug_layout(B, H, W, C, float(vote_thr), skip, 0, offs))
     raw = ws._buf.cpu().numpy()
     hs = raw[offs[0]:offs[0] + 4 * B * (C - 1) * H * W].view(np.float32).reshape(B, C - 1, H * W)
     slots = raw[offs[3]:offs[3] + 4 * B * C].view(np.int32).reshape(B, C)

@@ -180,3 +180,41 @@ def test_deferred_bias_relu_is_fused_only_into_max_pool():
     for a, b_ in zip(outs[False], outs[True]):
         assert torch.equal(a, b_)
     assert float(outs[True][2].min()) >= 0  # fetched by name: activated
+
+
+def test_load_keeps_depth_tower_weights_and_drops_constant_deconv_filters():
+    """(a) a checkpoint that carries '<layer>_p' entries loads each tower from its own
+    entry whatever the dict order; vgg16.npy-style dicts (no '_p' keys) still initialise both towers;
+    (b) the constant bilinear deconv filters of a checkpoint do not divert `deconv` to the dense path."""
+    from posecnn_amd.networks import is_bilinear_deconv_filter
+    rng = np.random.default_rng(4)
+    wa = rng.standard_normal((3, 3, 3, 64)).astype(F); wb = rng.standard_normal((3, 3, 3, 64)).astype(F)
+    ba = rng.standard_normal(64).astype(F); bb = rng.standard_normal(64).astype(F)
+
+    def fresh():
+        net = vgg16_convs_cpu("RGBD", 22, 64, (1.0,), 1.0, -1.0, trainable=False, is_train=False)
+        for n in ("conv1_1", "conv1_1_p"):   # the variables exist once the graph has been built
+            net.vars[n + "/weights"] = torch.zeros((64, 3, 3, 3)); net.vars[n + "/biases"] = torch.zeros(64)
+        return net
+    for order in (("conv1_1", "conv1_1_p"), ("conv1_1_p", "conv1_1")):
+        d = {k: ({"weights": wa, "biases": ba} if k == "conv1_1" else {"weights": wb, "biases": bb}) for k in order}
+        net = fresh(); net.load(d)
+        assert torch.equal(net.vars["conv1_1/biases"], torch.from_numpy(ba)), order
+        assert torch.equal(net.vars["conv1_1_p/biases"], torch.from_numpy(bb)), order
+        assert torch.equal(net.vars["conv1_1_p/weights"], torch.from_numpy(wb).permute(3, 2, 0, 1)), order
+    net = fresh(); net.load({"conv1_1": {"weights": wa, "biases": ba}})     # vgg16.npy: one entry feeds both towers
+    assert torch.equal(net.vars["conv1_1_p/biases"], torch.from_numpy(ba))
+
+    f16 = make_deconv_filter_1d(16)
+    tf_filter = np.zeros((16, 16, 64, 64), np.float64)                       # [k, k, c_out, c_in], network.py:151-157
+    for i in range(64):
+        tf_filter[:, :, i, i] = np.outer(f16, f16)
+    tf_filter = tf_filter.astype(F)
+    assert is_bilinear_deconv_filter(torch.from_numpy(tf_filter).permute(3, 2, 0, 1))
+    assert not is_bilinear_deconv_filter(torch.from_numpy(wa).permute(3, 2, 0, 1))
+    net = fresh(); assert net.fused_heads
+    net.load({"upscore": {"weights": tf_filter}})
+    assert "upscore/weights" not in net.vars and net.fused_heads           # same kernels as an unloaded network
+    trained = tf_filter.copy(); trained[3, 3, 0, 1] = 0.01                   # somebody fine-tuned the filter
+    net.load({"upscore": {"weights": trained}})
+    assert "upscore/weights" in net.vars and not net.fused_heads           # literal op order, dense conv_transpose

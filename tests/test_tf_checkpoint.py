@@ -34,13 +34,28 @@ def shape_proto(shape):
     return b"".join(pb_bytes(2, pb_varint(1, d)) for d in shape)
 
 
-def entry_proto(dtype, shape, shard, offset, size):
+def crc32c_bitwise(data, crc=0):
+    """Independent restatement (bit by bit, reflected polynomial 0x82F63B78) of the checksum the
+    reader computes natively."""
+    crc ^= 0xFFFFFFFF
+    for b in bytes(data):
+        crc ^= b
+        for _ in range(8):
+            crc = (crc >> 1) ^ 0x82F63B78 if crc & 1 else crc >> 1
+    return crc ^ 0xFFFFFFFF
+
+
+def masked(crc):
+    return (((crc >> 15) | (crc << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def entry_proto(dtype, shape, shard, offset, size, crc=0xDEADBEEF):
     out = pb_varint(1, dtype) + pb_bytes(2, shape_proto(shape))
     if shard:
         out += pb_varint(3, shard)
     if offset:
         out += pb_varint(4, offset)
-    out += pb_varint(5, size) + varint((6 << 3) | 5) + struct.pack("<I", 0xDEADBEEF)
+    out += pb_varint(5, size) + varint((6 << 3) | 5) + struct.pack("<I", crc)
     return out
 
 
@@ -91,7 +106,7 @@ def build_block(items, restart_interval=4):
     return bytes(buf)
 
 
-def write_bundle(prefix, tensors, shards=1, per_block=3, compress=False):
+def write_bundle(prefix, tensors, shards=1, per_block=3, compress=False, checksums=True):
     names = sorted(tensors)
     data = [bytearray() for _ in range(shards)]
     items = [(b"", pb_varint(1, shards) + pb_varint(2, 0) + pb_bytes(3, pb_varint(1, 1)))]
@@ -99,7 +114,8 @@ def write_bundle(prefix, tensors, shards=1, per_block=3, compress=False):
         a = np.array(tensors[name], order="C")   # (ascontiguousarray would turn a scalar into shape (1,))
         sid = n % shards
         dtype = {np.dtype(F): 1, np.dtype(np.int32): 3, np.dtype(np.int64): 9, np.dtype(np.float64): 2}[a.dtype]
-        items.append((name.encode(), entry_proto(dtype, a.shape, sid, len(data[sid]), a.nbytes)))
+        crc = masked(crc32c_bitwise(a.tobytes())) if checksums else 0xDEADBEEF
+        items.append((name.encode(), entry_proto(dtype, a.shape, sid, len(data[sid]), a.nbytes, crc)))
         data[sid] += a.tobytes()
     for sid in range(shards):
         with open("%s.data-%05d-of-%05d" % (prefix, sid, shards), "wb") as f:
@@ -109,7 +125,8 @@ def write_bundle(prefix, tensors, shards=1, per_block=3, compress=False):
     def emit(block):
         body, ctype = (snappy_compress(block), 1) if compress else (block, 0)
         handle = varint(len(out)) + varint(len(body))
-        out.extend(body + bytes([ctype]) + b"\0\0\0\0")
+        trailer = struct.pack("<I", masked(crc32c_bitwise(body + bytes([ctype])))) if checksums else b"\0\0\0\0"
+        out.extend(body + bytes([ctype]) + trailer)
         return handle
     for i in range(0, len(items), per_block):
         chunk = items[i:i + per_block]
@@ -180,3 +197,46 @@ def test_network_load_file_takes_a_checkpoint_prefix(tmp_path):
     assert net.load_file(prefix) == ["c"]
     assert torch.equal(net.vars["c/biases"], torch.from_numpy(b))
     assert torch.equal(net.vars["c/weights"], torch.from_numpy(w).permute(3, 2, 0, 1))
+
+
+def test_crc32c_known_answers():
+    """RFC 3720 appendix B.4 test vectors + the classic check value; pins the native checksum
+    independently of this file's writer."""
+    assert tfc.crc32c(b"123456789") == 0xE3069283
+    assert tfc.crc32c(bytes(32)) == 0x8A9136AA
+    assert tfc.crc32c(b"\xff" * 32) == 0x62A8AB43
+    assert tfc.crc32c(bytes(range(32))) == 0x46DD794E
+    assert tfc.crc32c(bytes(range(31, -1, -1))) == 0x113FDB5C
+    assert tfc.crc32c(b"") == 0
+    a, b = b"hello wor", b"ld, crc32c in pieces"
+    assert tfc.crc32c(b, tfc.crc32c(a)) == tfc.crc32c(a + b) == crc32c_bitwise(a + b)
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, 100003, dtype=np.uint8)
+    assert tfc.crc32c_array(x[3:]) == crc32c_bitwise(x[3:].tobytes())     # unaligned start, odd length
+    assert tfc.mask_crc(0) == 0xA282EAD8
+
+
+def test_checksums_are_verified(tmp_path):
+    rng = np.random.default_rng(1)
+    tensors = sample_tensors(rng)
+    prefix = str(tmp_path / "m.ckpt")
+    write_bundle(prefix, tensors, shards=2, per_block=2, compress=True)
+    assert set(tfc.read_checkpoint(prefix)) == set(tensors)
+    # one flipped bit in a tensor payload
+    shard = prefix + ".data-00001-of-00002"
+    raw = bytearray(open(shard, "rb").read()); raw[5] ^= 0x10
+    open(shard, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="crc32c"):
+        tfc.read_checkpoint(prefix)
+    assert set(tfc.read_checkpoint(prefix, verify=False)) == set(tensors)   # explicit opt-out still reads
+    # one flipped bit in an index block
+    write_bundle(prefix, tensors, shards=1, per_block=3)
+    raw = bytearray(open(prefix + ".index", "rb").read()); raw[12] ^= 0x01
+    open(prefix + ".index", "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="crc32c"):
+        tfc.read_index(prefix)
+    # files whose writer left the checksums blank are refused unless verification is turned off
+    write_bundle(prefix, tensors, checksums=False)
+    with pytest.raises(ValueError, match="crc32c"):
+        tfc.read_checkpoint(prefix)
+    assert set(tfc.read_checkpoint(prefix, verify=False)) == set(tensors)
