@@ -229,7 +229,9 @@ def main(argv=None):
     K[:2] *= W / 640.0   # same rule as lib/fcn/test.py:130-131
 
     net = vgg16_convs(a.input, C, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True,
-                      trainable=False, is_train=train, device=dev, seed=3, init="he")
+                      trainable=False, is_train=train, device=dev, seed=3, init="he", with_losses=False)
+    # (with_losses=False: the graph itself adds no loss layers — the log-softmax `prob` feeds only loss_cls,
+    # which nobody fetches here; im_segment_batch evaluates hard_label and average_distance_loss on request)
     synth.init_planted_heads(net)
     host, aux = make_host_inputs(100000 * rank, B, H, W, C, a.input, a.nbuf, extents, K, train)
     planted = [{k: torch.from_numpy(v).to(dev) for k, v in p.items()} for p, _, _ in aux]

@@ -271,10 +271,12 @@ int pcnn_conv3x3_c3_fwd(const float* x, const float* weights, const float* bias,
 
 /* pcnn_conv3x3_c3_fwd fused with the F(4x4,3x3) input transform of the NEXT 3x3 layer (conv1_1 ->
  * conv1_2, vgg16_convs.py:36-37): v f32 [36][T][Cout] = pcnn_winograd43_input_fwd(pcnn_conv3x3_c3_fwd(x)),
- * bit for bit, without the [B,H,W,Cout] activation in between. */
+ * bit for bit, without the [B,H,W,Cout] activation in between. groups >= 1: weights f32
+ * [groups][3,3,3,Cout], bias [groups][Cout], image b uses set b / (batch / groups) (both towers of an
+ * RGB-D network — conv1_1 and conv1_1_p, vgg16_convs.py:36,53 — in one launch). */
 int pcnn_conv3x3_c3_winograd43_fwd(const float* x, const float* weights, const float* bias, int batch,
-                                   int height, int width, int out_channels, int relu, float* v,
-                                   void* stream);
+                                   int height, int width, int out_channels, int groups, int relu,
+                                   float* v, void* stream);
 
 /* Data transforms of a Winograd F(2x2,3x3) evaluation of `Network.conv` for the deep 3x3 / stride 1 /
  * SAME layers of the trunk (network.py:159-187; vgg16_convs.py:42-52). All f32.
@@ -298,14 +300,21 @@ int pcnn_winograd43_input_fwd(const float* x, int batch, int height, int width, 
 int pcnn_winograd43_output_fwd(const float* m, const float* bias, int batch, int height, int width,
                                int channels, int relu, int pool, float* y, void* stream);
 
-/* F(4x4,3x3) GEMMs + output transform in one kernel for the Cin = 64 layers (conv1_2, conv2_1): y = [ReLU](A^T (v[k] * u[k]) A + bias) [max-pooled 2x2 when pool != 0] without
- * the transform-domain product m ever reaching HBM (fp32 MFMA, accumulators stay in registers).
- *   v  f32 [36][T][Cin]  from pcnn_winograd43_input_fwd / pcnn_conv3x3_c3_winograd43_fwd
- *   ut f32 [36][Cout][Cin]  the filter transform TRANSPOSED: ut[6i+j][co][ci] = (G g G^T)[i][j]
- *   y  f32 [B,H,W,Cout] or [B,H/2,W/2,Cout];  Cout % 64 == 0 */
-int pcnn_winograd43_gemm_output_fwd(const float* v, const float* ut, const float* bias, int batch,
-                                    int height, int width, int in_channels, int out_channels, int relu,
-                                    int pool, float* y, void* stream);
+/* F(4x4,3x3) contractions + output transform in ONE fp32-MFMA kernel (csrc/wino_mfma.hip), for every
+ * 3x3 / stride 1 / SAME layer of the trunk with Cin % 64 == 0 and Cout % 64 == 0 (conv1_2 ... conv5_3
+ * and the depth tower's twins, vgg16_convs.py:37-52,54-67):
+ *   y = [ReLU](A^T (v[k] . u[k]) A + bias)  — the transform-domain product never reaches HBM.
+ *   v    f32 [36][T][Cin]           from pcnn_winograd43_input_fwd / pcnn_conv3x3_c3_winograd43_fwd,
+ *                                   T = batch * ceil(H/4) * ceil(W/4)
+ *   ut   f32 [groups][36][Cout][Cin]  filter transforms TRANSPOSED: ut[g][6i+j][co][ci] = (G g_g G^T)[i][j]
+ *   bias f32 [groups][Cout]
+ *   groups >= 1: image b uses filter set b / (batch / groups) — the colour and depth towers of an RGB-D
+ *                network as one launch (batch % groups == 0)
+ *   pool 0: y f32 [batch,H,W,Cout];  1: y = max_pool_2x2 f32 [batch,H/2,W/2,Cout] only;
+ *        2: both (y and y_pool), for a layer like conv4_3 whose un-pooled output is read as well. */
+int pcnn_winograd43_conv_fwd(const float* v, const float* ut, const float* bias, int batch, int height,
+                             int width, int in_channels, int out_channels, int groups, int relu,
+                             int pool, float* y, float* y_pool, void* stream);
 
 /* pcnn_winograd43_output_fwd writing BOTH the activation y f32 [B,H,W,C] and its 2x2 max-pool y_pool f32
  * [B,H/2,W/2,C] in one pass (conv4_3 -> pool4, whose un-pooled output score_conv4 and roi_pool read too). */

@@ -115,7 +115,7 @@ __device__ __forceinline__ void fw_bt6(const f4* d, f4* r)
 __global__ __launch_bounds__(256) void conv3x3_c3_wino43_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ v, int H, int W, int Cout, int relu, int Ht, int Wt, int nseg,
-    long long plane)
+    long long plane, int imgs_per_group)
 {
   __shared__ float s_in[8][FW_INF];
   __shared__ __attribute__((aligned(16))) float s_y[6][FW_COLS][64];
@@ -126,6 +126,10 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wino43_kernel(
   const int cg = blockIdx.y;
   const int tx0 = seg * FW_TILES;
   const int py0 = 4 * ty - 1, px0 = 4 * tx0 - 1;   // image coordinates of patch pixel (0, 0)
+  // filter set of this image (groups: the colour and the depth tower in one launch)
+  const int grp = b / imgs_per_group;
+  w += (size_t)grp * 27 * Cout;
+  bias += (size_t)grp * Cout;
 
   // input window: rows py0-1 .. py0+6, columns px0-1 .. px0+34
   for (int i = tid; i < 8 * FW_INF; i += 256) {
@@ -207,10 +211,11 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wino43_kernel(
 }  // namespace
 
 extern "C" int pcnn_conv3x3_c3_winograd43_fwd(const float* x, const float* weights, const float* bias,
-                                              int B, int H, int W, int Cout, int relu, float* v,
+                                              int B, int H, int W, int Cout, int groups, int relu, float* v,
                                               void* stream_)
 {
   PCNN_REQUIRE(B >= 1 && H >= 1 && W >= 1, PCNN_EINVAL, "conv3x3_c3_winograd43: bad shape %dx%dx%d", B, H, W);
+  PCNN_REQUIRE(groups >= 1 && B % groups == 0, PCNN_EINVAL, "conv3x3_c3_winograd43: batch %d is not a multiple of groups %d", B, groups);
   PCNN_REQUIRE(Cout >= 64 && Cout % 64 == 0, PCNN_EINVAL,
                "conv3x3_c3_winograd43: output channels must be a multiple of 64 (got %d)", Cout);
   PCNN_REQUIRE(x && weights && bias && v, PCNN_ENULL, "conv3x3_c3_winograd43: NULL pointer");
@@ -223,7 +228,7 @@ extern "C" int pcnn_conv3x3_c3_winograd43_fwd(const float* x, const float* weigh
   PCNN_REQUIRE(blocks < (1ll << 31), PCNN_EINVAL, "conv3x3_c3_winograd43: grid too large");
   const long long plane = (long long)B * Ht * Wt * Cout;
   PCNN_LAUNCH(conv3x3_c3_wino43_kernel, dim3((unsigned)blocks, Cout / 64), dim3(256), 0, stream, x,
-              weights, bias, v, H, W, Cout, relu, Ht, Wt, nseg, plane);
+              weights, bias, v, H, W, Cout, relu, Ht, Wt, nseg, plane, B / groups);
   return check_launch("conv3x3_c3_winograd43_fwd");
 }
 

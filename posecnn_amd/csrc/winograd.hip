@@ -329,209 +329,6 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restr
   }
 }
 
-// ---- F(4x4,3x3): the 36 GEMMs and the output transform in ONE kernel, for the small-channel layers
-// (Cin 64 / 128: conv1_2 ... conv3_1). There the library GEMM is bound by streaming V in and M out
-// (K = 64: 4 flop per byte) and the output transform streams M once more; here M never leaves the
-// registers. A workgroup (4 waves) owns 32 consecutive tiles x 64 output channels; wave w owns 16 of
-// the channels. Per plane k (and 64-wide slice of Cin) the 32 x 64 block of V[k] and the 64 x 64 block
-// of the transposed filter transform Ut[k] go through LDS (double buffered, one barrier per stage;
-// rows padded to 68 floats = conflict-free ds_read_b128) into v_mfma_f32_16x16x4_f32:
-// lane l feeds A[row l&15][k l>>4], B[k l>>4][col l&15] and holds D[4(l>>4)+i][l&15] — so after
-// the last plane a lane has, for each of its 8 (tile, channel) elements, all 36 transform-domain
-// values in registers (144 accumulator VGPRs per 16-tile row block) and applies A^T m A, bias, ReLU
-// and the optional 2x2 max-pool itself. K runs in the order 16j + 4(l>>4) + i (one b128 read = 4 MFMAs), the same
-// for A and B.
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-// RB row blocks of 16 tiles per workgroup: RB = 2 (32 tiles, one workgroup per CU) or RB = 1 (two per CU)
-constexpr int WG_LD = 68;   // padded LDS row (floats)
-
-template <int V>
-struct wg_int { static constexpr int value = V; };
-
-// Compile-time unrolled software pipeline over stages [ST, NST): fetch runs PF stages ahead of
-// compute, stash moves the next stage from registers into the other LDS buffer.
-template <int CIN, int ST, int NST, int PF>
-struct wg_pipeline {
-  template <typename F, typename S, typename L, typename C>
-  static __device__ __forceinline__ void run(F&& fetch, S&& stash, L&& lds_read, C&& compute)
-  {
-    if constexpr (ST == 0) {
-      fetch(wg_int<0>{});
-      stash(wg_int<0>{});
-      wg_prefetch<1, PF, NST>(fetch);
-      __syncthreads();
-    }
-    if constexpr (ST < NST) {
-      lds_read(wg_int<ST>{});
-      if constexpr (ST + 1 < NST) stash(wg_int<ST + 1>{});
-      if constexpr (ST + 1 + PF < NST) fetch(wg_int<(ST + 1 + PF < NST ? ST + 1 + PF : 0)>{});
-      compute(wg_int<ST>{});
-      __syncthreads();
-      wg_pipeline<CIN, ST + 1, NST, PF>::run(fetch, stash, lds_read, compute);
-    }
-  }
-  template <int A, int N, int LIM, typename F>
-  static __device__ __forceinline__ void wg_prefetch(F&& fetch)
-  {
-    if constexpr (A <= N && A < LIM) {
-      fetch(wg_int<A>{});
-      wg_prefetch<A + 1, N, LIM>(fetch);
-    }
-  }
-};
-
-template <int CIN, bool POOL, int RB, int WG_PF = 2>
-__global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void wino43_gemm_output_kernel(
-    const float* __restrict__ v, const float* __restrict__ ut, const float* __restrict__ bias,
-    float* __restrict__ y, int H, int W, int Cout, int Ht, int Wt, long long T, int relu)
-{
-  __shared__ __attribute__((aligned(16))) float sA[2][16 * RB][WG_LD];
-  __shared__ __attribute__((aligned(16))) float sB[2][64][WG_LD];
-  constexpr int NH = CIN / 64;          // 64-wide K slices per plane
-  constexpr int NST = 36 * NH;          // pipeline stages
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const long long t0 = (long long)blockIdx.x * (16 * RB);
-  const int cg = blockIdx.y;
-  const int lr = lane & 15, lk = lane >> 4;
-
-  v4f acc[36][RB];
-#pragma unroll
-  for (int k = 0; k < 36; k++)
-#pragma unroll
-    for (int r = 0; r < RB; r++) acc[k][r] = (v4f){0.f, 0.f, 0.f, 0.f};
-
-  // global -> registers -> LDS. One workgroup per CU (the accumulators take the whole register
-  // file): loads run WG_PF stages ahead of the MFMAs, each stage parked in its own register set
-  // (2 float4 of A + 4 float4 of B per thread) until its turn to enter the LDS ring. (Measured: depth
-  // 2, 4 and 6 give the same time — the kernel is not bound by load latency.)
-  v4f ga[WG_PF][RB], gb[WG_PF][4];
-#define WG_FETCH(ST)                                                                                   \
-  do {                                                                                                 \
-    constexpr int st_ = (ST);                                                                          \
-    constexpr int set_ = st_ % WG_PF, k_ = st_ / NH, h_ = st_ % NH;                                    \
-    _Pragma("unroll") for (int r = 0; r < RB; r++) {                                                   \
-      const int q = tid + 256 * r, row = q >> 4, c4 = q & 15;                                          \
-      const long long t = t0 + row;                                                                    \
-      ga[set_][r] = t < T ? *reinterpret_cast<const v4f*>(v + ((long long)k_ * T + t) * CIN + h_ * 64 + c4 * 4) \
-                          : (v4f){0.f, 0.f, 0.f, 0.f};                                                 \
-    }                                                                                                  \
-    _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                    \
-      const int q = tid + 256 * r, n = q >> 4, c4 = q & 15;                                            \
-      gb[set_][r] = *reinterpret_cast<const v4f*>(ut + ((long long)k_ * Cout + cg * 64 + n) * CIN + h_ * 64 + c4 * 4); \
-    }                                                                                                  \
-  } while (0)
-#define WG_STASH(ST)                                                                                   \
-  do {                                                                                                 \
-    constexpr int st_ = (ST);                                                                          \
-    constexpr int set_ = st_ % WG_PF, buf_ = st_ & 1;                                                  \
-    _Pragma("unroll") for (int r = 0; r < RB; r++) {                                                   \
-      const int q = tid + 256 * r;                                                                     \
-      *reinterpret_cast<v4f*>(&sA[buf_][q >> 4][(q & 15) * 4]) = ga[set_][r];                          \
-    }                                                                                                  \
-    _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                    \
-      const int q = tid + 256 * r;                                                                     \
-      *reinterpret_cast<v4f*>(&sB[buf_][q >> 4][(q & 15) * 4]) = gb[set_][r];                          \
-    }                                                                                                  \
-  } while (0)
-
-  // program order per stage: LDS reads of this stage -> stash of the next -> global fetch of stage
-  // +WG_PF -> the 32 MFMAs -> barrier. The memory instructions are all in flight before the MFMA
-  // burst starts, and the barrier does not wait for the matrix pipe, so MFMAs issue nearly back to back.
-  v4f fa[RB][4], fb[4];
-  wg_pipeline<CIN, 0, NST, WG_PF>::run(
-      [&](auto st_c) { constexpr int ST = decltype(st_c)::value; WG_FETCH(ST); },
-      [&](auto st_c) { constexpr int ST = decltype(st_c)::value; WG_STASH(ST); },
-      [&](auto st_c) {
-        constexpr int ST = decltype(st_c)::value;
-        constexpr int buf = ST & 1;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          fb[j] = *reinterpret_cast<const v4f*>(&sB[buf][16 * wave + lr][16 * j + 4 * lk]);
-#pragma unroll
-          for (int r = 0; r < RB; r++) fa[r][j] = *reinterpret_cast<const v4f*>(&sA[buf][16 * r + lr][16 * j + 4 * lk]);
-        }
-      },
-      [&](auto st_c) {
-        constexpr int ST = decltype(st_c)::value;
-        constexpr int k = ST / NH;
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-#pragma unroll
-            for (int r = 0; r < RB; r++)
-              acc[k][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[r][j][i], fb[j][i], acc[k][r], 0, 0, 0);
-          }
-      });
-#undef WG_FETCH
-#undef WG_STASH
-
-  // epilogue: this lane's 8 (tile, channel) elements. Tile coordinates advance incrementally (one
-  // 32-bit division pair per row block, not three 64-bit divisions per element — those cost more
-  // instructions than the whole MFMA loop) and the stores of an element share one base pointer.
-  const int co = cg * 64 + 16 * wave + lr;
-  const float bv = bias[co];
-  const int Hp = H / 2, Wp = W / 2;
-#pragma unroll
-  for (int rb = 0; rb < RB; rb++) {
-    const long long tf = t0 + 16 * rb + 4 * lk;
-    unsigned rem = (unsigned)(tf % ((long long)Wt * Ht));   // tile inside its image (one 64-bit op pair per rb)
-    int b = (int)(tf / ((long long)Wt * Ht));
-    int ty = (int)(rem / (unsigned)Wt), tx = (int)(rem - (unsigned)ty * (unsigned)Wt);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      if (tf + i < T) {
-        float tmp[4][6];
-#pragma unroll
-        for (int jj = 0; jj < 6; jj++) {
-          float col[6], o[4];
-#pragma unroll
-          for (int ii = 0; ii < 6; ii++) col[ii] = acc[6 * ii + jj][rb][i];
-          at6(col, o);
-#pragma unroll
-          for (int a = 0; a < 4; a++) tmp[a][jj] = o[a];
-        }
-        float out[4][4];
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-          at6(tmp[a], out[a]);
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            float val = out[a][e] + bv;
-            if (relu) val = val > 0.f ? val : 0.f;
-            out[a][e] = val;
-          }
-        }
-        if (POOL) {
-          float* yp = y + (((long long)b * Hp + 2 * ty) * Wp + 2 * tx) * Cout + co;
-          const int rs = Wp * Cout;
-#pragma unroll
-          for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int e = 0; e < 2; e++)
-              if (2 * ty + a < Hp && 2 * tx + e < Wp) {
-                float p = out[2 * a][2 * e];
-                p = out[2 * a][2 * e + 1] > p ? out[2 * a][2 * e + 1] : p;
-                p = out[2 * a + 1][2 * e] > p ? out[2 * a + 1][2 * e] : p;
-                p = out[2 * a + 1][2 * e + 1] > p ? out[2 * a + 1][2 * e + 1] : p;
-                yp[a * rs + e * Cout] = p;
-              }
-        } else {
-          float* yp = y + (((long long)b * H + 4 * ty) * W + 4 * tx) * Cout + co;
-          const int rs = W * Cout;
-#pragma unroll
-          for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-              if (4 * ty + a < H && 4 * tx + e < W) yp[a * rs + e * Cout] = out[a][e];
-        }
-      }
-      if (++tx == Wt) { tx = 0; if (++ty == Ht) { ty = 0; b++; } }
-    }
-  }
-}
-
 int validate(int B, int H, int W, int C)
 {
   PCNN_REQUIRE(B >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, PCNN_EINVAL,
@@ -604,35 +401,6 @@ extern "C" int pcnn_winograd43_output_both_fwd(const float* m, const float* bias
   const long long total = T * (C / 4);
   PCNN_LAUNCH((wino43_output_kernel<2, f4>), dim3(grid_for(total)), dim3(256), 0, stream, m, bias, y, y_pool, H, W, C, Ht, Wt, relu, total, T * C);
   return check_launch("winograd43_output_both_fwd");
-}
-
-extern "C" int pcnn_winograd43_gemm_output_fwd(const float* v, const float* ut, const float* bias, int B,
-                                               int H, int W, int Cin, int Cout, int relu, int pool,
-                                               float* y, void* stream_)
-{
-  PCNN_REQUIRE(B >= 1 && H >= 1 && W >= 1, PCNN_EINVAL, "winograd43_gemm_output: bad shape %dx%dx%d", B, H, W);
-  // (Cin = 128 is implemented by the template but loses to the library GEMM + output transform, and
-  // one of its instances is miscompiled under the accumulator-register pressure — not offered)
-  PCNN_REQUIRE(Cin == 64, PCNN_EINVAL, "winograd43_gemm_output: input channels must be 64 (got %d)", Cin);
-  PCNN_REQUIRE(Cout >= 64 && Cout % 64 == 0, PCNN_EINVAL, "winograd43_gemm_output: output channels must be a multiple of 64 (got %d)", Cout);
-  PCNN_REQUIRE(!pool || (H % 2 == 0 && W % 2 == 0), PCNN_EINVAL, "winograd43_gemm_output: pooling needs even height/width");
-  PCNN_REQUIRE(v && ut && bias && y, PCNN_ENULL, "winograd43_gemm_output: NULL pointer");
-  PCNN_REQUIRE(aligned16(v) && aligned16(ut), PCNN_EINVAL, "winograd43_gemm_output: v and ut must be 16-byte aligned");
-  hipStream_t stream = (hipStream_t)stream_;
-  const int Ht = (H + 3) / 4, Wt = (W + 3) / 4;
-  const long long T = (long long)B * Ht * Wt;
-  // RB = 1 (16 tiles, 236 VGPRs, two workgroups per CU so that one's epilogue overlaps the other's MFMAs)
-  // measures 4-10 % faster than RB = 2 (32 tiles, one workgroup per CU, half the filter traffic)
-  const int rb = 1;
-  const int wg_tiles = 16 * rb;
-  const long long blocks = (T + wg_tiles - 1) / wg_tiles;
-  PCNN_REQUIRE(blocks < (1ll << 31), PCNN_EINVAL, "winograd43_gemm_output: grid too large");
-  const dim3 grid((unsigned)blocks, Cout / 64);
-#define WG_GO(CI, P, R) PCNN_LAUNCH((wino43_gemm_output_kernel<CI, P, R>), grid, dim3(256), 0, stream, v, ut, bias, y, H, W, Cout, Ht, Wt, T, relu)
-  if (rb == 1) { if (pool) WG_GO(64, true, 1); else WG_GO(64, false, 1); }
-  else { if (pool) WG_GO(64, true, 2); else WG_GO(64, false, 2); }
-#undef WG_GO
-  return check_launch("winograd43_gemm_output_fwd");
 }
 
 extern "C" int pcnn_winograd_input_fwd(const float* x, int B, int H, int W, int C, float* v,

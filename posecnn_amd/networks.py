@@ -111,6 +111,7 @@ class _RawConv(object):
         #         GEMM + output transform kernel still to run (with or without the max-pool)
         self.y, self.bias, self.relu, self.out, self.wino, self.first, self.gemm = y, bias, relu, None, wino, first, gemm
         self.dual = False
+        self.pooled = None   # the 2x2 max-pool of `out`, when the producing kernel wrote both
 
     @property
     def shape(self):
@@ -119,7 +120,9 @@ class _RawConv(object):
         if self.first is not None:
             return tuple(self.first[0].shape[:3]) + (self.first[1].shape[3],)
         if self.gemm is not None:
-            return (self.gemm[2], self.gemm[3], self.gemm[4], self.gemm[1].shape[1])
+            return (self.gemm[2], self.gemm[3], self.gemm[4], self.gemm[1].shape[-2])
+        if self.y is None and self.out is not None:
+            return tuple(self.out.shape)
         return tuple(self.y.shape)
 
 
@@ -150,7 +153,9 @@ class Network(object):
         self.winograd_min_channels = 64
         self.winograd_tile = 4
         self._wino_u = {}
-        self.winograd_fused_gemm = True      # F(4x4,3x3), Cin 64/128: GEMMs + output transform in one MFMA kernel
+        # F(4x4,3x3) layers with Cin, Cout multiples of 64: the 36 contractions + output transform run in
+        # the library's own fp32-MFMA kernel (csrc/wino_mfma.hip); False = library batched GEMM + transform kernel
+        self.winograd_mfma = True
         self.fuse_first_conv_into_winograd = True
         self.fused_first_conv = True  # 3-channel 3x3 convs go to the fused conv + bias + ReLU kernel
         self.defer_act = frozenset()  # conv layers whose bias + ReLU is left to the following max_pool
@@ -189,7 +194,7 @@ class Network(object):
                 raw.out = ops.conv3x3_c3(raw.first[0], raw.first[1], raw.bias, raw.relu)
             elif raw.gemm is not None:
                 v, ut, B, H, W = raw.gemm
-                raw.out = ops.winograd43_gemm_output(v, ut, raw.bias, B, H, W, raw.relu, pool=False)
+                raw.out = ops.winograd43_conv(v, ut, raw.bias, B, H, W, raw.relu, pool=0)
             else:
                 raw.out = self._bias_act(raw.y, raw.bias, raw.relu)
         return raw.out
@@ -206,30 +211,33 @@ class Network(object):
         return hit[1]
 
     def _winograd43_tail(self, name, v, w, b, relu, B_, H_, W_, c_i, c_o, timing):
-        """Everything after the F(4x4,3x3) input transform: fused MFMA kernel for the small-channel
-        layers, library batched GEMM + output transform kernel otherwise."""
-        # (measured, tools/bench_layers.py: the fused kernel wins for Cin = 64 — conv1_2 2.02 -> 1.48 ms,
-        # conv2_1 1.03 -> 0.86 ms — and loses to the library GEMM from Cin = 128 on)
-        fused = self.winograd_fused_gemm and c_i == 64 and c_o % 64 == 0
-        if fused:
+        """Everything after the F(4x4,3x3) input transform: the library's fp32-MFMA kernel (contractions
+        + output transform, optionally the following 2x2 max-pool) for Cin, Cout multiples of 64;
+        framework batched GEMM + output transform kernel otherwise."""
+        if self.winograd_mfma and c_i % 64 == 0 and c_o % 64 == 0:
             ut = self._winograd_filter(name, w, transposed=True)
-            executed = 2.0 * 36 * v.shape[1] * c_i * c_o
             if timing is not None:
-                timing[1].record()   # the fused GEMM + output kernel is timed by the library's own events
-            out = (_RawConv(None, b, relu, gemm=(v, ut, B_, H_, W_)) if name in self.defer_act
-                   else ops.winograd43_gemm_output(v, ut, b, B_, H_, W_, relu, pool=False))
+                timing[1].record()   # the MFMA kernel is timed by the library's own events
+                self.conv_timing.append((name, timing[2], timing[2], timing[0], timing[1]))
+            even = H_ % 2 == 0 and W_ % 2 == 0
+            if name in self.defer_act and even:
+                return _RawConv(None, b, relu, gemm=(v, ut, B_, H_, W_))      # the following max_pool decides
+            if name in self.dual_pool and even:
+                out = _RawConv(None, b, relu)
+                out.out, out.pooled = ops.winograd43_conv(v, ut, b, B_, H_, W_, relu, pool=2)
+                return out
+            return ops.winograd43_conv(v, ut, b, B_, H_, W_, relu, pool=0)
+        m = torch.bmm(v, self._winograd_filter(name, w))
+        executed = 2.0 * m.numel() * c_i
+        if timing is not None:
+            timing[1].record()   # transform + GEMMs; the output transform is timed by the library
+        if name in self.defer_act:
+            out = _RawConv(None, b, relu, wino=(m, B_, H_, W_))
+        elif name in self.dual_pool and H_ % 2 == 0 and W_ % 2 == 0:
+            out = _RawConv(None, b, relu, wino=(m, B_, H_, W_))
+            out.dual = True   # the following max_pool produces both tensors in one pass
         else:
-            m = torch.bmm(v, self._winograd_filter(name, w))
-            executed = 2.0 * m.numel() * c_i
-            if timing is not None:
-                timing[1].record()   # transform + GEMMs; the output transform is timed by the library
-            if name in self.defer_act:
-                out = _RawConv(None, b, relu, wino=(m, B_, H_, W_))
-            elif name in self.dual_pool and H_ % 2 == 0 and W_ % 2 == 0:
-                out = _RawConv(None, b, relu, wino=(m, B_, H_, W_))
-                out.dual = True   # the following max_pool produces both tensors in one pass
-            else:
-                out = ops.winograd_output(m, b, B_, H_, W_, relu, pool=False, tile=4)
+            out = ops.winograd_output(m, b, B_, H_, W_, relu, pool=False, tile=4)
         if timing is not None:
             e0, e1, extra = timing
             self.conv_timing.append((name, executed + extra, 2.0 * B_ * H_ * W_ * c_o * c_i * 9 + extra, e0, e1))
@@ -407,13 +415,15 @@ class Network(object):
     def max_pool(self, input, k_h, k_w, s_h, s_w, name, padding=DEFAULT_PADDING):
         assert padding in ("SAME", "VALID")
         if isinstance(input, _RawConv):
+            if input.pooled is not None and (k_h, k_w, s_h, s_w) == (2, 2, 2, 2):
+                return input.pooled   # written by the convolution's own kernel (pool = 2)
             if (input.out is None and (k_h, k_w, s_h, s_w) == (2, 2, 2, 2)
                     and input.shape[1] % 2 == 0 and input.shape[2] % 2 == 0):
                 if input.first is not None:
                     return F.max_pool2d(_nchw(self._activate(input)), 2, 2).permute(0, 2, 3, 1).contiguous()
                 if input.gemm is not None:
                     v, ut, B_, H_, W_ = input.gemm
-                    return ops.winograd43_gemm_output(v, ut, input.bias, B_, H_, W_, input.relu, pool=True)
+                    return ops.winograd43_conv(v, ut, input.bias, B_, H_, W_, input.relu, pool=1)
                 if input.wino is not None and input.dual and self.winograd_tile == 4:
                     m, B_, H_, W_ = input.wino
                     input.out, pooled = ops.winograd43_output_both(m, input.bias, B_, H_, W_, input.relu)
@@ -602,10 +612,8 @@ class vgg16_convs(Network):
         # roi_pool, so pool4 stays a plain max_pool)
         if fused_pool:
             self.defer_act = frozenset(n + sfx for n in ("conv1_2", "conv2_2", "conv3_3") for sfx in ("", "_p"))
-            # (conv4_3 -> pool4 could come out of one dual-output transform pass — opt in with
-            # net.dual_pool = {"conv4_3"}; on MI355X it measures 1.4 % slower end to end than the
-            # transform + a separate max_pool, so it is off)
-            self.dual_pool = frozenset()
+            # conv4_3 feeds score_conv4 and roi_pool un-pooled AND pool4: the MFMA kernel writes both
+            self.dual_pool = frozenset(("conv4_3", "conv4_3_p"))
         # fused_heads=False evaluates the heads in the reference's literal op order
         # (deconv -> 1x1 conv -> softmax -> argmax); True (default) uses the algebraically
         # identical low-resolution form + fused gfx950 epilogue (see setup()).
@@ -630,6 +638,7 @@ class vgg16_convs(Network):
         # average_distance_loss) run at train time; at test time only when asked for.
         self.with_losses = bool(is_train) if with_losses is None else bool(with_losses)
         self.planted = None
+        self.grouped_towers = True    # RGB-D inference: both towers as one grouped launch sequence
 
     def run(self, feed, planted=None):
         self.layers = dict(feed)
@@ -658,8 +667,102 @@ class vgg16_convs(Network):
             self.feed(t)
         return self
 
+    # the 3x3 layers of a VGG16 tower (vgg16_convs.py:36-52): (name, c_in, c_out, pool that follows)
+    TRUNK = (("conv1_1", 3, 64, None), ("conv1_2", 64, 64, "pool1"), ("conv2_1", 64, 128, None), ("conv2_2", 128, 128, "pool2"),
+             ("conv3_1", 128, 256, None), ("conv3_2", 256, 256, None), ("conv3_3", 256, 256, "pool3"),
+             ("conv4_1", 256, 512, None), ("conv4_2", 512, 512, None), ("conv4_3", 512, 512, "pool4"),
+             ("conv5_1", 512, 512, None), ("conv5_2", 512, 512, None), ("conv5_3", 512, 512, None))
+
+    def _trunk_vars(self, suffix):
+        """Creates (on first use) the variables of one tower in the order Network.conv would."""
+        t = self.trainable
+        out = []
+        for name, ci, co, _ in self.TRUNK:
+            w = self.make_var(name + suffix + "/weights", (co, ci, 3, 3),
+                              lambda s_, ci=ci: self._weight_init(ci * 9)(s_).contiguous(memory_format=torch.channels_last), t)
+            b = self.make_var(name + suffix + "/biases", (co,), lambda s_: torch.zeros(s_), t)
+            out.append((w, b))
+        return out
+
+    def _can_group_towers(self):
+        d = self.layers.get('data')
+        return (self.grouped_towers and self.input_format == 'RGBD' and isinstance(d, torch.Tensor) and d.is_cuda
+                and self.winograd_mfma and self.winograd_tile == 4 and self.winograd_min_channels == 64
+                and self.fused_first_conv and self.fuse_first_conv_into_winograd
+                and not (torch.is_grad_enabled() and self.trainable)
+                and d.shape[1] % 16 == 0 and d.shape[2] % 16 == 0 and self.layers['data_p'].shape == d.shape)
+
+    def _trunk_grouped(self):
+        """Both VGG16 towers of an RGB-D network (vgg16_convs.py:36-52 and :53-67) as ONE launch
+        sequence: the colour and the depth blob are stacked along the batch axis and every trunk
+        kernel runs once with `groups = 2` filter sets (image b uses set b // B). Identical arithmetic
+        to running the towers one after the other — each image still meets only its tower's weights —
+        with half the launches and twice the workgroups per launch (conv5_x alone has only 160
+        workgroups per tower for the 256 CUs). Registers conv4_3 / conv5_3 (+ '_p') and pool4."""
+        x = torch.cat([self.get_output('data'), self.get_output('data_p')], dim=0)
+        B2, H, W, _ = x.shape
+        B = B2 // 2
+        va, vb = self._trunk_vars(""), self._trunk_vars("_p")
+        key = tuple((w.data_ptr(), w._version, b.data_ptr(), b._version) for w, b in va + vb)
+        hit = self._wino_u.get("grouped")
+        if hit is None or hit[0] != key:
+            packed = []
+            for (name, ci, co, _), (w0, b0), (w1, b1) in zip(self.TRUNK, va, vb):
+                bias = torch.stack([b0, b1]).contiguous()
+                if ci == 3:   # the TF variable layout [ky, kx, ci, co] the first-conv kernel reads
+                    wt = torch.stack([w0.permute(2, 3, 1, 0), w1.permute(2, 3, 1, 0)]).contiguous()
+                else:
+                    wt = torch.stack([ops.winograd_filter(w0, 4).transpose(1, 2), ops.winograd_filter(w1, 4).transpose(1, 2)]).contiguous()
+                packed.append((wt, bias))
+            hit = (key, packed)
+            self._wino_u["grouped"] = hit
+        packed = hit[1]
+        y, h, w_ = None, H, W
+        for li, (name, ci, co, pool) in enumerate(self.TRUNK):
+            wt, bias = packed[li]
+            if ci == 3:
+                continue   # conv1_1 is evaluated inside conv1_2's input transform
+            if li == 1:
+                v = ops.conv3x3_c3_winograd43(x, packed[0][0], packed[0][1], True, groups=2)
+            else:
+                v = ops.winograd_input(y, 4)
+            mode = 0 if pool is None else (2 if name in self.dual_pool else 1)
+            out = ops.winograd43_conv(v, wt, bias, B2, h, w_, True, pool=mode, groups=2)
+            if mode == 2:
+                full, y = out
+            else:
+                full = y = out
+            if name in ("conv4_3", "conv5_3"):
+                self.layers[name], self.layers[name + "_p"] = full[:B], full[B:]
+            if pool is not None:
+                if mode == 0:
+                    y = _nhwc(F.max_pool2d(_nchw(y), 2, 2))
+                h, w_ = h // 2, w_ // 2
+                if pool == "pool4":
+                    self.layers["pool4"], self.layers["pool4_p"] = y[:B], y[B:]
+        return self
+
+    def hbm_table(self, B, H, W):
+        """Algorithmic HBM bytes per step of the library's streaming trunk kernels (for bench.py)."""
+        towers = 2 if self.input_format == 'RGBD' else 1
+        act = lambda div, ch: 4.0 * B * (H // div) * (W // div) * ch
+        x_in = (act(2, 64) + act(2, 128) + act(4, 128) + 2 * act(4, 256) + act(8, 256) + 2 * act(8, 512) + 3 * act(16, 512))
+        return {"conv3x3_c3_wino43_kernel": towers * (act(1, 3) + 2.25 * act(1, 64)),      # reads the frame, writes V of conv1_2
+                "wino43_input_kernel": towers * 3.25 * x_in}                             # reads X, writes V = 2.25 X
+
+    def mfma_table(self, B, H, W):
+        """Executed flops per step of the library's fp32-MFMA kernels (for bench.py)."""
+        towers = 2 if self.input_format == 'RGBD' else 1
+        tiles = lambda div: B * ((H // div + 3) // 4) * ((W // div + 3) // 4)
+        div = {"1": 1, "2": 2, "3": 4, "4": 8, "5": 16}
+        fl = sum(2.0 * 36 * tiles(div[n[4]]) * ci * co for n, ci, co, _ in self.TRUNK if ci != 3)
+        return {"wino43_mfma_kernel": towers * fl}
+
     def setup(self):
         t = self.trainable
+        if self._can_group_towers():
+            self._trunk_grouped()
+            return self._setup_heads()
         (self.feed('data')
              .conv(3, 3, 64, 1, 1, name='conv1_1', c_i=3, trainable=t)
              .conv(3, 3, 64, 1, 1, name='conv1_2', c_i=64, trainable=t)
@@ -698,7 +801,10 @@ class vgg16_convs(Network):
                  .conv(3, 3, 512, 1, 1, name='conv5_1_p', c_i=512, trainable=t)
                  .conv(3, 3, 512, 1, 1, name='conv5_2_p', c_i=512, trainable=t)
                  .conv(3, 3, 512, 1, 1, name='conv5_3_p', c_i=512, trainable=t))
+        return self._setup_heads()
 
+    def _setup_heads(self):
+        if self.input_format == 'RGBD':
             (self.feed('conv5_3', 'conv5_3_p')
                  .concat(3, name='concat_conv5')
                  .conv(1, 1, self.num_units, 1, 1, name='score_conv5', c_i=1024)

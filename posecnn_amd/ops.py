@@ -388,8 +388,9 @@ def conv3x3_c3(x, weights, bias, relu=True):
     return y
 
 
-def conv3x3_c3_winograd43(x, weights, bias, relu=True):
-    """winograd_input(conv3x3_c3(x, weights, bias, relu), tile=4) in one kernel: V [36, T, Cout]."""
+def conv3x3_c3_winograd43(x, weights, bias, relu=True, groups=1):
+    """winograd_input(conv3x3_c3(x, weights, bias, relu), tile=4) in one kernel: V [36, T, Cout].
+    groups > 1: weights [groups,3,3,3,Cout], bias [groups,Cout]; image b uses set b // (B // groups)."""
     x = _dev(x, "x", torch.float32)
     weights = _dev(weights, "weights", torch.float32)
     bias = _dev(bias, "bias", torch.float32)
@@ -397,11 +398,12 @@ def conv3x3_c3_winograd43(x, weights, bias, relu=True):
         raise ValueError("x must be [B,H,W,3]")
     B, H, W, _ = x.shape
     Cout = weights.shape[-1]
-    if tuple(weights.shape) != (3, 3, 3, Cout) or bias.numel() != Cout:
-        raise ValueError("weights must be [3,3,3,Cout] (ky,kx,ci,co) and bias [Cout]")
+    if weights.numel() != groups * 27 * Cout or tuple(weights.shape[-4:]) != (3, 3, 3, Cout) or bias.numel() != groups * Cout:
+        raise ValueError("weights must be [groups,3,3,3,Cout] (ky,kx,ci,co) and bias [groups,Cout]")
     v = torch.empty((36, B * ((H + 3) // 4) * ((W + 3) // 4), Cout), dtype=torch.float32, device=x.device)
     check("pcnn_conv3x3_c3_winograd43_fwd",
-          lib().pcnn_conv3x3_c3_winograd43_fwd(_ptr(x), _ptr(weights), _ptr(bias), B, H, W, Cout, 1 if relu else 0, _ptr(v), _stream(x)))
+          lib().pcnn_conv3x3_c3_winograd43_fwd(_ptr(x), _ptr(weights), _ptr(bias), B, H, W, Cout, int(groups),
+                                               1 if relu else 0, _ptr(v), _stream(x)))
     return v
 
 
@@ -469,21 +471,28 @@ def winograd43_output_both(m, bias, B, H, W, relu=True):
     return y, yp
 
 
-def winograd43_gemm_output(v, ut, bias, B, H, W, relu=True, pool=False):
-    """The 36 GEMMs + output transform of F(4x4,3x3) in one fp32-MFMA kernel (Cin = 64):
-    v [36,T,Cin], ut [36,Cout,Cin] (= winograd_filter(w, 4).transpose(1, 2)) -> y [B,H,W,Cout] or pooled."""
+def winograd43_conv(v, ut, bias, B, H, W, relu=True, pool=0, groups=1):
+    """The 36 Winograd-domain contractions + output transform of F(4x4,3x3) in one fp32-MFMA kernel:
+    v [36,T,Cin], ut [groups,36,Cout,Cin] (= winograd_filter(w, 4).transpose(1, 2) per group), bias
+    [groups,Cout] -> y [B,H,W,Cout] (pool=0), its 2x2 max-pool [B,H/2,W/2,Cout] (pool=1) or both (pool=2,
+    returns (y, y_pool)). `groups`: image b uses filter set b // (B // groups)."""
     v = _dev(v, "v", torch.float32)
     ut = _dev(ut, "ut", torch.float32)
     bias = _dev(bias, "bias", torch.float32)
-    Cin, Cout = v.shape[2], ut.shape[1]
-    if v.shape[0] != 36 or v.shape[1] != _wino_tiles(B, H, W, 4) or tuple(ut.shape) != (36, Cout, Cin) or bias.numel() != Cout:
-        raise ValueError("v must be [36, tiles, Cin], ut [36, Cout, Cin], bias [Cout]")
-    shape = (B, H // 2, W // 2, Cout) if pool else (B, H, W, Cout)
-    y = torch.empty(shape, dtype=torch.float32, device=v.device)
-    check("pcnn_winograd43_gemm_output_fwd",
-          lib().pcnn_winograd43_gemm_output_fwd(_ptr(v), _ptr(ut), _ptr(bias), B, H, W, Cin, Cout, 1 if relu else 0,
-                                                1 if pool else 0, _ptr(y), _stream(v)))
-    return y
+    Cin = v.shape[2]
+    if ut.dim() == 3:
+        ut = ut.unsqueeze(0)
+    Cout = ut.shape[2]
+    if (v.shape[0] != 36 or v.shape[1] != _wino_tiles(B, H, W, 4) or tuple(ut.shape) != (groups, 36, Cout, Cin)
+            or bias.numel() != groups * Cout):
+        raise ValueError("v must be [36, tiles, Cin], ut [groups, 36, Cout, Cin], bias [groups, Cout]")
+    pool = int(pool)
+    y = torch.empty((B, H // 2, W // 2, Cout) if pool == 1 else (B, H, W, Cout), dtype=torch.float32, device=v.device)
+    yp = torch.empty((B, H // 2, W // 2, Cout), dtype=torch.float32, device=v.device) if pool == 2 else None
+    check("pcnn_winograd43_conv_fwd",
+          lib().pcnn_winograd43_conv_fwd(_ptr(v), _ptr(ut), _ptr(bias), B, H, W, Cin, Cout, int(groups), 1 if relu else 0,
+                                         pool, _ptr(y), _ptr(yp), _stream(v)))
+    return (y, yp) if pool == 2 else y
 
 
 def conv3x3_winograd(x, u, bias, relu=True, pool=False, tile=2):

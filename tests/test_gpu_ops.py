@@ -607,39 +607,50 @@ def test_network_first_conv_fusion_is_transparent(gpu):
         same(a, b_, "fused vs unfused first conv")
 
 
-@pytest.mark.parametrize("shape,cout,pool", [((1, 8, 16, 64), 64, False), ((2, 12, 20, 64), 128, True), ((1, 30, 44, 64), 128, False),
-                                             ((1, 10, 6, 64), 256, True), ((3, 5, 7, 64), 64, False), ((1, 120, 160, 64), 64, True),
-                                             ((2, 30, 44, 64), 192, True), ((1, 34, 18, 64), 64, False), ((5, 9, 9, 64), 64, False)])
-def test_winograd43_fused_gemm_output_kernel(gpu, shape, cout, pool):
-    """GEMMs + output transform in one MFMA kernel against the unfused pair (library batched GEMM +
-    wino43_output_kernel) and a float64 direct convolution. Only the K summation order differs from the
-    library GEMM; A^T . A amplifies that rounding difference by up to 8 x 8, so the two f32 paths agree to
-    ~1e-5 of the output range — each is within F(4x4,3x3)'s usual error of the float64 reference."""
+@pytest.mark.parametrize("shape,cout,pool,groups", [
+    ((1, 8, 16, 64), 64, 0, 1), ((2, 12, 20, 64), 128, 1, 1), ((1, 30, 44, 64), 128, 0, 1), ((1, 10, 6, 64), 256, 1, 1),
+    ((3, 5, 7, 64), 64, 0, 1), ((1, 120, 160, 64), 64, 1, 1), ((2, 30, 44, 128), 192, 2, 1), ((1, 34, 18, 128), 64, 0, 1),
+    ((5, 9, 9, 64), 64, 0, 1), ((2, 60, 80, 256), 256, 0, 1), ((2, 30, 40, 512), 512, 2, 2), ((4, 16, 16, 512), 512, 0, 2),
+    ((2, 24, 20, 256), 512, 1, 2), ((6, 10, 14, 128), 128, 0, 3), ((2, 64, 64, 64), 64, 1, 2)])
+def test_winograd43_mfma_conv_kernel(gpu, shape, cout, pool, groups):
+    """The 36 Winograd-domain contractions + output transform in one fp32-MFMA kernel (csrc/wino_mfma.hip)
+    against (a) the unfused pair — library batched GEMM + wino43_output_kernel — and (b) a float64 direct
+    convolution, per group. Only the summation orders differ (K order inside the MFMA chain, column-wise
+    output transform); A^T . A amplifies that rounding difference by up to 8 x 8, so the f32 paths agree to
+    ~1e-5 of the output range, each within F(4x4,3x3)'s usual error of the float64 reference. Covers every
+    Cin of the trunk, partial tiles, tile counts that are no multiple of the 64-tile workgroup, all three
+    pooling modes and grouped (two-tower) launches."""
     import torch
     from posecnn_amd import ops
     torch.backends.cuda.matmul.allow_tf32 = False
     rng = np.random.default_rng(81)
     B, H, W, C = shape
-    if pool and (H % 2 or W % 2):
-        pytest.skip("pooling needs even sizes")
     x = np.maximum(rng.standard_normal(shape), 0).astype(F)
-    w = (rng.standard_normal((cout, C, 3, 3)) * np.sqrt(2.0 / (9 * C))).astype(F)
-    b = rng.standard_normal(cout).astype(F)
+    w = (rng.standard_normal((groups, cout, C, 3, 3)) * np.sqrt(2.0 / (9 * C))).astype(F)
+    b = rng.standard_normal((groups, cout)).astype(F)
     xt, wt, bt = T(gpu, x), T(gpu, w), T(gpu, b)
-    u = ops.winograd_filter(wt, 4)
     v = ops.winograd_input(xt, 4)
-    want = N(ops.winograd_output(torch.bmm(v, u), bt, B, H, W, True, pool, 4))
-    got = N(ops.winograd43_gemm_output(v, u.transpose(1, 2).contiguous(), bt, B, H, W, True, pool))
-    assert got.shape == want.shape
-    scale = np.abs(want).max()
-    assert np.abs(got - want).max() <= 3e-5 * scale, np.abs(got - want).max() / scale
-    ref = torch.nn.functional.conv2d(xt.double().permute(0, 3, 1, 2), wt.double(), bt.double(), padding=1).permute(0, 2, 3, 1)
-    ref = np.maximum(ref.cpu().numpy(), 0)
-    if pool:
-        ref = ref.reshape(B, H // 2, 2, W // 2, 2, cout).max(axis=(2, 4))
-    assert np.abs(got - ref).max() <= 5e-5 * np.abs(ref).max()
-    assert np.abs(got - want).max() <= 3e-5 * scale
-    # exhaustive agreement also in the worst element-wise sense: no isolated wrong values
-    assert (np.abs(got - want) > 1e-3 * scale).sum() == 0
-    with pytest.raises(ValueError):   # only Cin = 64 is offered
-        ops.winograd43_gemm_output(v[:, :, :32].contiguous(), u.transpose(1, 2)[:, :, :32].contiguous(), bt, B, H, W)
+    ut = torch.stack([ops.winograd_filter(wt[g], 4).transpose(1, 2) for g in range(groups)]).contiguous()
+    out = ops.winograd43_conv(v, ut, bt, B, H, W, True, pool, groups)
+    got_full, got_pool = (N(out[0]), N(out[1])) if pool == 2 else ((None, N(out)) if pool == 1 else (N(out), None))
+    Bg = B // groups
+    for g in range(groups):
+        sl = slice(g * Bg, (g + 1) * Bg)
+        ref = torch.nn.functional.conv2d(xt[sl].double().permute(0, 3, 1, 2), wt[g].double(), bt[g].double(), padding=1).permute(0, 2, 3, 1)
+        ref = np.maximum(ref.cpu().numpy(), 0)
+        vg = ops.winograd_input(xt[sl].contiguous(), 4)
+        want = N(ops.winograd_output(torch.bmm(vg, ops.winograd_filter(wt[g], 4)), bt[g], Bg, H, W, True, False, 4))
+        scale = np.abs(ref).max()
+        if got_full is not None:
+            assert got_full.shape == (B, H, W, cout)
+            assert np.abs(got_full[sl] - ref).max() <= 5e-5 * scale, (g, np.abs(got_full[sl] - ref).max() / scale)
+            assert np.abs(got_full[sl] - want).max() <= 3e-5 * scale
+            assert (np.abs(got_full[sl] - want) > 1e-3 * scale).sum() == 0   # no isolated wrong values
+        if got_pool is not None:
+            refp = ref.reshape(Bg, H // 2, 2, W // 2, 2, cout).max(axis=(2, 4))
+            assert got_pool.shape == (B, H // 2, W // 2, cout)
+            assert np.abs(got_pool[sl] - refp).max() <= 5e-5 * scale, (g, np.abs(got_pool[sl] - refp).max() / scale)
+    if pool == 2:   # the pooled tensor is exactly the max-pool of the full one
+        same(got_pool, got_full.reshape(B, H // 2, 2, W // 2, 2, cout).max(axis=(2, 4)), "pool of own output")
+    with pytest.raises(ValueError):   # channels must be multiples of 64
+        ops.winograd43_conv(v[:, :, :32].contiguous(), ut[:, :, :, :32].contiguous(), bt, B, H, W)

@@ -80,16 +80,6 @@ def main():
                 res["layers"][name].update({"winograd43_total_ms": round(ms_w4, 4), "winograd43_input_ms": round(ms_in4, 4),
                                             "winograd43_gemm_ms": round(ms_mm4, 4),
                                             "winograd43_gemm_TFLOPs": round(2.0 * v4.numel() * co / ms_mm4 / 1e9, 1)})
-                if ci == 64 and co % 64 == 0:
-                    ut4 = u4.transpose(1, 2).contiguous()
-                    ms_fg = timeit(lambda: ops.winograd43_gemm_output(v4, ut4, b, B, H, W, True, False))
-                    ms_fgp = timeit(lambda: ops.winograd43_gemm_output(v4, ut4, b, B, H, W, True, True))
-                    m4 = torch.bmm(v4, u4)
-                    ms_out = timeit(lambda: ops.winograd_output(m4, b, B, H, W, True, False, 4))
-                    res["layers"][name].update({"fused_gemm_output_ms": round(ms_fg, 4), "fused_gemm_output_pool_ms": round(ms_fgp, 4),
-                                                "unfused_gemm_plus_output_ms": round(ms_mm4 + ms_out, 4),
-                                                "fused_TFLOPs": round(2.0 * v4.numel() * co / ms_fg / 1e9, 1)})
-                    del m4
                 del v4
             if ci == 3:
                 xh = x.permute(0, 2, 3, 1).contiguous()

@@ -18,7 +18,7 @@ u = ops.winograd_filter(w, 4)
 v = ops.winograd_input(x, 4)
 want = ops.winograd_output(torch.bmm(v, u), b, B, H, W, True, pool, 4)
 for rep in range(3):
-    got = ops.winograd43_gemm_output(v, u.transpose(1, 2).contiguous(), b, B, H, W, True, pool)
+    got = ops.winograd43_conv(v, u.transpose(1, 2).contiguous(), b, B, H, W, True, 1 if pool else 0)
     d = (got - want).abs()
     bad = (d > 1e-3).nonzero()
     print("rep", rep, "bad", bad.shape[0], "of", d.numel(), "max", float(d.max()))
