@@ -20,8 +20,11 @@
 //    lets a 64 x 64 block fit the register file (360 KB of the CU's 512 KB) — 4x the tile of the
 //    round-1 kernel, i.e. 2.5x fewer operand bytes per flop through L2 -> LDS (16 B/clk/CU).
 //  * Operands go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no
-//    ds_write pass), double buffered, ONE barrier per 64-deep K stage: the 4 DMA instructions a
-//    wave issues for stage s+1 fly under the 32 MFMAs of stage s. The LDS image is the DMA's
+//    ds_write pass) through a ring of 3 stage buffers, ONE barrier per 64-deep K stage: the 4 DMA
+//    instructions a wave issues for stage s+2 fly under the MFMAs of stages s and s+1 (a stage of a
+//    Cin = 64 layer is a fresh HBM miss per plane: one stage of cover is not enough). The barrier
+//    is a raw s_barrier behind a COUNTED s_waitcnt vmcnt(4) — __syncthreads() would drain the DMA
+//    queue (vmcnt(0)) every stage. The LDS image is the DMA's
 //    lane-linear one (rows of 64 floats, unpadded); bank conflicts are avoided by an XOR swizzle of
 //    the 16-byte chunk index with the row (applied to the SOURCE address of the DMA and to the
 //    ds_read_b128 address — the same involution on both sides). One b128 read feeds 4 MFMAs (K is
@@ -43,15 +46,16 @@ using namespace pcnn;
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int WM_BT = 64;     // tiles per workgroup
+constexpr int WM_BT = 64;     // tiles per workgroup (template WR = 2; WR = 1: 32 tiles, 4 waves, two workgroups per CU)
 constexpr int WM_BC = 64;     // output channels per workgroup
 constexpr int WM_KC = 64;     // K (input channels) per pipeline stage
 constexpr int WM_LD = 64;     // LDS row (floats): unpadded, XOR-swizzled 16-byte chunks
 constexpr int WM_THREADS = 512;
+constexpr int WM_NBUF = 3;    // stage buffers in the LDS ring (prefetch distance 2)
 
 // 16 bytes per lane, global -> LDS, no register round trip. LDS destination = wave-uniform base +
 // 16 * lane (so the image is lane-linear); the per-lane SOURCE address carries the swizzle.
-__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base)
+__device__ __forceinline__ void glds16(const char* g, float* lds_wave_base)
 {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -69,15 +73,19 @@ __device__ __forceinline__ void at6_col(const float* m, float* t)
 }
 
 // POOL: 0 = y [.,H,W,Cout]; 1 = only max_pool_2x2(y) (written to y); 2 = both (y and ypool)
-template <int POOL>
-__global__ __launch_bounds__(WM_THREADS, 2) void wino43_mfma_kernel(
+// WR: wave rows — 2: 64 tiles x 64 channels, 8 waves, one workgroup per CU; 1: 32 x 64, 4 waves, two
+// workgroups per CU (finer work quanta for the layers with few tiles: conv5_x has 320 blocks of 64 tiles
+// for 256 CUs, i.e. a second round that is 25 % full).
+template <int POOL, int WR>
+__global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
     const float* __restrict__ v, const float* __restrict__ ut, const float* __restrict__ bias,
     float* __restrict__ y, float* __restrict__ ypool, int H, int W, int Cin, int Cout, int Ht, int Wt,
     long long T, long long tiles_per_group, int relu, int nbt, int ncb)
 {
-  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * 64 * WM_LD];   // sA[2][64][68] | sB[2][64][68]
-  float(*sA)[64][WM_LD] = reinterpret_cast<float(*)[64][WM_LD]>(smem);
-  float(*sB)[64][WM_LD] = reinterpret_cast<float(*)[64][WM_LD]>(smem + 2 * 64 * WM_LD);
+  constexpr int BT = 32 * WR, NW = 4 * WR, NT = 256 * WR;
+  __shared__ __attribute__((aligned(16))) float smem[WM_NBUF * (BT + 64) * WM_LD];   // sA[3][BT][64] | sB[3][64][64]
+  float(*sA)[BT][WM_LD] = reinterpret_cast<float(*)[BT][WM_LD]>(smem);
+  float(*sB)[64][WM_LD] = reinterpret_cast<float(*)[64][WM_LD]>(smem + WM_NBUF * BT * WM_LD);
 
   // XCD-aware block map: XCD x = blockIdx % 8 takes tile blocks tb == x (mod 8); on an XCD the
   // channel blocks of a tile block are consecutive
@@ -87,30 +95,38 @@ __global__ __launch_bounds__(WM_THREADS, 2) void wino43_mfma_kernel(
   if (tb >= nbt) return;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave & (WR - 1), wn = wave / WR;
   const int lr = lane & 15, lk = lane >> 4;
   // tile blocks never straddle a group: group g owns tiles [g tpg, (g+1) tpg) in nbg blocks of 64
-  const int nbg = (int)((tiles_per_group + WM_BT - 1) / WM_BT);
+  const int nbg = (int)((tiles_per_group + BT - 1) / BT);
   const int grp = tb / nbg;
-  const long long t0 = (long long)grp * tiles_per_group + (long long)(tb - grp * nbg) * WM_BT;
+  const long long t0 = (long long)grp * tiles_per_group + (long long)(tb - grp * nbg) * BT;
   const long long tend = (long long)(grp + 1) * tiles_per_group;   // first tile that is not this block's business
   const float* utg = ut + (size_t)grp * 36 * Cout * Cin;
   const int NK = Cin / WM_KC;
 
-  // staging: a stage = 64 rows x 256 B of V and of U^T = 2 x 16 DMA instructions of 4 rows each;
-  // wave w issues instructions 2w and 2w + 1 of both. Lane l of instruction ii lands at row
-  // 4 ii + (l >> 4), physical chunk l & 15, and therefore fetches logical chunk (l & 15) ^ (row & 15).
-  const int dr0 = 8 * wave + lk, dr1 = dr0 + 4;                 // the lane's rows in its two instructions
+  // staging: a stage = BT rows x 256 B of V and 64 rows of U^T = BT/4 + 16 DMA instructions of 4 rows
+  // each; wave w issues V instructions 2w, 2w + 1 and U^T instructions (16/NW) w ... Lane l of
+  // instruction ii lands at row 4 ii + (l >> 4), physical chunk l & 15, and therefore fetches logical
+  // chunk (l & 15) ^ (row & 15).
+  constexpr int UB = 16 / NW;                                   // U^T instructions per wave (2 or 4)
+  const int dr0 = 8 * wave + lk, dr1 = dr0 + 4;                 // the lane's V rows in its two instructions
   const int dc0 = (lr ^ (dr0 & 15)) * 4, dc1 = (lr ^ (dr1 & 15)) * 4;
+  const int ur0 = 4 * UB * wave + lk;                           // first U^T row; instruction i adds 4 i
   const long long tlast = tend - 1;
   const long long ta0 = t0 + dr0 < tend ? t0 + dr0 : tlast, ta1 = t0 + dr1 < tend ? t0 + dr1 : tlast;   // rows past the end: any finite data, never stored
-  const float* va0 = v + ta0 * Cin + dc0;
-  const float* va1 = v + ta1 * Cin + dc1;
-  const float* ub0 = utg + (size_t)(cb * WM_BC + dr0) * Cin + dc0;
-  const float* ub1 = utg + (size_t)(cb * WM_BC + dr1) * Cin + dc1;
+  // per-lane BYTE offsets (32 bit) from wave-uniform bases: the DMA then addresses as SGPR base + VGPR
+  // offset and the per-stage pointer arithmetic stays on the scalar unit
+  const unsigned va0 = (unsigned)((ta0 * Cin + dc0) * 4), va1 = (unsigned)((ta1 * Cin + dc1) * 4);
+  unsigned ub[UB];
+#pragma unroll
+  for (int i = 0; i < UB; i++) ub[i] = (unsigned)((((size_t)(cb * WM_BC + ur0 + 4 * i)) * Cin + (lr ^ ((ur0 + 4 * i) & 15)) * 4) * 4);
+  const char* vbase = reinterpret_cast<const char*>(v);
+  const char* ubase = reinterpret_cast<const char*>(utg);
   const long long vplane = T * Cin;
   const long long uplane = (long long)Cout * Cin;
-  const int ldsw = 8 * wave * WM_LD;                            // this wave's first row (floats) inside a block
+  const int ldsw = 8 * wave * WM_LD;                            // this wave's first V row (floats) inside a stage buffer
+  const int ldsu = 4 * UB * wave * WM_LD;                       // ... and its first U^T row
 
   v4f acc[6][2];
 #pragma unroll
@@ -125,79 +141,154 @@ __global__ __launch_bounds__(WM_THREADS, 2) void wino43_mfma_kernel(
 
 #define WM_DMA(BUF, VO, UO)                                                  \
   do {                                                                       \
-    glds16(va0 + (VO), &sA[BUF][0][0] + ldsw);                               \
-    glds16(va1 + (VO), &sA[BUF][0][0] + ldsw + 4 * WM_LD);                   \
-    glds16(ub0 + (UO), &sB[BUF][0][0] + ldsw);                               \
-    glds16(ub1 + (UO), &sB[BUF][0][0] + ldsw + 4 * WM_LD);                   \
+    const char* vs_ = vbase + (VO) * 4;                                      \
+    const char* us_ = ubase + (UO) * 4;                                      \
+    glds16(vs_ + va0, &sA[BUF][0][0] + ldsw);                                \
+    glds16(vs_ + va1, &sA[BUF][0][0] + ldsw + 4 * WM_LD);                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < UB; i_++)                         \
+      glds16(us_ + ub[i_], &sB[BUF][0][0] + ldsu + 4 * i_ * WM_LD);           \
   } while (0)
 
-  // stage 0 = plane k = 0 (xi = 0, nu = 0), kc = 0
-  WM_DMA(0, 0, 0);
-  __syncthreads();
+  // Stage order: nu outer, xi, then kc fastest; (pnu, pxi, pkc) is the prefetch pointer, two stages
+  // ahead of the compute pointer. Prologue: stages 0 and 1 in flight.
+  // The prefetch offsets (floats) advance incrementally on the scalar unit: next K slice +64; next
+  // plane of the column k += 6; next column k: 30 + nu -> nu + 1.
+  int pnu = 0, pxi = 0, pkc = 0;
+  long long pvo = 0, puo = 0;
+  const long long kback = (long long)(NK - 1) * WM_KC;
+  // branch-free (selects on the scalar unit), so that a stage body is ONE basic block and the DMA
+  // issue interleaves with the MFMAs; past the last stage the pointer parks on it (the two extra
+  // prefetches re-load the last stage into a free buffer and are drained before the epilogue)
+  const long long dvx = 6 * vplane - kback, dux = 6 * uplane - kback;       // next plane of the column
+  const long long dvn = -29 * vplane - kback, dun = -29 * uplane - kback;   // next column
+#define WM_PF_ADVANCE()                                                                          \
+  do {                                                                                           \
+    const bool wk_ = pkc + 1 == NK, wx_ = wk_ && pxi == 5, end_ = wx_ && pnu == 5;               \
+    pvo += end_ ? 0 : wx_ ? dvn : wk_ ? dvx : (long long)WM_KC;                                  \
+    puo += end_ ? 0 : wx_ ? dun : wk_ ? dux : (long long)WM_KC;                                  \
+    pkc = end_ ? pkc : wk_ ? 0 : pkc + 1;                                                        \
+    pxi = end_ ? pxi : wx_ ? 0 : wk_ ? pxi + 1 : pxi;                                            \
+    pnu = (wx_ && !end_) ? pnu + 1 : pnu;                                                        \
+  } while (0)
+  { WM_DMA(0, pvo, puo); WM_PF_ADVANCE(); }
+  { WM_DMA(1, pvo, puo); WM_PF_ADVANCE(); }
   int cur = 0;
 
   // ds_read side of the swizzle: row R = (..) + lr, logical chunk 4 j + lk -> physical (4 j + lk) ^ lr
   const int ra0 = (32 * wm + lr) * WM_LD, ra1 = ra0 + 16 * WM_LD, rb = (16 * wn + lr) * WM_LD;
 
-  // One pipeline stage on accumulator set XI. `nk`/`nkc` = plane and K slice of the NEXT stage.
-#define WM_STAGE(XI)                                                                                  \
+  // The K loop is software pipelined by half a stage: the 16 MFMAs of K groups 2, 3 of stage s-1 are
+  // issued AFTER the barrier of stage s, behind the LDS reads of groups 0, 1 of stage s — so the LDS
+  // latency that follows every barrier (all 8 waves would otherwise wait for their first operands at
+  // the same moment, with the matrix pipe idle) and the latency of the mid-stage reads are both
+  // covered by MFMAs that are already queued. Two operand register sets: X (groups 0, 1), Y (2, 3).
+  v4f xa0[2], xa1[2], xb[2], ya0[2], ya1[2], yb[2];
+  // The LDS reads are inline asm: hipcc's own s_waitcnt insertion collapses to lgkmcnt(0) across the
+  // loop back edge (it would wait for reads issued a moment ago), so the reads are invisible to it
+  // and the waits are placed by hand: lgkmcnt(0) inside the stage barrier retires the Y reads, one
+  // lgkmcnt(0) after Y's MFMAs retires the X reads. sched_barrier(0) pins the order around them.
+  const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)smem;
+  unsigned adA[4], adB[4];   // byte addresses of this lane's operand chunks in stage buffer 0, per K group
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const unsigned chb = (unsigned)(((4 * j + lk) ^ lr) * 16);
+    adA[j] = lds0 + (unsigned)ra0 * 4u + chb;
+    adB[j] = lds0 + (unsigned)(WM_NBUF * BT * WM_LD + rb) * 4u + chb;
+  }
+#define WM_DSREAD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(DST) : "v"(ADDR))
+#define WM_READ(SA0, SA1, SB, G0)                                                                     \
+  _Pragma("unroll") for (int g_ = 0; g_ < 2; g_++) {                                                  \
+    const unsigned aa_ = adA[(G0) + g_] + curA, ab_ = adB[(G0) + g_] + curB;                           \
+    WM_DSREAD(SB[g_], ab_, 0);                                                                        \
+    WM_DSREAD(SA0[g_], aa_, 0);                                                                       \
+    WM_DSREAD(SA1[g_], aa_, 4096);   /* 16 rows further */                                             \
+  }
+#define WM_MFMA1(SA0, SA1, SB, G, ACC)                                                                \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {                                                  \
+    ACC[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(SA0[G][i_], SB[G][i_], ACC[0], 0, 0, 0);            \
+    ACC[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(SA1[G][i_], SB[G][i_], ACC[1], 0, 0, 0);            \
+  }
+#define WM_MFMA(SA0, SA1, SB, ACC)                                                                    \
+  WM_MFMA1(SA0, SA1, SB, 0, ACC) WM_MFMA1(SA0, SA1, SB, 1, ACC)
+  // column NU of the transform domain is complete: t = A^T M[:, NU]; Y[a][e] += t[a] * A[NU][e]
+  // with A[NU][:] = (1,0,0,0) (1,1,1,1) (1,-1,1,-1) (1,2,4,8) (1,-2,4,-8) (0,0,0,1); accumulators recycled
+#define WM_FOLD(NU)                                                                                   \
   do {                                                                                                \
-    int nkc = kc + 1, nxi = (XI), nnu = nu;                                                           \
-    if (nkc == NK) { nkc = 0; nxi = (XI) + 1; if (nxi == 6) { nxi = 0; nnu = nu + 1; } }               \
-    if (nnu < 6) {                                                                                    \
-      const long long nk = 6 * nxi + nnu;                                                             \
-      WM_DMA(cur ^ 1, nk * vplane + nkc * WM_KC, nk * uplane + nkc * WM_KC);                           \
-    }                                                                                                 \
-    const float* pa = &sA[cur][0][0];                                                                 \
-    const float* pb = &sB[cur][0][0];                                                                 \
-    _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                   \
-      const int ch = ((4 * j + lk) ^ lr) * 4;                                                         \
-      const v4f fb = *reinterpret_cast<const v4f*>(pb + rb + ch);                                     \
-      const v4f fa0 = *reinterpret_cast<const v4f*>(pa + ra0 + ch);                                   \
-      const v4f fa1 = *reinterpret_cast<const v4f*>(pa + ra1 + ch);                                   \
-      _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                 \
-        acc[XI][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[i], fb[i], acc[XI][0], 0, 0, 0);         \
-        acc[XI][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[i], fb[i], acc[XI][1], 0, 0, 0);         \
+    const int n_ = (NU);                                                                              \
+    const float c0 = n_ == 5 ? 0.f : 1.f;                                                             \
+    const float c1 = n_ == 1 ? 1.f : n_ == 2 ? -1.f : n_ == 3 ? 2.f : n_ == 4 ? -2.f : 0.f;           \
+    const float c2 = (n_ == 1 || n_ == 2) ? 1.f : (n_ == 3 || n_ == 4) ? 4.f : 0.f;                   \
+    const float c3 = n_ == 1 ? 1.f : n_ == 2 ? -1.f : n_ == 3 ? 8.f : n_ == 4 ? -8.f : n_ == 5 ? 1.f : 0.f; \
+    _Pragma("unroll") for (int b_ = 0; b_ < 2; b_++)                                                  \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {                                              \
+        float m_[6], t_[4];                                                                           \
+        _Pragma("unroll") for (int x_ = 0; x_ < 6; x_++) m_[x_] = acc[x_][b_][i_];                     \
+        at6_col(m_, t_);                                                                              \
+        _Pragma("unroll") for (int a_ = 0; a_ < 4; a_++) {                                            \
+          yo[b_][i_][4 * a_ + 0] += t_[a_] * c0;                                                      \
+          yo[b_][i_][4 * a_ + 1] += t_[a_] * c1;                                                      \
+          yo[b_][i_][4 * a_ + 2] += t_[a_] * c2;                                                      \
+          yo[b_][i_][4 * a_ + 3] += t_[a_] * c3;                                                      \
+        }                                                                                             \
       }                                                                                               \
+    _Pragma("unroll") for (int x_ = 0; x_ < 6; x_++) acc[x_][0] = acc[x_][1] = (v4f){0.f, 0.f, 0.f, 0.f}; \
+  } while (0)
+
+  // One stage on accumulator set XI (XP = the set of the stage before when that was another plane):
+  //   own DMAs of this stage landed (counted wait: the next stage's stay in flight) -> barrier
+  //   (everybody's landed, everybody done reading the previous stage) -> DMA of stage s+2 into the
+  //   buffer the previous stage just freed -> reads X(s) -> MFMAs Y(s-1) -> reads Y(s) -> MFMAs X(s)
+#define WM_STAGE(XI, XP)                                                                              \
+  do {                                                                                                \
+    if constexpr (UB == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");   \
+    else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");                     \
+    const unsigned curA = (unsigned)cur * (BT * WM_LD * 4), curB = (unsigned)cur * (64 * WM_LD * 4);      \
+    WM_READ(xa0, xa1, xb, 0);                                                                         \
+    __builtin_amdgcn_sched_barrier(0);   /* the X reads go out first: their latency hides under Y's MFMAs */ \
+    if (kc > 0) { WM_MFMA(ya0, ya1, yb, acc[XI]); }                                                   \
+    else if ((XI) > 0) { WM_MFMA(ya0, ya1, yb, acc[XP]); }                                            \
+    else if (nu > 0) { WM_MFMA(ya0, ya1, yb, acc[5]); WM_FOLD(nu - 1); }                              \
+    {                                                                                                 \
+      const int nb = cur >= 1 ? cur - 1 : 2;   /* (cur + 2) % 3: the previous stage's buffer */         \
+      WM_DMA(nb, pvo, puo);                                                                           \
+      WM_PF_ADVANCE();                                                                                \
     }                                                                                                 \
-    __syncthreads();                                                                                  \
-    cur ^= 1;                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the X reads (issued 16 MFMAs ago) */        \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    WM_MFMA1(xa0, xa1, xb, 0, acc[XI]);                                                               \
+    __builtin_amdgcn_sched_barrier(0);   /* the Y reads go out between X's MFMA groups: nothing waits for them before the next barrier */ \
+    WM_READ(ya0, ya1, yb, 2);                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    WM_MFMA1(xa0, xa1, xb, 1, acc[XI]);                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* Y landed before the compiler may touch its registers (loop-carried) */ \
+    cur = cur == 2 ? 0 : cur + 1;                                                                     \
   } while (0)
 
   for (int nu = 0; nu < 6; nu++) {
-    for (int kc = 0; kc < NK; kc++) WM_STAGE(0);
-    for (int kc = 0; kc < NK; kc++) WM_STAGE(1);
-    for (int kc = 0; kc < NK; kc++) WM_STAGE(2);
-    for (int kc = 0; kc < NK; kc++) WM_STAGE(3);
-    for (int kc = 0; kc < NK; kc++) WM_STAGE(4);
-    for (int kc = 0; kc < NK; kc++) WM_STAGE(5);
-    // column nu of the transform domain is complete: t = A^T M[:, nu]; Y[a][e] += t[a] * A[nu][e]
-    // with A[nu][:] = (1,0,0,0) (1,1,1,1) (1,-1,1,-1) (1,2,4,8) (1,-2,4,-8) (0,0,0,1)
-    const float c0 = nu == 5 ? 0.f : 1.f;
-    const float c1 = nu == 1 ? 1.f : nu == 2 ? -1.f : nu == 3 ? 2.f : nu == 4 ? -2.f : 0.f;
-    const float c2 = (nu == 1 || nu == 2) ? 1.f : (nu == 3 || nu == 4) ? 4.f : 0.f;
-    const float c3 = nu == 1 ? 1.f : nu == 2 ? -1.f : nu == 3 ? 8.f : nu == 4 ? -8.f : nu == 5 ? 1.f : 0.f;
-#pragma unroll
-    for (int b = 0; b < 2; b++)
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        float m[6], t[4];
-#pragma unroll
-        for (int xi = 0; xi < 6; xi++) m[xi] = acc[xi][b][i];
-        at6_col(m, t);
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-          yo[b][i][4 * a + 0] += t[a] * c0;
-          yo[b][i][4 * a + 1] += t[a] * c1;
-          yo[b][i][4 * a + 2] += t[a] * c2;
-          yo[b][i][4 * a + 3] += t[a] * c3;
-        }
-      }
-#pragma unroll
-    for (int xi = 0; xi < 6; xi++) acc[xi][0] = acc[xi][1] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < NK; kc++) WM_STAGE(0, 5);
+    for (int kc = 0; kc < NK; kc++) WM_STAGE(1, 0);
+    for (int kc = 0; kc < NK; kc++) WM_STAGE(2, 1);
+    for (int kc = 0; kc < NK; kc++) WM_STAGE(3, 2);
+    for (int kc = 0; kc < NK; kc++) WM_STAGE(4, 3);
+    for (int kc = 0; kc < NK; kc++) WM_STAGE(5, 4);
   }
+  // drain: K groups 2, 3 of the last stage, the last column, and every LDS read before the buffers
+  // are recycled for the epilogue
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  WM_MFMA(ya0, ya1, yb, acc[5]);
+  WM_FOLD(5);
+  __syncthreads();
 #undef WM_STAGE
+#undef WM_READ
+#undef WM_DSREAD
+#undef WM_MFMA
+#undef WM_MFMA1
+#undef WM_FOLD
 #undef WM_DMA
+#undef WM_PF_ADVANCE
 
   // ---- epilogue -------------------------------------------------------------------------------
   // lane holds, per block b, tiles 32 wm + 16 b + 4 lk + i (i = 0..3) x channel 16 wn + lr
@@ -215,7 +306,7 @@ __global__ __launch_bounds__(WM_THREADS, 2) void wino43_mfma_kernel(
         yo[b][i][o] = val;
       }
 
-  float* sY = smem;   // [64 tiles][4][64 channels] floats = 64 KB (the staging buffers are free now)
+  float* sY = smem;   // [BT tiles][4][64 channels] floats (the staging buffers are free now)
   const int HtWt = Ht * Wt;
   if (POOL != 1) {
     // four passes, one output row a of the 4x4 tiles each: [tile][e][channel]
@@ -232,7 +323,7 @@ __global__ __launch_bounds__(WM_THREADS, 2) void wino43_mfma_kernel(
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < 8; r++) {
-        const int idx = tid + WM_THREADS * r;   // 4096 float4: (tile, e, c4)
+        const int idx = tid + NT * r;   // 4096 float4: (tile, e, c4)
         const int tl = idx >> 6, e = (idx >> 4) & 3, c4 = (idx & 15) * 4;
         const long long t = t0 + tl;
         if (t < tend) {
@@ -273,7 +364,7 @@ __global__ __launch_bounds__(WM_THREADS, 2) void wino43_mfma_kernel(
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-      const int idx = tid + WM_THREADS * r;
+      const int idx = tid + NT * r;
       const int tl = idx >> 6, w4 = (idx >> 4) & 3, c4 = (idx & 15) * 4;
       const long long t = t0 + tl;
       if (t < tend) {
@@ -308,15 +399,18 @@ extern "C" int pcnn_winograd43_conv_fwd(const float* v, const float* ut, const f
   const int Ht = (H + 3) / 4, Wt = (W + 3) / 4;
   const long long T = (long long)B * Ht * Wt;
   const long long tpg = T / groups;
-  const long long nbt = (long long)groups * ((tpg + WM_BT - 1) / WM_BT);
   const int ncb = Cout / WM_BC;
+  // 64-tile blocks (one 8-wave workgroup per CU) unless they would fill the 256 CUs fewer than ~4 times:
+  // then 32-tile blocks (two 4-wave workgroups per CU) waste less of the last round
+  const long long nbt64 = (long long)groups * ((tpg + 63) / 64);
+  const int wr = nbt64 * ncb >= 4 * 256 ? 2 : 1;
+  const long long nbt = wr == 2 ? nbt64 : (long long)groups * ((tpg + 31) / 32);
   const long long blocks = ((nbt + 7) / 8) * 8 * ncb;
   PCNN_REQUIRE(blocks < (1ll << 31), PCNN_EINVAL, "winograd43_conv: grid too large");
-#define WM_GO(P) PCNN_LAUNCH((wino43_mfma_kernel<P>), dim3((unsigned)blocks), dim3(WM_THREADS), 0, stream, v, ut, bias, y, y_pool, \
-                             H, W, Cin, Cout, Ht, Wt, T, tpg, relu, (int)nbt, ncb)
-  if (pool == 0) WM_GO(0);
-  else if (pool == 1) WM_GO(1);
-  else WM_GO(2);
+#define WM_GO(P, R) PCNN_LAUNCH((wino43_mfma_kernel<P, R>), dim3((unsigned)blocks), dim3(256 * R), 0, stream, v, ut, bias, y, y_pool, \
+                                H, W, Cin, Cout, Ht, Wt, T, tpg, relu, (int)nbt, ncb)
+  if (wr == 2) { if (pool == 0) WM_GO(0, 2); else if (pool == 1) WM_GO(1, 2); else WM_GO(2, 2); }
+  else { if (pool == 0) WM_GO(0, 1); else if (pool == 1) WM_GO(1, 1); else WM_GO(2, 1); }
 #undef WM_GO
   return check_launch("winograd43_conv_fwd");
 }

@@ -611,7 +611,9 @@ def test_network_first_conv_fusion_is_transparent(gpu):
     ((1, 8, 16, 64), 64, 0, 1), ((2, 12, 20, 64), 128, 1, 1), ((1, 30, 44, 64), 128, 0, 1), ((1, 10, 6, 64), 256, 1, 1),
     ((3, 5, 7, 64), 64, 0, 1), ((1, 120, 160, 64), 64, 1, 1), ((2, 30, 44, 128), 192, 2, 1), ((1, 34, 18, 128), 64, 0, 1),
     ((5, 9, 9, 64), 64, 0, 1), ((2, 60, 80, 256), 256, 0, 1), ((2, 30, 40, 512), 512, 2, 2), ((4, 16, 16, 512), 512, 0, 2),
-    ((2, 24, 20, 256), 512, 1, 2), ((6, 10, 14, 128), 128, 0, 3), ((2, 64, 64, 64), 64, 1, 2)])
+    ((2, 24, 20, 256), 512, 1, 2), ((6, 10, 14, 128), 128, 0, 3), ((2, 64, 64, 64), 64, 1, 2),
+    # enough tile blocks for the 64-tile / 8-wave variant (>= 1024 workgroups), single and grouped
+    ((2, 480, 640, 64), 128, 1, 1), ((2, 478, 638, 64), 128, 0, 2), ((4, 240, 320, 128), 256, 2, 2)])
 def test_winograd43_mfma_conv_kernel(gpu, shape, cout, pool, groups):
     """The 36 Winograd-domain contractions + output transform in one fp32-MFMA kernel (csrc/wino_mfma.hip)
     against (a) the unfused pair — library batched GEMM + wino43_output_kernel — and (b) a float64 direct
