@@ -316,6 +316,18 @@ int pcnn_winograd43_conv_fwd(const float* v, const float* ut, const float* bias,
                              int width, int in_channels, int out_channels, int groups, int relu,
                              int pool, float* y, float* y_pool, void* stream);
 
+/* Fully connected layer over a capacity-sized row buffer (`Network.fc`, network.py:392-422; fc6 / fc7 of
+ * vgg16_convs.py:188-192 behind the sync-free Hough layer): y[m] = [ReLU](x[m] . W + bias) for the rows
+ * m < min(rows_capacity, *num_rows_dev); rows at or past the count are written as zeros without touching
+ * an operand (a library GEMM would need the count on the host, or compute every padded row).
+ *   x    f32 [rows_capacity][in_features]      in_features % 64 == 0, >= 128
+ *   wt   f32 [out_features][in_features]       the TF weight variable [in, out] TRANSPOSED; out_features % 64 == 0
+ *   bias f32 [out_features];  num_rows_dev device int32[1] or NULL (= rows_capacity);  y f32 [rows_capacity][out_features]
+ * fp32 MFMA (exact f32), sum over k in ascending order within a lane-fixed interleave. */
+int pcnn_fc_rows_fwd(const float* x, const float* wt, const float* bias, int rows_capacity,
+                     int in_features, int out_features, int relu, const int32_t* num_rows_dev,
+                     float* y, void* stream);
+
 /* pcnn_winograd43_output_fwd writing BOTH the activation y f32 [B,H,W,C] and its 2x2 max-pool y_pool f32
  * [B,H/2,W/2,C] in one pass (conv4_3 -> pool4, whose un-pooled output score_conv4 and roi_pool read too). */
 int pcnn_winograd43_output_both_fwd(const float* m, const float* bias, int batch, int height, int width,

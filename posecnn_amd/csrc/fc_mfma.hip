@@ -1,0 +1,199 @@
+// fc_mfma.hip — the fully connected layers of the pose branch (`Network.fc`, lib/networks/network.py:392-422:
+// fc6 [R, 7*7*512] -> 4096 and fc7 4096 -> 4096 of lib/networks/vgg16_convs.py:188-192, relu_layer) on the
+// gfx950 matrix cores, over a CAPACITY-SIZED row buffer with the row count on the device.
+//
+// Why not the library GEMM: the sync-free Hough layer hands the pose branch `rows_capacity` ROI rows (3024
+// for 16 frames x 21 classes x 9 training rows) of which only `*num_rows_dev` exist (~470 in the bench). A
+// library GEMM needs M on the host — a device->host sync per batch — or computes all 3024 rows (4.8 ms of
+// fp32 MFMA per batch, measured). This kernel reads the count on the device: row blocks at or past it store
+// zeros and exit before touching an operand.
+//
+//   y[m, n] = [ReLU](sum_k x[m, k] wt[n, k] + bias[n])   m < min(M_cap, *num_rows_dev), else 0
+//
+// Same machinery as csrc/wino_mfma.hip, minus the Winograd planes: 64 x 64 block per 8-wave workgroup,
+// v_mfma_f32_16x16x4_f32 (exact f32), global -> LDS DMA into a 3-stage ring with XOR-swizzled 16-byte
+// chunks, one counted-wait barrier per 64-deep K stage, K loop software pipelined by half a stage, epilogue
+// through LDS for 256-byte row stores, XCD-aware block map (the column blocks that share a row block's x
+// rows run on one XCD). `wt` is the weight matrix TRANSPOSED ([N][K], K contiguous) so that both operands
+// are K-major rows for the DMA.
+#include "pcnn_device.h"
+
+namespace {
+
+using namespace pcnn;
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int FC_LD = 64;
+constexpr int FC_NBUF = 3;
+
+__device__ __forceinline__ void fc_glds16(const char* g, float* lds_wave_base)
+{
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(512, 2) void fc_rows_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
+    float* __restrict__ y, int K, int N, int Mcap, int relu, const int* __restrict__ num_rows_dev, int nbm,
+    int ncb)
+{
+  __shared__ __attribute__((aligned(16))) float smem[FC_NBUF * 128 * FC_LD];   // sA[3][64][64] | sB[3][64][64]
+  float* sAp = smem;
+  float* sBp = smem + FC_NBUF * 64 * FC_LD;
+
+  // XCD-aware block map: the weight matrix is the big operand (fc6: 411 MB) and every row block needs
+  // all of a column block's rows of it, so XCD x takes the column blocks cb == x (mod 8) and runs their
+  // row blocks back to back: W^T streams from HBM once, the (few) live x rows are re-read from L2 / MALL
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int tb = q % nbm;
+  const int cb = (q / nbm) * 8 + xcd;
+  if (cb >= ncb) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int m0 = tb * 64;
+  const int count = num_rows_dev ? min(Mcap, num_rows_dev[0]) : Mcap;
+  if (m0 >= count) {
+    // rows that do not exist: zeros, no operand traffic
+    for (int i = tid; i < 64 * 16; i += 512) {
+      const int r = m0 + (i >> 4);
+      if (r < Mcap) *reinterpret_cast<v4f*>(y + (size_t)r * N + cb * 64 + (i & 15) * 4) = (v4f){0.f, 0.f, 0.f, 0.f};
+    }
+    return;
+  }
+  const int NK = K / 64;
+  const int mlast = count - 1;
+
+  const int dr0 = 8 * wave + lk, dr1 = dr0 + 4;
+  const int ra_ = min(m0 + dr0, mlast), rb_ = min(m0 + dr1, mlast);   // rows past the count: any finite data, zeroed at the end
+  const unsigned va0 = (unsigned)(((size_t)ra_ * K + (lr ^ (dr0 & 15)) * 4) * 4);
+  const unsigned va1 = (unsigned)(((size_t)rb_ * K + (lr ^ (dr1 & 15)) * 4) * 4);
+  const unsigned ub0 = (unsigned)(((size_t)(cb * 64 + dr0) * K + (lr ^ (dr0 & 15)) * 4) * 4);
+  const unsigned ub1 = (unsigned)(((size_t)(cb * 64 + dr1) * K + (lr ^ (dr1 & 15)) * 4) * 4);
+  const char* xbase = reinterpret_cast<const char*>(x);
+  const char* wbase = reinterpret_cast<const char*>(wt);
+  const int ldsw = 8 * wave * FC_LD;
+
+#define FC_DMA(BUF, KO)                                                                  \
+  do {                                                                                   \
+    const char* xs_ = xbase + (size_t)(KO) * 4;                                          \
+    const char* ws_ = wbase + (size_t)(KO) * 4;                                          \
+    fc_glds16(xs_ + va0, sAp + (BUF) * 64 * FC_LD + ldsw);                               \
+    fc_glds16(xs_ + va1, sAp + (BUF) * 64 * FC_LD + ldsw + 4 * FC_LD);                   \
+    fc_glds16(ws_ + ub0, sBp + (BUF) * 64 * FC_LD + ldsw);                               \
+    fc_glds16(ws_ + ub1, sBp + (BUF) * 64 * FC_LD + ldsw + 4 * FC_LD);                   \
+  } while (0)
+
+  v4f acc0 = (v4f){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  int pk = 0;   // K offset (floats) of the prefetch pointer; parks on the last stage
+  FC_DMA(0, pk); pk = min(pk + 64, K - 64);
+  FC_DMA(1, pk); pk = min(pk + 64, K - 64);
+  int cur = 0;
+
+  const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)smem;
+  const int ra0 = (32 * wm + lr) * FC_LD, rb = (16 * wn + lr) * FC_LD;
+  unsigned adA[4], adB[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const unsigned chb = (unsigned)(((4 * j + lk) ^ lr) * 16);
+    adA[j] = lds0 + (unsigned)ra0 * 4u + chb;
+    adB[j] = lds0 + (unsigned)(FC_NBUF * 64 * FC_LD + rb) * 4u + chb;
+  }
+  v4f xa0[2], xa1[2], xb[2], ya0[2], ya1[2], yb[2];
+#pragma unroll
+  for (int g = 0; g < 2; g++) xa0[g] = xa1[g] = xb[g] = ya0[g] = ya1[g] = yb[g] = (v4f){0.f, 0.f, 0.f, 0.f};
+#define FC_DSREAD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(DST) : "v"(ADDR))
+#define FC_READ(SA0, SA1, SB, G0)                                             \
+  _Pragma("unroll") for (int g_ = 0; g_ < 2; g_++) {                          \
+    const unsigned aa_ = adA[(G0) + g_] + curo, ab_ = adB[(G0) + g_] + curo;  \
+    FC_DSREAD(SB[g_], ab_, 0);                                                \
+    FC_DSREAD(SA0[g_], aa_, 0);                                               \
+    FC_DSREAD(SA1[g_], aa_, 4096);                                            \
+  }
+#define FC_MFMA1(SA0, SA1, SB, G)                                                             \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {                                          \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(SA0[G][i_], SB[G][i_], acc0, 0, 0, 0);        \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(SA1[G][i_], SB[G][i_], acc1, 0, 0, 0);        \
+  }
+
+  // stage s: own DMAs landed (the next stage's stay in flight) -> barrier -> reads X(s) -> MFMAs Y(s-1)
+  // + DMA of stage s+2 -> X landed -> MFMAs X(s), reads Y(s) in between. Y of "stage -1" is zeros.
+  for (int s = 0; s < NK; s++) {
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const unsigned curo = (unsigned)cur * (64 * FC_LD * 4);
+    FC_READ(xa0, xa1, xb, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    FC_MFMA1(ya0, ya1, yb, 0) FC_MFMA1(ya0, ya1, yb, 1)
+    {
+      const int nb = cur >= 1 ? cur - 1 : 2;
+      FC_DMA(nb, pk);
+      pk = min(pk + 64, K - 64);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    FC_MFMA1(xa0, xa1, xb, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    FC_READ(ya0, ya1, yb, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    FC_MFMA1(xa0, xa1, xb, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  FC_MFMA1(ya0, ya1, yb, 0) FC_MFMA1(ya0, ya1, yb, 1)
+  __syncthreads();   // drains the two parked prefetches and every LDS read before the buffers are recycled
+#undef FC_DMA
+#undef FC_READ
+#undef FC_DSREAD
+#undef FC_MFMA1
+
+  // epilogue: lane holds rows 32 wm + 16 b + 4 lk + i (b = 0: acc0, 1: acc1) x column 16 wn + lr
+  const int col = 16 * wn + lr;
+  const float bv = bias[cb * 64 + col];
+  float* sY = smem;   // [64 rows][64 columns]
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    float v0 = acc0[i] + bv, v1 = acc1[i] + bv;
+    if (relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+    sY[(32 * wm + 4 * lk + i) * 64 + col] = v0;
+    sY[(32 * wm + 16 + 4 * lk + i) * 64 + col] = v1;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int idx = tid + 512 * r;   // 1024 float4: (row, c4)
+    const int row = idx >> 4, c4 = (idx & 15) * 4;
+    const int m = m0 + row;
+    if (m < Mcap) {
+      const v4f val = m < count ? *reinterpret_cast<const v4f*>(&sY[row * 64 + c4]) : (v4f){0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<v4f*>(y + (size_t)m * N + cb * 64 + c4) = val;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int pcnn_fc_rows_fwd(const float* x, const float* wt, const float* bias, int rows_capacity,
+                                int in_features, int out_features, int relu, const int32_t* num_rows_dev,
+                                float* y, void* stream_)
+{
+  PCNN_REQUIRE(rows_capacity >= 0, PCNN_EINVAL, "fc_rows: negative row capacity");
+  PCNN_REQUIRE(in_features >= 128 && in_features % 64 == 0, PCNN_EINVAL,
+               "fc_rows: in_features must be a multiple of 64, >= 128 (got %d)", in_features);
+  PCNN_REQUIRE(out_features >= 64 && out_features % 64 == 0, PCNN_EINVAL,
+               "fc_rows: out_features must be a multiple of 64 (got %d)", out_features);
+  if (rows_capacity == 0) return PCNN_OK;
+  PCNN_REQUIRE(x && wt && bias && y, PCNN_ENULL, "fc_rows: NULL pointer");
+  PCNN_REQUIRE(aligned16(x) && aligned16(wt) && aligned16(y), PCNN_EINVAL, "fc_rows: pointers must be 16-byte aligned");
+  PCNN_REQUIRE((long long)rows_capacity * in_features < (1ll << 30) && (long long)out_features * in_features < (1ll << 30),
+               PCNN_EINVAL, "fc_rows: operand larger than the 32-bit byte offsets of the kernel");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int nbm = (rows_capacity + 63) / 64, ncb = out_features / 64;
+  const long long blocks = (long long)((ncb + 7) / 8) * 8 * nbm;
+  PCNN_LAUNCH(fc_rows_mfma_kernel, dim3((unsigned)blocks), dim3(512), 0, stream, x, wt, bias, y, in_features,
+              out_features, rows_capacity, relu, num_rows_dev, nbm, ncb);
+  return check_launch("fc_rows_fwd");
+}

@@ -46,11 +46,9 @@ using namespace pcnn;
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int WM_BT = 64;     // tiles per workgroup (template WR = 2; WR = 1: 32 tiles, 4 waves, two workgroups per CU)
 constexpr int WM_BC = 64;     // output channels per workgroup
 constexpr int WM_KC = 64;     // K (input channels) per pipeline stage
 constexpr int WM_LD = 64;     // LDS row (floats): unpadded, XOR-swizzled 16-byte chunks
-constexpr int WM_THREADS = 512;
 constexpr int WM_NBUF = 3;    // stage buffers in the LDS ring (prefetch distance 2)
 
 // 16 bytes per lane, global -> LDS, no register round trip. LDS destination = wave-uniform base +
@@ -76,7 +74,9 @@ __device__ __forceinline__ void at6_col(const float* m, float* t)
 // WR: wave rows — 2: 64 tiles x 64 channels, 8 waves, one workgroup per CU; 1: 32 x 64, 4 waves, two
 // workgroups per CU (finer work quanta for the layers with few tiles: conv5_x has 320 blocks of 64 tiles
 // for 256 CUs, i.e. a second round that is 25 % full).
-template <int POOL, int WR>
+// ABL (tools/wino_ablate.hip only; the library instantiates 0): leave one ingredient of the K loop out to
+// see what it costs — 1 no barrier, 2 no DMA, 4 no LDS reads, 8 no MFMAs, 16 no column fold, 32 no epilogue.
+template <int POOL, int WR, int ABL = 0>
 __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
     const float* __restrict__ v, const float* __restrict__ ut, const float* __restrict__ bias,
     float* __restrict__ y, float* __restrict__ ypool, int H, int W, int Cin, int Cout, int Ht, int Wt,
@@ -140,14 +140,14 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
       for (int o = 0; o < 16; o++) yo[b][i][o] = 0.f;
 
 #define WM_DMA(BUF, VO, UO)                                                  \
-  do {                                                                       \
+  if constexpr (!(ABL & 2)) {                                                \
     const char* vs_ = vbase + (VO) * 4;                                      \
     const char* us_ = ubase + (UO) * 4;                                      \
     glds16(vs_ + va0, &sA[BUF][0][0] + ldsw);                                \
     glds16(vs_ + va1, &sA[BUF][0][0] + ldsw + 4 * WM_LD);                    \
     _Pragma("unroll") for (int i_ = 0; i_ < UB; i_++)                         \
       glds16(us_ + ub[i_], &sB[BUF][0][0] + ldsu + 4 * i_ * WM_LD);           \
-  } while (0)
+  }
 
   // Stage order: nu outer, xi, then kc fastest; (pnu, pxi, pkc) is the prefetch pointer, two stages
   // ahead of the compute pointer. Prologue: stages 0 and 1 in flight.
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
   int cur = 0;
 
   // ds_read side of the swizzle: row R = (..) + lr, logical chunk 4 j + lk -> physical (4 j + lk) ^ lr
-  const int ra0 = (32 * wm + lr) * WM_LD, ra1 = ra0 + 16 * WM_LD, rb = (16 * wn + lr) * WM_LD;
+  const int ra0 = (32 * wm + lr) * WM_LD, rb = (16 * wn + lr) * WM_LD;   // (+ 16 rows for the second block)
 
   // The K loop is software pipelined by half a stage: the 16 MFMAs of K groups 2, 3 of stage s-1 are
   // issued AFTER the barrier of stage s, behind the LDS reads of groups 0, 1 of stage s — so the LDS
@@ -195,7 +195,9 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
     adA[j] = lds0 + (unsigned)ra0 * 4u + chb;
     adB[j] = lds0 + (unsigned)(WM_NBUF * BT * WM_LD + rb) * 4u + chb;
   }
-#define WM_DSREAD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(DST) : "v"(ADDR))
+#define WM_DSREAD(DST, ADDR, OFF)                                                                     \
+  if constexpr (!(ABL & 4)) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(DST) : "v"(ADDR)); \
+  else asm volatile("" : "+v"(DST) : "v"(ADDR))
 #define WM_READ(SA0, SA1, SB, G0)                                                                     \
   _Pragma("unroll") for (int g_ = 0; g_ < 2; g_++) {                                                  \
     const unsigned aa_ = adA[(G0) + g_] + curA, ab_ = adB[(G0) + g_] + curB;                           \
@@ -204,6 +206,7 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
     WM_DSREAD(SA1[g_], aa_, 4096);   /* 16 rows further */                                             \
   }
 #define WM_MFMA1(SA0, SA1, SB, G, ACC)                                                                \
+  if constexpr (ABL & 8) { asm volatile("" :: "v"(SA0[G]), "v"(SA1[G]), "v"(SB[G])); } else           \
   _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {                                                  \
     ACC[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(SA0[G][i_], SB[G][i_], ACC[0], 0, 0, 0);            \
     ACC[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(SA1[G][i_], SB[G][i_], ACC[1], 0, 0, 0);            \
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
   // column NU of the transform domain is complete: t = A^T M[:, NU]; Y[a][e] += t[a] * A[NU][e]
   // with A[NU][:] = (1,0,0,0) (1,1,1,1) (1,-1,1,-1) (1,2,4,8) (1,-2,4,-8) (0,0,0,1); accumulators recycled
 #define WM_FOLD(NU)                                                                                   \
-  do {                                                                                                \
+  if constexpr (!(ABL & 16)) {                                                                        \
     const int n_ = (NU);                                                                              \
     const float c0 = n_ == 5 ? 0.f : 1.f;                                                             \
     const float c1 = n_ == 1 ? 1.f : n_ == 2 ? -1.f : n_ == 3 ? 2.f : n_ == 4 ? -2.f : 0.f;           \
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
         }                                                                                             \
       }                                                                                               \
     _Pragma("unroll") for (int x_ = 0; x_ < 6; x_++) acc[x_][0] = acc[x_][1] = (v4f){0.f, 0.f, 0.f, 0.f}; \
-  } while (0)
+  }
 
   // One stage on accumulator set XI (XP = the set of the stage before when that was another plane):
   //   own DMAs of this stage landed (counted wait: the next stage's stay in flight) -> barrier
@@ -240,7 +243,8 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
   //   buffer the previous stage just freed -> reads X(s) -> MFMAs Y(s-1) -> reads Y(s) -> MFMAs X(s)
 #define WM_STAGE(XI, XP)                                                                              \
   do {                                                                                                \
-    if constexpr (UB == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");   \
+    if constexpr (ABL & 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                 \
+    else if constexpr (UB == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
     else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");                     \
     const unsigned curA = (unsigned)cur * (BT * WM_LD * 4), curB = (unsigned)cur * (64 * WM_LD * 4);      \
     WM_READ(xa0, xa1, xb, 0);                                                                         \
@@ -290,6 +294,19 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
 #undef WM_DMA
 #undef WM_PF_ADVANCE
 
+  if constexpr (ABL & 32) {   // keep the accumulators alive, store one value per lane
+    float k_ = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int o = 0; o < 16; o++) k_ += yo[b][i][o];
+#pragma unroll
+    for (int x_ = 0; x_ < 6; x_++) k_ += acc[x_][0][0] + acc[x_][1][1];
+    if (k_ == 12345.678f) y[tid] = k_;
+    return;
+  }
   // ---- epilogue -------------------------------------------------------------------------------
   // lane holds, per block b, tiles 32 wm + 16 b + 4 lk + i (i = 0..3) x channel 16 wn + lr
   const int col = 16 * wn + lr;

@@ -198,11 +198,15 @@ def im_segment_batch(net, data, K, extents, points, symmetry, data_p=None, plant
     pool = ops.roi_pool_add2(net.get_output("conv5_3"), 1.0 / 16.0, net.get_output("conv4_3"), 1.0 / 8.0, rois,
                              num_rows=count)
     net.layers["pool_score"] = pool
-    (net.feed("pool_score")
-        .fc(4096, height=7, width=7, channel=512, name="fc6")
-        .fc(4096, num_in=4096, name="fc7")
-        .fc(4 * net.num_classes, relu=False, name="fc8")
-        .tanh(name="poses_tanh"))
+    net.rows_count = count   # fc6 / fc7 skip the rows past the device-side count
+    try:
+        (net.feed("pool_score")
+            .fc(4096, height=7, width=7, channel=512, name="fc6")
+            .fc(4096, num_in=4096, name="fc7")
+            .fc(4 * net.num_classes, relu=False, name="fc8")
+            .tanh(name="poses_tanh"))
+    finally:
+        net.rows_count = None
     poses_tanh = net.get_output("poses_tanh")
     # poses[i,:4] = poses_tanh[i, 4c:4c+4]  (lib/fcn/test.py:206-211), on the device
     cls = rois[:, 1].long().clamp(min=0)

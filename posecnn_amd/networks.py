@@ -160,6 +160,7 @@ class Network(object):
         self.fused_first_conv = True  # 3-channel 3x3 convs go to the fused conv + bias + ReLU kernel
         self.defer_act = frozenset()  # conv layers whose bias + ReLU is left to the following max_pool
         self.dual_pool = frozenset()  # ... and those whose un-pooled output other layers read too (Winograd only)
+        self.rows_count = None        # device int32[1]: true row count of capacity-sized ROI rows fed to `fc` (or None)
 
     # ---- plumbing ------------------------------------------------------------------------------
     def setup(self):
@@ -492,6 +493,16 @@ class Network(object):
             feed_in = input
         w = self.make_var(name + "/weights", (dim, num_out), self._weight_init(dim), trainable)
         b = self.make_var(name + "/biases", (num_out,), lambda s: torch.zeros(s), trainable)
+        rows = getattr(self, "rows_count", None)
+        if (rows is not None and feed_in.is_cuda and dim % 64 == 0 and dim >= 128 and num_out % 64 == 0
+                and not (torch.is_grad_enabled() and (w.requires_grad or feed_in.requires_grad))):
+            # capacity-sized rows behind the sync-free Hough layer: only the first *rows_count rows exist
+            key = (w.data_ptr(), w._version)
+            hit = self._wino_u.get(("fc", name))
+            if hit is None or hit[0] != key:
+                hit = (key, w.detach().t().contiguous())
+                self._wino_u[("fc", name)] = hit
+            return ops.fc_rows(feed_in.contiguous(), hit[1], b, relu, num_rows=rows)
         y = torch.addmm(b, feed_in, w)
         return F.relu(y) if relu else y
 

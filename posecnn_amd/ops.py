@@ -495,6 +495,23 @@ def winograd43_conv(v, ut, bias, B, H, W, relu=True, pool=0, groups=1):
     return (y, yp) if pool == 2 else y
 
 
+def fc_rows(x, wt, bias, relu=True, num_rows=None):
+    """`Network.fc` on a capacity-sized row buffer: y[m] = [ReLU](x[m] @ wt.T + bias) for m < *num_rows
+    (device int32[1]; None = every row), zeros past it. x [M, K], wt [N, K] (the TF weight [K, N] transposed),
+    K % 64 == 0, N % 64 == 0. One fp32-MFMA kernel, no host synchronisation."""
+    x = _dev(x, "x", torch.float32)
+    wt = _dev(wt, "wt", torch.float32)
+    bias = _dev(bias, "bias", torch.float32)
+    if x.dim() != 2 or wt.dim() != 2 or wt.shape[1] != x.shape[1] or bias.numel() != wt.shape[0]:
+        raise ValueError("x must be [M, K], wt [N, K], bias [N]")
+    M, K = x.shape
+    N = wt.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    nr = _dev(num_rows, "num_rows", torch.int32) if num_rows is not None else None
+    check("pcnn_fc_rows_fwd", lib().pcnn_fc_rows_fwd(_ptr(x), _ptr(wt), _ptr(bias), M, K, N, 1 if relu else 0, _ptr(nr), _ptr(y), _stream(x)))
+    return y
+
+
 def conv3x3_winograd(x, u, bias, relu=True, pool=False, tile=2):
     """3x3 / stride 1 / SAME convolution + bias [+ ReLU] [+ 2x2 max-pool] as Winograd F(tile x tile, 3x3):
     input transform (gfx950 kernel) -> (tile+2)^2 fp32 GEMMs (library, MFMA) -> output transform

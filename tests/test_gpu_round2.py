@@ -215,3 +215,59 @@ def test_batch_pipeline_rgbd_matches_cpu_reference(gpu, train):
         assert loss_gpu == 0.0 and not w_gpu.any()   # is_train = 0: no targets -> ADL skips every row
     hl = net.get_output("gt_label_weight").cpu().numpy()
     assert hl.shape == (B, H, W, 22) and set(np.unique(hl)) <= {0.0, 1.0}
+
+
+# ---- fc6 / fc7 on capacity-sized rows --------------------------------------------------------------
+@pytest.mark.parametrize("M,K,N,count,relu", [(200, 25088, 256, 77, True), (3024, 4096, 4096, 468, True), (64, 128, 64, 64, False),
+                                             (130, 1024, 192, 0, True), (65, 640, 128, None, True), (1, 256, 64, 1, False)])
+def test_fc_rows_matches_float64_and_skips_padding(gpu, M, K, N, count, relu):
+    """`Network.fc` (network.py:392-422) as one fp32-MFMA kernel over a capacity-sized row buffer: rows below
+    the device-side count equal x @ W + b (f32 roundoff against a float64 reference, same as the library
+    GEMM), rows at or past it are exactly zero whatever the buffer held (NaN poison)."""
+    import torch
+    from posecnn_amd import ops
+    torch.backends.cuda.matmul.allow_tf32 = False
+    g = torch.Generator(device="cpu").manual_seed(M + K)
+    x = torch.randn((M, K), generator=g).to(gpu)
+    w = (torch.randn((K, N), generator=g) / K ** 0.5).to(gpu)
+    b = torch.randn((N,), generator=g).to(gpu)
+    n = M if count is None else count
+    if n < M:
+        x[n:] = float("nan")      # padding rows must never reach the result
+    cnt = None if count is None else torch.tensor([count], dtype=torch.int32, device=gpu)
+    y = ops.fc_rows(x, w.t().contiguous(), b, relu, num_rows=cnt)
+    assert y.shape == (M, N)
+    ref = x[:n].double() @ w.double() + b.double()
+    if relu:
+        ref = torch.relu(ref)
+    lib = torch.addmm(b, x[:n], w)
+    if relu:
+        lib = torch.relu(lib)
+    if n:
+        scale = float(ref.abs().max())
+        err = float((y[:n].double() - ref).abs().max())
+        err_lib = float((lib.double() - ref).abs().max())
+        assert err <= max(2.0 * err_lib, 2e-6 * scale), (err, err_lib, scale)
+    assert not y[n:].cpu().numpy().view(np.uint32).any()
+
+
+def test_fc_layer_uses_the_row_count(gpu):
+    """Network.fc routes to the MFMA kernel when `rows_count` is set and gives the library result on the
+    live rows (fc6 -> fc7 chain on ROI-pooled shaped input)."""
+    import torch
+    from posecnn_amd.networks import Network
+
+    class Tiny(Network):
+        def setup(self):
+            pass
+    net = Tiny(device=gpu, trainable=False)
+    x = torch.randn((40, 7, 7, 64), device=gpu)
+    net.layers = {"in": x}
+    with torch.no_grad():
+        net.feed("in").fc(128, height=7, width=7, channel=64, name="fa").fc(64, num_in=128, name="fb")
+        want = net.get_output("fb").clone()
+        net.rows_count = torch.tensor([25], dtype=torch.int32, device=gpu)
+        net.feed("in").fc(128, height=7, width=7, channel=64, name="fa").fc(64, num_in=128, name="fb")
+        got = net.get_output("fb")
+    assert float((got[:25] - want[:25]).abs().max()) <= 1e-5 * float(want.abs().max())
+    assert float(got[25:].abs().max()) == 0.0
