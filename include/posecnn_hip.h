@@ -138,7 +138,7 @@ int pcnn_hough_voting_lowres_fwd(const int32_t* label, const float* z, const flo
 /* Diagnostics for tests: byte offsets of intermediate buffers inside the workspace.
  * offsets[8] = { hough space f32 [B][C-1][H*W] (SIZE_MAX unless threshold_vote > 0), pixel records
  * (48 B each), class totals i32 [B][C], slot classes i32 [B][C], slot counts i32 [B], record
- * offsets i32 [B][C], tile maxima int2 [B][C-1][tiles], record capacity per image (a count) }. */
+ * offsets i32 [B][C], row maxima int2 [B][C-1][H] (votes, first cell), record capacity per image (a count) }. */
 int pcnn_hough_voting_debug_layout(int batch, int height, int width, int num_classes,
                                    float threshold_vote, int skip_pixels, int rois_per_image,
                                    size_t* offsets);

@@ -13,13 +13,14 @@
 //               ballots; every skip-th pixel of each class that passes label_threshold becomes a
 //               32-byte record {x, y, thr(d), 1/|uv|, u, v, |uv|, d}: everything the inner loop
 //               of compute_hough_kernel :269-285 recomputes per (cell, pixel) pair, hoisted.
-//   hv_vote     gather formulation, 32x32-cell tiles: each workgroup first culls the class'
-//               records against its tile (vote window + a conservative cone test) into LDS, then
-//               every thread evaluates the exact vote predicate for its 4 cells against the
-//               survivors (LDS broadcast reads). Votes are integers, so evaluation order is
-//               free. Only votes are produced; the reference's second pass (mean depth, box
-//               extents, :296-331) is evaluated lazily, at the cells that can reach an output.
-//   hv_select   (threshold_vote <= 0) per class: first argmax over tile maxima
+//   hv_vote     interval formulation on bands of 8 Hough rows (one wave per row): the records that can
+//               reach a band are a contiguous range of the class' y-sorted list (64-ary search);
+//               a record's vote cone cut by a row is one dx-interval -> +1 / -1 in the row's LDS
+//               difference array; a wave-wide prefix sum yields the votes and the row maximum.
+//               Votes are integers, so evaluation order is free. Only votes are produced; the
+//               reference's second pass (mean depth, box extents, :296-331) is evaluated lazily,
+//               at the cells that can reach an output.
+//   hv_select   (threshold_vote <= 0) per class: first argmax over the row maxima
 //               (thrust::max_element :752-762), then one wave recomputes that cell's depth sum
 //               in canonical pixel order and its box extents.
 //   hv_localmax + hv_gather (threshold_vote > 0): compute_max_indexes_kernel :335-383 in
@@ -37,7 +38,6 @@ using namespace pcnn;
 
 constexpr int HV_CHUNK = 2048;      // label pixels per hist/scatter workgroup (4 waves x 8 x 64)
 constexpr int HV_TILE = 32;         // Hough tile edge (cells)
-constexpr int HV_BATCH = 512;       // records culled into LDS per round of hv_vote
 constexpr int LM_CHUNK = 1024;      // consecutive Hough cells per hv_localmax workgroup
 constexpr float HV_FILTER_EPS = 2e-5f;
 
@@ -60,7 +60,7 @@ struct __attribute__((aligned(16))) HvMax {
 
 struct HvLayout {
   int nchunk, ntx, nty, ntiles, reccap, cap, capmax, nlm;
-  size_t off_hist, off_tot, off_slots, off_nslots, off_recoff, off_rec, off_tilemax, off_maxima,
+  size_t off_hist, off_tot, off_slots, off_nslots, off_recoff, off_kmax, off_rec, off_tilemax, off_maxima,
       off_nmax, off_hs, off_chunkcnt, off_chunkcand, off_flags, total;
 };
 
@@ -84,8 +84,9 @@ HvLayout hv_layout(int B, int H, int W, int C, bool need_hs, int skip, int rois_
   L.off_slots = take(sizeof(int) * (size_t)B * C);
   L.off_nslots = take(sizeof(int) * (size_t)B);
   L.off_recoff = take(sizeof(int) * (size_t)B * C);
+  L.off_kmax = take(sizeof(int) * (size_t)B * C);   // f32 bits: largest vote window thr of a class' records
   L.off_rec = take(sizeof(HvRec) * (size_t)B * L.reccap);
-  L.off_tilemax = take(sizeof(int2) * (size_t)B * (C - 1) * L.ntiles);
+  L.off_tilemax = take(sizeof(int2) * (size_t)B * (C - 1) * H);   // per Hough ROW: (max votes, first cell)
   L.off_maxima = take(sizeof(HvMax) * (size_t)B * L.capmax);
   L.off_nmax = take(sizeof(int) * (size_t)B);
   if (need_hs) {
@@ -189,8 +190,8 @@ struct ZeroJob {
 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void hv_hist_kernel(const int* __restrict__ label,
-                                                      int* __restrict__ hist, int HW, int C,
-                                                      int nchunk, ZeroJob zj)
+                                                      int* __restrict__ hist, int* __restrict__ kmax_g,
+                                                      int HW, int C, int nchunk, ZeroJob zj)
 {
   __shared__ int sh[PCNN_MAX_CLASSES];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(256) void hv_hist_kernel(const int* __restrict__ la
   }
   __syncthreads();
   if (tid < C) hist[((size_t)n * nchunk + chunk) * C + tid] = sh[tid];
+  if (chunk == 0 && tid < C) kmax_g[n * C + tid] = 0;   // max-reduced by hv_scatter (+0.0f)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -244,14 +246,16 @@ __global__ __launch_bounds__(256) void hv_scatter_kernel(
     const int* __restrict__ label, const HvVertexSrc vs,
     const float* __restrict__ extents, const float* __restrict__ meta,
     const int* __restrict__ hist, int* __restrict__ tot_g, int* __restrict__ slots_g,
-    int* __restrict__ nslots_g, int* __restrict__ recoff_g, HvRec* __restrict__ rec, int HW, int W,
+    int* __restrict__ nslots_g, int* __restrict__ recoff_g, int* __restrict__ kmax_g,
+    HvRec* __restrict__ rec, int HW, int W,
     int C, int nchunk, int skip, int label_thr, int num_meta, int reccap, float inlier)
 {
   __shared__ int s_pre[PCNN_MAX_CLASSES], s_tot[PCNN_MAX_CLASSES], s_recoff[PCNN_MAX_CLASSES];
   __shared__ int s_wh[4][PCNN_MAX_CLASSES];
+  __shared__ int s_kmax[PCNN_MAX_CLASSES];   // f32 bits: largest vote window of this block's records, per class
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int chunk = blockIdx.x, n = blockIdx.y;
-  if (tid < PCNN_MAX_CLASSES) { s_pre[tid] = 0; s_tot[tid] = 0; }
+  if (tid < PCNN_MAX_CLASSES) { s_pre[tid] = 0; s_tot[tid] = 0; s_kmax[tid] = 0; }
   __syncthreads();
   const int* h = hist + (size_t)n * nchunk * C;
   for (int idx = tid; idx < nchunk * C; idx += 256) {
@@ -360,207 +364,217 @@ __global__ __launch_bounds__(256) void hv_scatter_kernel(
         R.b = make_float4(u, v, n1, d);
         R.c = cone_coefficients(u, v, n1, rn1, inlier);
         rec[(size_t)n * reccap + ro + my_rank / skip] = R;
+        // largest vote window of the class (hv_vote's band search): positive finite floats order like their bits
+        if (thr == thr && thr > 0.f) atomicMax(&s_kmax[l], __float_as_int(fminf(thr, 1e6f)));
       }
     }
   }
+  __syncthreads();
+  if (tid < C && s_kmax[tid] > 0) atomicMax(&kmax_g[n * C + tid], s_kmax[tid]);   // one global atomic per class per block
 }
 
 // ---------------------------------------------------------------------------------------------
-// Adds +1 over columns [c_lo, c_hi] (tile-relative, inclusive, already clipped) of a tile row.
+// hv_vote: one workgroup = (image, class slot, BAND of HV_BAND Hough rows), one wave per row.
+//
+// The round-1 kernel tiled the Hough space 32 x 32 and every one of the ~24 000 active tile blocks
+// re-streamed its class' ~1500 records to cull them (1.1 GB of L2 reads per launch, 112 M (record,
+// tile row) interval evaluations, 2 LDS atomics each on a 33-word row). Rows are the natural unit
+// of the interval form — a record's vote cone cut by a Hough row is ONE interval — so:
+//   * the records of a class are emitted in ascending pixel order, i.e. sorted by y: the records that
+//     can reach a band of rows are a CONTIGUOUS range [lo, hi) of the list, found by a 64-ary search
+//     on y with the class' largest vote window (`kmax`, a max-reduction in hv_scatter) — no cull
+//     pass, and a band reads only its own range, once, through LDS for all its 8 rows;
+//   * a (record, row) pair is evaluated once for the whole row (not once per 32-cell tile the window
+//     overlaps): 24 M evaluations per launch instead of 112 M;
+//   * each wave owns its row's difference array of W + 1 counters in LDS: interval -> +1 / -1, one
+//     wave-wide prefix sum turns differences into votes, the row maximum (first cell among equals)
+//     falls out of the same pass.
+// Votes are integers: order-free, bit-identical to the per-cell definition (compute_hough_kernel
+// :253-294); the exact IEEE predicate still decides the cells within the rounding uncertainty of an
+// interval end and the records without a closed form.
+constexpr int HV_BAND = 8;            // Hough rows (= waves) per workgroup
+constexpr int HV_RCHUNK = 256;        // records staged in LDS per round
+
 __device__ __forceinline__ void diff_add(int* row, int c_lo, int c_hi)
 {
   atomicAdd(row + c_lo, 1);
   atomicAdd(row + c_hi + 1, -1);
 }
 
-__global__ __launch_bounds__(256) void hv_vote_kernel(
+// Votes of one record for the Hough row `yrow`: columns [0, W) of the row's difference array `drow`.
+__device__ __forceinline__ void vote_row(const float4 a, const float4 b, const float4 c, int yrow, int W,
+                                         float inlier, int* drow)
+{
+  const int x = (int)a.x, y = (int)a.y;
+  const int dyi = yrow - y;
+  const float dy = (float)dyi;
+  if (!(fabsf(dy) < a.z)) return;                         // |dy| < thr (.cu.cc:286-288)
+  // columns with |dx| < thr:  |dx| <= kx,  kx = ceil(thr) - 1
+  const float kxf = fminf(ceilf(a.z) - 1.f, 65536.f);
+  const int kx = (int)kxf;
+  const int w_lo = max(x - kx, 0), w_hi = min(x + kx, W - 1);   // vote window, clipped to the row
+  if (w_lo > w_hi) return;
+  const int mode = (int)c.w;
+  bool per_cell = (mode == 0);
+  // sure interval [lo, hi] of columns and two ranges [ul0, ul1], [ur0, ur1] of columns too close to
+  // an interval end to trust the closed form: those are decided by the exact predicate. The f32
+  // predicate can move an end by <= 5 ulp(q) / |dq/dx| = 6.9e-7 r^2 / |dy| cells (r = distance
+  // pixel -> cell); the uncertain half-width is 0.01 + 2e-6 r^2 / |dy|.
+  int lo = 1, hi = 0, ul0 = 1, ul1 = 0, ur0 = 1, ur1 = 0;
+  if (!per_cell) {
+    if (dyi == 0) {
+      // q = sign(dx) * u / n1 for every dx != 0; dx = 0 is 0/0 = NaN -> never a vote
+      const float sgn = b.x * a.w;
+      if (sgn > inlier + 1e-5f) { lo = x + 1; hi = 0x3fffffff; }
+      else if (sgn < -(inlier + 1e-5f)) { lo = -0x3fffffff; hi = x - 1; }
+      else if (fabsf(sgn) < inlier - 1e-5f) { /* empty */ }
+      else per_cell = true;
+    } else {
+      const float r1 = dy * c.x, r2 = dy * c.y;
+      const float rl = fminf(r1, r2), rh = fmaxf(r1, r2);
+      const float BIG = 3.0e9f;
+      float L, R;  // open interval (L, R) in dx; +-BIG = unbounded
+      if (mode == 1) {
+        if (dy * c.z > 0.f) { L = rl; R = rh; } else { L = 1.f; R = -1.f; }
+      } else if (mode == 2) { L = rh; R = BIG; }
+      else { L = -BIG; R = rl; }
+      if (L <= R) {
+        const float ady = fabsf(dy), rdy = 2e-6f / ady;
+        const float dL = L > -BIG ? 0.01f + rdy * (L * L + dy * dy) : 0.f;
+        const float dR = R < BIG ? 0.01f + rdy * (R * R + dy * dy) : 0.f;
+        const float CL = 70000.f;
+        const float slo = fminf(fmaxf(floorf(L + dL) + 1.f, -CL), CL);   // first sure dx
+        const float shi = fminf(fmaxf(ceilf(R - dR) - 1.f, -CL), CL);    // last sure dx
+        lo = x + (int)slo;
+        hi = x + (int)shi;
+        if (L > -BIG) { ul0 = x + (int)fminf(fmaxf(ceilf(L - dL), -CL), CL); ul1 = lo - 1; }
+        if (R < BIG) { ur0 = hi + 1; ur1 = x + (int)fminf(fmaxf(floorf(R + dR), -CL), CL); }
+        if (lo > hi) {  // no sure cell: one exact range from the lowest to the highest candidate
+          ul0 = L > -BIG ? ul0 : w_lo;
+          ul1 = R < BIG ? ur1 : w_hi;
+          ur0 = 1; ur1 = 0;
+        }
+      }
+    }
+  }
+  if (per_cell) {
+    for (int cxa = w_lo; cxa <= w_hi; cxa++)
+      if (angle_pass_exact(b.x, b.y, b.z, (float)(cxa - x), dy, inlier)) diff_add(drow, cxa, cxa);
+    return;
+  }
+  lo = max(lo, w_lo);
+  hi = min(hi, w_hi);
+  if (lo <= hi) diff_add(drow, lo, hi);
+  for (int cxa = max(ul0, w_lo); cxa <= min(ul1, w_hi); cxa++)
+    if (angle_pass_exact(b.x, b.y, b.z, (float)(cxa - x), dy, inlier)) diff_add(drow, cxa, cxa);
+  for (int cxa = max(ur0, w_lo); cxa <= min(ur1, w_hi); cxa++)
+    if (angle_pass_exact(b.x, b.y, b.z, (float)(cxa - x), dy, inlier)) diff_add(drow, cxa, cxa);
+}
+
+// first index i in [0, m) with rec[i].a.y >= yq (m if none); records are sorted by y. One wave, 64-ary.
+__device__ __forceinline__ int first_record_at_or_below_row(const HvRec* __restrict__ r0, int m, float yq)
+{
+  int lo = 0, hi = m;   // answer in [lo, hi]
+  const int lane = lane_id();
+  while (hi - lo > 0) {
+    const int span = hi - lo;
+    const int step = (span + 63) / 64;
+    const int i = lo + lane * step;                 // probes lo, lo + step, ...
+    const bool ge = i < hi ? (r0[i].a.y >= yq) : true;
+    const unsigned long long mask = __ballot(ge);   // monotone: 0..0 1..1
+    const int f = mask ? __ffsll((long long)mask) - 1 : 64;
+    // the answer lies in (probe f-1, probe f]
+    const int nlo = f == 0 ? lo : lo + (f - 1) * step + 1;
+    const int nhi = f == 64 ? hi : min(lo + f * step, hi);
+    if (step == 1) return nhi;
+    lo = nlo;
+    hi = nhi;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(64 * HV_BAND) void hv_vote_kernel(
     const HvRec* __restrict__ rec, const int* __restrict__ nslots_g,
     const int* __restrict__ slots_g, const int* __restrict__ tot_g,
-    const int* __restrict__ recoff_g, int2* __restrict__ tilemax, float* __restrict__ hs, int H,
-    int W, int C, int skip, float inlier, int ntx, int ntiles, int reccap, int need_hs)
+    const int* __restrict__ recoff_g, const int* __restrict__ kmax_g, int2* __restrict__ rowmax,
+    float* __restrict__ hs, int H, int W, int C, int skip, float inlier, int reccap, int need_hs)
 {
-  const int n = blockIdx.z, s = blockIdx.y, tile = blockIdx.x;
+  const int n = blockIdx.z, s = blockIdx.y, band = blockIdx.x;
   if (s >= nslots_g[n]) return;
+  const int nrows = blockDim.x >> 6;   // rows of this band = waves (HV_BAND, fewer for very wide images)
   const int cls = slots_g[n * C + s];
   const int m = (tot_g[n * C + cls] + skip - 1) / skip;
   const HvRec* r0 = rec + (size_t)n * reccap + recoff_g[n * C + cls];
 
-  __shared__ float4 sA[HV_BATCH];
-  __shared__ float4 sB[HV_BATCH];
-  __shared__ float4 sC[HV_BATCH];
-  __shared__ int s_diff[HV_TILE][HV_TILE + 1];  // per-row difference array of the tile's votes
-  __shared__ int s_cnt;
-  __shared__ int s_rv[4], s_ri[4];
-
+  extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [HV_BAND][W + 1] difference arrays
+  __shared__ float4 sA[HV_RCHUNK], sB[HV_RCHUNK], sC[HV_RCHUNK];
+  __shared__ int s_range[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tx0 = (tile % ntx) * HV_TILE, ty0 = (tile / ntx) * HV_TILE;
-  for (int i = tid; i < HV_TILE * (HV_TILE + 1); i += 256) (&s_diff[0][0])[i] = 0;
+  const int W1 = W + 1;
+  const int y0 = band * nrows;
+  const int yrow = y0 + wave;
+  int* drow = s_dyn + wave * W1;
+  for (int i = tid; i < nrows * W1; i += 64 * nrows) s_dyn[i] = 0;
 
-  // conservative cone cull: every cell of the tile lies within asin(r / L) of the direction to
-  // the tile centre, so a record whose angle to the centre exceeds acos(inlier) + asin(r / L)
-  // cannot vote here. 1e-3 of slack covers the float evaluation of this test.
-  const bool cone_ok = inlier > 0.f && inlier < 1.f;
-  const float c0 = inlier, s0 = sqrtf(fmaxf(0.f, 1.f - inlier * inlier));
-  const float tcx = (float)tx0 + 15.5f, tcy = (float)ty0 + 15.5f;
-  const float rad = 21.93f + 1.0f;
-
-  // vote phase geometry: a half wave (32 lanes = the 32 rows of the tile) per record
-  const int row = tid & 31, half = tid >> 5;
-  const int yrow = ty0 + row;
-  int* drow = &s_diff[row][0];
-
-  for (int b0 = 0; b0 < m; b0 += HV_BATCH) {
-    if (tid == 0) s_cnt = 0;
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < HV_BATCH / 256; q++) {
-      int ri = b0 + q * 256 + tid;
-      bool keep = false;
-      float4 a, b;
-      if (ri < m) {
-        a = r0[ri].a;
-        b = r0[ri].b;  // issued together with `a`: one L2 round trip per round instead of two
-        int x = (int)a.x, y = (int)a.y;
-        int ddx = max(0, max(tx0 - x, x - (tx0 + HV_TILE - 1)));
-        int ddy = max(0, max(ty0 - y, y - (ty0 + HV_TILE - 1)));
-        if ((float)ddx < a.z && (float)ddy < a.z) {
-          keep = true;
-          if (cone_ok) {
-            float Dx = tcx - a.x, Dy = tcy - a.y;
-            float L2 = Dx * Dx + Dy * Dy;
-            if (L2 > rad * rad) {
-              float rL = __builtin_amdgcn_rsqf(L2);
-              float sA_ = rad * rL;
-              float cA = sqrtf(fmaxf(0.f, 1.f - sA_ * sA_));
-              float cosDU = (Dx * b.x + Dy * b.y) * rL * a.w;  // NaN when rn1 is poisoned -> keep
-              if (cosDU < c0 * cA - s0 * sA_ - 1e-3f) keep = false;
-            }
-          }
-        }
-      }
-      unsigned long long mask = __ballot(keep);
-      if (mask) {
-        int leader = __ffsll((long long)mask) - 1;
-        int basep = 0;
-        if (lane == leader) basep = atomicAdd(&s_cnt, __popcll(mask));
-        basep = __shfl(basep, leader);
-        if (keep) {
-          int pos = basep + __popcll(mask & lanemask_lt());
-          sA[pos] = a;
-          sB[pos] = b;
-          sC[pos] = r0[ri].c;
-        }
-      }
-    }
-    __syncthreads();
-    const int cnt = s_cnt;
-    // Votes are integers and order-free: every (record, row) adds +1 over an interval of columns
-    // through the row's difference array (2 LDS atomics) instead of testing the row's 32 cells.
-    for (int k = half; k < cnt; k += 8) {
-      const float4 a = sA[k], b = sB[k], c = sC[k];
-      const int x = (int)a.x, y = (int)a.y;
-      const int dyi = yrow - y;
-      const float dy = (float)dyi;
-      if (!(fabsf(dy) < a.z)) continue;                       // |dy| < thr (.cu.cc:286-288)
-      // columns with |dx| < thr:  |dx| <= kx,  kx = ceil(thr) - 1
-      const float kxf = fminf(ceilf(a.z) - 1.f, 65536.f);
-      const int kx = (int)kxf;
-      int w_lo = max(x - kx, tx0), w_hi = min(x + kx, tx0 + HV_TILE - 1);  // window ∩ tile columns
-      if (w_lo > w_hi) continue;
-      const int mode = (int)c.w;
-      bool per_cell = (mode == 0);
-      // sure interval [lo, hi] of absolute columns and two ranges [ul0, ul1], [ur0, ur1] of columns
-      // too close to an interval end to trust the closed form: those are decided by the exact
-      // predicate. The f32 predicate can move an end by <= 5 ulp(q) / |dq/dx| = 6.9e-7 r^2 / |dy|
-      // cells (r = distance pixel -> cell); the uncertain half-width is 0.01 + 2e-6 r^2 / |dy|.
-      int lo = 1, hi = 0, ul0 = 1, ul1 = 0, ur0 = 1, ur1 = 0;
-      if (!per_cell) {
-        if (dyi == 0) {
-          // q = sign(dx) * u / n1 for every dx != 0; dx = 0 is 0/0 = NaN -> never a vote
-          const float sgn = b.x * a.w;
-          if (sgn > inlier + 1e-5f) { lo = x + 1; hi = 0x3fffffff; }
-          else if (sgn < -(inlier + 1e-5f)) { lo = -0x3fffffff; hi = x - 1; }
-          else if (fabsf(sgn) < inlier - 1e-5f) { /* empty */ }
-          else per_cell = true;
-        } else {
-          const float r1 = dy * c.x, r2 = dy * c.y;
-          const float rl = fminf(r1, r2), rh = fmaxf(r1, r2);
-          const float BIG = 3.0e9f;
-          float L, R;  // open interval (L, R) in dx; +-BIG = unbounded
-          if (mode == 1) {
-            if (dy * c.z > 0.f) { L = rl; R = rh; } else { L = 1.f; R = -1.f; }
-          } else if (mode == 2) { L = rh; R = BIG; }
-          else { L = -BIG; R = rl; }
-          if (L <= R) {
-            const float ady = fabsf(dy), rdy = 2e-6f / ady;
-            const float dL = L > -BIG ? 0.01f + rdy * (L * L + dy * dy) : 0.f;
-            const float dR = R < BIG ? 0.01f + rdy * (R * R + dy * dy) : 0.f;
-            const float CL = 70000.f;
-            const float slo = fminf(fmaxf(floorf(L + dL) + 1.f, -CL), CL);   // first sure dx
-            const float shi = fminf(fmaxf(ceilf(R - dR) - 1.f, -CL), CL);    // last sure dx
-            lo = x + (int)slo;
-            hi = x + (int)shi;
-            if (L > -BIG) { ul0 = x + (int)fminf(fmaxf(ceilf(L - dL), -CL), CL); ul1 = lo - 1; }
-            if (R < BIG) { ur0 = hi + 1; ur1 = x + (int)fminf(fmaxf(floorf(R + dR), -CL), CL); }
-            if (lo > hi) {  // no sure cell: one exact range from the lowest to the highest candidate
-              ul0 = L > -BIG ? ul0 : w_lo;
-              ul1 = R < BIG ? ur1 : w_hi;
-              ur0 = 1; ur1 = 0;
-            }
-          }
-        }
-      }
-      if (per_cell) {
-        for (int cxa = w_lo; cxa <= w_hi; cxa++)
-          if (angle_pass_exact(b.x, b.y, b.z, (float)(cxa - x), dy, inlier)) diff_add(drow, cxa - tx0, cxa - tx0);
-        continue;
-      }
-      lo = max(lo, w_lo);
-      hi = min(hi, w_hi);
-      if (lo <= hi) diff_add(drow, lo - tx0, hi - tx0);
-      for (int cxa = max(ul0, w_lo); cxa <= min(ul1, w_hi); cxa++)
-        if (angle_pass_exact(b.x, b.y, b.z, (float)(cxa - x), dy, inlier)) diff_add(drow, cxa - tx0, cxa - tx0);
-      for (int cxa = max(ur0, w_lo); cxa <= min(ur1, w_hi); cxa++)
-        if (angle_pass_exact(b.x, b.y, b.z, (float)(cxa - x), dy, inlier)) diff_add(drow, cxa - tx0, cxa - tx0);
-    }
-    __syncthreads();
+  // records that can reach the band: y in (y0 - kmax - 1, y0 + HV_BAND - 1 + kmax + 1), kmax = the class'
+  // largest window half-size ceil(thr) - 1 (|dy| < thr  <=>  |dy| <= ceil(thr) - 1)
+  const float tmax = __int_as_float(kmax_g[n * C + cls]);   // max thr of the class' records (>= 0, finite)
+  const float kmaxf = fminf(ceilf(tmax) - 1.f, 65536.f);
+  if (wave == 0) {
+    const int lo = first_record_at_or_below_row(r0, m, (float)y0 - kmaxf);
+    if (lane == 0) s_range[0] = lo;
   }
-
-  // difference arrays -> votes (one thread per row), then the tile maximum as before
-  if (tid < HV_TILE) {
-    int acc = 0;
-    for (int cxr = 0; cxr < HV_TILE; cxr++) { acc += s_diff[tid][cxr]; s_diff[tid][cxr] = acc; }
+  if (wave == nrows - 1) {
+    const int hi = first_record_at_or_below_row(r0, m, (float)(y0 + nrows - 1) + kmaxf + 1.f);
+    if (lane == 0) s_range[1] = hi;
   }
   __syncthreads();
-  const int cx = tx0 + (tid & 31);
-  const int cy0 = ty0 + (tid >> 5);
-  int votes[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) votes[j] = s_diff[(tid >> 5) + 8 * j][tid & 31];
+  const int lo = s_range[0], hi = s_range[1];
 
-  // tile maximum: most votes, lowest cell index among equals (first maximum in index order)
-  int bv = -1, bi = 0x7fffffff;
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    int cy = cy0 + 8 * j;
-    if (cx < W && cy < H) {
-      int idx = cy * W + cx;
-      if (need_hs) hs[((size_t)n * (C - 1) + s) * ((size_t)H * W) + idx] = (float)votes[j];
-      if (votes[j] > bv || (votes[j] == bv && idx < bi)) { bv = votes[j]; bi = idx; }
+  for (int b0 = lo; b0 < hi; b0 += HV_RCHUNK) {
+    const int cnt = min(HV_RCHUNK, hi - b0);
+    for (int k = tid; k < cnt; k += 64 * nrows) {
+      sA[k] = r0[b0 + k].a;
+      sB[k] = r0[b0 + k].b;
+      sC[k] = r0[b0 + k].c;
     }
+    __syncthreads();
+    if (yrow < H)
+      for (int k = lane; k < cnt; k += 64) vote_row(sA[k], sB[k], sC[k], yrow, W, inlier, drow);
+    __syncthreads();
+  }
+
+  // difference array -> votes: lane owns a contiguous strip of the row, wave-wide exclusive scan of
+  // the strip sums; the row maximum (most votes, lowest column among equals) comes out of the same pass
+  if (yrow >= H) return;
+  const int per = (W + 63) / 64;
+  const int c0 = lane * per, c1 = min(c0 + per, W);
+  int sum = 0;
+  for (int cx = c0; cx < c1; cx++) sum += drow[cx];
+  int pre = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(pre, off);
+    if (lane >= off) pre += o;
+  }
+  int acc = pre - sum;   // votes carried into the strip
+  int bv = -1, bi = 0x7fffffff;
+  for (int cx = c0; cx < c1; cx++) {
+    acc += drow[cx];
+    drow[cx] = acc;      // votes (same-wave LDS: in order)
+    if (acc > bv) { bv = acc; bi = yrow * W + cx; }
+  }
+  if (need_hs) {
+    __builtin_amdgcn_wave_barrier();
+    float* hrow = hs + ((size_t)n * (C - 1) + s) * ((size_t)H * W) + (size_t)yrow * W;
+    for (int cx = lane; cx < W; cx += 64) hrow[cx] = (float)drow[cx];
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
-    int ov = __shfl_xor(bv, off), oi = __shfl_xor(bi, off);
+    const int ov = __shfl_xor(bv, off), oi = __shfl_xor(bi, off);
     if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
   }
-  if (lane == 0) { s_rv[wave] = bv; s_ri[wave] = bi; }
-  __syncthreads();
-  if (tid == 0) {
-    for (int w2 = 1; w2 < 4; w2++)
-      if (s_rv[w2] > bv || (s_rv[w2] == bv && s_ri[w2] < bi)) { bv = s_rv[w2]; bi = s_ri[w2]; }
-    tilemax[((size_t)n * (C - 1) + s) * ntiles + tile] = make_int2(bv, bi);
-  }
+  if (lane == 0) rowmax[((size_t)n * (C - 1) + s) * H + yrow] = make_int2(bv, bi);
 }
 
 constexpr int WCD_CAP = 1024;  // floats of LDS per wave for wave_cell_data
@@ -775,7 +789,14 @@ __global__ __launch_bounds__(256) void hv_lmflag_kernel(const int* __restrict__ 
   const int tid = threadIdx.x;
   const int tx0 = (tile % ntx) * HV_TILE, ty0 = (tile / ntx) * HV_TILE;
   const size_t base = ((size_t)n * (C - 1) + s) * ((size_t)H * W);
-  const bool live = (float)tilemax[((size_t)n * (C - 1) + s) * ntiles + tile].x > vote_thr;
+  // `tilemax` holds per-ROW maxima: the tile is live when one of its rows is (a superset of the exact test)
+  bool live = false;
+  {
+    const int2* rm = tilemax + ((size_t)n * (C - 1) + s) * H;
+    const int yy = ty0 + (tid & 31);
+    const bool mine = tid < HV_TILE && yy < H && (float)rm[yy].x > vote_thr;
+    live = __syncthreads_or(mine ? 1 : 0) != 0;
+  }
   if (live) {
     for (int i = tid; i < TS * TS; i += 256) {
       const int ly = i / TS, lx = i - ly * TS;
@@ -1075,6 +1096,8 @@ int validate_common(int B, int H, int W, int C, int skip)
   PCNN_REQUIRE(B >= 1, PCNN_EINVAL, "hough_voting: label must be 3-dimensional with batch >= 1 (got %d)", B);
   PCNN_REQUIRE(H >= 1 && W >= 1, PCNN_EINVAL, "hough_voting: bad image size %dx%d", H, W);
   PCNN_REQUIRE((long long)H * W < (1ll << 24), PCNN_EINVAL, "hough_voting: image too large (%dx%d)", H, W);
+  PCNN_REQUIRE(W <= 12000, PCNN_EINVAL, "hough_voting: images wider than 12000 are not supported (got %d): a Hough "
+               "row lives in LDS", W);
   PCNN_REQUIRE(C >= 2 && C <= PCNN_MAX_CLASSES, PCNN_EINVAL,
                "hough_voting: num_classes must be in [2, %d] (got %d)", PCNN_MAX_CLASSES, C);
   PCNN_REQUIRE(skip >= 1, PCNN_EINVAL, "hough_voting: skip_pixels must be >= 1 (got %d)", skip);
@@ -1173,18 +1196,22 @@ int hough_fwd_impl(const int32_t* label, const HvVertexSrc vs,
   zj.p[3] = top_weight; zj.words[3] = (unsigned)rows_capacity * 4 * C;
   zj.p[4] = (float*)top_domain; zj.words[4] = (unsigned)rows_capacity;
 
-  PCNN_LAUNCH(hv_hist_kernel, dim3(L.nchunk, B), dim3(256), 0, stream, label, hist, HW, C,
+  int* kmax = (int*)(ws + L.off_kmax);
+  PCNN_LAUNCH(hv_hist_kernel, dim3(L.nchunk, B), dim3(256), 0, stream, label, hist, kmax, HW, C,
                      L.nchunk, zj);
   PCNN_LAUNCH(hv_scatter_kernel, dim3(L.nchunk, B), dim3(256), 0, stream, label, vs,
-                     extents, meta, hist, tot, slots, nslots, recoff, rec, HW, W, C, L.nchunk,
+                     extents, meta, hist, tot, slots, nslots, recoff, kmax, rec, HW, W, C, L.nchunk,
                      skip, label_thr, num_meta, L.reccap, inlier);
-  PCNN_LAUNCH(hv_vote_kernel, dim3(L.ntiles, C - 1, B), dim3(256), 0, stream, rec, nslots,
-                     slots, tot, recoff, tilemax, hs, H, W, C, skip, inlier, L.ntx, L.ntiles,
-                     L.reccap, need_hs ? 1 : 0);
+  // rows per band: HV_BAND, fewer when 8 difference arrays of W + 1 counters would not fit 48 KB of LDS
+  int band_rows = HV_BAND;
+  while (band_rows > 1 && sizeof(int) * band_rows * (size_t)(W + 1) > 48 * 1024) band_rows--;
+  PCNN_LAUNCH(hv_vote_kernel, dim3((H + band_rows - 1) / band_rows, C - 1, B), dim3(64 * band_rows),
+              sizeof(int) * band_rows * (size_t)(W + 1), stream, rec, nslots, slots, tot, recoff, kmax, tilemax, hs,
+              H, W, C, skip, inlier, L.reccap, need_hs ? 1 : 0);
   if (!need_hs) {
     PCNN_LAUNCH(hv_select_kernel, dim3(C - 1, B), dim3(256), 0, stream, rec, nslots, slots,
                        tot, recoff, tilemax, extents, meta, maxima, nmax, W, C, skip, inlier,
-                       L.ntiles, L.reccap, L.cap, L.capmax, num_meta);
+                       H, L.reccap, L.cap, L.capmax, num_meta);
   } else {
     unsigned char* flags = (unsigned char*)(ws + L.off_flags);
     PCNN_LAUNCH(hv_lmflag_kernel, dim3(L.ntiles, C - 1, B), dim3(256), 0, stream, nslots, tilemax, hs,
