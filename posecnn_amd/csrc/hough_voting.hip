@@ -169,17 +169,28 @@ __device__ float4 cone_coefficients(float u, float v, float n1, float rn1, float
   const double U = u, V = v, N = n1, cc = (double)inlier;
   const double k = cc * cc;
   const double A = U * U - k * N * N;
-  if (!(fabs(A) > 1e-4 * N * N)) return c;  // a cone edge (nearly) parallel to the rows
+  if (A == 0.0) return c;   // exactly degenerate (measure zero): cell by cell
   const double disc = k * (U * U + V * V - k * N * N);
   if (!(disc >= 0.0)) return c;
   const double D = N * sqrt(disc);
-  const double ra = (-U * V + D) / A, rb = (-U * V - D) / A;
+  // numerically stable root pair (no cancellation): q = -(UV + sgn(UV) D), roots q / A and C / q. When a
+  // cone edge is (nearly) parallel to the rows A -> 0 and the first root runs off to infinity while the
+  // second stays exact — round 1 gave such records up (|A| < 1e-4 N^2 -> cell-by-cell evaluation of the whole
+  // window: ~200 exact predicates per (record, row), a lane-serial tail worth ~20 % of the kernel's
+  // instructions). A root beyond +-1e6 is clamped there: |dy| >= 1 puts it >= 1e6 cells away, outside every
+  // vote window (<= 65536), which is all hv_vote needs to know about it.
+  const double UV = U * V, Cq = V * V - k * N * N;
+  const double q = -(UV + (UV >= 0.0 ? D : -D));
+  double ra = q / A, rb = q != 0.0 ? Cq / q : -UV / A;
+  const double LIM = 1e6;
+  ra = ra > LIM ? LIM : (ra < -LIM ? -LIM : ra);
+  rb = rb > LIM ? LIM : (rb < -LIM ? -LIM : rb);
+  if (!(ra == ra) || !(rb == rb)) return c;
   const double g = U * (ra + rb) * 0.5 + V;
   c.x = (float)ra;
   c.y = (float)rb;
   c.z = (float)g;
   c.w = A < 0.0 ? 1.f : (U > 0.0 ? 2.f : 3.f);
-  if (!(fabsf(c.x) < 1e6f) || !(fabsf(c.y) < 1e6f)) c.w = 0.f;
   return c;
 }
 
@@ -438,6 +449,11 @@ __device__ __forceinline__ void vote_row(const float4 a, const float4 b, const f
         if (dy * c.z > 0.f) { L = rl; R = rh; } else { L = 1.f; R = -1.f; }
       } else if (mode == 2) { L = rh; R = BIG; }
       else { L = -BIG; R = rl; }
+      // an end more than 1e5 cells away is outside every vote window (kx <= 65536): unbounded on that
+      // side, or no cell at all — and no "uncertain" band around it
+      const float FAR = 1.0e5f;
+      if (L > FAR || R < -FAR) { L = 1.f; R = -1.f; }
+      else { if (L < -FAR) L = -BIG; if (R > FAR) R = BIG; }
       if (L <= R) {
         const float ady = fabsf(dy), rdy = 2e-6f / ady;
         const float dL = L > -BIG ? 0.01f + rdy * (L * L + dy * dy) : 0.f;
@@ -465,10 +481,18 @@ __device__ __forceinline__ void vote_row(const float4 a, const float4 b, const f
   lo = max(lo, w_lo);
   hi = min(hi, w_hi);
   if (lo <= hi) diff_add(drow, lo, hi);
-  for (int cxa = max(ul0, w_lo); cxa <= min(ul1, w_hi); cxa++)
+  // the (at most a few) cells near the two ends, ONE loop for both ranges: a wave takes as many trips as
+  // its busiest lane, and most lanes have zero or one such cell
+  ul0 = max(ul0, w_lo); ul1 = min(ul1, w_hi);
+  ur0 = max(ur0, w_lo); ur1 = min(ur1, w_hi);
+  int cxa = ul0 <= ul1 ? ul0 : ur0;
+  int endc = ul0 <= ul1 ? ul1 : ur1;
+  bool second = !(ul0 <= ul1);
+  while (cxa <= endc) {
     if (angle_pass_exact(b.x, b.y, b.z, (float)(cxa - x), dy, inlier)) diff_add(drow, cxa, cxa);
-  for (int cxa = max(ur0, w_lo); cxa <= min(ur1, w_hi); cxa++)
-    if (angle_pass_exact(b.x, b.y, b.z, (float)(cxa - x), dy, inlier)) diff_add(drow, cxa, cxa);
+    cxa++;
+    if (cxa > endc && !second) { second = true; cxa = ur0; endc = ur1; }
+  }
 }
 
 // first index i in [0, m) with rec[i].a.y >= yq (m if none); records are sorted by y. One wave, 64-ary.
@@ -493,7 +517,7 @@ __device__ __forceinline__ int first_record_at_or_below_row(const HvRec* __restr
   return lo;
 }
 
-__global__ __launch_bounds__(64 * HV_BAND) void hv_vote_kernel(
+__global__ __launch_bounds__(64 * HV_BAND, 8) void hv_vote_kernel(
     const HvRec* __restrict__ rec, const int* __restrict__ nslots_g,
     const int* __restrict__ slots_g, const int* __restrict__ tot_g,
     const int* __restrict__ recoff_g, const int* __restrict__ kmax_g, int2* __restrict__ rowmax,

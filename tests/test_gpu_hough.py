@@ -290,7 +290,7 @@ def gpu_hough_space(gpu, label, vertex, ext, meta, vote_thr, skip, label_thr):
     return hs, slots, nslots, [o.cpu().numpy() for o in out]
 
 
-@pytest.mark.parametrize("case", ["synthetic", "plateau", "boundary"])
+@pytest.mark.parametrize("case", ["synthetic", "plateau", "boundary", "cone_edge"])
 def test_every_hough_cell_matches_oracle(gpu, case):
     if case == "synthetic":
         label, vertex, meta, _ = frames(140, 2, H=240, W=320, n_obj=4)
@@ -302,6 +302,32 @@ def test_every_hough_cell_matches_oracle(gpu, case):
         ext = np.full((C, 3), 0.2, F)
         meta = np.stack([config.make_meta_data(config.DEMO_INTRINSICS)] * 2)
         skip, label_thr = 4, 100
+    elif case == "cone_edge":
+        # vote cones with an edge (nearly) parallel to the Hough rows: |u| / |uv| = inlierThreshold to within a
+        # few ulps, so the quadratic of the interval form degenerates (A -> 0, one root at infinity); also the
+        # mirror cases |v| / |uv| = 0.9 and exact axis directions. Every cell must still equal the oracle's.
+        H, W, C = 96, 128, 3
+        rng = np.random.default_rng(11)
+        label = np.zeros((1, H, W), np.int32); label[0, 20:76, 24:104] = 1
+        vertex = np.zeros((1, H, W, 3 * C), F)
+        base = []
+        s19 = np.sqrt(0.19)
+        for su in (1, -1):
+            for sv in (1, -1):
+                base += [(0.9 * su, s19 * sv), (s19 * su, 0.9 * sv)]
+        base += [(1.0, 0.0), (-1.0, 0.0), (0.0, 1.0), (0.0, -1.0)]
+        ys, xs = np.nonzero(label[0])
+        for i, (y, x) in enumerate(zip(ys, xs)):
+            u, v = base[i % len(base)]
+            mag = F(rng.uniform(0.3, 3.0))
+            uu, vv = F(u) * mag, F(v) * mag
+            for _ in range(int(rng.integers(0, 4))):   # a few ulps off the degenerate direction, either way
+                uu = np.nextafter(uu, F(np.inf) if rng.random() < 0.5 else F(-np.inf), dtype=F)
+            vertex[0, y, x, 3], vertex[0, y, x, 4] = uu, vv
+        vertex[0, ..., 5] = np.log(0.9)
+        ext = np.full((C, 3), 0.12, F)
+        meta = config.make_meta_data(config.DEMO_INTRINSICS)[None]
+        skip, label_thr = 1, 100
     else:
         H, W, C = 128, 160, 3
         rng = np.random.default_rng(3)
