@@ -826,6 +826,31 @@ int oracle_backproject_bwd(const float* top_diff, const float* depth, const floa
   return 0;
 }
 
+/* canonical exp of the softmax layers (network.py:474-488), all-f32, one IEEE operation per step, no
+ * FMA (this file is built -ffp-contract=off) — the same sequence as exp_softmax_f32 in
+ * posecnn_amd/csrc/pcnn_device.h and tests/np_ref.py; the bits of TF's exp are unknowable. */
+float oracle_exp_softmax(float x)
+{
+  if (x != x) return x;
+  x = fminf(fmaxf(x, -104.f), 88.f);
+  const float kf = rintf(x * 1.44269502f);
+  float r = x - kf * 0.693145752f;
+  r = r - kf * 1.42860677e-06f;
+  float p = 1.98412698e-04f;
+  p = p * r + 1.38888889e-03f;
+  p = p * r + 8.33333377e-03f;
+  p = p * r + 4.16666679e-02f;
+  p = p * r + 1.66666672e-01f;
+  p = p * r + 0.5f;
+  p = p * r + 1.0f;
+  p = p * r + 1.0f;
+  const int k = (int)kf;
+  union { unsigned u; float f; } sc;
+  if (k < -126) { sc.u = (unsigned)(k + 64 + 127) << 23; return (p * sc.f) * 5.42101086e-20f; }
+  sc.u = (unsigned)(k + 127) << 23;
+  return p * sc.f;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* softmax_high_dimension + argmax_2d, lib/networks/network.py:474-488, 432-434                 */
 /* (tf.reduce_max, tf.exp(x - m), tf.reduce_sum ascending, tf.div, tf.argmax = first maximum)    */
@@ -839,7 +864,7 @@ int oracle_softmax_argmax(const float* score, long N, int C, float* prob, int* l
     for (int c = 1; c < C; c++) m = fmaxf(m, s[c]);
     float e[1024];
     float sum = 0;
-    for (int c = 0; c < C; c++) { e[c] = oracle_expf(s[c] - m); sum += e[c]; }
+    for (int c = 0; c < C; c++) { e[c] = oracle_exp_softmax(s[c] - m); sum += e[c]; }
     int best = 0;
     float bestp = e[0] / sum;
     for (int c = 0; c < C; c++) {

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void softmax_argmax_kernel(const float* __rest
     float sum = 0.f;
 #pragma unroll
     for (int c = 0; c < CMAX; c++)
-      if (c < C) { e[c] = exp_f32(e[c] - m); sum += e[c]; }
+      if (c < C) { e[c] = exp_softmax_f32(e[c] - m); sum += e[c]; }
     int best = 0;
     float bestp = div_rn(e[0], sum);
 #pragma unroll

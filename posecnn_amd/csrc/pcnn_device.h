@@ -87,6 +87,34 @@ __device__ __forceinline__ float exp_f32(float xf)
   return (float)(p * two_k);
 }
 
+// Canonical exp of the SOFTMAX layers (network.py:474-488: tf.exp(x - max)), all-f32: TF's / cuDNN's
+// bits are unknowable, so any fixed IEEE sequence is as canonical as another — this one costs ~25 f32
+// VALU operations instead of the ~30 f64 ones of exp_f32 (the label-head epilogue evaluates 22 per
+// pixel and was ALU-bound on it). Every step is one IEEE f32 operation with one rounding (no FMA:
+// the library is built -ffp-contract=off), so the C oracle and the numpy restatement reproduce it bit
+// for bit:  k = rint(x log2e);  r = (x - k ln2_hi) - k ln2_lo  (ln2_hi has 15 significant bits: k ln2_hi
+// is exact);  p = Horner degree 7 (1/n!);  result = p 2^k, scaled in two exact steps below 2^-126.
+// Relative error <= 2e-7 (the truncation r^8/8! is 5e-9).
+__device__ __forceinline__ float exp_softmax_f32(float x)
+{
+  if (x != x) return x;
+  x = fminf(fmaxf(x, -104.f), 88.f);
+  const float kf = __builtin_rintf(x * 1.44269502f);
+  float r = x - kf * 0.693145752f;
+  r = r - kf * 1.42860677e-06f;
+  float p = 1.98412698e-04f;
+  p = p * r + 1.38888889e-03f;
+  p = p * r + 8.33333377e-03f;
+  p = p * r + 4.16666679e-02f;
+  p = p * r + 1.66666672e-01f;
+  p = p * r + 0.5f;
+  p = p * r + 1.0f;
+  p = p * r + 1.0f;
+  const int k = (int)kf;
+  if (k < -126) return (p * __int_as_float((k + 64 + 127) << 23)) * 5.42101086e-20f;   // 2^-64
+  return p * __int_as_float((k + 127) << 23);
+}
+
 // float -> int as the reference's `int v = round(x)` behaves on the GPU: saturating, NaN -> 0.
 __device__ __forceinline__ int round_to_int_sat(float x)
 {

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(UP_SEG) void upscore_softmax_argmax_kernel(
     float sum = 0.f;
 #pragma unroll
     for (int c = 0; c < CMAX; c++)
-      if (c < C) { e[c] = exp_f32(e[c] - m); sum += e[c]; }
+      if (c < C) { e[c] = exp_softmax_f32(e[c] - m); sum += e[c]; }
     float bestp = div_rn(e[0], sum);
 #pragma unroll
     for (int c = 0; c < CMAX; c++)

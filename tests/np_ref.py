@@ -26,6 +26,26 @@ def exp_f32(x):
     return np.where(np.isnan(x), x, out)
 
 
+def exp_softmax_f32(x):
+    """canonical exp of the softmax layers: the all-f32 sequence of exp_softmax_f32 (pcnn_device.h) /
+    oracle_exp_softmax — every numpy operation below is one IEEE float32 operation."""
+    x = np.asarray(x, dtype=np.float32)
+    xc = np.minimum(np.maximum(x, F(-104.0)), F(88.0)).astype(F)
+    with np.errstate(invalid="ignore", under="ignore", over="ignore"):
+        kf = np.rint(xc * F(1.44269502)).astype(F)
+        r = (xc - kf * F(0.693145752)).astype(F)
+        r = (r - kf * F(1.42860677e-06)).astype(F)
+        p = np.full_like(r, F(1.98412698e-04))
+        for c in (1.38888889e-03, 8.33333377e-03, 4.16666679e-02, 1.66666672e-01, 0.5, 1.0, 1.0):
+            p = (p * r + F(c)).astype(F)
+        k = np.where(np.isnan(kf), 0, kf).astype(np.int64)
+        low = k < -126
+        s1 = np.ldexp(F(1.0), np.where(low, k + 64, k).astype(np.int32)).astype(F)
+        out = (p * s1).astype(F)
+        out = np.where(low, (out * F(5.42101086e-20)).astype(F), out)
+    return np.where(np.isnan(x), x, out).astype(F)
+
+
 def project_box(cls, extents, meta, d):
     """hough_voting_gpu_op.cu.cc:84-120, factor 0.6; d may be an array."""
     d = np.asarray(d, dtype=np.float32)
@@ -315,10 +335,10 @@ def backproject(data, label, depth, meta, label_3d, G, ksize, thr):
 
 
 def softmax_argmax(score):
-    """network.py:474-488, 432-434 with the canonical expf"""
+    """network.py:474-488, 432-434 with the canonical softmax exp"""
     s = score.astype(np.float32)
     m = np.fmax.reduce(s, axis=-1, keepdims=True)
-    e = exp_f32((s - m).astype(np.float32))
+    e = exp_softmax_f32((s - m).astype(np.float32))
     tot = np.zeros(s.shape[:-1] + (1,), np.float32)
     for c in range(s.shape[-1]):
         tot = (tot + e[..., c:c + 1]).astype(np.float32)
