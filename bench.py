@@ -241,24 +241,44 @@ def main(argv=None):
         resident = [tuple(None if t is None else t.to(dev) for t in hb) for hb in host]
         uploader = None
     else:
-        uploader = pipeline.FrameUploader(host, dev, depth=2)
+        # (--graph: one captured step per device slot, so slot k always holds host batch k: nbuf = slots = 2)
+        uploader = pipeline.FrameUploader(host, dev, depth=1 if a.graph else 2)
+    if a.graph:
+        assert len(host) == 2 and not a.resident_inputs, "--graph uses --nbuf 2 and pinned-host inputs"
     feed_cache = None
     last = {}
     drain = pdist.HostDrain(depth=2)
     seq = {"i": 0}
 
+    graphs = {}
+
+    def step(data, data_p, k):
+        nonlocal feed_cache
+        if feed_cache is None:
+            feed_cache = fcn._feed(net, data, data_p, K, extents, pts, symmetry, C, dev)
+        return fcn.im_segment_batch(net, data, K, extents, pts, symmetry, data_p=data_p,
+                                    planted=planted[k], feed_cache=feed_cache,
+                                    with_losses=a.losses != "none", gt_poses=gts[k])
+
     def launch(_unused):
         """Enqueue one batch: (H2D wait) backbone + heads + Hough voting + RoI/pose branch + losses +
         all-gather + async D2H. No host synchronisation in here."""
-        nonlocal feed_cache
         i = seq["i"]
         seq["i"] += 1
         data, data_p = uploader.get(i) if uploader is not None else resident[i % len(resident)]
-        if feed_cache is None:
-            feed_cache = fcn._feed(net, data, data_p, K, extents, pts, symmetry, C, dev)
-        det = fcn.im_segment_batch(net, data, K, extents, pts, symmetry, data_p=data_p,
-                                   planted=planted[i % len(planted)], feed_cache=feed_cache,
-                                   with_losses=a.losses != "none", gt_poses=gts[i % len(gts)])
+        k = i % len(planted)
+        if a.graph and last.get("graph_ready"):
+            if k not in graphs:   # capture once per device slot (its tensors are the graph's static inputs)
+                def fn(data=data, data_p=data_p, k=k):
+                    d = step(data, data_p, k)
+                    return d.rows, d.count, d.label_2d, net.get_output("poses_weight")
+                graphs[k] = pipeline.GraphedStep(fn, warmup=1, device=dev)
+            rows, count, label_2d, pw = graphs[k].replay()
+            det = fcn.Detections(rows, count, label_2d)
+            last["poses_weight"] = pw
+        else:
+            det = step(data, data_p, k)
+            last["poses_weight"] = net.layers.get("poses_weight")
         if uploader is not None:
             uploader.release(i)
         packed = pdist.all_gather_packed(det.rows, det.count, frame_offset=rank * B)
@@ -304,6 +324,10 @@ def main(argv=None):
         # handles, allocator pools), then K timed steps -> value_cold
         run(a.warmup)
         torch.cuda.synchronize()
+        if a.graph:
+            last["graph_ready"] = True      # everything is warm: from here on the step is a hipGraph replay
+            run(2 * len(host))              # (captures one graph per device slot, untimed)
+            torch.cuda.synchronize()
         elapsed_cold, _ = timed(a.steps)
         # (2) the steady state a throughput job runs in: under sustained load the GPU's clocks keep rising
         # for several seconds (measured round 1: 962 / 1023 / 1132 frames/s after 0 / 2 / 8 s). Untimed.
@@ -311,16 +335,26 @@ def main(argv=None):
         while time.perf_counter() - t_pre < a.prewarm_seconds:
             run(4)
             torch.cuda.synchronize()
-        _lib.profile_enable(True)   # HIP events around every library kernel, on the launch stream
-        net.conv_timing = []        # ... and around every remaining framework convolution / GEMM of the trunk
+        if not a.graph:
+            _lib.profile_enable(True)   # HIP events around every library kernel, on the launch stream
+            net.conv_timing = []        # ... and around every remaining framework convolution / GEMM of the trunk
         elapsed, ndet = timed(a.steps)
+        host_launch_ms = 1000.0 * last["host_launch_s"] / a.steps
+        if a.graph:
+            # per-kernel events cannot be recorded inside a graph replay: time the same kernels once more, eagerly
+            last["graph_ready"] = False
+            net.conv_timing = []
+            _lib.profile_enable(True)
+            run(a.steps)
+            torch.cuda.synchronize()
         kern = _lib.profile_report()
         _lib.profile_enable(False)
+        if a.graph:
+            last["graph_ready"] = True
         conv_ms = sum(e0.elapsed_time(e1) for _, _, _, e0, e1 in net.conv_timing)
         conv_flops = sum(f for _, f, _, _, _ in net.conv_timing)
         conv_direct_flops = sum(f for _, _, f, _, _ in net.conv_timing)
         net.conv_timing = None
-        host_launch_ms = 1000.0 * last["host_launch_s"] / a.steps
         if a.latency:
             # per-frame latency: one batch at a time, upload -> kernels -> D2H -> host NMS, synchronously
             times = []
@@ -366,7 +400,7 @@ def main(argv=None):
     per_class = torch.bincount((lab.reshape(B, -1).long() + C * torch.arange(B, device=dev).unsqueeze(1)).flatten(),
                                minlength=C * B).reshape(B, C)[:, 1:]
     pairs = float(((per_class + net.skip_pixels - 1) // net.skip_pixels * (per_class > 500)).sum().item()) * H * W
-    adl_rows = int((net.get_output("poses_weight").sum(dim=1) > 0).sum().item()) if a.losses != "none" else 0
+    adl_rows = int((last["poses_weight"].sum(dim=1) > 0).sum().item()) if a.losses != "none" and last.get("poses_weight") is not None else 0
 
     # HBM-bound kernels of the library: algorithmic bytes per step / live event time per step
     act = lambda div, ch: 4.0 * B * (H // div) * (W // div) * ch
@@ -442,6 +476,7 @@ def main(argv=None):
                      "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"},
         "prewarm_seconds": a.prewarm_seconds,
         "host_launch_ms_per_step": host_launch_ms,
+        "step_submission": "hipGraph replay (one graph per device slot)" if a.graph else "eager launches",
         "kernels_us": {k: round(v["avg_us"], 2) for k, v in sorted(kern.items())},
         "kernel_calls_per_step": {k: round(v["calls"] / a.steps, 2) for k, v in sorted(kern.items())},
     }

@@ -71,3 +71,33 @@ class FrameUploader:
 def pin(t):
     """Page-locked copy of a CPU tensor (what the feed_dict blobs live in)."""
     return t.contiguous().pin_memory() if t is not None else None
+
+
+class GraphedStep:
+    """One whole batch step captured in a hipGraph (torch.cuda.CUDAGraph on ROCm) and replayed:
+    the ~150 kernel launches of a step (gfx950 library kernels + the few framework ops left)
+    become ONE host call, so a batch-1 frame is no longer bound by the host's launch rate.
+
+    `fn()` must enqueue the step on the current stream with static shapes, read its inputs from
+    fixed tensors (the caller refills them before `replay()`), never synchronise with the host,
+    and return a tensor / tuple of tensors — those live in the graph's private pool and are
+    overwritten by the next replay. Every entry of libposecnn_hip.so is capture-legal (no
+    allocation, no sync, stream argument); kernel timing (`pcnn_profile_enable`) must be off."""
+
+    def __init__(self, fn, warmup=3, device=None):
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):          # warm-up off the default stream: MIOpen find, workspaces, caches
+            for _ in range(warmup):
+                fn()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outputs = fn()
+        torch.cuda.synchronize(self.device)
+
+    def replay(self):
+        self.graph.replay()
+        return self.outputs

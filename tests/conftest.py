@@ -14,6 +14,7 @@ if TESTS not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: tens of seconds on the CPU (the reference's kernels through the serial SIMT shim at full size)")
     # the oracle is test infrastructure: build it on demand (gcc only, a second or two)
     so = os.path.join(ROOT, "oracle", "liboracle.so")
     src = os.path.join(ROOT, "oracle", "pcnn_oracle.c")

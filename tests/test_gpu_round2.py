@@ -271,3 +271,68 @@ def test_fc_layer_uses_the_row_count(gpu):
         got = net.get_output("fb")
     assert float((got[:25] - want[:25]).abs().max()) <= 1e-5 * float(want.abs().max())
     assert float(got[25:].abs().max()) == 0.0
+
+
+# ---- realistic geometry: the reference's demo depth frames and real YCB models (tests/golden/make_demo_fixtures.py) ----
+def _demo_fixture():
+    import os
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    fr = np.load(os.path.join(g, "demo_frames.npz"))
+    mo = np.load(os.path.join(g, "lov_models.npz"))
+    return fr["depth"], fr["label"], mo["points"], mo["extents"]
+
+
+def _vertex_from_depth(label, depth, C=22):
+    """What the vertex head is trained to emit (lib/gt_synthesize_layer/minibatch.py:583-594): per foreground pixel
+    the unit direction to its object's centre and the log of its depth — here from the REAL depth image, with a
+    deterministic per-pixel angular perturbation so that cones are not perfectly aligned."""
+    H, W = label.shape
+    v = np.zeros((H, W, 3 * C), F)
+    yy, xx = np.mgrid[0:H, 0:W]
+    wob = (((xx * 73856093) ^ (yy * 19349663)) % 1000 / 1000.0 - 0.5) * 0.12     # +-0.06 rad
+    for c in np.unique(label):
+        if c == 0:
+            continue
+        m = label == c
+        cy, cx = yy[m].mean(), xx[m].mean()
+        ang = np.arctan2(cy - yy[m], cx - xx[m]) + wob[m]
+        v[m, 3 * c] = np.cos(ang)
+        v[m, 3 * c + 1] = np.sin(ang)
+        v[m, 3 * c + 2] = np.log(np.maximum(depth[m].astype(np.float64) / config.DEMO_FACTOR_DEPTH, 0.25))
+    return v
+
+
+@pytest.mark.parametrize("frame", [0, 1, 2, 3, 4])
+def test_hough_on_demo_frame_geometry(gpu, frame):
+    """Full-size parity (480x640, C = 22, skip 10, labelThreshold 500, the file's extents and the demo intrinsics) on
+    masks and depths taken from the reference's own demo frames, both vote_threshold branches."""
+    depth, label, points, ext = _demo_fixture()
+    assert np.array_equal(ext, config.LOV_EXTENTS)
+    lab = label[frame].astype(np.int32)[None]
+    ver = _vertex_from_depth(lab[0], depth[frame])[None]
+    meta = config.make_meta_data(config.DEMO_INTRINSICS)[None]
+    for vote_thr, per_thr in ((-1.0, 0.02), (40.0, 0.0002)):
+        want = oracle.hough_voting(lab, ver, ext, meta, None, 0, vote_thr, per_thr, 10, padded=True)
+        got = run_gpu(gpu, lab, ver, ext, meta, None, 0, vote_thr, per_thr, 10)
+        compare(got, want)
+        assert int(got[5][1]) >= (6 if vote_thr < 0 else 1)
+
+
+def test_average_distance_on_real_models(gpu):
+    """average_distance_loss with the real 2620-point YCB models (data/LOV/models/*/points.xyz), including the two
+    classes lov.py:38 marks symmetric (16 wood block, 21 foam brick: nearest-neighbour search over all 2620 points)."""
+    from posecnn_amd import ops
+    _, _, points, _ = _demo_fixture()
+    assert points.shape == (22, 2620, 3)
+    rng = np.random.default_rng(5)
+    R, C = 9, 22
+    pred = np.zeros((R, 4 * C), F); tgt = np.zeros((R, 4 * C), F); wgt = np.zeros((R, 4 * C), F)
+    for n, c in enumerate((1, 16, 5, 21, 11, 16, 14, 21, 3)):
+        pred[n, 4 * c:4 * c + 4] = np.tanh(rng.standard_normal(4)).astype(F)
+        tgt[n, 4 * c:4 * c + 4] = synth.random_unit_quats(rng, 1)[0]
+        wgt[n, 4 * c:4 * c + 4] = 1
+    loss, diff = ops.average_distance_loss(T(gpu, pred), T(gpu, tgt), T(gpu, wgt), T(gpu, points), T(gpu, config.LOV_SYMMETRY), 0.01)
+    wl, wd = oracle.average_distance(pred, tgt, wgt, points, config.LOV_SYMMETRY, 0.01)
+    assert wl[0] > 0
+    same(N(loss), wl, "loss")
+    same(N(diff), wd, "bottom_diff")

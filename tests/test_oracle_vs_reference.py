@@ -193,3 +193,22 @@ def test_backproject_matches_reference_kernels(ref):
     want = oracle.backproject_bwd(g, depth, meta, B, H, W, Cd, G)
     assert np.abs(bd).sum() > 0
     bits_equal(bd, want, "bottom_diff")
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("vote_thr,per_thr", [(-1.0, 0.02), (50.0, 0.0005)])
+def test_hough_voting_matches_reference_kernels_at_the_real_config(ref, vote_thr, per_thr):
+    """the pin at the REAL configuration — one full 480x640 frame, C = 22, skip_pixels 10,
+    labelThreshold 500, demo intrinsics and extents (lov_color_2d.yml, vgg16_convs.py:20-29), both branches of
+    vote_threshold (thrust::max_element / compute_max_indexes_kernel). The reference's own kernel bodies run
+    serially through the SIMT shim (~20 s per branch with two objects in the frame); the oracle must reproduce
+    every output row AND every cell of the Hough space bit for bit."""
+    label, vertex, meta, fr = small_frames(7, 1, 480, 640, 22, 2)
+    ext = config.LOV_EXTENTS
+    assert all((label[0] == o[0]).sum() > 500 for o in fr[0]["objects"])
+    want, whs = ref_hough(ref, label, vertex, ext, meta, None, 0, vote_thr, per_thr, 10, 500)
+    got = oracle.hough_voting(label, vertex, ext, meta, None, 0, vote_thr, per_thr, 10, label_thr=500, padded=True, want_hs=True)
+    assert int(want[5][1]) >= 2
+    for name, w, g in zip(("top_box", "top_pose", "top_target", "top_weight", "top_domain", "num_rois"), want, got[:6]):
+        bits_equal(w, g, name)
+    bits_equal(whs, got[6], "hough_space (every cell of the 480x640 space)")
