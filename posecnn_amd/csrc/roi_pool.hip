@@ -1,13 +1,26 @@
 // roi_pool.hip — gfx950 ROI max pooling, NHWC (replaces TF1 ops "RoiPool"/"RoiPoolGrad",
 // lib/roi_pooling_layer/roi_pooling_op.cc:306-347,384-461 + roi_pooling_op_gpu.cu.cc:20-254).
 //
-// Layout-driven design: features are NHWC, so the 512 channels of one spatial position are one
-// contiguous 2 KB row. A workgroup owns one (roi, ph, pw) bin; its threads each own 4 consecutive
-// channels (one dwordx4 per position) and walk the bin h-major, so every load instruction of a
-// wave is a fully coalesced 1 KB row segment and the bin geometry (the reference recomputes it
-// per output element, :45-75) is computed once per workgroup in scalar registers.
+// Forward: separable, staged through LDS. Features are NHWC, so a 32-channel chunk of one spatial
+// position is one 128 B line. A workgroup owns one (roi, bin row ph, channel chunk): phase 1 reduces
+// every feature column the ROI covers over the bin row's h range into LDS as (max value, first h
+// that attains it) — all 256 threads issue distinct 16 B loads, each feature line is read once per
+// bin row instead of once per bin that touches it; phase 2 lets thread (pw, c) finish the bin with a
+// horizontal scan of the staged columns. The reference walks each bin h-major with a strict `>`
+// (roi_pooling_op_gpu.cu.cc:77-93), i.e. the first maximum in (h, w) order wins; "max value, then
+// smallest h, then smallest w" over the staged columns selects the same element, so values and
+// argmax stay bit-identical. ROIs wider than the LDS window fall back to reading columns from
+// global memory inside phase 2 (same routine, no staging).
 // The fused `add2` entry pools conv5_3 and conv4_3 and adds them (vgg16_convs.py:177-187) without
-// writing either pooled tensor or any argmax (inference does not consume them).
+// writing either pooled tensor or any argmax (inference does not consume them); it keeps the
+// register-only bin-per-workgroup form, which measures faster for a value-only max (see below).
+//
+// Backward: tile-binned ordered gather. A workgroup owns (image, row h, 8 consecutive w, 256
+// channels); wave 0 compacts — in ascending ROI order, by ballot — the ROIs of that image whose
+// rectangle touches the tile into an LDS list, then every thread walks the short list for its
+// channel. The reference gathers over *all* ROIs per output element (:135-229); here the
+// O(B*H*W*C*R) test collapses to one scan of the ROI table per tile while the summation order per
+// element (roi, ph, pw ascending) — and therefore every bit of the result — is unchanged.
 #include <cfloat>
 
 #include "pcnn_device.h"
@@ -16,115 +29,154 @@ namespace {
 
 using namespace pcnn;
 
-struct Bin {
-  int hstart, hend, wstart, wend, batch, cls;
-  bool empty;
+constexpr int RP_THREADS = 256;
+constexpr int RP_CHUNK = 32;        // channels per workgroup (one 128 B line per position)
+constexpr int RP_LDS_WORDS = 4096;  // 16 KB window => 8 workgroups/CU keep all 32 wave slots busy
+
+struct RoiGeom {
+  int batch, cls, sw, sh, ew, eh;
+  float bin_h, bin_w;
 };
 
-// roi_pooling_op_gpu.cu.cc:45-75
-__device__ __forceinline__ Bin make_bin(const float* __restrict__ roi, float scale, int ph, int pw,
-                                        int PH, int PW, int H, int W)
+// roi_pooling_op_gpu.cu.cc:45-62
+__device__ __forceinline__ RoiGeom roi_geometry(const float* __restrict__ roi, float scale, int PH,
+                                                int PW)
 {
-  Bin b;
-  b.batch = (int)roi[0];
-  b.cls = (int)roi[1];
-  int roi_start_w = (int)roundf(roi[2] * scale);
-  int roi_start_h = (int)roundf(roi[3] * scale);
-  int roi_end_w = (int)roundf(roi[4] * scale);
-  int roi_end_h = (int)roundf(roi[5] * scale);
-  int roi_width = max(roi_end_w - roi_start_w + 1, 1);
-  int roi_height = max(roi_end_h - roi_start_h + 1, 1);
-  float bin_size_h = div_rn((float)roi_height, (float)PH);
-  float bin_size_w = div_rn((float)roi_width, (float)PW);
-  int hstart = (int)floorf((float)ph * bin_size_h);
-  int wstart = (int)floorf((float)pw * bin_size_w);
-  int hend = (int)ceilf((float)(ph + 1) * bin_size_h);
-  int wend = (int)ceilf((float)(pw + 1) * bin_size_w);
-  b.hstart = min(max(hstart + roi_start_h, 0), H);
-  b.hend = min(max(hend + roi_start_h, 0), H);
-  b.wstart = min(max(wstart + roi_start_w, 0), W);
-  b.wend = min(max(wend + roi_start_w, 0), W);
-  b.empty = (b.hend <= b.hstart) || (b.wend <= b.wstart);
-  return b;
+  RoiGeom g;
+  g.batch = (int)roi[0];
+  g.cls = (int)roi[1];
+  g.sw = (int)roundf(roi[2] * scale);
+  g.sh = (int)roundf(roi[3] * scale);
+  g.ew = (int)roundf(roi[4] * scale);
+  g.eh = (int)roundf(roi[5] * scale);
+  g.bin_h = div_rn((float)max(g.eh - g.sh + 1, 1), (float)PH);
+  g.bin_w = div_rn((float)max(g.ew - g.sw + 1, 1), (float)PW);
+  return g;
 }
 
-// one workgroup per (roi, ph, pw); thread t owns channels [4t, 4t+3] (+ 4*blockDim strides)
-__global__ __launch_bounds__(128) void roi_pool_fwd_vec4(const float* __restrict__ data,
-                                                         const float* __restrict__ rois,
-                                                         float* __restrict__ top,
-                                                         int* __restrict__ argmax, int B, int H,
-                                                         int W, int C, int roi_cols, int PH, int PW,
-                                                         float scale)
+// feature range [lo, hi) of pooled bin p along one axis, clipped to the map (:64-75)
+__device__ __forceinline__ void bin_span(float bin, int p, int start, int limit, int& lo, int& hi)
 {
-  const int bin = blockIdx.x;
-  const int pw = bin % PW, ph = (bin / PW) % PH, n = bin / (PW * PH);
-  const Bin b = make_bin(rois + (size_t)n * roi_cols, scale, ph, pw, PH, PW, H, W);
-  if (b.batch < 0 || b.batch >= B) {  // CHECK_GE/LT in the CPU op (roi_pooling_op.cc:146-147); GPU op reads OOB
-    for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {
-      float4 z = make_float4(0, 0, 0, 0);
-      *reinterpret_cast<float4*>(top + (size_t)bin * C + c) = z;
-      if (argmax) *reinterpret_cast<int4*>(argmax + (size_t)bin * C + c) = make_int4(-1, -1, -1, -1);
-    }
-    return;
+  lo = min(max((int)floorf((float)p * bin) + start, 0), limit);
+  hi = min(max((int)ceilf((float)(p + 1) * bin) + start, 0), limit);
+}
+
+// vertical reduction of one feature column, one channel: max over h in [hlo, hhi) and the first h
+// attaining it (-1 if nothing compares greater than -FLT_MAX, e.g. NaN columns)
+__device__ __forceinline__ void column_max(const float* __restrict__ img, int W, int C, int ch,
+                                           int hlo, int hhi, int w, float& best, int& row)
+{
+  best = -FLT_MAX;
+  row = -1;
+  const float* p = img + ((size_t)hlo * W + w) * C + ch;
+  for (int h = hlo; h < hhi; ++h, p += (size_t)W * C) {
+    const float v = *p;
+    if (v > best) { best = v; row = h; }
   }
-  const float* img = data + (size_t)b.batch * H * W * C;
-  for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {
-    const float init = b.empty ? 0.f : -FLT_MAX;
-    float4 mv = make_float4(init, init, init, init);
-    int4 mi = make_int4(-1, -1, -1, -1);
-    for (int h = b.hstart; h < b.hend; ++h)
-      for (int w = b.wstart; w < b.wend; ++w) {
-        const int base = (h * W + w) * C + c;
-        const float4 v = *reinterpret_cast<const float4*>(img + base);
-        if (v.x > mv.x) { mv.x = v.x; mi.x = base; }
-        if (v.y > mv.y) { mv.y = v.y; mi.y = base + 1; }
-        if (v.z > mv.z) { mv.z = v.z; mi.z = base + 2; }
-        if (v.w > mv.w) { mv.w = v.w; mi.w = base + 3; }
+}
+
+// phase 1: columns [w0, w0+ncols) x channels [c0, c0+cc) -> LDS (value, optionally first row)
+template <bool VEC>
+__device__ __forceinline__ void stage_columns(const float* __restrict__ img, int W, int C, int c0,
+                                              int cc, int hlo, int hhi, int w0, int ncols,
+                                              float* __restrict__ sval, int* __restrict__ srow)
+{
+  if (VEC) {
+    const int groups = cc >> 2;
+    for (int i = threadIdx.x; i < ncols * groups; i += RP_THREADS) {
+      const int g = i % groups, col = i / groups;
+      float4 mv = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+      int4 mh = make_int4(-1, -1, -1, -1);
+      const float* p = img + ((size_t)hlo * W + w0 + col) * C + c0 + 4 * g;
+      for (int h = hlo; h < hhi; ++h, p += (size_t)W * C) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        if (v.x > mv.x) { mv.x = v.x; mh.x = h; }
+        if (v.y > mv.y) { mv.y = v.y; mh.y = h; }
+        if (v.z > mv.z) { mv.z = v.z; mh.z = h; }
+        if (v.w > mv.w) { mv.w = v.w; mh.w = h; }
       }
-    *reinterpret_cast<float4*>(top + (size_t)bin * C + c) = mv;
-    if (argmax) *reinterpret_cast<int4*>(argmax + (size_t)bin * C + c) = mi;
-  }
-}
-
-// generic path: any C, and pool_channel == 1 (pools only channel roi_cls, :87-88); one thread per output
-__global__ __launch_bounds__(256) void roi_pool_fwd_scalar(const float* __restrict__ data,
-                                                           const float* __restrict__ rois,
-                                                           float* __restrict__ top,
-                                                           int* __restrict__ argmax, long long total,
-                                                           int B, int H, int W, int C, int roi_cols,
-                                                           int PH, int PW, float scale,
-                                                           int pool_channel)
-{
-  for (long long index = (long long)blockIdx.x * 256 + threadIdx.x; index < total;
-       index += (long long)gridDim.x * 256) {
-    long long t = index;
-    int c = 1;
-    if (!pool_channel) { c = (int)(t % C); t /= C; }
-    int pw = (int)(t % PW); t /= PW;
-    int ph = (int)(t % PH); t /= PH;
-    int n = (int)t;
-    const Bin b = make_bin(rois + (size_t)n * roi_cols, scale, ph, pw, PH, PW, H, W);
-    float maxval = b.empty ? 0.f : -FLT_MAX;
-    int maxidx = -1;
-    const int cc = pool_channel ? b.cls : c;
-    if (b.batch >= 0 && b.batch < B && cc >= 0 && cc < C) {
-      const float* img = data + (size_t)b.batch * H * W * C;
-      for (int h = b.hstart; h < b.hend; ++h)
-        for (int w = b.wstart; w < b.wend; ++w) {
-          int bottom_index = (h * W + w) * C + cc;
-          float v = img[bottom_index];
-          if (v > maxval) { maxval = v; maxidx = bottom_index; }
-        }
-    } else {
-      maxval = 0.f;
+      *reinterpret_cast<float4*>(sval + col * cc + 4 * g) = mv;
+      if (srow) *reinterpret_cast<int4*>(srow + col * cc + 4 * g) = mh;
     }
-    top[index] = maxval;
-    if (argmax) argmax[index] = maxidx;
+  } else {
+    for (int i = threadIdx.x; i < ncols * cc; i += RP_THREADS) {
+      const int c = i % cc, col = i / cc;
+      float mv;
+      int mh;
+      column_max(img, W, C, c0 + c, hlo, hhi, w0 + col, mv, mh);
+      sval[col * cc + c] = mv;
+      if (srow) srow[col * cc + c] = mh;
+    }
   }
 }
 
-// pool_score = roi_pool(conv5_3, 1/16) + roi_pool(conv4_3, 1/8), vgg16_convs.py:177-187
-__global__ __launch_bounds__(128) void roi_pool_add2_vec4(
+// grid: (roi, ph, channel chunk), chunk fastest. pool_channel: one chunk holding channel roi_cls.
+template <bool VEC>
+__global__ __launch_bounds__(RP_THREADS) void roi_pool_fwd_staged(
+    const float* __restrict__ data, const float* __restrict__ rois, float* __restrict__ top,
+    int* __restrict__ argmax, int B, int H, int W, int C, int roi_cols, int PH, int PW, float scale,
+    int pool_channel, int nchunks)
+{
+  __shared__ __attribute__((aligned(16))) float smem[RP_LDS_WORDS];
+  const int chunk = blockIdx.x % nchunks;
+  const int ph = (blockIdx.x / nchunks) % PH;
+  const int n = blockIdx.x / (nchunks * PH);
+  const RoiGeom g = roi_geometry(rois + (size_t)n * roi_cols, scale, PH, PW);
+  const int c0 = pool_channel ? g.cls : chunk * RP_CHUNK;
+  const int cc = pool_channel ? 1 : min(RP_CHUNK, C - c0);
+  const int out_c = pool_channel ? 1 : C;  // channels per output bin
+  const int oc0 = pool_channel ? 0 : c0;
+  const size_t row0 = ((size_t)n * PH + ph) * PW;
+  // CHECK_GE/LT in the CPU op (roi_pooling_op.cc:146-147); the reference GPU op would read out of bounds
+  const bool valid = g.batch >= 0 && g.batch < B && c0 >= 0 && c0 < C;
+  int hlo, hhi, w0, w1, tmp;
+  bin_span(g.bin_h, ph, g.sh, H, hlo, hhi);
+  bin_span(g.bin_w, 0, g.sw, W, w0, tmp);
+  bin_span(g.bin_w, PW - 1, g.sw, W, tmp, w1);
+  const int ncols = max(w1 - w0, 0);
+  const bool row_empty = hhi <= hlo;
+  const float* img = data + (size_t)(valid ? g.batch : 0) * H * W * C;
+  const int per_col = argmax ? 2 : 1;
+  const bool staged = valid && !row_empty && (long long)ncols * cc * per_col <= RP_LDS_WORDS;
+  float* sval = smem;
+  int* srow = argmax ? reinterpret_cast<int*>(smem + ncols * cc) : nullptr;
+  if (staged) {
+    stage_columns<VEC>(img, W, C, c0, cc, hlo, hhi, w0, ncols, sval, srow);
+    __syncthreads();
+  }
+  for (int j = threadIdx.x; j < PW * cc; j += RP_THREADS) {
+    const int c = j % cc, pw = j / cc;
+    int wlo, whi;
+    bin_span(g.bin_w, pw, g.sw, W, wlo, whi);
+    const bool empty = row_empty || whi <= wlo;
+    float best = (empty || !valid) ? 0.f : -FLT_MAX;
+    int brow = -1, bcol = -1;
+    if (valid && !empty) {
+      for (int w = wlo; w < whi; ++w) {
+        float v;
+        int r = -1;
+        if (staged) {
+          v = sval[(w - w0) * cc + c];
+          if (srow) r = srow[(w - w0) * cc + c];
+        } else {
+          column_max(img, W, C, c0 + c, hlo, hhi, w, v, r);
+        }
+        if (v > best || (v == best && r < brow)) { best = v; brow = r; bcol = w; }
+      }
+    }
+    const size_t o = (row0 + pw) * out_c + oc0 + c;
+    top[o] = best;
+    if (argmax) argmax[o] = brow < 0 ? -1 : (brow * W + bcol) * C + c0 + c;
+  }
+}
+
+// pool_score = roi_pool(conv5_3, 1/16) + roi_pool(conv4_3, 1/8), vgg16_convs.py:177-187.
+// One workgroup per (roi, ph, pw) bin, thread t owns channels [4t, 4t+3]: registers only. The
+// LDS-staged form above was measured for this op too (tools/bench_roi_pool.py, 16 frames x 468
+// rows): 169 us with 256 threads, 137 us with one wave per bin row, against 130 us for this
+// kernel (397 vs 165 us inside the bench step) — without an argmax to resolve, the work per bin
+// row is too thin to pay for the barrier and the second pass, so the fused op stays register-only.
+__global__ __launch_bounds__(128) void roi_pool_add2_perbin(
     const float* __restrict__ data_a, int Ha, int Wa, float scale_a,
     const float* __restrict__ data_b, int Hb, int Wb, float scale_b,
     const float* __restrict__ rois, float* __restrict__ out, int B, int C, int roi_cols, int PH,
@@ -133,88 +185,128 @@ __global__ __launch_bounds__(128) void roi_pool_add2_vec4(
   const int bin = blockIdx.x;
   const int pw = bin % PW, ph = (bin / PW) % PH, n = bin / (PW * PH);
   const float* roi = rois + (size_t)n * roi_cols;
-  const Bin ba = make_bin(roi, scale_a, ph, pw, PH, PW, Ha, Wa);
-  const Bin bb = make_bin(roi, scale_b, ph, pw, PH, PW, Hb, Wb);
-  // rows past the device-side count are padding of a capacity-sized ROI buffer: they pool to 0
-  const bool ok = ba.batch >= 0 && ba.batch < B && (num_rows_dev == nullptr || n < num_rows_dev[0]);
+  const RoiGeom ga = roi_geometry(roi, scale_a, PH, PW);
+  const RoiGeom gb = roi_geometry(roi, scale_b, PH, PW);
+  int ha0, ha1, hb0, hb1, wa0, wa1, wb0, wb1;
+  bin_span(ga.bin_h, ph, ga.sh, Ha, ha0, ha1);
+  bin_span(gb.bin_h, ph, gb.sh, Hb, hb0, hb1);
+  bin_span(ga.bin_w, pw, ga.sw, Wa, wa0, wa1);
+  bin_span(gb.bin_w, pw, gb.sw, Wb, wb0, wb1);
+  const bool ok = ga.batch >= 0 && ga.batch < B && (num_rows_dev == nullptr || n < num_rows_dev[0]);
+  const bool ea = ha1 <= ha0 || wa1 <= wa0, eb = hb1 <= hb0 || wb1 <= wb0;
   for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {
     float4 ma = make_float4(0, 0, 0, 0), mb = ma;
     if (ok) {
-      const float* ia = data_a + (size_t)ba.batch * Ha * Wa * C;
-      const float* ib = data_b + (size_t)bb.batch * Hb * Wb * C;
-      const float inita = ba.empty ? 0.f : -FLT_MAX, initb = bb.empty ? 0.f : -FLT_MAX;
+      const float* ia = data_a + (size_t)ga.batch * Ha * Wa * C;
+      const float* ib = data_b + (size_t)gb.batch * Hb * Wb * C;
+      const float inita = ea ? 0.f : -FLT_MAX, initb = eb ? 0.f : -FLT_MAX;
       ma = make_float4(inita, inita, inita, inita);
       mb = make_float4(initb, initb, initb, initb);
-      for (int h = ba.hstart; h < ba.hend; ++h)
-        for (int w = ba.wstart; w < ba.wend; ++w) {
+      for (int h = ha0; h < ha1; ++h)
+        for (int w = wa0; w < wa1; ++w) {
           const float4 v = *reinterpret_cast<const float4*>(ia + (h * Wa + w) * C + c);
           ma.x = v.x > ma.x ? v.x : ma.x; ma.y = v.y > ma.y ? v.y : ma.y;
           ma.z = v.z > ma.z ? v.z : ma.z; ma.w = v.w > ma.w ? v.w : ma.w;
         }
-      for (int h = bb.hstart; h < bb.hend; ++h)
-        for (int w = bb.wstart; w < bb.wend; ++w) {
+      for (int h = hb0; h < hb1; ++h)
+        for (int w = wb0; w < wb1; ++w) {
           const float4 v = *reinterpret_cast<const float4*>(ib + (h * Wb + w) * C + c);
           mb.x = v.x > mb.x ? v.x : mb.x; mb.y = v.y > mb.y ? v.y : mb.y;
           mb.z = v.z > mb.z ? v.z : mb.z; mb.w = v.w > mb.w ? v.w : mb.w;
         }
     }
-    // tf.add_n([pool5, pool4]) (network.py:362-369): pool5 + pool4
-    float4 r = make_float4(ma.x + mb.x, ma.y + mb.y, ma.z + mb.z, ma.w + mb.w);
-    *reinterpret_cast<float4*>(out + (size_t)bin * C + c) = r;
+    *reinterpret_cast<float4*>(out + (size_t)bin * C + c) =
+        make_float4(ma.x + mb.x, ma.y + mb.y, ma.z + mb.z, ma.w + mb.w);
   }
 }
 
-// ROIPoolBackward, roi_pooling_op_gpu.cu.cc:135-229 (gather form; ROIs ascending => deterministic)
-__global__ __launch_bounds__(256) void roi_pool_bwd_kernel(
+constexpr int RB_TILE_W = 8;
+constexpr int RB_LIST = 512;
+
+struct RoiEntry {
+  int idx, cls, sw, sh, ew, eh;
+  float bin_h, bin_w;
+};
+
+// grid.x: (image, h, tile of RB_TILE_W columns); grid.y: blocks of 256 channels
+__global__ __launch_bounds__(256) void roi_pool_bwd_binned(
     const float* __restrict__ top_diff, const float* __restrict__ rois,
-    const int* __restrict__ argmax, float* __restrict__ bottom_diff, long long total, int H, int W,
-    int C, int R, int roi_cols, int PH, int PW, float scale, int pool_channel)
+    const int* __restrict__ argmax, float* __restrict__ bottom_diff, int H, int W, int C, int R,
+    int roi_cols, int PH, int PW, float scale, int pool_channel)
 {
-  for (long long index = (long long)blockIdx.x * 256 + threadIdx.x; index < total;
-       index += (long long)gridDim.x * 256) {
-    long long t = index;
-    int c = (int)(t % C); t /= C;
-    int w = (int)(t % W); t /= W;
-    int h = (int)(t % H); t /= H;
-    int n = (int)t;
-    float gradient = 0;
-    for (int roi_n = 0; roi_n < R; ++roi_n) {
-      const float* roi = rois + (size_t)roi_n * roi_cols;
-      int roi_batch_ind = (int)roi[0];
-      int roi_cls = (int)roi[1];
-      if (n != roi_batch_ind) continue;
-      if (pool_channel && c != roi_cls) continue;
-      int roi_start_w = (int)roundf(roi[2] * scale);
-      int roi_start_h = (int)roundf(roi[3] * scale);
-      int roi_end_w = (int)roundf(roi[4] * scale);
-      int roi_end_h = (int)roundf(roi[5] * scale);
-      if (!(w >= roi_start_w && w <= roi_end_w && h >= roi_start_h && h <= roi_end_h)) continue;
-      size_t offset = pool_channel ? (size_t)roi_n * PH * PW : (size_t)roi_n * PH * PW * C;
-      const float* otd = top_diff + offset;
-      const int* oam = argmax + offset;
-      int roi_width = max(roi_end_w - roi_start_w + 1, 1);
-      int roi_height = max(roi_end_h - roi_start_h + 1, 1);
-      float bin_size_h = div_rn((float)roi_height, (float)PH);
-      float bin_size_w = div_rn((float)roi_width, (float)PW);
-      int phstart = (int)floorf(div_rn((float)(h - roi_start_h), bin_size_h));
-      int phend = (int)ceilf(div_rn((float)(h - roi_start_h + 1), bin_size_h));
-      int pwstart = (int)floorf(div_rn((float)(w - roi_start_w), bin_size_w));
-      int pwend = (int)ceilf(div_rn((float)(w - roi_start_w + 1), bin_size_w));
-      phstart = min(max(phstart, 0), PH);
-      phend = min(max(phend, 0), PH);
-      pwstart = min(max(pwstart, 0), PW);
-      pwend = min(max(pwend, 0), PW);
-      for (int ph = phstart; ph < phend; ++ph)
-        for (int pw = pwstart; pw < pwend; ++pw) {
-          if (pool_channel) {
-            if (oam[ph * PW + pw] == (h * W + w) * C + c) gradient += otd[ph * PW + pw];
-          } else {
-            if (oam[(ph * PW + pw) * C + c] == (h * W + w) * C + c)
-              gradient += otd[(ph * PW + pw) * C + c];
-          }
+  __shared__ RoiEntry s_list[RB_LIST];
+  __shared__ int s_count, s_cursor;
+  const int tiles_w = (W + RB_TILE_W - 1) / RB_TILE_W;
+  const int tw = blockIdx.x % tiles_w;
+  const int h = (blockIdx.x / tiles_w) % H;
+  const int n = blockIdx.x / (tiles_w * H);
+  const int w_lo = tw * RB_TILE_W, w_hi = min(W, w_lo + RB_TILE_W);
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  const bool lane_ok = c < C;
+  const int lane = threadIdx.x & 63;
+  float acc[RB_TILE_W];
+#pragma unroll
+  for (int j = 0; j < RB_TILE_W; ++j) acc[j] = 0.f;
+
+  int cursor = 0;
+  while (cursor < R) {
+    if (threadIdx.x < 64) {
+      // ordered compaction of the ROIs of image n that touch this tile; ascending roi index is the
+      // reference's summation order (:150)
+      int count = 0, r = cursor;
+      while (r < R && count <= RB_LIST - 64) {
+        const int i = r + lane;
+        bool hit = false;
+        RoiEntry e;
+        if (i < R) {
+          const RoiGeom g = roi_geometry(rois + (size_t)i * roi_cols, scale, PH, PW);
+          // :161-166 — the element must lie inside the (unclipped) ROI rectangle
+          hit = g.batch == n && h >= g.sh && h <= g.eh && w_lo <= g.ew && w_hi - 1 >= g.sw;
+          e.idx = i; e.cls = g.cls; e.sw = g.sw; e.sh = g.sh; e.ew = g.ew; e.eh = g.eh;
+          e.bin_h = g.bin_h; e.bin_w = g.bin_w;
         }
+        const unsigned long long mask = __ballot(hit);
+        if (hit) s_list[count + __popcll(mask & ((1ull << lane) - 1ull))] = e;
+        count += __popcll(mask);
+        r += 64;
+      }
+      if (lane == 0) { s_count = count; s_cursor = r; }
     }
-    bottom_diff[index] = gradient;
+    __syncthreads();
+    const int count = s_count;
+    cursor = s_cursor;
+    for (int k = 0; k < count; ++k) {
+      const RoiEntry e = s_list[k];
+      if (!lane_ok || (pool_channel && c != e.cls)) continue;
+      // bins whose span can contain row h / column w (:180-191)
+      int phs = (int)floorf(div_rn((float)(h - e.sh), e.bin_h));
+      int phe = (int)ceilf(div_rn((float)(h - e.sh + 1), e.bin_h));
+      phs = min(max(phs, 0), PH);
+      phe = min(max(phe, 0), PH);
+      const size_t base = (size_t)e.idx * PH * PW;
+#pragma unroll
+      for (int j = 0; j < RB_TILE_W; ++j) {
+        const int w = w_lo + j;
+        if (w >= w_hi || w < e.sw || w > e.ew) continue;
+        int pws = (int)floorf(div_rn((float)(w - e.sw), e.bin_w));
+        int pwe = (int)ceilf(div_rn((float)(w - e.sw + 1), e.bin_w));
+        pws = min(max(pws, 0), PW);
+        pwe = min(max(pwe, 0), PW);
+        const int want = (h * W + w) * C + c;
+        for (int ph = phs; ph < phe; ++ph)
+          for (int pw = pws; pw < pwe; ++pw) {
+            const size_t o = pool_channel ? base + ph * PW + pw : (base + ph * PW + pw) * C + c;
+            if (argmax[o] == want) acc[j] += top_diff[o];
+          }
+      }
+    }
+    __syncthreads();
+  }
+  if (lane_ok) {
+    float* dst = bottom_diff + (((size_t)n * H + h) * W + w_lo) * C + c;
+#pragma unroll
+    for (int j = 0; j < RB_TILE_W; ++j)
+      if (w_lo + j < w_hi) dst[(size_t)j * C] = acc[j];
   }
 }
 
@@ -244,17 +336,15 @@ extern "C" int pcnn_roi_pool_fwd(const float* data, const float* rois, int B, in
   if (R == 0) return PCNN_OK;
   PCNN_REQUIRE(data && rois && top, PCNN_ENULL, "roi_pool: NULL pointer");
   hipStream_t stream = (hipStream_t)stream_;
-  const bool vec = !pool_channel && (C % 4 == 0) && aligned16(data) && aligned16(top) &&
-                   (!argmax || aligned16(argmax));
-  if (vec) {
-    const int threads = C >= 512 ? 128 : 64;
-    PCNN_LAUNCH(roi_pool_fwd_vec4, dim3(R * PH * PW), dim3(threads), 0, stream, data, rois,
-                       top, argmax, B, H, W, C, roi_cols, PH, PW, scale);
+  const int nchunks = pool_channel ? 1 : (C + RP_CHUNK - 1) / RP_CHUNK;
+  const long long blocks = (long long)R * PH * nchunks;
+  PCNN_REQUIRE(blocks < (1ll << 31), PCNN_EINVAL, "roi_pool: too many bin rows (%lld)", blocks);
+  if (!pool_channel && (C % 4 == 0) && aligned16(data)) {
+    PCNN_LAUNCH(roi_pool_fwd_staged<true>, dim3((unsigned)blocks), dim3(RP_THREADS), 0, stream, data,
+                rois, top, argmax, B, H, W, C, roi_cols, PH, PW, scale, pool_channel, nchunks);
   } else {
-    long long total = (long long)R * PH * PW * (pool_channel ? 1 : C);
-    int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    PCNN_LAUNCH(roi_pool_fwd_scalar, dim3(blocks), dim3(256), 0, stream, data, rois, top,
-                       argmax, total, B, H, W, C, roi_cols, PH, PW, scale, pool_channel);
+    PCNN_LAUNCH(roi_pool_fwd_staged<false>, dim3((unsigned)blocks), dim3(RP_THREADS), 0, stream, data,
+                rois, top, argmax, B, H, W, C, roi_cols, PH, PW, scale, pool_channel, nchunks);
   }
   return check_launch("roi_pool_fwd");
 }
@@ -274,9 +364,11 @@ extern "C" int pcnn_roi_pool_add2_fwd(const float* data_a, int Ha, int Wa, float
   PCNN_REQUIRE(aligned16(data_a) && aligned16(data_b) && aligned16(out), PCNN_EINVAL,
                "roi_pool_add2: tensors must be 16-byte aligned");
   hipStream_t stream = (hipStream_t)stream_;
-  const int threads = C >= 512 ? 128 : 64;
-  PCNN_LAUNCH(roi_pool_add2_vec4, dim3(R * PH * PW), dim3(threads), 0, stream, data_a, Ha,
-                     Wa, scale_a, data_b, Hb, Wb, scale_b, rois, out, B, C, roi_cols, PH, PW, num_rows_dev);
+  const long long blocks = (long long)R * PH * PW;
+  PCNN_REQUIRE(blocks < (1ll << 31), PCNN_EINVAL, "roi_pool_add2: too many bins (%lld)", blocks);
+  PCNN_LAUNCH(roi_pool_add2_perbin, dim3((unsigned)blocks), dim3(C >= 512 ? 128 : 64), 0, stream,
+              data_a, Ha, Wa, scale_a, data_b, Hb, Wb, scale_b, rois, out, B, C, roi_cols, PH, PW,
+              num_rows_dev);
   return check_launch("roi_pool_add2_fwd");
 }
 
@@ -289,9 +381,11 @@ extern "C" int pcnn_roi_pool_bwd(const float* top_diff, const float* rois, const
   PCNN_REQUIRE(bottom_diff, PCNN_ENULL, "roi_pool_bwd: NULL output");
   PCNN_REQUIRE(R == 0 || (top_diff && rois && argmax), PCNN_ENULL, "roi_pool_bwd: NULL input");
   hipStream_t stream = (hipStream_t)stream_;
-  long long total = (long long)B * H * W * C;
-  int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-  PCNN_LAUNCH(roi_pool_bwd_kernel, dim3(blocks), dim3(256), 0, stream, top_diff, rois,
-                     argmax, bottom_diff, total, H, W, C, R, roi_cols, PH, PW, scale, pool_channel);
+  const long long tiles = (long long)B * H * ((W + RB_TILE_W - 1) / RB_TILE_W);
+  PCNN_REQUIRE(tiles < (1ll << 31) && (C + 255) / 256 < 65536, PCNN_EINVAL,
+               "roi_pool_bwd: feature map too large for one launch");
+  PCNN_LAUNCH(roi_pool_bwd_binned, dim3((unsigned)tiles, (unsigned)((C + 255) / 256)), dim3(256), 0,
+              stream, top_diff, rois, argmax, bottom_diff, H, W, C, R, roi_cols, PH, PW, scale,
+              pool_channel);
   return check_launch("roi_pool_bwd");
 }

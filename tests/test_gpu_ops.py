@@ -107,6 +107,42 @@ def test_roi_pool_backward(gpu):
         same(N(d.grad), want, "bottom_diff pc=%d" % pc)
 
 
+
+def test_roi_pool_ties_wide_rois_and_long_roi_lists(gpu):
+    """Cases aimed at the staged/binned kernels: heavy value ties (first maximum in (h, w) order must
+    win), ROIs wider than the LDS column window (direct fallback), malformed ROIs (end < start: the
+    forward pools one cell, the backward's rectangle test drops it), a ROI table longer than the
+    backward's LDS list (several compaction passes), C not a multiple of the chunk."""
+    import torch
+    from posecnn_amd import ops
+    rng = np.random.default_rng(15)
+    B, H, W, C = 2, 9, 150, 40
+    data = rng.integers(-2, 3, (B, H, W, C)).astype(F)      # 5 distinct values -> ties everywhere
+    R = 1200
+    rois = random_rois(rng, R, B, C, W * 4, H * 4)
+    rois[:40, 2] = 0; rois[:40, 4] = W * 4 - 1                # full-width ROIs: 150 columns
+    rois[40:60, 4] = rois[40:60, 2] - 13                      # x2 < x1
+    rois[60:80, 5] = rois[60:80, 3] - 9                       # y2 < y1
+    rois[80:700, 0] = 1                                       # > RB_LIST ROIs on one image ...
+    rois[80:700, 2:6] = [0, 0, W * 4 - 1, H * 4 - 1]          # ... all touching every tile
+    for pc in (0, 1):
+        d = T(gpu, data).requires_grad_(True)
+        top, arg = ops.roi_pool(d, T(gpu, rois), 4, 6, 0.25, pc)
+        wt, wa = oracle.roi_pool(data, rois, 4, 6, 0.25, pc)
+        same(N(top), wt, "top pc=%d" % pc)
+        same(N(arg), wa, "argmax pc=%d" % pc)
+        g = rng.integers(-3, 4, tuple(top.shape)).astype(F) * F(0.37)
+        top.backward(T(gpu, g))
+        want = oracle.roi_pool_bwd(g, rois, wa, B, H, W, C, 4, 6, 0.25, pc)
+        same(N(d.grad), want, "bottom_diff pc=%d" % pc)
+    # fused two-tensor entry on ROIs wider than the shared window
+    a = rng.integers(-2, 3, (B, H, W, C)).astype(F)
+    b = rng.integers(-2, 3, (B, 2 * H, 2 * W, C)).astype(F)
+    out = ops.roi_pool_add2(T(gpu, a), 0.25, T(gpu, b), 0.5, T(gpu, rois[:120]))
+    pa, _ = oracle.roi_pool(a, rois[:120], 7, 7, 0.25, 0)
+    pb, _ = oracle.roi_pool(b, rois[:120], 7, 7, 0.5, 0)
+    same(N(out), pa + pb, "pool_score wide")
+
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(1, 480, 640, 22), (2, 33, 47, 22), (1, 5, 7, 3), (1, 1, 1, 16)])
 def test_hard_label(gpu, shape):

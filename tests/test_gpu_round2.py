@@ -210,7 +210,7 @@ def test_batch_pipeline_rgbd_matches_cpu_reference(gpu, train):
         assert np.array_equal(w_gpu, ref["poses_weight"])              # same rows matched a gt pose
         same(net.get_output("poses_target")[:n].cpu().numpy(), ref["poses_target"], "poses_target")
         assert (w_gpu.sum(axis=1) > 0).sum() >= n // 2
-        assert loss_gpu > 0 and abs(loss_gpu - float(ref["loss_pose"])) <= 1e-4 * max(1.0, abs(float(ref["loss_pose"])))
+        assert loss_gpu > 0 and abs(loss_gpu - float(np.ravel(ref["loss_pose"])[0])) <= 1e-4 * max(1.0, abs(float(np.ravel(ref["loss_pose"])[0])))
     else:
         assert loss_gpu == 0.0 and not w_gpu.any()   # is_train = 0: no targets -> ADL skips every row
     hl = net.get_output("gt_label_weight").cpu().numpy()
