@@ -40,6 +40,19 @@ def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
+def exp_softmax(x):
+    """oracle_exp_softmax (the all-f32 canonical exp of the softmax layers), element-wise"""
+    x = np.asarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    L = lib()
+    L.oracle_exp_softmax.restype = c_float
+    L.oracle_exp_softmax.argtypes = [c_float]
+    flat_in, flat_out = x.ravel(), out.ravel()
+    for i in range(flat_in.size):
+        flat_out[i] = L.oracle_exp_softmax(c_float(float(flat_in[i])))
+    return out
+
+
 def expf(x):
     x = np.asarray(x, dtype=np.float32)
     out = np.empty_like(x)

@@ -51,6 +51,28 @@ def test_expf_matches_correctly_rounded_double():
     assert oracle.expf(np.array([-200], F))[0] == 0
 
 
+def test_exp_softmax_canonical_sequence():
+    """The all-f32 exp of the softmax layers: the C oracle and the numpy restatement agree bit for
+    bit, the value is within 2 ulp of the correctly rounded exp on the softmax domain (x <= 0) and
+    the edge cases behave (NaN passes through, clamped tails, subnormal results)."""
+    import np_ref
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([-rng.exponential(4.0, 60000), np.linspace(-110, 0, 20001), rng.uniform(-1, 1, 5000),
+                         [0.0, -0.0, -87.3, -87.4, -88.0, -100.0, -103.9, -104.0, -150.0, 1.0, 88.0, 100.0]]).astype(F)
+    got = oracle.exp_softmax(xs)
+    with np.errstate(all="ignore"):
+        same_bits = got.view(np.uint32) == np_ref.exp_softmax_f32(xs).view(np.uint32)
+        want = np.exp(np.clip(xs.astype(np.float64), -104, 88))
+    assert same_bits.all()
+    normal = want >= 1.2e-38
+    ulp = np.spacing(want.astype(F)).astype(np.float64)
+    assert np.max(np.abs(got[normal].astype(np.float64) - want[normal]) / ulp[normal]) <= 2.0
+    assert np.all(np.abs(got[~normal].astype(np.float64) - want[~normal]) <= 2 * 1.4e-45 + 4e-7 * want[~normal])
+    assert np.all(got[xs == 0] == 1.0)
+    assert np.isnan(oracle.exp_softmax(np.array([np.nan], F))[0])
+    assert np.all(np.diff(oracle.exp_softmax(np.linspace(-104, 0, 4001).astype(F))) >= 0)   # monotone on a grid
+
+
 def _one_object(H=64, W=96, C=3, cls=1, z=1.0, label_thr_pixels=600):
     label = np.zeros((1, H, W), np.int32)
     label[0, 20:50, 30:70] = cls  # 1200 px
