@@ -238,7 +238,13 @@ def main(argv=None):
     gts = [None if g is None else torch.from_numpy(g).to(dev) for _, g, _ in aux]
     pts = torch.from_numpy(synth.make_model_points(C, config.NUM_MODEL_POINTS, extents=extents)).to(dev)
     if a.resident_inputs:
-        resident = [tuple(None if t is None else t.to(dev) for t in hb) for hb in host]
+        resident = []
+        for hb in host:
+            slot = pipeline.alloc_adjacent(hb, dev)
+            for d_, h_ in zip(slot, hb):
+                if d_ is not None:
+                    d_.copy_(h_)
+            resident.append(slot)
         uploader = None
     else:
         # (--graph: one captured step per device slot, so slot k always holds host batch k: nbuf = slots = 2)

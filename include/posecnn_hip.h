@@ -323,10 +323,13 @@ int pcnn_winograd43_conv_fwd(const float* v, const float* ut, const float* bias,
  *   x    f32 [rows_capacity][in_features]      in_features % 64 == 0, >= 128
  *   wt   f32 [out_features][in_features]       the TF weight variable [in, out] TRANSPOSED; out_features % 64 == 0
  *   bias f32 [out_features];  num_rows_dev device int32[1] or NULL (= rows_capacity);  y f32 [rows_capacity][out_features]
+ *   addend f32 [rows_capacity][out_features] or NULL: added before the ReLU — a 1x1 convolution over a channel
+ *        concatenation (`concat` + `conv(1, 1, ...)` of the RGB-D heads, vgg16_convs.py:104-113) is the sum of
+ *        two such products, one per tower, so the concatenated tensor is never built
  * fp32 MFMA (exact f32), sum over k in ascending order within a lane-fixed interleave. */
 int pcnn_fc_rows_fwd(const float* x, const float* wt, const float* bias, int rows_capacity,
                      int in_features, int out_features, int relu, const int32_t* num_rows_dev,
-                     float* y, void* stream);
+                     const float* addend, float* y, void* stream);
 
 /* pcnn_winograd43_output_fwd writing BOTH the activation y f32 [B,H,W,C] and its 2x2 max-pool y_pool f32
  * [B,H/2,W/2,C] in one pass (conv4_3 -> pool4, whose un-pooled output score_conv4 and roi_pool read too). */

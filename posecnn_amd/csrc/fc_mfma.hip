@@ -35,8 +35,8 @@ __device__ __forceinline__ void fc_glds16(const char* g, float* lds_wave_base)
 
 __global__ __launch_bounds__(512, 2) void fc_rows_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
-    float* __restrict__ y, int K, int N, int Mcap, int relu, const int* __restrict__ num_rows_dev, int nbm,
-    int ncb)
+    const float* __restrict__ addend, float* __restrict__ y, int K, int N, int Mcap, int relu,
+    const int* __restrict__ num_rows_dev, int nbm, int ncb, int tall)
 {
   __shared__ __attribute__((aligned(16))) float smem[FC_NBUF * 128 * FC_LD];   // sA[3][64][64] | sB[3][64][64]
   float* sAp = smem;
@@ -45,10 +45,12 @@ __global__ __launch_bounds__(512, 2) void fc_rows_mfma_kernel(
   // XCD-aware block map: the weight matrix is the big operand (fc6: 411 MB) and every row block needs
   // all of a column block's rows of it, so XCD x takes the column blocks cb == x (mod 8) and runs their
   // row blocks back to back: W^T streams from HBM once, the (few) live x rows are re-read from L2 / MALL
+  // `tall` (x is the big operand: the 1x1 head convolutions, 76 800 rows x 64..128 columns): the other
+  // way round — XCD x takes the row blocks tb == x (mod 8) and runs their column blocks back to back.
   const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-  const int tb = q % nbm;
-  const int cb = (q / nbm) * 8 + xcd;
-  if (cb >= ncb) return;
+  const int tb = tall ? (q / ncb) * 8 + xcd : q % nbm;
+  const int cb = tall ? q % ncb : (q / nbm) * 8 + xcd;
+  if (cb >= ncb || tb >= nbm) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   const int lr = lane & 15, lk = lane >> 4;
@@ -156,10 +158,8 @@ __global__ __launch_bounds__(512, 2) void fc_rows_mfma_kernel(
   float* sY = smem;   // [64 rows][64 columns]
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    float v0 = acc0[i] + bv, v1 = acc1[i] + bv;
-    if (relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
-    sY[(32 * wm + 4 * lk + i) * 64 + col] = v0;
-    sY[(32 * wm + 16 + 4 * lk + i) * 64 + col] = v1;
+    sY[(32 * wm + 4 * lk + i) * 64 + col] = acc0[i] + bv;
+    sY[(32 * wm + 16 + 4 * lk + i) * 64 + col] = acc1[i] + bv;
   }
   __syncthreads();
 #pragma unroll
@@ -168,7 +168,15 @@ __global__ __launch_bounds__(512, 2) void fc_rows_mfma_kernel(
     const int row = idx >> 4, c4 = (idx & 15) * 4;
     const int m = m0 + row;
     if (m < Mcap) {
-      const v4f val = m < count ? *reinterpret_cast<const v4f*>(&sY[row * 64 + c4]) : (v4f){0.f, 0.f, 0.f, 0.f};
+      v4f val = (v4f){0.f, 0.f, 0.f, 0.f};
+      if (m < count) {
+        val = *reinterpret_cast<const v4f*>(&sY[row * 64 + c4]);
+        if (addend) val += *reinterpret_cast<const v4f*>(addend + (size_t)m * N + cb * 64 + c4);
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) val[e] = val[e] > 0.f ? val[e] : 0.f;
+        }
+      }
       *reinterpret_cast<v4f*>(y + (size_t)m * N + cb * 64 + c4) = val;
     }
   }
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void fc_rows_mfma_kernel(
 
 extern "C" int pcnn_fc_rows_fwd(const float* x, const float* wt, const float* bias, int rows_capacity,
                                 int in_features, int out_features, int relu, const int32_t* num_rows_dev,
-                                float* y, void* stream_)
+                                const float* addend, float* y, void* stream_)
 {
   PCNN_REQUIRE(rows_capacity >= 0, PCNN_EINVAL, "fc_rows: negative row capacity");
   PCNN_REQUIRE(in_features >= 128 && in_features % 64 == 0, PCNN_EINVAL,
@@ -187,13 +195,14 @@ extern "C" int pcnn_fc_rows_fwd(const float* x, const float* wt, const float* bi
                "fc_rows: out_features must be a multiple of 64 (got %d)", out_features);
   if (rows_capacity == 0) return PCNN_OK;
   PCNN_REQUIRE(x && wt && bias && y, PCNN_ENULL, "fc_rows: NULL pointer");
-  PCNN_REQUIRE(aligned16(x) && aligned16(wt) && aligned16(y), PCNN_EINVAL, "fc_rows: pointers must be 16-byte aligned");
+  PCNN_REQUIRE(aligned16(x) && aligned16(wt) && aligned16(y) && aligned16(addend), PCNN_EINVAL, "fc_rows: pointers must be 16-byte aligned");
   PCNN_REQUIRE((long long)rows_capacity * in_features < (1ll << 30) && (long long)out_features * in_features < (1ll << 30),
                PCNN_EINVAL, "fc_rows: operand larger than the 32-bit byte offsets of the kernel");
   hipStream_t stream = (hipStream_t)stream_;
   const int nbm = (rows_capacity + 63) / 64, ncb = out_features / 64;
-  const long long blocks = (long long)((ncb + 7) / 8) * 8 * nbm;
-  PCNN_LAUNCH(fc_rows_mfma_kernel, dim3((unsigned)blocks), dim3(512), 0, stream, x, wt, bias, y, in_features,
-              out_features, rows_capacity, relu, num_rows_dev, nbm, ncb);
+  const int tall = (long long)rows_capacity > (long long)out_features;   // which operand is the big one
+  const long long blocks = tall ? (long long)((nbm + 7) / 8) * 8 * ncb : (long long)((ncb + 7) / 8) * 8 * nbm;
+  PCNN_LAUNCH(fc_rows_mfma_kernel, dim3((unsigned)blocks), dim3(512), 0, stream, x, wt, bias, addend, y, in_features,
+              out_features, rows_capacity, relu, num_rows_dev, nbm, ncb, tall);
   return check_launch("fc_rows_fwd");
 }

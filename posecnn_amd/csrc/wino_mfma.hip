@@ -71,9 +71,8 @@ __device__ __forceinline__ void at6_col(const float* m, float* t)
 }
 
 // POOL: 0 = y [.,H,W,Cout]; 1 = only max_pool_2x2(y) (written to y); 2 = both (y and ypool)
-// WR: wave rows — 2: 64 tiles x 64 channels, 8 waves, one workgroup per CU; 1: 32 x 64, 4 waves, two
-// workgroups per CU (finer work quanta for the layers with few tiles: conv5_x has 320 blocks of 64 tiles
-// for 256 CUs, i.e. a second round that is 25 % full).
+// WR: wave rows — 1 (what the library launches): 32 tiles x 64 channels, 4 waves, two workgroups per CU;
+// 2: 64 x 64, 8 waves, one workgroup per CU (kept for the ablation harness; see the launcher for the numbers).
 // ABL (tools/wino_ablate.hip only; the library instantiates 0): leave one ingredient of the K loop out to
 // see what it costs — 1 no barrier, 2 no DMA, 4 no LDS reads, 8 no MFMAs, 16 no column fold, 32 no epilogue.
 template <int POOL, int WR, int ABL = 0>
@@ -83,7 +82,8 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
     long long T, long long tiles_per_group, int relu, int nbt, int ncb)
 {
   constexpr int BT = 32 * WR, NW = 4 * WR, NT = 256 * WR;
-  __shared__ __attribute__((aligned(16))) float smem[WM_NBUF * (BT + 64) * WM_LD];   // sA[3][BT][64] | sB[3][64][64]
+  constexpr int RING = WM_NBUF * (BT + 64) * WM_LD, STAGE2 = 2 * BT * 4 * 64;
+  __shared__ __attribute__((aligned(16))) float smem[RING > STAGE2 ? RING : STAGE2];   // sA[3][BT][64] | sB[3][64][64]; epilogue: 2 x [BT][4][64]
   float(*sA)[BT][WM_LD] = reinterpret_cast<float(*)[BT][WM_LD]>(smem);
   float(*sB)[64][WM_LD] = reinterpret_cast<float(*)[64][WM_LD]>(smem + WM_NBUF * BT * WM_LD);
 
@@ -323,42 +323,57 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
         yo[b][i][o] = val;
       }
 
-  float* sY = smem;   // [BT tiles][4][64 channels] floats (the staging buffers are free now)
+  // Staging through LDS: [BT tiles][4][64 channels] floats per pass, two buffers (the ring is free
+  // now) so that a pass needs ONE barrier: pass a+1 writes the buffer whose readers all arrived at
+  // barrier a. Writer lanes (lr, lk) hit rows 4 lk tiles apart = the same banks, so the 16-channel
+  // group is XORed with lk (reader: same XOR, wave-uniform, float4 alignment kept).
+  constexpr int SYF = BT * 4 * 64;
+  const int wcol = col ^ (16 * lk);
+  // The thread's 8 store slots: tile wave + NW r, pixel column re, channels rc4..rc4+3. Tile
+  // coordinates by carries from the block's first tile (one 64-bit division per thread, not per store).
   const int HtWt = Ht * Wt;
+  const int bimg0 = (int)(t0 / HtWt);
+  const int rem0 = (int)(t0 - (long long)bimg0 * HtWt);
+  const int ty0 = rem0 / Wt, tx0 = rem0 - ty0 * Wt;
+  const int re = (tid >> 4) & 3, rc4 = (tid & 15) * 4;
+  int s_img[8], s_tyx[8];   // image; ty | tx << 16 (ty = 0xffff: not this block's tile)
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const int tl = wave + NW * r;
+    const unsigned n = (unsigned)(tx0 + tl), q = n / (unsigned)Wt, tx = n - q * (unsigned)Wt;
+    const unsigned m = (unsigned)ty0 + q, q2 = m / (unsigned)Ht, ty = m - q2 * (unsigned)Ht;
+    s_img[r] = bimg0 + (int)q2;
+    s_tyx[r] = t0 + tl < tend ? (int)(ty | (tx << 16)) : 0xffff;
+  }
   if (POOL != 1) {
     // four passes, one output row a of the 4x4 tiles each: [tile][e][channel]
 #pragma unroll
     for (int a = 0; a < 4; a++) {
+      float* sY = smem + (a & 1) * SYF;
 #pragma unroll
       for (int b = 0; b < 2; b++)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const int tl = 32 * wm + 16 * b + 4 * lk + i;
 #pragma unroll
-          for (int e = 0; e < 4; e++) sY[(tl * 4 + e) * 64 + col] = yo[b][i][4 * a + e];
+          for (int e = 0; e < 4; e++) sY[(tl * 4 + e) * 64 + wcol] = yo[b][i][4 * a + e];
         }
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < 8; r++) {
-        const int idx = tid + NT * r;   // 4096 float4: (tile, e, c4)
-        const int tl = idx >> 6, e = (idx >> 4) & 3, c4 = (idx & 15) * 4;
-        const long long t = t0 + tl;
-        if (t < tend) {
-          const int bimg = (int)(t / HtWt);
-          const int rem = (int)(t - (long long)bimg * HtWt);
-          const int ty = rem / Wt, tx = rem - ty * Wt;
-          const int oy = 4 * ty + a, ox = 4 * tx + e;
-          if (oy < H && ox < W)
-            *reinterpret_cast<v4f*>(y + (((long long)bimg * H + oy) * W + ox) * Cout + cb * WM_BC + c4) =
-                *reinterpret_cast<const v4f*>(&sY[(tl * 4 + e) * 64 + c4]);
-        }
+        const int tl = wave + NW * r;
+        const int ty = s_tyx[r] & 0xffff, tx = s_tyx[r] >> 16;
+        const int oy = 4 * ty + a, ox = 4 * tx + re;
+        if (oy < H && ox < W)   // ty = 0xffff fails here
+          *reinterpret_cast<v4f*>(y + (((long long)s_img[r] * H + oy) * W + ox) * Cout + cb * WM_BC + rc4) =
+              *reinterpret_cast<const v4f*>(&sY[(tl * 4 + re) * 64 + (rc4 ^ (16 * ((tl >> 2) & 3)))]);
       }
-      __syncthreads();
     }
   }
   if (POOL != 0) {
     // pooled 2x2 windows of the 4x4 tile: [tile][2 a' + e'][channel]
     float* yp = POOL == 1 ? y : ypool;
+    float* sY = smem;   // pass "4": buffer 0 again (its readers of pass 2 are behind barrier 3)
     const int Hp = H / 2, Wp = W / 2;
 #pragma unroll
     for (int b = 0; b < 2; b++)
@@ -375,24 +390,18 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
             p = p1 > p ? p1 : p;
             p = p2 > p ? p2 : p;
             p = p3 > p ? p3 : p;
-            sY[(tl * 4 + 2 * a2 + e2) * 64 + col] = p;
+            sY[(tl * 4 + 2 * a2 + e2) * 64 + wcol] = p;
           }
       }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-      const int idx = tid + NT * r;
-      const int tl = idx >> 6, w4 = (idx >> 4) & 3, c4 = (idx & 15) * 4;
-      const long long t = t0 + tl;
-      if (t < tend) {
-        const int bimg = (int)(t / HtWt);
-        const int rem = (int)(t - (long long)bimg * HtWt);
-        const int ty = rem / Wt, tx = rem - ty * Wt;
-        const int py = 2 * ty + (w4 >> 1), px = 2 * tx + (w4 & 1);
-        if (py < Hp && px < Wp)
-          *reinterpret_cast<v4f*>(yp + (((long long)bimg * Hp + py) * Wp + px) * Cout + cb * WM_BC + c4) =
-              *reinterpret_cast<const v4f*>(&sY[(tl * 4 + w4) * 64 + c4]);
-      }
+      const int tl = wave + NW * r;
+      const int ty = s_tyx[r] & 0xffff, tx = s_tyx[r] >> 16;
+      const int py = 2 * ty + (re >> 1), px = 2 * tx + (re & 1);
+      if (py < Hp && px < Wp)
+        *reinterpret_cast<v4f*>(yp + (((long long)s_img[r] * Hp + py) * Wp + px) * Cout + cb * WM_BC + rc4) =
+            *reinterpret_cast<const v4f*>(&sY[(tl * 4 + re) * 64 + (rc4 ^ (16 * ((tl >> 2) & 3)))]);
     }
   }
 }
@@ -417,17 +426,17 @@ extern "C" int pcnn_winograd43_conv_fwd(const float* v, const float* ut, const f
   const long long T = (long long)B * Ht * Wt;
   const long long tpg = T / groups;
   const int ncb = Cout / WM_BC;
-  // 64-tile blocks (one 8-wave workgroup per CU) unless they would fill the 256 CUs fewer than ~4 times:
-  // then 32-tile blocks (two 4-wave workgroups per CU) waste less of the last round
-  const long long nbt64 = (long long)groups * ((tpg + 63) / 64);
-  const int wr = nbt64 * ncb >= 4 * 256 ? 2 : 1;
-  const long long nbt = wr == 2 ? nbt64 : (long long)groups * ((tpg + 31) / 32);
+  // 32-tile blocks, two independent 4-wave workgroups per CU, for every layer: the pair drifts out of phase,
+  // so one workgroup's barrier waits, column folds, epilogue stores and block turnover run under the other's
+  // MFMAs. Measured against 64-tile blocks (one 8-wave workgroup per CU, 2/3 of the operand bytes per flop,
+  // still instantiated by tools/wino_ablate.hip): conv3_2 1.87 -> 1.75 ms, conv3_1 1.02 -> 0.95, conv4_2
+  // 1.79 -> 1.78, 12-layer total 16.25 -> 15.86 ms.
+  const long long nbt = (long long)groups * ((tpg + 31) / 32);
   const long long blocks = ((nbt + 7) / 8) * 8 * ncb;
   PCNN_REQUIRE(blocks < (1ll << 31), PCNN_EINVAL, "winograd43_conv: grid too large");
-#define WM_GO(P, R) PCNN_LAUNCH((wino43_mfma_kernel<P, R>), dim3((unsigned)blocks), dim3(256 * R), 0, stream, v, ut, bias, y, y_pool, \
-                                H, W, Cin, Cout, Ht, Wt, T, tpg, relu, (int)nbt, ncb)
-  if (wr == 2) { if (pool == 0) WM_GO(0, 2); else if (pool == 1) WM_GO(1, 2); else WM_GO(2, 2); }
-  else { if (pool == 0) WM_GO(0, 1); else if (pool == 1) WM_GO(1, 1); else WM_GO(2, 1); }
+#define WM_GO(P) PCNN_LAUNCH((wino43_mfma_kernel<P, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, v, ut, bias, y, y_pool, \
+                             H, W, Cin, Cout, Ht, Wt, T, tpg, relu, (int)nbt, ncb)
+  if (pool == 0) WM_GO(0); else if (pool == 1) WM_GO(1); else WM_GO(2);
 #undef WM_GO
   return check_launch("winograd43_conv_fwd");
 }

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import ops
+from . import ops, pipeline
 
 DEFAULT_PADDING = "SAME"
 
@@ -650,6 +650,8 @@ class vgg16_convs(Network):
         self.with_losses = bool(is_train) if with_losses is None else bool(with_losses)
         self.planted = None
         self.grouped_towers = True    # RGB-D inference: both towers as one grouped launch sequence
+        self.head_gemm = True         # 1x1 head convs (incl. the RGB-D concat) on the library's own fp32-MFMA row kernel
+        self._head_wt = {}
 
     def run(self, feed, planted=None):
         self.layers = dict(feed)
@@ -667,6 +669,46 @@ class vgg16_convs(Network):
                           lambda s: self._weight_init(c_i)(s).contiguous(memory_format=torch.channels_last))
         b = self.make_var(name + "/biases", (c_o,), lambda s: torch.zeros(s))
         return _nhwc(F.conv2d(_nchw(x), w, None)), b
+
+    def _head_conv1x1(self, sources, c_o, name, relu=True):
+        """`[concat(3) ->] conv(1, 1, c_o, 1, 1, name)` over the channel concatenation of `sources`
+        (vgg16_convs.py:104-113 for RGB-D, :128-133 for COLOR) — same variables as Network.conv creates.
+        On the GPU inference path a 1x1 convolution is a row product, and one over a concatenation is
+        the SUM of one product per source: pcnn_fc_rows_fwd runs them back to back (`addend`), so the
+        [B,h,w,1024] concatenation is neither written nor re-read, and bias + ReLU ride in the last
+        product's epilogue."""
+        xs = [self.get_output(n) for n in sources]
+        cis = [int(x.shape[-1]) for x in xs]
+        c_i = sum(cis)
+        fast = (self.head_gemm and all(isinstance(x, torch.Tensor) and x.is_cuda for x in xs) and c_o % 64 == 0
+                and all(c % 64 == 0 and c >= 128 for c in cis) and not (torch.is_grad_enabled() and self.trainable))
+        if not fast:
+            if len(sources) > 1:
+                self.feed(*sources).concat(3, name='concat_' + sources[0].split('_')[0])
+            else:
+                self.feed(sources[0])
+            return self.conv(1, 1, c_o, 1, 1, name=name, relu=relu, c_i=c_i)
+        w = self.make_var(name + "/weights", (c_o, c_i, 1, 1),
+                          lambda s: self._weight_init(c_i)(s).contiguous(memory_format=torch.channels_last), self.trainable)
+        b = self.make_var(name + "/biases", (c_o,), lambda s: torch.zeros(s), self.trainable)
+        key = (w.data_ptr(), w._version)
+        hit = self._head_wt.get(name)
+        if hit is None or hit[0] != key:
+            w2 = w.detach().reshape(c_o, c_i)
+            parts, off = [], 0
+            for c in cis:
+                parts.append(w2[:, off:off + c].contiguous())
+                off += c
+            hit = (key, parts, torch.zeros_like(b))
+            self._head_wt[name] = hit
+        parts, zero_b = hit[1], hit[2]
+        B_, h, w_ = xs[0].shape[:3]
+        partial = None
+        for j in range(len(xs) - 1, 0, -1):     # the other towers first, as addends
+            partial = ops.fc_rows(xs[j].reshape(-1, cis[j]), parts[j], zero_b, relu=False, addend=partial)
+        out = ops.fc_rows(xs[0].reshape(-1, cis[0]), parts[0], b.detach(), relu=relu, addend=partial).view(B_, h, w_, c_o)
+        self.layers[name] = out
+        return self.feed(out)
 
     def _plant(self, key, name):
         """Benchmark aid (DESIGN.md §synthetic workload): add a low-resolution synthetic scene to
@@ -710,7 +752,10 @@ class vgg16_convs(Network):
         to running the towers one after the other — each image still meets only its tower's weights —
         with half the launches and twice the workgroups per launch (conv5_x alone has only 160
         workgroups per tower for the 256 CUs). Registers conv4_3 / conv5_3 (+ '_p') and pool4."""
-        x = torch.cat([self.get_output('data'), self.get_output('data_p')], dim=0)
+        d, dp = self.get_output('data'), self.get_output('data_p')
+        x = pipeline.stacked_view(d, dp)        # free when the uploader placed the blobs back to back
+        if x is None:
+            x = torch.cat([d, dp], dim=0)
         B2, H, W, _ = x.shape
         B = B2 // 2
         va, vb = self._trunk_vars(""), self._trunk_vars("_p")
@@ -815,22 +860,10 @@ class vgg16_convs(Network):
         return self._setup_heads()
 
     def _setup_heads(self):
-        if self.input_format == 'RGBD':
-            (self.feed('conv5_3', 'conv5_3_p')
-                 .concat(3, name='concat_conv5')
-                 .conv(1, 1, self.num_units, 1, 1, name='score_conv5', c_i=1024)
-                 .deconv(4, 4, self.num_units, 2, 2, name='upscore_conv5', trainable=False))
-
-            (self.feed('conv4_3', 'conv4_3_p')
-                 .concat(3, name='concat_conv4')
-                 .conv(1, 1, self.num_units, 1, 1, name='score_conv4', c_i=1024))
-        else:
-            (self.feed('conv5_3')
-                 .conv(1, 1, self.num_units, 1, 1, name='score_conv5', c_i=512)
-                 .deconv(4, 4, self.num_units, 2, 2, name='upscore_conv5', trainable=False))
-
-            (self.feed('conv4_3')
-                 .conv(1, 1, self.num_units, 1, 1, name='score_conv4', c_i=512))
+        towers = ('', '_p') if self.input_format == 'RGBD' else ('',)
+        (self._head_conv1x1(['conv5_3' + t for t in towers], self.num_units, 'score_conv5')
+             .deconv(4, 4, self.num_units, 2, 2, name='upscore_conv5', trainable=False))
+        self._head_conv1x1(['conv4_3' + t for t in towers], self.num_units, 'score_conv4')
 
         (self.feed('score_conv4', 'upscore_conv5')
              .add(name='add_score')
@@ -873,12 +906,9 @@ class vgg16_convs(Network):
                  .hard_label(threshold=self.threshold_label, name='gt_label_weight'))
 
         if self.vertex_reg:
-            (self.feed('conv5_3')
-                 .conv(1, 1, 128, 1, 1, name='score_conv5_vertex', relu=False, c_i=512)
+            (self._head_conv1x1(['conv5_3'], 128, 'score_conv5_vertex', relu=False)
                  .deconv(4, 4, 128, 2, 2, name='upscore_conv5_vertex', trainable=False))
-
-            (self.feed('conv4_3')
-                 .conv(1, 1, 128, 1, 1, name='score_conv4_vertex', relu=False, c_i=512))
+            self._head_conv1x1(['conv4_3'], 128, 'score_conv4_vertex', relu=False)
 
             (self.feed('score_conv4_vertex', 'upscore_conv5_vertex')
                  .add(name='add_score_vertex')

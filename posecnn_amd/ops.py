@@ -495,10 +495,10 @@ def winograd43_conv(v, ut, bias, B, H, W, relu=True, pool=0, groups=1):
     return (y, yp) if pool == 2 else y
 
 
-def fc_rows(x, wt, bias, relu=True, num_rows=None):
-    """`Network.fc` on a capacity-sized row buffer: y[m] = [ReLU](x[m] @ wt.T + bias) for m < *num_rows
-    (device int32[1]; None = every row), zeros past it. x [M, K], wt [N, K] (the TF weight [K, N] transposed),
-    K % 64 == 0, N % 64 == 0. One fp32-MFMA kernel, no host synchronisation."""
+def fc_rows(x, wt, bias, relu=True, num_rows=None, addend=None):
+    """`Network.fc` on a capacity-sized row buffer: y[m] = [ReLU](x[m] @ wt.T + bias [+ addend[m]]) for
+    m < *num_rows (device int32[1]; None = every row), zeros past it. x [M, K], wt [N, K] (the TF weight
+    [K, N] transposed), K % 64 == 0, N % 64 == 0. One fp32-MFMA kernel, no host synchronisation."""
     x = _dev(x, "x", torch.float32)
     wt = _dev(wt, "wt", torch.float32)
     bias = _dev(bias, "bias", torch.float32)
@@ -508,7 +508,10 @@ def fc_rows(x, wt, bias, relu=True, num_rows=None):
     N = wt.shape[0]
     y = torch.empty((M, N), dtype=torch.float32, device=x.device)
     nr = _dev(num_rows, "num_rows", torch.int32) if num_rows is not None else None
-    check("pcnn_fc_rows_fwd", lib().pcnn_fc_rows_fwd(_ptr(x), _ptr(wt), _ptr(bias), M, K, N, 1 if relu else 0, _ptr(nr), _ptr(y), _stream(x)))
+    ad = _dev(addend, "addend", torch.float32) if addend is not None else None
+    if ad is not None and tuple(ad.shape) != (M, N):
+        raise ValueError("addend must be [M, N]")
+    check("pcnn_fc_rows_fwd", lib().pcnn_fc_rows_fwd(_ptr(x), _ptr(wt), _ptr(bias), M, K, N, 1 if relu else 0, _ptr(nr), _ptr(ad), _ptr(y), _stream(x)))
     return y
 
 

@@ -40,7 +40,7 @@ class FrameUploader:
         k = i % self.nslots
         src = self.host[i % len(self.host)]
         if self.slots[k] is None:
-            self.slots[k] = tuple(None if t is None else torch.empty(t.shape, dtype=t.dtype, device=self.device) for t in src)
+            self.slots[k] = alloc_adjacent(src, self.device)
         with torch.cuda.stream(self.stream):
             if self.free[k] is not None:
                 self.stream.wait_event(self.free[k])   # the kernels that read the old contents are done
@@ -66,6 +66,31 @@ class FrameUploader:
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         self.free[k] = ev
+
+
+def alloc_adjacent(like, device):
+    """Device tensors shaped like the (CPU) tensors in `like`, carved in order out of ONE allocation
+    (256-byte aligned). Blobs of equal shape that follow each other — the colour and the depth blob of
+    an RGB-D batch — are then adjacent in HBM, and `stacked_view` can hand both towers to one grouped
+    launch without a concatenation pass."""
+    offs, total = [], 0
+    for t in like:
+        offs.append(total)
+        if t is not None:
+            total += (t.numel() * t.element_size() + 255) // 256 * 256
+    flat = torch.empty(max(total, 1), dtype=torch.uint8, device=device)
+    return tuple(None if t is None else flat[o:o + t.numel() * t.element_size()].view(t.dtype).view(t.shape)
+                 for t, o in zip(like, offs))
+
+
+def stacked_view(a, b):
+    """[2B, ...] view over `a` followed by `b` if they are adjacent contiguous blocks of one allocation
+    (see alloc_adjacent), else None."""
+    if (a.shape != b.shape or a.dtype != b.dtype or not a.is_contiguous() or not b.is_contiguous()
+            or a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr()
+            or b.data_ptr() != a.data_ptr() + a.numel() * a.element_size()):
+        return None
+    return a.as_strided((2 * a.shape[0],) + tuple(a.shape[1:]), a.stride())
 
 
 def pin(t):

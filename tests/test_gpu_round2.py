@@ -251,6 +251,28 @@ def test_fc_rows_matches_float64_and_skips_padding(gpu, M, K, N, count, relu):
     assert not y[n:].cpu().numpy().view(np.uint32).any()
 
 
+def test_fc_rows_addend_is_a_conv_over_a_concatenation(gpu):
+    """conv(1,1) over concat(a, b) (the RGB-D heads, vgg16_convs.py:104-113) == fc_rows(a, Wa, bias,
+    addend=fc_rows(b, Wb, 0)): checked against the float64 product and the framework's convolution of
+    the materialised concatenation; and through the network: `head_gemm` on/off agree."""
+    import torch
+    import torch.nn.functional as F
+    from posecnn_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(31)
+    B, h, w, C, N = 2, 15, 20, 512, 64
+    a = torch.randn((B, h, w, C), generator=g).to(gpu)
+    b = torch.randn((B, h, w, C), generator=g).to(gpu)
+    W = (torch.randn((N, 2 * C), generator=g) / (2 * C) ** 0.5).to(gpu)
+    bias = torch.randn((N,), generator=g).to(gpu)
+    part = ops.fc_rows(b.reshape(-1, C), W[:, C:].contiguous(), torch.zeros_like(bias), relu=False)
+    y = ops.fc_rows(a.reshape(-1, C), W[:, :C].contiguous(), bias, relu=True, addend=part).view(B, h, w, N)
+    cat = torch.cat([a, b], dim=3)
+    ref = torch.relu(cat.double().reshape(-1, 2 * C) @ W.double().t() + bias.double()).view(B, h, w, N)
+    lib = torch.relu(F.conv2d(cat.permute(0, 3, 1, 2), W.view(N, 2 * C, 1, 1), bias)).permute(0, 2, 3, 1)
+    err, err_lib = float((y.double() - ref).abs().max()), float((lib.double() - ref).abs().max())
+    assert err <= max(2.0 * err_lib, 2e-6 * float(ref.abs().max())), (err, err_lib)
+
+
 def test_fc_layer_uses_the_row_count(gpu):
     """Network.fc routes to the MFMA kernel when `rows_count` is set and gives the library result on the
     live rows (fc6 -> fc7 chain on ROI-pooled shaped input)."""

@@ -10,20 +10,20 @@
 
 #include "../posecnn_amd/csrc/wino_mfma.hip"
 
-template <int ABL>
+template <int ABL, int WR>
 static float run(const float* v, const float* ut, const float* bias, float* y, int H, int W, int Cin, int Cout, long long T, int iters)
 {
   const int Ht = (H + 3) / 4, Wt = (W + 3) / 4;
-  const long long nbt = (T + 63) / 64;
+  const long long nbt = (T + 32 * WR - 1) / (32 * WR);
   const int ncb = Cout / 64;
   const long long blocks = ((nbt + 7) / 8) * 8 * ncb;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 2; i++)
-    hipLaunchKernelGGL((wino43_mfma_kernel<0, 2, ABL>), dim3((unsigned)blocks), dim3(512), 0, 0, v, ut, bias, y, (float*)nullptr, H, W, Cin, Cout, Ht, Wt, T, T, 1, (int)nbt, ncb);
+    hipLaunchKernelGGL((wino43_mfma_kernel<0, WR, ABL>), dim3((unsigned)blocks), dim3(256 * WR), 0, 0, v, ut, bias, y, (float*)nullptr, H, W, Cin, Cout, Ht, Wt, T, T, 1, (int)nbt, ncb);
   hipEventRecord(e0, 0);
   for (int i = 0; i < iters; i++)
-    hipLaunchKernelGGL((wino43_mfma_kernel<0, 2, ABL>), dim3((unsigned)blocks), dim3(512), 0, 0, v, ut, bias, y, (float*)nullptr, H, W, Cin, Cout, Ht, Wt, T, T, 1, (int)nbt, ncb);
+    hipLaunchKernelGGL((wino43_mfma_kernel<0, WR, ABL>), dim3((unsigned)blocks), dim3(256 * WR), 0, 0, v, ut, bias, y, (float*)nullptr, H, W, Cin, Cout, Ht, Wt, T, T, 1, (int)nbt, ncb);
   hipEventRecord(e1, 0);
   hipEventSynchronize(e1);
   float ms = 0;
@@ -36,9 +36,10 @@ int main(int argc, char** argv)
   // image geometry: B images of H x W with T = B * (H/4) * (W/4) tiles
   const int B = argc > 1 ? atoi(argv[1]) : 32, H = argc > 2 ? atoi(argv[2]) : 60, W = argc > 3 ? atoi(argv[3]) : 80;
   const int Cin = argc > 4 ? atoi(argv[4]) : 512, Cout = argc > 5 ? atoi(argv[5]) : 512;
+  const int wr = argc > 6 ? atoi(argv[6]) : 2;
   const long long T = (long long)B * ((H + 3) / 4) * ((W + 3) / 4);
   float *v, *ut, *bias, *y;
-  hipMalloc(&v, sizeof(float) * 36 * T * Cin);
+  hipMalloc(&v, sizeof(float) * 36 * ((T + 63) / 64 * 64) * Cin);
   hipMalloc(&ut, sizeof(float) * 36 * (size_t)Cout * Cin);
   hipMalloc(&bias, sizeof(float) * Cout);
   hipMalloc(&y, sizeof(float) * (size_t)B * H * W * Cout);
@@ -49,8 +50,8 @@ int main(int argc, char** argv)
   hipMemcpy(bias, h.data(), sizeof(float) * Cout, hipMemcpyHostToDevice);
   const double fl = 2.0 * 36 * T * Cin * Cout;
   const int it = 10;
-#define R(ABL, WHAT) { float ms = run<ABL>(v, ut, bias, y, H, W, Cin, Cout, T, it); printf("%-44s %8.3f ms  %6.1f TFLOP/s-equivalent\n", WHAT, ms, fl / ms / 1e9); }
-  printf("T=%lld Cin=%d Cout=%d\n", T, Cin, Cout);
+#define R(ABL, WHAT) { float ms = wr == 2 ? run<ABL, 2>(v, ut, bias, y, H, W, Cin, Cout, T, it) : run<ABL, 1>(v, ut, bias, y, H, W, Cin, Cout, T, it); printf("%-44s %8.3f ms  %6.1f TFLOP/s-equivalent\n", WHAT, ms, fl / ms / 1e9); }
+  printf("T=%lld Cin=%d Cout=%d WR=%d\n", T, Cin, Cout, wr);
   R(0, "full kernel");
   R(32, "no epilogue");
   R(32 | 16, "no epilogue, no column fold");
