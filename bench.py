@@ -49,6 +49,8 @@ def parse_args(argv=None):
     ap.add_argument("--resident-inputs", action="store_true", help="A/B: frames already in HBM (no H2D in the timed region)")
     ap.add_argument("--latency", action="store_true", help="per-frame synchronous loop; reports p50/p99 latency")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (see posecnn_amd/pipeline.py)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the batches alternate over: with 2, batch i+1's trunk overlaps batch i's heads / Hough / RoI tail")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nbuf", type=int, default=2, help="distinct synthetic batches cycled through")
     ap.add_argument("--prewarm-seconds", type=float, default=8.0,
@@ -266,9 +268,23 @@ def main(argv=None):
                                     planted=planted[k], feed_cache=feed_cache,
                                     with_losses=a.losses != "none", gt_poses=gts[k])
 
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(max(1, a.streams) - 1)]
+    multi = {"on": len(streams) > 1}
+
     def launch(_unused):
         """Enqueue one batch: (H2D wait) backbone + heads + Hough voting + RoI/pose branch + losses +
-        all-gather + async D2H. No host synchronisation in here."""
+        all-gather + async D2H. No host synchronisation in here. With --streams > 1 consecutive batches
+        go to different HIP streams (everything a batch allocates, reads and writes is stream-local:
+        caching-allocator pools, library workspaces, upload slots and the drain are keyed by stream or
+        fenced by events)."""
+        first = seq["i"] == 0
+        with torch.cuda.stream(streams[seq["i"] % len(streams)] if multi["on"] and not first else streams[0]):
+            t = _launch()
+        if first and len(streams) > 1:
+            torch.cuda.synchronize()   # batch 0 fills the per-network caches (filter transforms, packed weights) every stream reads
+        return t
+
+    def _launch():
         i = seq["i"]
         seq["i"] += 1
         data, data_p = uploader.get(i) if uploader is not None else resident[i % len(resident)]
@@ -341,18 +357,23 @@ def main(argv=None):
         while time.perf_counter() - t_pre < a.prewarm_seconds:
             run(4)
             torch.cuda.synchronize()
-        if not a.graph:
+        sep_profile = a.graph or len(streams) > 1
+        if not sep_profile:
             _lib.profile_enable(True)   # HIP events around every library kernel, on the launch stream
             net.conv_timing = []        # ... and around every remaining framework convolution / GEMM of the trunk
         elapsed, ndet = timed(a.steps)
         host_launch_ms = 1000.0 * last["host_launch_s"] / a.steps
-        if a.graph:
-            # per-kernel events cannot be recorded inside a graph replay: time the same kernels once more, eagerly
+        if sep_profile:
+            # per-kernel events cannot be recorded inside a graph replay, and with two streams a kernel's
+            # event pair also spans whatever the other stream ran in between: time the same kernels once
+            # more, eagerly on one stream
             last["graph_ready"] = False
+            multi["on"] = False
             net.conv_timing = []
             _lib.profile_enable(True)
             run(a.steps)
             torch.cuda.synchronize()
+            multi["on"] = len(streams) > 1
         kern = _lib.profile_report()
         _lib.profile_enable(False)
         if a.graph:
@@ -482,7 +503,8 @@ def main(argv=None):
                      "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"},
         "prewarm_seconds": a.prewarm_seconds,
         "host_launch_ms_per_step": host_launch_ms,
-        "step_submission": "hipGraph replay (one graph per device slot)" if a.graph else "eager launches",
+        "step_submission": ("hipGraph replay (one graph per device slot)" if a.graph else "eager launches")
+                           + ("; batches alternate over %d HIP streams (per-kernel times from a separate single-stream pass)" % len(streams) if len(streams) > 1 else ""),
         "kernels_us": {k: round(v["avg_us"], 2) for k, v in sorted(kern.items())},
         "kernel_calls_per_step": {k: round(v["calls"] / a.steps, 2) for k, v in sorted(kern.items())},
     }
