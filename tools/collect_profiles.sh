@@ -1,9 +1,11 @@
 set -x
-O=/root/repo/gpurun_out/r2p; mkdir -p $O
+O=/root/repo/gpurun_out/${1:-r2p}; mkdir -p $O
 cd /root/repo
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
-python bench.py --graph --no-cpu-baseline > $O/bench_graph.json 2> $O/bench_graph.err
-python bench.py --latency --batch 1 --input COLOR --losses test --no-cpu-baseline --graph > $O/bench_latency_b1.json 2> $O/bench_latency_b1.err
+python bench.py --streams 1 --no-cpu-baseline > $O/bench_streams1.json 2> $O/bench_streams1.err
+python bench.py --streams 1 --graph --no-cpu-baseline > $O/bench_graph.json 2> $O/bench_graph.err
+python bench.py --streams 1 --resident-inputs --no-cpu-baseline > $O/bench_resident.json 2> $O/bench_resident.err
+python bench.py --streams 1 --latency --batch 1 --input COLOR --losses test --no-cpu-baseline --graph > $O/bench_latency_b1.json 2> $O/bench_latency_b1.err
 python bench.py --config linemod --no-cpu-baseline > $O/bench_linemod.json 2> $O/bench_linemod.err
 python bench.py --input COLOR --losses test --resident-inputs --no-cpu-baseline > $O/bench_color_test_resident.json 2> $O/bench_color.err
 cd /tmp && export TMPDIR=/tmp
