@@ -92,12 +92,12 @@ __global__ __launch_bounds__(256) void conv3x3_c3_bias_relu_kernel(
 
 // conv1_1 + bias + ReLU feeding conv1_2's Winograd F(4x4,3x3) input transform directly: the
 // 78.6 MB/frame activation between the two layers is neither written nor read back. A workgroup owns
-// one row of FW_TILES 4x4 output tiles: phase 1 computes the (4+2) x (4*FW_TILES+2) pixel patch of
+// one row of FW_TILES 4x4 output tiles (4: 30 KB of LDS, five workgroups per CU; 8 tiles measured 6 % slower): phase 1 computes the (4+2) x (4*FW_TILES+2) pixel patch of
 // relu(conv1_1) those tiles need into LDS (zeros outside the image: conv1_2's SAME padding), phase 2
 // applies B^T d B to each tile's 6x6 patch with exactly the expressions of wino43_input_kernel
 // (csrc/winograd.hip), so V is bit-identical to the unfused pair.
-constexpr int FW_TILES = 8;
-constexpr int FW_COLS = 4 * FW_TILES + 2;   // 34 patch columns
+constexpr int FW_TILES = 4;
+constexpr int FW_COLS = 4 * FW_TILES + 2;   // 18 patch columns
 constexpr int FW_INF = (FW_COLS + 2) * CF_CIN;
 
 __device__ __forceinline__ void fw_bt6(const f4* d, f4* r)
@@ -179,30 +179,44 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wino43_kernel(
     }
   }
   __syncthreads();
-  // phase 2: thread = (tile, channel quad)
-  if (tid < FW_TILES * 16) {
-    const int t = tid >> 4, q = tid & 15;
+  // phase 2: thread = (tile, channel quad, pair of transform rows). Three waves share a tile's patch:
+  // wave p produces rows 2p, 2p+1 of B^T d B — the same expression trees as fw_bt6 / wino43_input_kernel,
+  // only the rows it owns — so all of the block's transform work is spread over 192 threads instead of
+  // sitting in 64 of them while the rest idle (the block is short: occupancy, not arithmetic, is what the
+  // kernel is short of).
+  if (wave < 3) {
+    const int t = (tid & 63) >> 4, q = tid & 15, pr = wave;
     const int tx = tx0 + t;
     if (tx < Wt) {
-      f4 tmp[6][6];
+      f4 tmp[2][6];
 #pragma unroll
       for (int s2 = 0; s2 < 6; s2++) {
-        f4 col[6];
+        f4 d[6];
 #pragma unroll
-        for (int r = 0; r < 6; r++) col[r] = *reinterpret_cast<const f4*>(&s_y[r][4 * t + s2][q * 4]);
-        f4 o[6];
-        fw_bt6(col, o);
-#pragma unroll
-        for (int i = 0; i < 6; i++) tmp[i][s2] = o[i];
+        for (int r = 0; r < 6; r++) d[r] = *reinterpret_cast<const f4*>(&s_y[r][4 * t + s2][q * 4]);
+        if (pr == 0) {
+          tmp[0][s2] = (4.f * d[0] - 5.f * d[2]) + d[4];
+          const f4 a = d[4] - 4.f * d[2], b2 = d[3] - 4.f * d[1];
+          tmp[1][s2] = a + b2;
+        } else if (pr == 1) {
+          const f4 a = d[4] - 4.f * d[2], b2 = d[3] - 4.f * d[1];
+          tmp[0][s2] = a - b2;
+          const f4 c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
+          tmp[1][s2] = c + e;
+        } else {
+          const f4 c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
+          tmp[0][s2] = c - e;
+          tmp[1][s2] = (4.f * d[1] - 5.f * d[3]) + d[5];
+        }
       }
       const long long tile = ((long long)b * Ht + ty) * Wt + tx;
       float* vo = v + tile * Cout + cg * 64 + q * 4;
 #pragma unroll
-      for (int i = 0; i < 6; i++) {
+      for (int i = 0; i < 2; i++) {
         f4 o[6];
         fw_bt6(tmp[i], o);
 #pragma unroll
-        for (int j = 0; j < 6; j++) *reinterpret_cast<f4*>(vo + (6 * i + j) * plane) = o[j];
+        for (int j = 0; j < 6; j++) *reinterpret_cast<f4*>(vo + (6 * (2 * pr + i) + j) * plane) = o[j];
       }
     }
   }
