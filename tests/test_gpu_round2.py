@@ -158,6 +158,55 @@ def _rgbd_inputs(rng, B, H, W):
     return data, data_p
 
 
+def test_winograd_mfma_trunk_at_full_size_against_direct_convolutions(gpu, capsys):
+    """The default trunk (F(4x4,3x3) on the fp32 matrix cores, both towers grouped) against the same
+    network with every 3x3 layer as a direct library convolution, at the REAL configuration: 4 RGB-D
+    frames of 480x640, 22 classes — 1.2 M label decisions, the Hough layer and the pose branch behind
+    them. Both are f32 with different summation orders; labels may differ only at near-ties."""
+    import torch
+    from posecnn_amd import fcn
+    from posecnn_amd.networks import vgg16_convs
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    B, H, W = 4, 480, 640
+    net = vgg16_convs("RGBD", 22, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True, trainable=False,
+                      is_train=False, seed=3, init="he", with_losses=False, device=gpu)
+    synth.init_planted_heads(net)
+    K = config.DEMO_INTRINSICS.copy()
+    rng = np.random.default_rng(21)
+    data, data_p = _rgbd_inputs(rng, B, H, W)
+    planted_np, _ = synth.make_planted_batch(77, B, H=H, W=W, K=K, n_obj=5)
+    planted = {k: T(gpu, v) for k, v in planted_np.items()}
+    pts = T(gpu, synth.make_model_points(22, 256))
+    outs = {}
+    for mode, minch in (("winograd_mfma", 64), ("direct", 0)):
+        net.winograd_min_channels = minch
+        with torch.no_grad():
+            det = fcn.im_segment_batch(net, T(gpu, data), K, config.LOV_EXTENTS, pts, config.LOV_SYMMETRY,
+                                       data_p=T(gpu, data_p), planted=planted)
+            n = int(det.count.item())
+            outs[mode] = (N(det.label_2d), N(net.get_output("prob_normalized")), N(det.rows[:n]),
+                          N(net.get_output("conv5_3")), N(net.get_output("conv4_3_p")))
+    net.winograd_min_channels = 64
+    a, b = outs["winograd_mfma"], outs["direct"]
+    flips = int((a[0] != b[0]).sum())
+    report = {"label_flips": flips, "of": a[0].size, "max_prob_diff": float(np.abs(a[1] - b[1]).max()),
+              "conv5_3_rel_err": float(np.abs(a[3] - b[3]).max() / np.abs(b[3]).max()),
+              "conv4_3_p_rel_err": float(np.abs(a[4] - b[4]).max() / np.abs(b[4]).max()), "detections": int(a[2].shape[0])}
+    assert flips <= 2e-5 * a[0].size, report
+    assert report["max_prob_diff"] < 1e-3 and report["conv5_3_rel_err"] < 1e-4, report
+    assert a[2].shape == b[2].shape and np.array_equal(a[2][:, :2], b[2][:, :2]) and a[2].shape[0] >= 3 * B, report
+    report["max_box_diff_px"] = float(np.abs(a[2][:, 2:6] - b[2][:, 2:6]).max())
+    report["max_quat_diff"] = float(np.abs(a[2][:, 7:11] - b[2][:, 7:11]).max())
+    report["max_trans_diff"] = float(np.abs(a[2][:, 11:] - b[2][:, 11:]).max())
+    # translations come out of the Hough layer's hard inlier test (mean depth over the voters of the winning
+    # cell, .cu.cc:269-294): a 1e-6 change of the vertex field can move single voters across the 0.9
+    # threshold, which shifts the mean by O(1/voters) — millimetres, whatever computed the dense layers
+    assert report["max_quat_diff"] < 1e-4 and report["max_trans_diff"] < 5e-3, report
+    with capsys.disabled():
+        print("\nfull-size winograd-MFMA vs direct:", report)
+
+
 def test_batches_on_alternating_streams_equal_the_serial_run(gpu):
     """bench.py --streams 2: consecutive batches go to different HIP streams so that one batch's trunk
     overlaps the other's heads / Hough / RoI tail. Everything a batch touches is stream-local (allocator
