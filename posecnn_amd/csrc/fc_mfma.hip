@@ -11,8 +11,10 @@
 //   y[m, n] = [ReLU](sum_k x[m, k] wt[n, k] + bias[n])   m < min(M_cap, *num_rows_dev), else 0
 //
 // Same machinery as csrc/wino_mfma.hip, minus the Winograd planes: 64 x 64 block per 8-wave workgroup,
-// v_mfma_f32_16x16x4_f32 (exact f32), global -> LDS DMA into a 3-stage ring with XOR-swizzled 16-byte
-// chunks, one counted-wait barrier per 64-deep K stage, K loop software pipelined by half a stage, epilogue
+// v_mfma_f32_16x16x4_f32 (exact f32), global -> LDS DMA into a 2-stage ring (64 KB: TWO workgroups per
+// CU, which like the trunk's pairs drift out of phase and cover each other's barrier and DMA waits —
+// fc6 at 468 rows 1.38 -> 1.15 ms against the 3-stage ring with one workgroup per CU) with XOR-swizzled
+// 16-byte chunks, one barrier per 64-deep K stage, K loop software pipelined by half a stage, epilogue
 // through LDS for 256-byte row stores, XCD-aware block map (the column blocks that share a row block's x
 // rows run on one XCD). `wt` is the weight matrix TRANSPOSED ([N][K], K contiguous) so that both operands
 // are K-major rows for the DMA.
@@ -25,7 +27,7 @@ using namespace pcnn;
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int FC_LD = 64;
-constexpr int FC_NBUF = 3;
+constexpr int FC_NBUF = 2;
 
 __device__ __forceinline__ void fc_glds16(const char* g, float* lds_wave_base)
 {
@@ -33,7 +35,7 @@ __device__ __forceinline__ void fc_glds16(const char* g, float* lds_wave_base)
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(512, 2) void fc_rows_mfma_kernel(
+__global__ __launch_bounds__(512, 4) void fc_rows_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ addend, float* __restrict__ y, int K, int N, int Mcap, int relu,
     const int* __restrict__ num_rows_dev, int nbm, int ncb, int tall)
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(512, 2) void fc_rows_mfma_kernel(
   v4f acc0 = (v4f){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
   int pk = 0;   // K offset (floats) of the prefetch pointer; parks on the last stage
   FC_DMA(0, pk); pk = min(pk + 64, K - 64);
-  FC_DMA(1, pk); pk = min(pk + 64, K - 64);
+  if (FC_NBUF == 3) { FC_DMA(1, pk); pk = min(pk + 64, K - 64); }
   int cur = 0;
 
   const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)smem;
@@ -122,13 +124,14 @@ __global__ __launch_bounds__(512, 2) void fc_rows_mfma_kernel(
   // stage s: own DMAs landed (the next stage's stay in flight) -> barrier -> reads X(s) -> MFMAs Y(s-1)
   // + DMA of stage s+2 -> X landed -> MFMAs X(s), reads Y(s) in between. Y of "stage -1" is zeros.
   for (int s = 0; s < NK; s++) {
-    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (FC_NBUF == 3) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const unsigned curo = (unsigned)cur * (64 * FC_LD * 4);
     FC_READ(xa0, xa1, xb, 0);
     __builtin_amdgcn_sched_barrier(0);
     FC_MFMA1(ya0, ya1, yb, 0) FC_MFMA1(ya0, ya1, yb, 1)
     {
-      const int nb = cur >= 1 ? cur - 1 : 2;
+      const int nb = FC_NBUF == 3 ? (cur >= 1 ? cur - 1 : 2) : (cur ^ 1);
       FC_DMA(nb, pk);
       pk = min(pk + 64, K - 64);
     }
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void fc_rows_mfma_kernel(
     FC_MFMA1(xa0, xa1, xb, 1)
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    cur = cur == 2 ? 0 : cur + 1;
+    cur = FC_NBUF == 3 ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1);
   }
   __builtin_amdgcn_sched_barrier(0);
   FC_MFMA1(ya0, ya1, yb, 0) FC_MFMA1(ya0, ya1, yb, 1)
