@@ -326,10 +326,15 @@ int pcnn_winograd43_conv_fwd(const float* v, const float* ut, const float* bias,
  *   addend f32 [rows_capacity][out_features] or NULL: added before the ReLU — a 1x1 convolution over a channel
  *        concatenation (`concat` + `conv(1, 1, ...)` of the RGB-D heads, vgg16_convs.py:104-113) is the sum of
  *        two such products, one per tower, so the concatenated tensor is never built
- * fp32 MFMA (exact f32), sum over k in ascending order within a lane-fixed interleave (DESIGN.md §3.2c). */
+ *   workspace (optional, pcnn_fc_rows_workspace_bytes): lets launches with few live rows split K over up to 8
+ *        workgroups per output block — decided on the device from *num_rows_dev — and sum the partial products
+ *        in a fixed order; without it (NULL / too small) every block runs its whole K (same results up to f32
+ *        summation order, slower when the live rows are few: fc6 at 75 rows is bound by HBM latency then)
+ * fp32 MFMA (exact f32), sum over k in ascending order within a lane-fixed interleave (DESIGN.md §3.2e). */
+int pcnn_fc_rows_workspace_bytes(int rows_capacity, int in_features, int out_features, size_t* bytes);
 int pcnn_fc_rows_fwd(const float* x, const float* wt, const float* bias, int rows_capacity,
                      int in_features, int out_features, int relu, const int32_t* num_rows_dev,
-                     const float* addend, float* y, void* stream);
+                     const float* addend, float* y, void* workspace, size_t workspace_bytes, void* stream);
 
 /* pcnn_winograd43_output_fwd writing BOTH the activation y f32 [B,H,W,C] and its 2x2 max-pool y_pool f32
  * [B,H/2,W/2,C] in one pass (conv4_3 -> pool4, whose un-pooled output score_conv4 and roi_pool read too). */

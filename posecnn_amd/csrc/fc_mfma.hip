@@ -35,10 +35,25 @@ __device__ __forceinline__ void fc_glds16(const char* g, float* lds_wave_base)
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Split-K factor, decided ON THE DEVICE from the live row count (same value in every workgroup of the
+// launch and in the reduction kernel): with few live rows there are few (row block, column block)
+// workgroups — fc6 at 75 rows: 128 for 512 slots, each streaming its 6.4 MB weight slab through a
+// 2-deep ring, i.e. bound by HBM latency (0.92 ms for 411 MB). Splitting K over up to `smax` workgroups
+// multiplies the loads in flight; the partial products meet in a fixed-order reduction (deterministic).
+__device__ __forceinline__ int fc_split(int count, int ncb, int NK, int smax, int ws_rows)
+{
+  if (smax <= 1 || count > ws_rows) return 1;
+  const int live = ((count + 63) >> 6) * ncb;
+  int S = min(smax, 1024 / max(live, 1));
+  S = min(S, NK / 8);            // at least 8 stages (512 of K) per split
+  return max(S, 1);
+}
+
 __global__ __launch_bounds__(512, 4) void fc_rows_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ addend, float* __restrict__ y, int K, int N, int Mcap, int relu,
-    const int* __restrict__ num_rows_dev, int nbm, int ncb, int tall)
+    const int* __restrict__ num_rows_dev, int nbm, int ncb, int tall, float* __restrict__ part,
+    int smax, int ws_rows)
 {
   __shared__ __attribute__((aligned(16))) float smem[FC_NBUF * 128 * FC_LD];   // sA[3][64][64] | sB[3][64][64]
   float* sAp = smem;
@@ -58,15 +73,20 @@ __global__ __launch_bounds__(512, 4) void fc_rows_mfma_kernel(
   const int lr = lane & 15, lk = lane >> 4;
   const int m0 = tb * 64;
   const int count = num_rows_dev ? min(Mcap, num_rows_dev[0]) : Mcap;
+  const int ks = blockIdx.y;
+  const int S = fc_split(count, ncb, K / 64, smax, ws_rows);
+  if (ks >= S) return;
   if (m0 >= count) {
     // rows that do not exist: zeros, no operand traffic
+    if (ks > 0) return;
     for (int i = tid; i < 64 * 16; i += 512) {
       const int r = m0 + (i >> 4);
       if (r < Mcap) *reinterpret_cast<v4f*>(y + (size_t)r * N + cb * 64 + (i & 15) * 4) = (v4f){0.f, 0.f, 0.f, 0.f};
     }
     return;
   }
-  const int NK = K / 64;
+  const int kfirst = (int)((long long)(K / 64) * ks / S), klast = (int)((long long)(K / 64) * (ks + 1) / S);   // this split's stages
+  const int NK = klast - kfirst;
   const int mlast = count - 1;
 
   const int dr0 = 8 * wave + lk, dr1 = dr0 + 4;
@@ -90,9 +110,10 @@ __global__ __launch_bounds__(512, 4) void fc_rows_mfma_kernel(
   } while (0)
 
   v4f acc0 = (v4f){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-  int pk = 0;   // K offset (floats) of the prefetch pointer; parks on the last stage
-  FC_DMA(0, pk); pk = min(pk + 64, K - 64);
-  if (FC_NBUF == 3) { FC_DMA(1, pk); pk = min(pk + 64, K - 64); }
+  int pk = kfirst * 64;   // K offset (floats) of the prefetch pointer; parks on the split's last stage
+  const int kpark = klast * 64 - 64;
+  FC_DMA(0, pk); pk = min(pk + 64, kpark);
+  if (FC_NBUF == 3) { FC_DMA(1, pk); pk = min(pk + 64, kpark); }
   int cur = 0;
 
   const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)smem;
@@ -133,7 +154,7 @@ __global__ __launch_bounds__(512, 4) void fc_rows_mfma_kernel(
     {
       const int nb = FC_NBUF == 3 ? (cur >= 1 ? cur - 1 : 2) : (cur ^ 1);
       FC_DMA(nb, pk);
-      pk = min(pk + 64, K - 64);
+      pk = min(pk + 64, kpark);
     }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -157,7 +178,7 @@ __global__ __launch_bounds__(512, 4) void fc_rows_mfma_kernel(
 
   // epilogue: lane holds rows 32 wm + 16 b + 4 lk + i (b = 0: acc0, 1: acc1) x column 16 wn + lr
   const int col = 16 * wn + lr;
-  const float bv = bias[cb * 64 + col];
+  const float bv = S > 1 ? 0.f : bias[cb * 64 + col];
   float* sY = smem;   // [64 rows][64 columns]
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -170,6 +191,11 @@ __global__ __launch_bounds__(512, 4) void fc_rows_mfma_kernel(
     const int idx = tid + 512 * r;   // 1024 float4: (row, c4)
     const int row = idx >> 4, c4 = (idx & 15) * 4;
     const int m = m0 + row;
+    if (S > 1) {   // partial product of this K range; bias, addend, ReLU and the zero rows belong to the reduction
+      if (m < count)
+        *reinterpret_cast<v4f*>(part + ((size_t)ks * ws_rows + m) * N + cb * 64 + c4) = *reinterpret_cast<const v4f*>(&sY[row * 64 + c4]);
+      continue;
+    }
     if (m < Mcap) {
       v4f val = (v4f){0.f, 0.f, 0.f, 0.f};
       if (m < count) {
@@ -185,11 +211,57 @@ __global__ __launch_bounds__(512, 4) void fc_rows_mfma_kernel(
   }
 }
 
+// y[m] = [ReLU](sum_{ks < S} part[ks][m] + bias + addend[m]) in ascending ks order; rows between the count
+// and the end of its 64-row block are zeroed (whole blocks past the count: by the product kernel)
+__global__ __launch_bounds__(256) void fc_rows_reduce_kernel(
+    const float* __restrict__ part, const float* __restrict__ bias, const float* __restrict__ addend,
+    float* __restrict__ y, int K, int N, int Mcap, int relu, const int* __restrict__ num_rows_dev, int ncb,
+    int smax, int ws_rows)
+{
+  const int count = num_rows_dev ? min(Mcap, num_rows_dev[0]) : Mcap;
+  const int S = fc_split(count, ncb, K / 64, smax, ws_rows);
+  if (S <= 1) return;
+  const int n4 = N >> 2;
+  const long long total = (long long)min(Mcap, ((count + 63) >> 6) << 6) * n4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int m = (int)(i / n4), c4 = (int)(i - (long long)m * n4) * 4;
+    v4f val = (v4f){0.f, 0.f, 0.f, 0.f};
+    if (m < count) {
+      for (int ks = 0; ks < S; ks++) val += *reinterpret_cast<const v4f*>(part + ((size_t)ks * ws_rows + m) * N + c4);
+      val += *reinterpret_cast<const v4f*>(bias + c4);
+      if (addend) val += *reinterpret_cast<const v4f*>(addend + (size_t)m * N + c4);
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) val[e] = val[e] > 0.f ? val[e] : 0.f;
+      }
+    }
+    *reinterpret_cast<v4f*>(y + (size_t)m * N + c4) = val;
+  }
+}
+
+constexpr int FC_SMAX = 8;        // K splits at most
+constexpr int FC_WS_ROWS = 512;   // rows the split-K workspace holds (more live rows never split)
+
+bool fc_can_split(int rows_capacity, int in_features, int out_features)
+{
+  return rows_capacity <= out_features && in_features >= 1024;   // not the tall (1x1 conv) shape; a K worth splitting
+}
+
 }  // namespace
+
+extern "C" int pcnn_fc_rows_workspace_bytes(int rows_capacity, int in_features, int out_features, size_t* bytes)
+{
+  PCNN_REQUIRE(bytes, PCNN_ENULL, "fc_rows_workspace_bytes: NULL output");
+  PCNN_REQUIRE(rows_capacity >= 0 && in_features >= 1 && out_features >= 1, PCNN_EINVAL, "fc_rows_workspace_bytes: bad shape");
+  const int ws_rows = rows_capacity < FC_WS_ROWS ? (rows_capacity + 63) / 64 * 64 : FC_WS_ROWS;
+  *bytes = fc_can_split(rows_capacity, in_features, out_features) ? sizeof(float) * (size_t)FC_SMAX * ws_rows * out_features : 0;
+  return PCNN_OK;
+}
 
 extern "C" int pcnn_fc_rows_fwd(const float* x, const float* wt, const float* bias, int rows_capacity,
                                 int in_features, int out_features, int relu, const int32_t* num_rows_dev,
-                                const float* addend, float* y, void* stream_)
+                                const float* addend, float* y, void* workspace, size_t workspace_bytes,
+                                void* stream_)
 {
   PCNN_REQUIRE(rows_capacity >= 0, PCNN_EINVAL, "fc_rows: negative row capacity");
   PCNN_REQUIRE(in_features >= 128 && in_features % 64 == 0, PCNN_EINVAL,
@@ -205,7 +277,17 @@ extern "C" int pcnn_fc_rows_fwd(const float* x, const float* wt, const float* bi
   const int nbm = (rows_capacity + 63) / 64, ncb = out_features / 64;
   const int tall = (long long)rows_capacity > (long long)out_features;   // which operand is the big one
   const long long blocks = tall ? (long long)((nbm + 7) / 8) * 8 * ncb : (long long)((ncb + 7) / 8) * 8 * nbm;
-  PCNN_LAUNCH(fc_rows_mfma_kernel, dim3((unsigned)blocks), dim3(512), 0, stream, x, wt, bias, addend, y, in_features,
-              out_features, rows_capacity, relu, num_rows_dev, nbm, ncb, tall);
+  // split-K for launches with few live rows (decided on the device): needs the caller's workspace
+  const int ws_rows = rows_capacity < FC_WS_ROWS ? (rows_capacity + 63) / 64 * 64 : FC_WS_ROWS;
+  const size_t need = sizeof(float) * (size_t)FC_SMAX * ws_rows * out_features;
+  const int smax = (workspace && workspace_bytes >= need && fc_can_split(rows_capacity, in_features, out_features) && aligned16(workspace)) ? FC_SMAX : 1;
+  float* part = smax > 1 ? static_cast<float*>(workspace) : nullptr;
+  PCNN_LAUNCH(fc_rows_mfma_kernel, dim3((unsigned)blocks, smax), dim3(512), 0, stream, x, wt, bias, addend, y, in_features,
+              out_features, rows_capacity, relu, num_rows_dev, nbm, ncb, tall, part, smax, ws_rows);
+  if (smax > 1) {
+    const long long items = (long long)ws_rows * (out_features / 4);
+    PCNN_LAUNCH(fc_rows_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, part, bias, addend, y,
+                in_features, out_features, rows_capacity, relu, num_rows_dev, ncb, smax, ws_rows);
+  }
   return check_launch("fc_rows_fwd");
 }

@@ -511,7 +511,11 @@ def fc_rows(x, wt, bias, relu=True, num_rows=None, addend=None):
     ad = _dev(addend, "addend", torch.float32) if addend is not None else None
     if ad is not None and tuple(ad.shape) != (M, N):
         raise ValueError("addend must be [M, N]")
-    check("pcnn_fc_rows_fwd", lib().pcnn_fc_rows_fwd(_ptr(x), _ptr(wt), _ptr(bias), M, K, N, 1 if relu else 0, _ptr(nr), _ptr(ad), _ptr(y), _stream(x)))
+    nbytes = ctypes.c_size_t()
+    check("pcnn_fc_rows_workspace_bytes", lib().pcnn_fc_rows_workspace_bytes(M, K, N, ctypes.byref(nbytes)))
+    ws = _ws(x.device, "fc_rows").get(nbytes.value, x.device) if nbytes.value else None   # split-K partials (few live rows)
+    check("pcnn_fc_rows_fwd", lib().pcnn_fc_rows_fwd(_ptr(x), _ptr(wt), _ptr(bias), M, K, N, 1 if relu else 0, _ptr(nr), _ptr(ad), _ptr(y),
+                                                    _ptr(ws), nbytes.value, _stream(x)))
     return y
 
 

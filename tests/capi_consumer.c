@@ -38,6 +38,13 @@ int main(void)
   CHECK(pcnn_average_distance_fwd(NULL, NULL, NULL, NULL, NULL, 1, 22, 10, -1.0f, NULL, NULL, NULL, NULL, 0, NULL) == PCNN_EINVAL);
   CHECK(pcnn_roi_pool_fwd(NULL, NULL, 1, 30, 40, 512, 3, 5, 7, 7, 0.0625f, 0, NULL, NULL, NULL) == PCNN_EINVAL);
   CHECK(pcnn_backproject_fwd(NULL, NULL, NULL, NULL, NULL, 1, 8, 8, 4, 3, 48, 4, -1, 0.1f, NULL, NULL, NULL, NULL) == PCNN_EINVAL);
+  /* Network.fc over a row buffer: split-K workspace only for the wide shape (fc6), none for the tall 1x1-conv shape */
+  {
+    size_t fc6 = 0, head = 1;
+    CHECK(pcnn_fc_rows_workspace_bytes(336, 25088, 4096, &fc6) == PCNN_OK && fc6 >= 8u * 336u * 4096u * 4u);
+    CHECK(pcnn_fc_rows_workspace_bytes(76800, 512, 64, &head) == PCNN_OK && head == 0);
+    CHECK(pcnn_fc_rows_fwd(NULL, NULL, NULL, 16, 100, 64, 1, NULL, NULL, NULL, NULL, 0, NULL) == PCNN_EINVAL);
+  }
   printf("capi_consumer ok: abi %d, hough workspace %zu / %zu / %zu bytes\n", pcnn_abi_version(), small, big, wide);
   return 0;
 }

@@ -311,7 +311,8 @@ def test_batch_pipeline_rgbd_matches_cpu_reference(gpu, train):
 
 # ---- fc6 / fc7 on capacity-sized rows --------------------------------------------------------------
 @pytest.mark.parametrize("M,K,N,count,relu", [(200, 25088, 256, 77, True), (3024, 4096, 4096, 468, True), (64, 128, 64, 64, False),
-                                             (130, 1024, 192, 0, True), (65, 640, 128, None, True), (1, 256, 64, 1, False)])
+                                             (130, 1024, 192, 0, True), (65, 640, 128, None, True), (1, 256, 64, 1, False),
+                                             (336, 4096, 128, 70, True), (200, 25088, 256, 200, True), (600, 2048, 1024, 513, False)])
 def test_fc_rows_matches_float64_and_skips_padding(gpu, M, K, N, count, relu):
     """`Network.fc` (network.py:392-422) as one fp32-MFMA kernel over a capacity-sized row buffer: rows below
     the device-side count equal x @ W + b (f32 roundoff against a float64 reference, same as the library
@@ -339,8 +340,11 @@ def test_fc_rows_matches_float64_and_skips_padding(gpu, M, K, N, count, relu):
         scale = float(ref.abs().max())
         err = float((y[:n].double() - ref).abs().max())
         err_lib = float((lib.double() - ref).abs().max())
-        assert err <= max(2.0 * err_lib, 2e-6 * scale), (err, err_lib, scale)
+        assert err <= max(3.0 * err_lib, 4e-6 * scale), (err, err_lib, scale)   # f32 summation-order noise, K up to 25088
     assert not y[n:].cpu().numpy().view(np.uint32).any()
+    # split-K (few live rows, decided on the device) sums its partial products in a fixed order: run to run identical
+    y2 = ops.fc_rows(x, w.t().contiguous(), b, relu, num_rows=cnt)
+    assert torch.equal(y, y2)
 
 
 def test_fc_rows_addend_is_a_conv_over_a_concatenation(gpu):
