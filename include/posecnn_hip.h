@@ -311,10 +311,17 @@ int pcnn_winograd43_output_fwd(const float* m, const float* bias, int batch, int
  *   groups >= 1: image b uses filter set b / (batch / groups) — the colour and depth towers of an RGB-D
  *                network as one launch (batch % groups == 0)
  *   pool 0: y f32 [batch,H,W,Cout];  1: y = max_pool_2x2 f32 [batch,H/2,W/2,Cout] only;
- *        2: both (y and y_pool), for a layer like conv4_3 whose un-pooled output is read as well. */
+ *        2: both (y and y_pool), for a layer like conv4_3 whose un-pooled output is read as well.
+ *   workspace (optional, pcnn_winograd43_conv_workspace_bytes; 0 bytes for launches that fill the chip): lets a
+ *        small launch (batch-1 conv4_x / conv5_x: tens of workgroups of 288 stages each) split Cin over up to 8
+ *        workgroups per output block; the partial outputs are summed in a fixed order before bias / ReLU / pooling.
+ *        NULL or too small: no split (same result up to f32 summation order). */
+int pcnn_winograd43_conv_workspace_bytes(int batch, int height, int width, int in_channels, int out_channels,
+                                         int groups, size_t* bytes);
 int pcnn_winograd43_conv_fwd(const float* v, const float* ut, const float* bias, int batch, int height,
                              int width, int in_channels, int out_channels, int groups, int relu,
-                             int pool, float* y, float* y_pool, void* stream);
+                             int pool, float* y, float* y_pool, void* workspace, size_t workspace_bytes,
+                             void* stream);
 
 /* Fully connected layer over a capacity-sized row buffer (`Network.fc`, network.py:392-422; fc6 / fc7 of
  * vgg16_convs.py:188-192 behind the sync-free Hough layer): y[m] = [ReLU](x[m] . W + bias) for the rows

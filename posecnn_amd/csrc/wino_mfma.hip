@@ -79,7 +79,7 @@ template <int POOL, int WR, int ABL = 0>
 __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
     const float* __restrict__ v, const float* __restrict__ ut, const float* __restrict__ bias,
     float* __restrict__ y, float* __restrict__ ypool, int H, int W, int Cin, int Cout, int Ht, int Wt,
-    long long T, long long tiles_per_group, int relu, int nbt, int ncb)
+    long long T, long long tiles_per_group, int relu, int nbt, int ncb, int ksplit, long long ysplit_stride)
 {
   constexpr int BT = 32 * WR, NW = 4 * WR, NT = 256 * WR;
   constexpr int RING = WM_NBUF * (BT + 64) * WM_LD, STAGE2 = 2 * BT * 4 * 64;
@@ -103,7 +103,11 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
   const long long t0 = (long long)grp * tiles_per_group + (long long)(tb - grp * nbg) * BT;
   const long long tend = (long long)(grp + 1) * tiles_per_group;   // first tile that is not this block's business
   const float* utg = ut + (size_t)grp * 36 * Cout * Cin;
-  const int NK = Cin / WM_KC;
+  // `ksplit` > 1 (small launches, see the launcher): workgroup blockIdx.y contracts only its slice of Cin and
+  // writes a raw partial output (the host passes zero bias, no ReLU, POOL = 0); a reduction kernel finishes
+  const int ks = blockIdx.y;
+  const int NK = Cin / WM_KC / ksplit;
+  y += (long long)ks * ysplit_stride;
 
   // staging: a stage = BT rows x 256 B of V and 64 rows of U^T = BT/4 + 16 DMA instructions of 4 rows
   // each; wave w issues V instructions 2w, 2w + 1 and U^T instructions (16/NW) w ... Lane l of
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
   // The prefetch offsets (floats) advance incrementally on the scalar unit: next K slice +64; next
   // plane of the column k += 6; next column k: 30 + nu -> nu + 1.
   int pnu = 0, pxi = 0, pkc = 0;
-  long long pvo = 0, puo = 0;
+  long long pvo = (long long)ks * NK * WM_KC, puo = pvo;   // this split's first input channel
   const long long kback = (long long)(NK - 1) * WM_KC;
   // branch-free (selects on the scalar unit), so that a stage body is ONE basic block and the DMA
   // issue interleaves with the MFMAs; past the last stage the pointer parks on it (the two extra
@@ -406,11 +410,77 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
   }
 }
 
+// Split-Cin reduction: y = [ReLU](sum_s part[s] + bias) [2x2 max-pooled], partials in ascending order.
+// POOL as in the main kernel. One thread per float4 of the (pooled, for POOL != 0) output.
+template <int POOL>
+__global__ __launch_bounds__(256) void wino43_splitk_reduce_kernel(
+    const float* __restrict__ part, int S, long long stride, const float* __restrict__ bias, int relu,
+    float* __restrict__ y, float* __restrict__ ypool, int B, int H, int W, int C, int imgs_per_group)
+{
+  const int c4n = C >> 2;
+  const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
+  const long long total = (long long)B * Ho * Wo * c4n;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c4 = (int)(i % c4n) * 4;
+    long long r = i / c4n;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    const v4f bv = *reinterpret_cast<const v4f*>(bias + (size_t)(b / imgs_per_group) * C + c4);
+    v4f best = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < (POOL ? 4 : 1); q++) {
+      const int yy = POOL ? 2 * oy + (q >> 1) : oy, xx = POOL ? 2 * ox + (q & 1) : ox;
+      const long long o = (((long long)b * H + yy) * W + xx) * C + c4;
+      v4f v = *reinterpret_cast<const v4f*>(part + o);
+      for (int s2 = 1; s2 < S; s2++) v += *reinterpret_cast<const v4f*>(part + s2 * stride + o);
+      v += bv;
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      }
+      if (POOL != 1) *reinterpret_cast<v4f*>(y + o) = v;
+      if (q == 0) best = v;
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) best[e] = v[e] > best[e] ? v[e] : best[e];
+      }
+    }
+    if (POOL != 0) {
+      float* yp = POOL == 1 ? y : ypool;
+      *reinterpret_cast<v4f*>(yp + (((long long)b * Ho + oy) * Wo + ox) * C + c4) = best;
+    }
+  }
+}
+
+// Cin split of a launch too small to fill the chip (batch-1 conv4_x / conv5_x: 80 / 24 workgroups of 288
+// stages each for 512 slots — pure per-workgroup latency): double while the grid stays within the slots
+int wino43_cin_split(long long nbt, int ncb, int Cin)
+{
+  const int NK = Cin / WM_KC;
+  int S = 1;
+  if (nbt * ncb >= 128) return 1;   // (152 workgroups — batch-1 conv3_x — measured slower split in two: the partials cost more than they buy)
+  while (S < 8 && nbt * ncb * S * 2 <= 512 && NK % (2 * S) == 0) S *= 2;
+  return S;
+}
+
 }  // namespace
+
+extern "C" int pcnn_winograd43_conv_workspace_bytes(int B, int H, int W, int Cin, int Cout, int groups, size_t* bytes)
+{
+  PCNN_REQUIRE(bytes, PCNN_ENULL, "winograd43_conv_workspace_bytes: NULL output");
+  PCNN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Cin >= 64 && Cout >= 64 && groups >= 1 && B % groups == 0, PCNN_EINVAL,
+               "winograd43_conv_workspace_bytes: bad shape");
+  const long long tpg = (long long)B * ((H + 3) / 4) * ((W + 3) / 4) / groups;
+  const int S = wino43_cin_split((long long)groups * ((tpg + 31) / 32), Cout / WM_BC, Cin);
+  *bytes = S > 1 ? sizeof(float) * ((size_t)S * B * H * W * Cout + (size_t)groups * Cout) : 0;
+  return PCNN_OK;
+}
 
 extern "C" int pcnn_winograd43_conv_fwd(const float* v, const float* ut, const float* bias, int B, int H,
                                         int W, int Cin, int Cout, int groups, int relu, int pool,
-                                        float* y, float* y_pool, void* stream_)
+                                        float* y, float* y_pool, void* workspace, size_t workspace_bytes,
+                                        void* stream_)
 {
   PCNN_REQUIRE(B >= 1 && H >= 1 && W >= 1, PCNN_EINVAL, "winograd43_conv: bad shape %dx%dx%d", B, H, W);
   PCNN_REQUIRE(Cin >= 64 && Cin % 64 == 0, PCNN_EINVAL, "winograd43_conv: input channels must be a multiple of 64 (got %d)", Cin);
@@ -434,9 +504,27 @@ extern "C" int pcnn_winograd43_conv_fwd(const float* v, const float* ut, const f
   const long long nbt = (long long)groups * ((tpg + 31) / 32);
   const long long blocks = ((nbt + 7) / 8) * 8 * ncb;
   PCNN_REQUIRE(blocks < (1ll << 31), PCNN_EINVAL, "winograd43_conv: grid too large");
-#define WM_GO(P) PCNN_LAUNCH((wino43_mfma_kernel<P, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, v, ut, bias, y, y_pool, \
-                             H, W, Cin, Cout, Ht, Wt, T, tpg, relu, (int)nbt, ncb)
-  if (pool == 0) WM_GO(0); else if (pool == 1) WM_GO(1); else WM_GO(2);
-#undef WM_GO
+  // optional Cin split for launches that cannot fill the chip (needs the caller's workspace)
+  int S = wino43_cin_split(nbt, ncb, Cin);
+  const size_t out_elems = (size_t)B * H * W * Cout;
+  if (S > 1 && !(workspace && aligned16(workspace) && workspace_bytes >= sizeof(float) * (S * out_elems + (size_t)groups * Cout))) S = 1;
+#define WM_GO(P, Y, BIAS, RELU, KS, STRIDE) PCNN_LAUNCH((wino43_mfma_kernel<P, 1>), dim3((unsigned)blocks, KS), dim3(256), 0, stream, v, ut, BIAS, Y, y_pool, \
+                             H, W, Cin, Cout, Ht, Wt, T, tpg, RELU, (int)nbt, ncb, KS, (long long)(STRIDE))
+  if (S == 1) {
+    if (pool == 0) WM_GO(0, y, bias, relu, 1, 0); else if (pool == 1) WM_GO(1, y, bias, relu, 1, 0); else WM_GO(2, y, bias, relu, 1, 0);
+  } else {
+    float* part = static_cast<float*>(workspace);
+    float* zero_bias = part + S * out_elems;
+    if (hipMemsetAsync(zero_bias, 0, sizeof(float) * (size_t)groups * Cout, stream) != hipSuccess) return check_launch("winograd43_conv_fwd (memset)");
+    WM_GO(0, part, zero_bias, 0, S, out_elems);
+    const long long items = (long long)B * (pool ? (H / 2) * (W / 2) : H * W) * (Cout / 4);
+    const unsigned rgrid = (unsigned)((items + 255) / 256 < 65536 ? (items + 255) / 256 : 65536);
+    if (pool == 0)
+      PCNN_LAUNCH(wino43_splitk_reduce_kernel<0>, dim3(rgrid), dim3(256), 0, stream, part, S, (long long)out_elems, bias, relu, y, y_pool, B, H, W, Cout, B / groups);
+    else if (pool == 1)
+      PCNN_LAUNCH(wino43_splitk_reduce_kernel<1>, dim3(rgrid), dim3(256), 0, stream, part, S, (long long)out_elems, bias, relu, y, y_pool, B, H, W, Cout, B / groups);
+    else
+      PCNN_LAUNCH(wino43_splitk_reduce_kernel<2>, dim3(rgrid), dim3(256), 0, stream, part, S, (long long)out_elems, bias, relu, y, y_pool, B, H, W, Cout, B / groups);
+  }
   return check_launch("winograd43_conv_fwd");
 }

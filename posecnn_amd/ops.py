@@ -489,9 +489,13 @@ def winograd43_conv(v, ut, bias, B, H, W, relu=True, pool=0, groups=1):
     pool = int(pool)
     y = torch.empty((B, H // 2, W // 2, Cout) if pool == 1 else (B, H, W, Cout), dtype=torch.float32, device=v.device)
     yp = torch.empty((B, H // 2, W // 2, Cout), dtype=torch.float32, device=v.device) if pool == 2 else None
+    nbytes = ctypes.c_size_t()
+    check("pcnn_winograd43_conv_workspace_bytes",
+          lib().pcnn_winograd43_conv_workspace_bytes(B, H, W, Cin, Cout, int(groups), ctypes.byref(nbytes)))
+    ws = _ws(v.device, "wino43_conv").get(nbytes.value, v.device) if nbytes.value else None   # Cin-split partials (small launches only)
     check("pcnn_winograd43_conv_fwd",
           lib().pcnn_winograd43_conv_fwd(_ptr(v), _ptr(ut), _ptr(bias), B, H, W, Cin, Cout, int(groups), 1 if relu else 0,
-                                         pool, _ptr(y), _ptr(yp), _stream(v)))
+                                         pool, _ptr(y), _ptr(yp), _ptr(ws), nbytes.value, _stream(v)))
     return (y, yp) if pool == 2 else y
 
 
