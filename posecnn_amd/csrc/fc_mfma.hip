@@ -18,6 +18,8 @@
 // through LDS for 256-byte row stores, XCD-aware block map (the column blocks that share a row block's x
 // rows run on one XCD). `wt` is the weight matrix TRANSPOSED ([N][K], K contiguous) so that both operands
 // are K-major rows for the DMA.
+#include <algorithm>
+
 #include "pcnn_device.h"
 
 namespace {
@@ -280,7 +282,10 @@ extern "C" int pcnn_fc_rows_fwd(const float* x, const float* wt, const float* bi
   // split-K for launches with few live rows (decided on the device): needs the caller's workspace
   const int ws_rows = rows_capacity < FC_WS_ROWS ? (rows_capacity + 63) / 64 * 64 : FC_WS_ROWS;
   const size_t need = sizeof(float) * (size_t)FC_SMAX * ws_rows * out_features;
-  const int smax = (workspace && workspace_bytes >= need && fc_can_split(rows_capacity, in_features, out_features) && aligned16(workspace)) ? FC_SMAX : 1;
+  // grid.y = the most splits a launch may use; every split of every block is a workgroup that must at least
+  // be launched to find out that it has nothing to do, so a big capacity (train mode: 48 x 64 blocks) gets none
+  const int smax_cap = (int)std::min<long long>(FC_SMAX, std::max<long long>(1, 4096 / ((long long)nbm * ncb)));
+  const int smax = (workspace && workspace_bytes >= need && fc_can_split(rows_capacity, in_features, out_features) && aligned16(workspace)) ? smax_cap : 1;
   float* part = smax > 1 ? static_cast<float*>(workspace) : nullptr;
   PCNN_LAUNCH(fc_rows_mfma_kernel, dim3((unsigned)blocks, smax), dim3(512), 0, stream, x, wt, bias, addend, y, in_features,
               out_features, rows_capacity, relu, num_rows_dev, nbm, ncb, tall, part, smax, ws_rows);

@@ -13,7 +13,7 @@
 //               ballots; every skip-th pixel of each class that passes label_threshold becomes a
 //               32-byte record {x, y, thr(d), 1/|uv|, u, v, |uv|, d}: everything the inner loop
 //               of compute_hough_kernel :269-285 recomputes per (cell, pixel) pair, hoisted.
-//   hv_vote     interval formulation on bands of 8 Hough rows (one wave per row): the records that can
+//   hv_vote     interval formulation on bands of 4 Hough rows (two waves per row): the records that can
 //               reach a band are a contiguous range of the class' y-sorted list (64-ary search);
 //               a record's vote cone cut by a row is one dx-interval -> +1 / -1 in the row's LDS
 //               difference array; a wave-wide prefix sum yields the votes and the row maximum.
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void hv_scatter_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// hv_vote: one workgroup = (image, class slot, BAND of HV_BAND Hough rows), one wave per row.
+// hv_vote: one workgroup = (image, class slot, BAND of HV_BAND / HV_WPR Hough rows), HV_WPR waves per row.
 //
 // The round-1 kernel tiled the Hough space 32 x 32 and every one of the ~24 000 active tile blocks
 // re-streamed its class' ~1500 records to cull them (1.1 GB of L2 reads per launch, 112 M (record,
@@ -403,7 +403,8 @@ __global__ __launch_bounds__(256) void hv_scatter_kernel(
 // Votes are integers: order-free, bit-identical to the per-cell definition (compute_hough_kernel
 // :253-294); the exact IEEE predicate still decides the cells within the rounding uncertainty of an
 // interval end and the records without a closed form.
-constexpr int HV_BAND = 8;            // Hough rows (= waves) per workgroup
+constexpr int HV_BAND = 8;            // waves per workgroup
+constexpr int HV_WPR = 2;             // waves per Hough row (1: 213 us, 2: 186 us, 4: 209 us per 16-frame launch; 16 waves x 2: 222 us)
 constexpr int HV_RCHUNK = 256;        // records staged in LDS per round
 
 __device__ __forceinline__ void diff_add(int* row, int c_lo, int c_hi)
@@ -521,11 +522,15 @@ __global__ __launch_bounds__(64 * HV_BAND, 8) void hv_vote_kernel(
     const HvRec* __restrict__ rec, const int* __restrict__ nslots_g,
     const int* __restrict__ slots_g, const int* __restrict__ tot_g,
     const int* __restrict__ recoff_g, const int* __restrict__ kmax_g, int2* __restrict__ rowmax,
-    float* __restrict__ hs, int H, int W, int C, int skip, float inlier, int reccap, int need_hs)
+    float* __restrict__ hs, int H, int W, int C, int skip, float inlier, int reccap, int need_hs, int wpr)
 {
   const int n = blockIdx.z, s = blockIdx.y, band = blockIdx.x;
   if (s >= nslots_g[n]) return;
-  const int nrows = blockDim.x >> 6;   // rows of this band = waves (HV_BAND, fewer for very wide images)
+  // `wpr` waves share a row (each takes every wpr-th 64-record slice of a chunk): the launch ends with its
+  // longest workgroup — a band through the middle of a large object — so the records of a row are spread
+  // over more lanes rather than the band over more rows
+  const int nwaves = blockDim.x >> 6;
+  const int nrows = nwaves / wpr;      // rows of this band (fewer for very wide images)
   const int cls = slots_g[n * C + s];
   const int m = (tot_g[n * C + cls] + skip - 1) / skip;
   const HvRec* r0 = rec + (size_t)n * reccap + recoff_g[n * C + cls];
@@ -536,9 +541,10 @@ __global__ __launch_bounds__(64 * HV_BAND, 8) void hv_vote_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int W1 = W + 1;
   const int y0 = band * nrows;
-  const int yrow = y0 + wave;
-  int* drow = s_dyn + wave * W1;
-  for (int i = tid; i < nrows * W1; i += 64 * nrows) s_dyn[i] = 0;
+  const int row = wave % nrows, part = wave / nrows;
+  const int yrow = y0 + row;
+  int* drow = s_dyn + row * W1;
+  for (int i = tid; i < nrows * W1; i += 64 * nwaves) s_dyn[i] = 0;
 
   // records that can reach the band: y in (y0 - kmax - 1, y0 + HV_BAND - 1 + kmax + 1), kmax = the class'
   // largest window half-size ceil(thr) - 1 (|dy| < thr  <=>  |dy| <= ceil(thr) - 1)
@@ -548,7 +554,7 @@ __global__ __launch_bounds__(64 * HV_BAND, 8) void hv_vote_kernel(
     const int lo = first_record_at_or_below_row(r0, m, (float)y0 - kmaxf);
     if (lane == 0) s_range[0] = lo;
   }
-  if (wave == nrows - 1) {
+  if (wave == nwaves - 1) {
     const int hi = first_record_at_or_below_row(r0, m, (float)(y0 + nrows - 1) + kmaxf + 1.f);
     if (lane == 0) s_range[1] = hi;
   }
@@ -557,20 +563,20 @@ __global__ __launch_bounds__(64 * HV_BAND, 8) void hv_vote_kernel(
 
   for (int b0 = lo; b0 < hi; b0 += HV_RCHUNK) {
     const int cnt = min(HV_RCHUNK, hi - b0);
-    for (int k = tid; k < cnt; k += 64 * nrows) {
+    for (int k = tid; k < cnt; k += 64 * nwaves) {
       sA[k] = r0[b0 + k].a;
       sB[k] = r0[b0 + k].b;
       sC[k] = r0[b0 + k].c;
     }
     __syncthreads();
     if (yrow < H)
-      for (int k = lane; k < cnt; k += 64) vote_row(sA[k], sB[k], sC[k], yrow, W, inlier, drow);
+      for (int k = part * 64 + lane; k < cnt; k += 64 * wpr) vote_row(sA[k], sB[k], sC[k], yrow, W, inlier, drow);
     __syncthreads();
   }
 
   // difference array -> votes: lane owns a contiguous strip of the row, wave-wide exclusive scan of
   // the strip sums; the row maximum (most votes, lowest column among equals) comes out of the same pass
-  if (yrow >= H) return;
+  if (yrow >= H || part != 0) return;
   const int per = (W + 63) / 64;
   const int c0 = lane * per, c1 = min(c0 + per, W);
   int sum = 0;
@@ -1227,11 +1233,12 @@ int hough_fwd_impl(const int32_t* label, const HvVertexSrc vs,
                      extents, meta, hist, tot, slots, nslots, recoff, kmax, rec, HW, W, C, L.nchunk,
                      skip, label_thr, num_meta, L.reccap, inlier);
   // rows per band: HV_BAND, fewer when 8 difference arrays of W + 1 counters would not fit 48 KB of LDS
-  int band_rows = HV_BAND;
+  const int wpr = HV_WPR;
+  int band_rows = HV_BAND / wpr;
   while (band_rows > 1 && sizeof(int) * band_rows * (size_t)(W + 1) > 48 * 1024) band_rows--;
-  PCNN_LAUNCH(hv_vote_kernel, dim3((H + band_rows - 1) / band_rows, C - 1, B), dim3(64 * band_rows),
+  PCNN_LAUNCH(hv_vote_kernel, dim3((H + band_rows - 1) / band_rows, C - 1, B), dim3(64 * band_rows * wpr),
               sizeof(int) * band_rows * (size_t)(W + 1), stream, rec, nslots, slots, tot, recoff, kmax, tilemax, hs,
-              H, W, C, skip, inlier, L.reccap, need_hs ? 1 : 0);
+              H, W, C, skip, inlier, L.reccap, need_hs ? 1 : 0, wpr);
   if (!need_hs) {
     PCNN_LAUNCH(hv_select_kernel, dim3(C - 1, B), dim3(256), 0, stream, rec, nslots, slots,
                        tot, recoff, tilemax, extents, meta, maxima, nmax, W, C, skip, inlier,
