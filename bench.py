@@ -518,8 +518,15 @@ def main(argv=None):
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         except Exception as e:  # the baseline is reported, never required for the GPU number
             out["cpu_baseline"] = {"error": repr(e)}
-    print(json.dumps(out), flush=True)
+    # the JSON line is the LAST thing this process writes: tear the process group down first and flush the C
+    # stdio buffer (RCCL prints a version banner through printf, which would otherwise land after the line)
     pdist.shutdown()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

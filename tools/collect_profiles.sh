@@ -7,6 +7,7 @@ python bench.py --streams 1 --graph --no-cpu-baseline > $O/bench_graph.json 2> $
 python bench.py --streams 1 --resident-inputs --no-cpu-baseline > $O/bench_resident.json 2> $O/bench_resident.err
 python bench.py --streams 1 --latency --batch 1 --input COLOR --losses test --no-cpu-baseline --graph > $O/bench_latency_b1.json 2> $O/bench_latency_b1.err
 python bench.py --config linemod --no-cpu-baseline > $O/bench_linemod.json 2> $O/bench_linemod.err
+python bench.py --force-process-group --no-cpu-baseline > $O/bench_rccl_world1.json 2> $O/bench_rccl_world1.err
 python bench.py --input COLOR --losses test --resident-inputs --no-cpu-baseline > $O/bench_color_test_resident.json 2> $O/bench_color.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python /root/repo/bench.py --steps 10 --warmup 3 --prewarm-seconds 4 --no-cpu-baseline > $O/bench_traced.json 2> $O/prof.log
@@ -24,5 +25,8 @@ done
 cd /root/repo
 python tools/bench_wino_mfma.py --no-library > $O/layers_mfma.json 2> $O/layers_mfma.err
 python tools/bench_ops.py > $O/ops.json 2> $O/ops.err
+python tools/bench_wino_mfma.py --no-library --batch 1 --groups 1 > $O/layers_mfma_batch1.json 2>> $O/layers_mfma.err
+python tools/bench_fc_rows.py > $O/fc_rows.txt 2>&1
+python tools/bench_roi_pool.py > $O/roi_pool.txt 2>&1
 rm -rf $O/prof/*.db $O/pmc_*/ 2>/dev/null
 ls -la $O
