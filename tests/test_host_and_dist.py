@@ -144,3 +144,26 @@ def test_all_gather_detections_world1_is_local():
     g, c = pdist.all_gather_detections(rows, torch.tensor([1], dtype=torch.int32))
     assert g.shape == (1, 4, 14) and c.tolist() == [1]
     assert pdist.flatten_gathered(g, c).shape == (1, 14)
+
+
+def test_upload_slots_are_adjacent_and_stack_as_a_view():
+    """pipeline.alloc_adjacent carves a batch's blobs out of one allocation so that the colour and the
+    depth blob of an RGB-D batch are back to back; stacked_view then hands both towers to the grouped
+    trunk as ONE [2B,H,W,3] view (no concatenation), and refuses anything that is not adjacent."""
+    import torch
+    from posecnn_amd import pipeline
+    a = torch.arange(4 * 6 * 8 * 3, dtype=torch.float32).reshape(4, 6, 8, 3)
+    b = -a
+    lab = torch.zeros(4, 6, 8, dtype=torch.int32)
+    slot = pipeline.alloc_adjacent((a, b, None, lab), "cpu")
+    assert slot[2] is None and [t.shape for t in slot if t is not None] == [a.shape, b.shape, lab.shape]
+    assert slot[3].dtype == torch.int32 and all(t.data_ptr() % 256 == 0 for t in slot if t is not None)
+    slot[0].copy_(a); slot[1].copy_(b)
+    v = pipeline.stacked_view(slot[0], slot[1])
+    assert v is not None and v.shape == (8, 6, 8, 3) and v.data_ptr() == slot[0].data_ptr()
+    assert torch.equal(v[:4], a) and torch.equal(v[4:], b)
+    assert pipeline.stacked_view(a, b) is None                      # separate allocations
+    assert pipeline.stacked_view(slot[1], slot[0]) is None          # wrong order
+    assert pipeline.stacked_view(slot[0], slot[1][:, :3]) is None   # shape mismatch
+    odd = pipeline.alloc_adjacent((torch.zeros(3, 5, 7, 3), torch.zeros(3, 5, 7, 3)), "cpu")   # 1260 B: padded to 256
+    assert pipeline.stacked_view(odd[0], odd[1]) is None
