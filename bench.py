@@ -457,6 +457,16 @@ def main(argv=None):
                            "unit": "TFLOP/s", "frac": fl / (t * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "us_per_step": round(t, 1)})
             lib_conv_ms += t / 1e3
             lib_conv_flops += fl
+    # fc6 / fc7 on the live rows + the head 1x1 products (all fc_rows_mfma_kernel): executed flops of the rows that exist
+    live_rows = int(last["det"].count.item()) * (9 if train else 1)
+    head_rows = B * (H // 8) * (W // 8)
+    fc_flops = 2.0 * live_rows * (7 * 7 * 512 * 4096 + 4096 * 4096) \
+        + 2.0 * head_rows * 512 * (64 * towers + 128) * 1.25      # conv4_3 heads + conv5_3 heads (a quarter of the pixels)
+    t_fc = us("fc_rows_mfma_kernel")
+    if t_fc:
+        others.append({"kernel": "fc_rows_mfma_kernel", "bound": "mfma", "achieved": fc_flops / (t_fc * 1e-6) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,
+                       "unit": "TFLOP/s", "frac": fc_flops / (t_fc * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "us_per_step": round(t_fc, 1),
+                       "note": "fc6 + fc7 on %d live rows and the 1x1 head products" % live_rows})
     # the trunk as a whole: every kernel whose name says it belongs to a convolution
     trunk_ms = sum(v["avg_us"] * v["calls"] for k, v in kern.items() if k.startswith(("wino", "conv3x3", "bias_"))) / 1e3 / a.steps \
         + conv_ms / a.steps
