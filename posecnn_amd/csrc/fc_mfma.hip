@@ -3,7 +3,7 @@
 // gfx950 matrix cores, over a CAPACITY-SIZED row buffer with the row count on the device.
 //
 // Why not the library GEMM: the sync-free Hough layer hands the pose branch `rows_capacity` ROI rows (3024
-// for 16 frames x 21 classes x 9 training rows) of which only `*num_rows_dev` exist (~470 in the bench). A
+// for 16 frames x 21 classes x 9 training rows) of which only `*num_rows_dev` exist (~680 in the bench). A
 // library GEMM needs M on the host — a device->host sync per batch — or computes all 3024 rows (4.8 ms of
 // fp32 MFMA per batch, measured). This kernel reads the count on the device: row blocks at or past it store
 // zeros and exit before touching an operand.

@@ -10,15 +10,17 @@
 // v_mfma_f32_16x16x4_f32 (no xf32/TF32 on gfx950; 157 TFLOP/s peak). Design for the chip, not for a
 // generic GEMM:
 //
-//  * Workgroup = 64 tiles x 64 output channels, 8 waves (2 per SIMD so that one wave's LDS / global
-//    / VALU work hides under the other's MFMAs). Wave (wm, wn) owns tiles [32 wm, 32 wm + 32) x
-//    channels [16 wn, 16 wn + 16): two 16x16 accumulator blocks.
+//  * Workgroup = 32 tiles x 64 output channels, 4 waves, TWO workgroups per CU (one wave of each per
+//    SIMD, so that one workgroup's LDS / global / VALU work, barrier waits and epilogue hide under the
+//    other's MFMAs; the 64-tile / 8-wave / one-per-CU shape, WR = 2, measures 2-7 % slower and is kept
+//    for the ablation harness). Wave wn owns the block's 32 tiles x channels [16 wn, 16 wn + 16): two
+//    16x16 accumulator blocks.
 //  * The transform-domain product M NEVER exists, not even in registers as a whole: planes are
 //    processed column by column (nu outer, xi inner). Once the 6 planes of column nu are summed
 //    over all of Cin, t = A^T M[:, nu] (4 values) is folded into the 16 outputs Y += t (x) A[nu, :]
 //    and the 6 accumulators are recycled. 22 live values per (tile, channel) instead of 36 is what
-//    lets a 64 x 64 block fit the register file (360 KB of the CU's 512 KB) — 4x the tile of the
-//    round-1 kernel, i.e. 2.5x fewer operand bytes per flop through L2 -> LDS (16 B/clk/CU).
+//    lets 64 x 64 elements per CU (two 32 x 64 blocks) fit the register file (360 KB of the CU's
+//    512 KB) — 4x the tile of the round-1 kernel.
 //  * Operands go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no
 //    ds_write pass) through a ring of 3 stage buffers, ONE barrier per 64-deep K stage: the 4 DMA
 //    instructions a wave issues for stage s+2 fly under the MFMAs of stages s and s+1 (a stage of a
@@ -29,9 +31,11 @@
 //    the 16-byte chunk index with the row (applied to the SOURCE address of the DMA and to the
 //    ds_read_b128 address — the same involution on both sides). One b128 read feeds 4 MFMAs (K is
 //    consumed in the order 16 j + 4 (lane >> 4) + i for both operands).
-//  * Epilogue: bias + ReLU (+ 2x2 max-pool of the 4x4 tile) in registers, then through LDS so that
-//    every store instruction writes whole 256-byte channel rows (the C/D layout alone would give
-//    64-byte segments).
+//  * Epilogue: bias + ReLU (+ 2x2 max-pool of the 4x4 tile) in registers, then through LDS (two staging
+//    buffers, one barrier per pass) so that every store instruction writes whole 256-byte channel rows
+//    (the C/D layout alone would give 64-byte segments).
+//  * Launches too small to fill the chip (batch-1 conv4_x / conv5_x) split Cin over grid.y; a reduction
+//    kernel sums the raw partial outputs in a fixed order and applies bias / ReLU / pooling.
 //  * blockIdx -> (tile block, channel block) is XCD-aware: a tile block's V rows are shared by the
 //    Cout / 64 workgroups that run back to back on ONE XCD (same L2), tile blocks are dealt round
 //    robin to the 8 XCDs.
