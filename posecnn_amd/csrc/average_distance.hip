@@ -226,9 +226,7 @@ extern "C" int pcnn_average_distance_fwd(const float* prediction, const float* t
   PCNN_REQUIRE(loss, PCNN_ENULL, "average_distance: loss is NULL");
   hipStream_t stream = (hipStream_t)stream_;
   if (R == 0) {
-    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), stream);
-    if (e != hipSuccess) { pcnn::set_error("average_distance: %s", hipGetErrorString(e)); return PCNN_EHIP; }
-    return PCNN_OK;
+    return pcnn::zero_async(loss, sizeof(float), stream, "average_distance");
   }
   PCNN_REQUIRE(prediction && target && weight && point && symmetry && bottom_diff, PCNN_ENULL,
                "average_distance: NULL pointer");

@@ -35,6 +35,25 @@ int check_launch(const char* what)
   return PCNN_OK;
 }
 
+// ---- zero fill ------------------------------------------------------------------------------
+// A kernel, not hipMemsetAsync: inside a stream capture (posecnn_amd/pipeline.py GraphedStep) the memset
+// node of this ROCm corrupted neighbouring allocations on replay with changed inputs
+// (tests/test_gpu_round2.py::test_hipgraph_replay_equals_the_eager_step found it).
+__global__ __launch_bounds__(256) void zero_fill_kernel(unsigned int* __restrict__ p, size_t n)
+{
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+
+int zero_async(void* p, size_t bytes, hipStream_t stream, const char* what)
+{
+  if (bytes == 0) return PCNN_OK;
+  const size_t n = bytes / 4;   // every buffer of this library is a multiple of 4 bytes
+  const size_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream,
+                     static_cast<unsigned int*>(p), n);
+  return check_launch(what);
+}
+
 // ---- per-kernel timing ----------------------------------------------------------------------
 bool g_profile_on = false;
 

@@ -122,12 +122,9 @@ extern "C" int pcnn_hard_label_bwd(float* grad_prob, float* grad_gt, int64_t N, 
   PCNN_REQUIRE(grad_prob && grad_gt, PCNN_ENULL, "hard_label_bwd: NULL output");
   hipStream_t stream = (hipStream_t)stream_;
   // HardlabelBackward, hard_label_op_gpu.cu.cc:55-63: zeros
-  hipError_t e = hipMemsetAsync(grad_prob, 0, sizeof(float) * (size_t)N * C, stream);
-  if (e == hipSuccess) e = hipMemsetAsync(grad_gt, 0, sizeof(float) * (size_t)N, stream);
-  if (e != hipSuccess) {
-    pcnn::set_error("hard_label_bwd: %s", hipGetErrorString(e));
-    return PCNN_EHIP;
-  }
+  int st = pcnn::zero_async(grad_prob, sizeof(float) * (size_t)N * C, stream, "hard_label_bwd");
+  if (st == PCNN_OK) st = pcnn::zero_async(grad_gt, sizeof(float) * (size_t)N, stream, "hard_label_bwd");
+  if (st != PCNN_OK) return st;
   return PCNN_OK;
 }
 

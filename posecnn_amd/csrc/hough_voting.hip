@@ -1311,12 +1311,9 @@ extern "C" int pcnn_hough_voting_bwd(float* grad_label, float* grad_vertex, int 
   PCNN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && C >= 1, PCNN_EINVAL, "hough_voting_bwd: bad shape");
   hipStream_t stream = (hipStream_t)stream_;
   // set_gradients, hough_voting_gpu_op.cu.cc:608-612
-  hipError_t e = hipMemsetAsync(grad_label, 0, sizeof(float) * (size_t)B * H * W, stream);
-  if (e == hipSuccess)
-    e = hipMemsetAsync(grad_vertex, 0, sizeof(float) * (size_t)B * H * W * PCNN_VERTEX_CHANNELS * C, stream);
-  if (e != hipSuccess) {
-    set_error("hough_voting_bwd: %s", hipGetErrorString(e));
-    return PCNN_EHIP;
-  }
+  int st = zero_async(grad_label, sizeof(float) * (size_t)B * H * W, stream, "hough_voting_bwd");
+  if (st == PCNN_OK)
+    st = zero_async(grad_vertex, sizeof(float) * (size_t)B * H * W * PCNN_VERTEX_CHANNELS * C, stream, "hough_voting_bwd");
+  if (st != PCNN_OK) return st;
   return PCNN_OK;
 }

@@ -20,6 +20,7 @@ namespace pcnn {
 // ---- error plumbing (host) -------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);  // hipGetLastError -> PCNN_EHIP
+int zero_async(void* p, size_t bytes, hipStream_t stream, const char* what);  // zero-fill kernel (graph-capture safe)
 
 #define PCNN_REQUIRE(cond, status, ...)  \
   do {                                   \

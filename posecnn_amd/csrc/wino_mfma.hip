@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
   const long long tend = (long long)(grp + 1) * tiles_per_group;   // first tile that is not this block's business
   const float* utg = ut + (size_t)grp * 36 * Cout * Cin;
   // `ksplit` > 1 (small launches, see the launcher): workgroup blockIdx.y contracts only its slice of Cin and
-  // writes a raw partial output (the host passes zero bias, no ReLU, POOL = 0); a reduction kernel finishes
+  // writes a raw partial output (the host passes no bias, no ReLU, POOL = 0); a reduction kernel finishes
   const int ks = blockIdx.y;
   const int NK = Cin / WM_KC / ksplit;
   y += (long long)ks * ysplit_stride;
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
   // lane holds, per block b, tiles 32 wm + 16 b + 4 lk + i (i = 0..3) x channel 16 wn + lr
   const int col = 16 * wn + lr;
   const int co = cb * WM_BC + col;
-  const float bv = bias[(size_t)grp * Cout + co];
+  const float bv = bias ? bias[(size_t)grp * Cout + co] : 0.f;   // (no bias: the raw partial output of a Cin split)
 #pragma unroll
   for (int b = 0; b < 2; b++)
 #pragma unroll
@@ -518,9 +518,7 @@ extern "C" int pcnn_winograd43_conv_fwd(const float* v, const float* ut, const f
     if (pool == 0) WM_GO(0, y, bias, relu, 1, 0); else if (pool == 1) WM_GO(1, y, bias, relu, 1, 0); else WM_GO(2, y, bias, relu, 1, 0);
   } else {
     float* part = static_cast<float*>(workspace);
-    float* zero_bias = part + S * out_elems;
-    if (hipMemsetAsync(zero_bias, 0, sizeof(float) * (size_t)groups * Cout, stream) != hipSuccess) return check_launch("winograd43_conv_fwd (memset)");
-    WM_GO(0, part, zero_bias, 0, S, out_elems);
+    WM_GO(0, part, (const float*)nullptr, 0, S, out_elems);
     const long long items = (long long)B * (pool ? (H / 2) * (W / 2) : H * W) * (Cout / 4);
     const unsigned rgrid = (unsigned)((items + 255) / 256 < 65536 ? (items + 255) / 256 : 65536);
     if (pool == 0)

@@ -207,6 +207,66 @@ def test_winograd_mfma_trunk_at_full_size_against_direct_convolutions(gpu, capsy
         print("\nfull-size winograd-MFMA vs direct:", report)
 
 
+@pytest.mark.parametrize("B,fmt,train", [(2, "RGBD", True), (1, "COLOR", False)])
+def test_hipgraph_replay_equals_the_eager_step(gpu, B, fmt, train):
+    """pipeline.GraphedStep (bench.py --graph / --latency): one whole step — trunk, heads, Hough voting,
+    RoI pooling, fc6-8 on device-counted rows, the loss layers — captured into a hipGraph and replayed
+    on new frame contents must give the eager step's detections bit for bit. Batch 1 exercises the
+    Cin-split trunk launches and split-K fc6 (a memset node and two extra kernels inside the graph)."""
+    import torch
+    from posecnn_amd import fcn, pipeline
+    from posecnn_amd.networks import vgg16_convs
+    H, W = 240, 320
+    net = vgg16_convs(fmt, 22, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True, trainable=False,
+                      is_train=train, seed=3, init="he", with_losses=False, device=gpu)
+    synth.init_planted_heads(net)
+    K = config.DEMO_INTRINSICS.copy(); K[:2] *= W / 640.0
+    rng = np.random.default_rng(8)
+    pts = T(gpu, synth.make_model_points(22, 256))
+    frames = []
+    for i in range(3):
+        data, data_p = _rgbd_inputs(rng, B, H, W)
+        planted_np, scenes = synth.make_planted_batch(60 + i, B, H=H, W=W, K=K, n_obj=3)
+        frames.append((T(gpu, data), T(gpu, data_p) if fmt == "RGBD" else None, {k: T(gpu, v) for k, v in planted_np.items()},
+                       T(gpu, synth.make_gt_poses(scenes, K, seed=i)) if train else None))
+    # static inputs of the graph: refilled before every replay
+    sdata, sdata_p = frames[0][0].clone(), None if frames[0][1] is None else frames[0][1].clone()
+    splant = {k: v.clone() for k, v in frames[0][2].items()}
+    sgt = None if frames[0][3] is None else frames[0][3].clone()
+
+    # the constant feeds (extents, meta data, model points ...) are uploaded once, outside the capture
+    feed = fcn._feed(net, sdata, sdata_p, K, config.LOV_EXTENTS, pts, config.LOV_SYMMETRY, 22, gpu)
+
+    def step():
+        det = fcn.im_segment_batch(net, sdata, K, config.LOV_EXTENTS, pts, config.LOV_SYMMETRY, data_p=sdata_p,
+                                   planted=splant, feed_cache=feed, with_losses=True, gt_poses=sgt)
+        return det.rows, det.count, det.label_2d, net.get_output("loss_pose")
+
+    def fill(f):
+        sdata.copy_(f[0])
+        if sdata_p is not None:
+            sdata_p.copy_(f[1])
+        for k in splant:
+            splant[k].copy_(f[2][k])
+        if sgt is not None:
+            sgt.copy_(f[3])
+
+    with torch.no_grad():
+        eager = []
+        for f in frames:
+            fill(f)
+            eager.append([t.clone() for t in step()])
+        torch.cuda.synchronize()
+        g = pipeline.GraphedStep(step, warmup=1, device=gpu)
+        for j in (1, 2, 0, 1):
+            fill(frames[j])
+            out = [t.clone() for t in g.replay()]
+            torch.cuda.synchronize()
+            assert int(out[1]) == int(eager[j][1]) and int(out[1]) > 0
+            for got, want, name in zip(out, eager[j], ("rows", "count", "label_2d", "loss_pose")):
+                same(N(got).reshape(-1), N(want).reshape(-1), "%s of frame set %d" % (name, j))
+
+
 def test_batches_on_alternating_streams_equal_the_serial_run(gpu):
     """bench.py --streams 2: consecutive batches go to different HIP streams so that one batch's trunk
     overlaps the other's heads / Hough / RoI tail. Everything a batch touches is stream-local (allocator
