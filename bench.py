@@ -51,6 +51,9 @@ def parse_args(argv=None):
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (see posecnn_amd/pipeline.py)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the batches alternate over: with 2, batch i+1's trunk overlaps batch i's heads / Hough / RoI tail")
+    ap.add_argument("--backproject-grid", type=int, default=None,
+                    help="also run the backprojecting layer on each batch's head features (G^3 voxels per frame); "
+                         "default 128 for --config linemod (configs[4] names it), 0 = off otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nbuf", type=int, default=2, help="distinct synthetic batches cycled through")
     ap.add_argument("--prewarm-seconds", type=float, default=8.0,
@@ -204,7 +207,7 @@ def main(argv=None):
 
     import numpy as np
     import torch
-    from posecnn_amd import _lib, config, fcn, pipeline, synth
+    from posecnn_amd import _lib, config, fcn, ops, pipeline, synth
     from posecnn_amd.networks import vgg16_convs
 
     rank, world, local = pdist.init_from_env(force=a.force_process_group)
@@ -229,6 +232,7 @@ def main(argv=None):
     train = a.losses == "train"
     K = config.DEMO_INTRINSICS.copy()
     K[:2] *= W / 640.0   # same rule as lib/fcn/test.py:130-131
+    G3 = a.backproject_grid if a.backproject_grid is not None else (128 if a.config == "linemod" else 0)
 
     net = vgg16_convs(a.input, C, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True,
                       trainable=False, is_train=train, device=dev, seed=3, init="he", with_losses=False)
@@ -239,6 +243,18 @@ def main(argv=None):
     planted = [{k: torch.from_numpy(v).to(dev) for k, v in p.items()} for p, _, _ in aux]
     gts = [None if g is None else torch.from_numpy(g).to(dev) for _, g, _ in aux]
     pts = torch.from_numpy(synth.make_model_points(C, config.NUM_MODEL_POINTS, extents=extents)).to(dev)
+    bp = None
+    if G3 > 0:
+        # the backprojecting layer (lib/backprojecting_layer, Network.backproject network.py:224-226) on this
+        # batch's own tensors: 64-channel head features at full resolution + the class probabilities, lifted into
+        # a G^3 voxel grid with a synthetic depth map (BASELINE configs[4]: "stress HBM on backprojecting")
+        ident = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], np.float32)
+        m3 = config.make_meta_data(K, voxel_step=(6.0 / G3, 6.0 / G3, 7.0 / G3), voxel_min=(-3, -3, -3),
+                                   pose_world2live=ident, pose_live2world=ident).reshape(1, 1, 1, 48)
+        gen = torch.Generator(device="cpu").manual_seed(99)
+        bp = {"meta": torch.from_numpy(np.repeat(m3, B, axis=0)).to(dev),
+              "depth": (1.5 + 0.5 * torch.rand((B, H, W, 1), generator=gen)).to(dev),
+              "label_3d": torch.zeros((B, G3, G3, G3, C), device=dev)}
     if a.resident_inputs:
         resident = []
         for hb in host:
@@ -264,9 +280,14 @@ def main(argv=None):
         nonlocal feed_cache
         if feed_cache is None:
             feed_cache = fcn._feed(net, data, data_p, K, extents, pts, symmetry, C, dev)
-        return fcn.im_segment_batch(net, data, K, extents, pts, symmetry, data_p=data_p,
-                                    planted=planted[k], feed_cache=feed_cache,
-                                    with_losses=a.losses != "none", gt_poses=gts[k])
+        det = fcn.im_segment_batch(net, data, K, extents, pts, symmetry, data_p=data_p,
+                                   planted=planted[k], feed_cache=feed_cache,
+                                   with_losses=a.losses != "none", gt_poses=gts[k])
+        if bp is not None:
+            feat = ops.deconv_bilinear(net.get_output("dropout"), int(16 * net.scale), int(8 * net.scale))   # `upscore` [B,H,W,64]
+            top = ops.backproject(feat, net.get_output("prob_normalized"), bp["depth"], bp["meta"], bp["label_3d"], G3, 3, 0.02)
+            last["backproject"] = top[0]
+        return det
 
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(max(1, a.streams) - 1)]
     multi = {"on": len(streams) > 1}
@@ -437,6 +458,8 @@ def main(argv=None):
         "upscore_softmax_argmax_kernel": 4.0 * B * H * W * (C + 1) + act(8, C),
     }
     hbm.update(net.hbm_table(B, H, W)) if hasattr(net, "hbm_table") else None
+    if G3 > 0:   # writes data + flag [G^3, 64] and label [G^3, C], reads label_3d [G^3, C]
+        hbm["backproject_fused_kernel"] = 4.0 * B * G3 ** 3 * (2 * 64 + 2 * C)
 
     def us(k):  # per step, all template instances of a kernel together
         t = sum(v["avg_us"] * v["calls"] for n, v in kern.items() if n == k or n.startswith(k + "<"))
@@ -477,6 +500,8 @@ def main(argv=None):
                 % (cfg_name, B, W, H, name_of, C - 1, towers, "s" if towers > 1 else "", 1 if train else 0))
     if a.losses != "none":
         workload += " + hard_label + average_distance_loss (%d rows with pose targets)" % adl_rows
+    if G3 > 0:
+        workload += " + upscore deconv + backproject into a %d^3 grid (%.1f GB of voxel features per step)" % (G3, 4.0 * B * G3 ** 3 * (2 * 64 + C) / 1e9)
     workload += " + all-gather + D2H + NMS; inputs from %s" % ("HBM (resident)" if a.resident_inputs else "pinned host memory (H2D inside the timed region)")
     out = {
         "metric": "%s frames/sec (%dx%d, %d classes)" % (name_of, W, H, C - 1),
