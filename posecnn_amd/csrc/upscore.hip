@@ -335,7 +335,14 @@ __global__ __launch_bounds__(UP_SEG) void upscore_softmax_argmax_kernel(
         if (c < C) s_out[tid * C + c] = e[c];
     __syncthreads();
     float* o = prob + (((long long)b * Ho + oy) * Wo + ox0) * C;
-    for (int i = tid; i < npx * C; i += UP_SEG) o[i] = s_out[i];
+    const int nfl = npx * C;
+    if (((nfl | (UP_SEG * C)) & 3) == 0 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+      // the segment's run of npx * C floats starts 16-byte aligned: dwordx4 stores (4x fewer store instructions)
+      for (int i = tid * 4; i < nfl; i += UP_SEG * 4)
+        *reinterpret_cast<float4*>(o + i) = *reinterpret_cast<const float4*>(s_out + i);
+    } else {
+      for (int i = tid; i < nfl; i += UP_SEG) o[i] = s_out[i];
+    }
   }
 }
 
