@@ -269,9 +269,11 @@ __global__ __launch_bounds__(UP_SEG) void upscore_softmax_argmax_kernel(
   const int ncx = tlast.i0 + (tlast.n > 0 ? tlast.n : 1) - cx0;
   float* s_z = smem;                       // [ty.n][ncx][C]
   float* s_out = smem + s_out_off;         // [UP_SEG][C]
-  for (int i = tid; i < ty.n * ncx * C; i += UP_SEG) {
-    const int c = i % C, cx = (i / C) % ncx, ry = i / (C * ncx);
-    s_z[i] = z[(((long long)b * H + ty.i0 + ry) * W + cx0 + cx) * C + c];
+  // a row's ncx cells x C channels are one contiguous run of z: straight copies, no index arithmetic per element
+  const int rowlen = ncx * C;
+  for (int ry = 0; ry < ty.n; ry++) {
+    const float* src = z + (((long long)b * H + ty.i0 + ry) * W + cx0) * C;
+    for (int i = tid; i < rowlen; i += UP_SEG) s_z[ry * rowlen + i] = src[i];
   }
   __syncthreads();
 
