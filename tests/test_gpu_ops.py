@@ -649,7 +649,9 @@ def test_network_first_conv_fusion_is_transparent(gpu):
     ((5, 9, 9, 64), 64, 0, 1), ((2, 60, 80, 256), 256, 0, 1), ((2, 30, 40, 512), 512, 2, 2), ((4, 16, 16, 512), 512, 0, 2),
     ((2, 24, 20, 256), 512, 1, 2), ((6, 10, 14, 128), 128, 0, 3), ((2, 64, 64, 64), 64, 1, 2),
     # enough tile blocks for the 64-tile / 8-wave variant (>= 1024 workgroups), single and grouped
-    ((2, 480, 640, 64), 128, 1, 1), ((2, 478, 638, 64), 128, 0, 2), ((4, 240, 320, 128), 256, 2, 2)])
+    ((2, 480, 640, 64), 128, 1, 1), ((2, 478, 638, 64), 128, 0, 2), ((4, 240, 320, 128), 256, 2, 2),
+    # launches small enough for the Cin split (S = 8 / 4 / 2), ragged tiles, every pool mode, grouped
+    ((1, 14, 18, 512), 512, 1, 1), ((2, 30, 38, 256), 256, 2, 2), ((1, 6, 6, 128), 64, 0, 1), ((2, 10, 14, 512), 128, 0, 2)])
 def test_winograd43_mfma_conv_kernel(gpu, shape, cout, pool, groups):
     """The 36 Winograd-domain contractions + output transform in one fp32-MFMA kernel (csrc/wino_mfma.hip)
     against (a) the unfused pair — library batched GEMM + wino43_output_kernel — and (b) a float64 direct
