@@ -148,33 +148,48 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wino43_kernel(
     for (int t = 0; t < 27; t++) wq[t] = *reinterpret_cast<const f4*>(w + (size_t)t * Cout + c0);
     const f4 bq = *reinterpret_cast<const f4*>(bias + c0);
     __syncthreads();
-    // phase 1: 6 x 34 patch pixels, 16 per iteration (4 waves x 4 slots)
-    for (int it = 0; it < (6 * FW_COLS + 15) / 16; it++) {
+    // phase 1: the 6 x FW_COLS patch as pairs of horizontally adjacent pixels, 16 pairs per iteration (4 waves x
+    // 4 slots): a pair shares 6 of its 9 window floats per filter row (12 LDS reads instead of 18) and gives the
+    // lane two independent FMA chains; each pixel still sums (ky, kx, ci) ascending, as the stand-alone kernel does
+    constexpr int NPAIR = FW_COLS / 2;
+    static_assert(FW_COLS % 2 == 0, "pixel pairs");
+    for (int it = 0; it < (6 * NPAIR + 15) / 16; it++) {
       const int p = it * 16 + wave * 4 + slot;
-      if (p < 6 * FW_COLS) {
-        const int r = p / FW_COLS, cx = p - r * FW_COLS;
+      if (p < 6 * NPAIR) {
+        const int r = p / NPAIR, cx = 2 * (p - r * NPAIR);
         const int yy = py0 + r, xx = px0 + cx;
-        f4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        const bool rowok = yy >= 0 && yy < H;
+        const bool ok0 = rowok && xx >= 0 && xx < W, ok1 = rowok && xx + 1 >= 0 && xx + 1 < W;
+        if (ok0 || ok1) {
 #pragma unroll
           for (int ky = 0; ky < 3; ky++) {
-            const float* win = &s_in[r + ky][cx * CF_CIN];
+            const float* win = &s_in[r + ky][cx * CF_CIN];   // 12 floats: columns cx-1 .. cx+2
+            float wv[12];
+#pragma unroll
+            for (int j = 0; j < 12; j++) wv[j] = win[j];
 #pragma unroll
             for (int j = 0; j < 9; j++) {
-              const float val = win[j];
-              const f4 vv = {val, val, val, val};
-              acc = __builtin_elementwise_fma(wq[ky * 9 + j], vv, acc);
+              const f4 v0 = {wv[j], wv[j], wv[j], wv[j]};
+              const f4 v1 = {wv[j + 3], wv[j + 3], wv[j + 3], wv[j + 3]};
+              acc0 = __builtin_elementwise_fma(wq[ky * 9 + j], v0, acc0);
+              acc1 = __builtin_elementwise_fma(wq[ky * 9 + j], v1, acc1);
             }
           }
-          acc = acc + bq;
+          acc0 = acc0 + bq;
+          acc1 = acc1 + bq;
           if (relu) {
-            acc.x = acc.x > 0.f ? acc.x : 0.f;
-            acc.y = acc.y > 0.f ? acc.y : 0.f;
-            acc.z = acc.z > 0.f ? acc.z : 0.f;
-            acc.w = acc.w > 0.f ? acc.w : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              acc0[e] = acc0[e] > 0.f ? acc0[e] : 0.f;
+              acc1[e] = acc1[e] > 0.f ? acc1[e] : 0.f;
+            }
           }
+          if (!ok0) acc0 = (f4){0.f, 0.f, 0.f, 0.f};
+          if (!ok1) acc1 = (f4){0.f, 0.f, 0.f, 0.f};
         }
-        *reinterpret_cast<f4*>(&s_y[r][cx][quad * 4]) = acc;
+        *reinterpret_cast<f4*>(&s_y[r][cx][quad * 4]) = acc0;
+        *reinterpret_cast<f4*>(&s_y[r][cx + 1][quad * 4]) = acc1;
       }
     }
   }
