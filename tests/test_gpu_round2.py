@@ -427,6 +427,17 @@ def test_fc_rows_addend_is_a_conv_over_a_concatenation(gpu):
     lib = torch.relu(F.conv2d(cat.permute(0, 3, 1, 2), W.view(N, 2 * C, 1, 1), bias)).permute(0, 2, 3, 1)
     err, err_lib = float((y.double() - ref).abs().max()), float((lib.double() - ref).abs().max())
     assert err <= max(2.0 * err_lib, 2e-6 * float(ref.abs().max())), (err, err_lib)
+    # the addend also rides through the split-K reduction (few rows, long K: partial products + fixed-order sum)
+    M, K2, N2 = 100, 2048, 128
+    x = torch.randn((M, K2), generator=g).to(gpu)
+    W2 = (torch.randn((N2, K2), generator=g) / K2 ** 0.5).to(gpu)
+    b2 = torch.randn((N2,), generator=g).to(gpu)
+    add = torch.randn((M, N2), generator=g).to(gpu)
+    cnt = torch.tensor([77], dtype=torch.int32, device=gpu)
+    y2 = ops.fc_rows(x, W2, b2, relu=True, num_rows=cnt, addend=add)
+    ref2 = torch.relu(x[:77].double() @ W2.double().t() + b2.double() + add[:77].double())
+    assert float((y2[:77].double() - ref2).abs().max()) <= 4e-6 * float(ref2.abs().max()) + 1e-6
+    assert not y2[77:].cpu().numpy().view(np.uint32).any()
 
 
 def test_fc_layer_uses_the_row_count(gpu):
