@@ -31,10 +31,12 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int FC_LD = 64;
 constexpr int FC_NBUF = 2;
 
-__device__ __forceinline__ void fc_glds16(const char* g, float* lds_wave_base)
+// 16 bytes per lane, global -> LDS: SGPR base + 32-bit VGPR byte offset, LDS base in M0 (spelled out in asm
+// like wino_mfma.hip's glds16_s: through the builtin the compiler builds 64-bit VGPR addresses per load).
+__device__ __forceinline__ void fc_glds16_s(const char* sbase, unsigned voff, unsigned lds_addr)
 {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"
+               :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
 }
 
 // Split-K factor, decided ON THE DEVICE from the live row count (same value in every workgroup of the
@@ -70,7 +72,8 @@ __global__ __launch_bounds__(512, 4) void fc_rows_mfma_kernel(
   const int tb = tall ? (q / ncb) * 8 + xcd : q % nbm;
   const int cb = tall ? q % ncb : (q / nbm) * 8 + xcd;
   if (cb >= ncb || tb >= nbm) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS bases and M0 stay on the SALU
   const int wm = wave & 1, wn = wave >> 1;
   const int lr = lane & 15, lk = lane >> 4;
   const int m0 = tb * 64;
@@ -100,15 +103,20 @@ __global__ __launch_bounds__(512, 4) void fc_rows_mfma_kernel(
   const char* xbase = reinterpret_cast<const char*>(x);
   const char* wbase = reinterpret_cast<const char*>(wt);
   const int ldsw = 8 * wave * FC_LD;
+  const unsigned lds_base_ = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)smem;
+  const unsigned lds_a0 = lds_base_ + (unsigned)ldsw * 4u;                               // wave-uniform: M0 of the DMA
+  const unsigned lds_b0 = lds_base_ + (unsigned)(FC_NBUF * 64 * FC_LD + ldsw) * 4u;
 
 #define FC_DMA(BUF, KO)                                                                  \
   do {                                                                                   \
     const char* xs_ = xbase + (size_t)(KO) * 4;                                          \
     const char* ws_ = wbase + (size_t)(KO) * 4;                                          \
-    fc_glds16(xs_ + va0, sAp + (BUF) * 64 * FC_LD + ldsw);                               \
-    fc_glds16(xs_ + va1, sAp + (BUF) * 64 * FC_LD + ldsw + 4 * FC_LD);                   \
-    fc_glds16(ws_ + ub0, sBp + (BUF) * 64 * FC_LD + ldsw);                               \
-    fc_glds16(ws_ + ub1, sBp + (BUF) * 64 * FC_LD + ldsw + 4 * FC_LD);                   \
+    const unsigned la_ = lds_a0 + (unsigned)(BUF) * (64 * FC_LD * 4);                    \
+    const unsigned lb_ = lds_b0 + (unsigned)(BUF) * (64 * FC_LD * 4);                    \
+    fc_glds16_s(xs_, va0, la_);                                                          \
+    fc_glds16_s(xs_, va1, la_ + 4 * FC_LD * 4);                                          \
+    fc_glds16_s(ws_, ub0, lb_);                                                          \
+    fc_glds16_s(ws_, ub1, lb_ + 4 * FC_LD * 4);                                          \
   } while (0)
 
   v4f acc0 = (v4f){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;

@@ -63,6 +63,16 @@ __device__ __forceinline__ void glds16(const char* g, float* lds_wave_base)
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// The same DMA with the addressing spelled out: SGPR base + 32-bit VGPR byte offset, LDS base in M0. Through
+// the builtin the compiler turned most of these into 64-bit VGPR addresses (a v_mov_b64 + v_lshl_add_u64 pair
+// per load, ~20 VALU instructions per stage next to 32 MFMAs); here the per-stage pointer arithmetic stays on
+// the scalar unit. Completion is tracked by the hand-placed s_waitcnt vmcnt(N) of the stage barrier.
+__device__ __forceinline__ void glds16_s(const char* sbase, unsigned voff, unsigned lds_addr)
+{
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"
+               :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+
 // Output transform, one column of the 6x6 transform domain at a time:
 //   t = A^T m   with A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
 __device__ __forceinline__ void at6_col(const float* m, float* t)
@@ -98,7 +108,8 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
   const int tb = (q / ncb) * 8 + x;
   if (tb >= nbt) return;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: everything derived from it (LDS bases, M0) stays on the SALU
   const int wm = wave & (WR - 1), wn = wave / WR;
   const int lr = lane & 15, lk = lane >> 4;
   // tile blocks never straddle a group: group g owns tiles [g tpg, (g+1) tpg) in nbg blocks of 64
@@ -135,6 +146,10 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
   const long long uplane = (long long)Cout * Cin;
   const int ldsw = 8 * wave * WM_LD;                            // this wave's first V row (floats) inside a stage buffer
   const int ldsu = 4 * UB * wave * WM_LD;                       // ... and its first U^T row
+  // LDS byte addresses of those rows in stage buffer 0 (wave-uniform: M0 of the DMA)
+  const unsigned lds_base_ = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)smem;
+  const unsigned lds_a0 = lds_base_ + (unsigned)ldsw * 4u;
+  const unsigned lds_b0 = lds_base_ + (unsigned)(WM_NBUF * BT * WM_LD + ldsu) * 4u;
 
   v4f acc[6][2];
 #pragma unroll
@@ -151,10 +166,12 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
   if constexpr (!(ABL & 2)) {                                                \
     const char* vs_ = vbase + (VO) * 4;                                      \
     const char* us_ = ubase + (UO) * 4;                                      \
-    glds16(vs_ + va0, &sA[BUF][0][0] + ldsw);                                \
-    glds16(vs_ + va1, &sA[BUF][0][0] + ldsw + 4 * WM_LD);                    \
+    const unsigned la_ = lds_a0 + (unsigned)(BUF) * (BT * WM_LD * 4);          \
+    const unsigned lb_ = lds_b0 + (unsigned)(BUF) * (64 * WM_LD * 4);          \
+    glds16_s(vs_, va0, la_);                                                 \
+    glds16_s(vs_, va1, la_ + 4 * WM_LD * 4);                                 \
     _Pragma("unroll") for (int i_ = 0; i_ < UB; i_++)                         \
-      glds16(us_ + ub[i_], &sB[BUF][0][0] + ldsu + 4 * i_ * WM_LD);           \
+      glds16_s(us_, ub[i_], lb_ + 4 * i_ * WM_LD * 4);                        \
   }
 
   // Stage order: nu outer, xi, then kc fastest; (pnu, pxi, pkc) is the prefetch pointer, two stages
