@@ -523,6 +523,9 @@ extern "C" int pcnn_winograd43_conv_fwd(const float* v, const float* ut, const f
   const long long nbt = (long long)groups * ((tpg + 31) / 32);
   const long long blocks = ((nbt + 7) / 8) * 8 * ncb;
   PCNN_REQUIRE(blocks < (1ll << 31), PCNN_EINVAL, "winograd43_conv: grid too large");
+  // the kernel addresses a plane of V and of U^T with 32-bit byte offsets from 64-bit plane bases
+  PCNN_REQUIRE(T * Cin < (1ll << 30) && (long long)Cout * Cin < (1ll << 30), PCNN_EINVAL,
+               "winograd43_conv: a transform plane of %lld x %d (or %d x %d) floats exceeds the kernel's 32-bit byte offsets", T, Cin, Cout, Cin);
   // optional Cin split for launches that cannot fill the chip (needs the caller's workspace)
   int S = wino43_cin_split(nbt, ncb, Cin);
   const size_t out_elems = (size_t)B * H * W * Cout;
