@@ -59,7 +59,8 @@ def parse_args(argv=None):
     ap.add_argument("--prewarm-seconds", type=float, default=8.0,
                     help="untimed sustained-load warm-up between the cold and the headline measurement")
     ap.add_argument("--blas", default="hipblas", choices=["default", "hipblas", "hipblaslt"],
-                    help="library behind the remaining fp32 library GEMMs (fc6-8, 1x1 heads); see tools/probe_bmm.py")
+                    help="library behind torch's own fp32 GEMMs — none is left on the default inference path; matters only "
+                         "for the non-default graph switches (strict_numerics, fused_heads=False); see tools/probe_bmm.py")
     ap.add_argument("--force-process-group", action="store_true",
                     help="initialise RCCL and run the detection all-gather through it even at world size 1")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: launch / rendezvous / collective / JSON plumbing on gloo")
@@ -94,21 +95,46 @@ def dry_run(a, pdist):
     rows[:3, 1] = 1 + rank
     rows[:3, 6] = 1.0
     count = torch.tensor([3], dtype=torch.int32)
-    seen = 0
-    pdist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        t = drain.submit(pdist.all_gather_packed(rows, count, frame_offset=rank * B))
-        flat = drain.collect(t)
+    seen, ranks_seen = 0, 0
+    lanes = max(1, a.streams)   # --streams N: N batches in flight, their collectives issued in batch order from alternating lanes
+    inflight = []               # (step, work handle | None, gathered buffer)
+
+    def issue(step):
+        r_ = rows.clone()
+        r_[:3, 2] = float(step)                      # tag: which batch this block belongs to
+        buf = pdist.pack_detections(r_, count, rank * B)
+        if not torch.distributed.is_initialized():
+            return step, None, buf.unsqueeze(0)
+        flat = torch.empty((world * buf.shape[0], buf.shape[1]), dtype=buf.dtype)
+        work = torch.distributed.all_gather_into_tensor(flat, buf, async_op=True)   # every rank issues these in the same order
+        return step, work, flat.view(world, buf.shape[0], buf.shape[1])
+
+    def retire(item):
+        nonlocal seen, ranks_seen
+        step, work, packed = item
+        if work is not None:
+            work.wait()
+        flat = drain.collect(drain.submit(packed))
         assert flat.shape == (3 * world, pdist.DET_COLS)
         assert sorted(set(np.round(flat[:, 0]).astype(int))) == sorted(r * B + i for r in range(world) for i in range(3))
+        assert set(np.round(flat[:, 2]).astype(int)) == {step}, "blocks of different batches were mixed"
+        ranks_seen = max(ranks_seen, len(set((flat[:, 0] // B).astype(int).tolist())))
         seen += flat.shape[0]
+
+    pdist.barrier()
+    t0 = time.perf_counter()
+    for step in range(a.steps):
+        inflight.append(issue(step))
+        if len(inflight) >= lanes:
+            retire(inflight.pop(0))
+    while inflight:
+        retire(inflight.pop(0))
     pdist.barrier()
     elapsed = pdist.max_over_ranks(time.perf_counter() - t0, torch.device("cpu"))
     if rank == 0:
         print(json.dumps({"metric": "dry-run (no GPU work)", "value": B * world * a.steps / max(elapsed, 1e-9), "unit": "frames/s",
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "dry_run": True,
-                          "detections_gathered_per_step": seen / a.steps,
+                          "detections_gathered_per_step": seen / a.steps, "ranks_seen": ranks_seen, "batches_in_flight": lanes,
                           "process_group": bool(torch.distributed.is_initialized())}), flush=True)
     pdist.shutdown()
 
@@ -289,6 +315,11 @@ def main(argv=None):
             last["backproject"] = top[0]
         return det
 
+    if a.graph and a.streams > 1:
+        # library workspaces (Hough, ADL, split-K / Cin-split partials) are keyed by the stream that is
+        # current when they are first requested; during capture that is torch's one capture stream, so two graphs
+        # would bake in the SAME scratch buffers and then replay concurrently. Graph replays therefore run on one stream.
+        a.streams = 1
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(max(1, a.streams) - 1)]
     multi = {"on": len(streams) > 1}
 
@@ -333,6 +364,8 @@ def main(argv=None):
         flat = drain.collect(ticket)
         rois, poses = fcn.finalize_batch(flat, flat.shape[0])
         last["rois"] = rois
+        if flat.shape[0]:   # detections carry GLOBAL frame indices (rank * B + local): whose frames reached this rank?
+            last["ranks_seen"] = max(last.get("ranks_seen", 0), len(set((flat[:, 0] // B).astype(int).tolist())))
         return rois.shape[0]
 
     def run(n):
@@ -545,8 +578,10 @@ def main(argv=None):
     }
     if lat is not None:
         out["latency"] = lat
-    if dist_note := (world == 1 and a.force_process_group):
-        out["process_group"] = "RCCL initialised at world size 1; the detection all-gather ran through it"
+    out["process_group"] = ({"backend": torch.distributed.get_backend(), "ranks_seen": int(last.get("ranks_seen", 0)),
+                             "world_size": world, "collective": "all_gather_into_tensor of the packed detection block, once per step"}
+                            if torch.distributed.is_initialized() else
+                            {"backend": None, "ranks_seen": 1, "world_size": 1, "collective": "none (single process; --force-process-group runs it through RCCL)"})
     if world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(a, K, H, W, C, extents, symmetry, net, train)

@@ -223,6 +223,7 @@ extern "C" int pcnn_average_distance_fwd(const float* prediction, const float* t
   PCNN_REQUIRE(margin >= 0, PCNN_EINVAL, "average_distance: Need margin >= 0, got %g", (double)margin);
   PCNN_REQUIRE(R >= 0 && C >= 1 && P >= 1, PCNN_EINVAL, "average_distance: bad shape R=%d C=%d P=%d", R, C, P);
   PCNN_REQUIRE((long long)R * P < (1ll << 31), PCNN_EINVAL, "average_distance: R*P overflows int32");
+  PCNN_REQUIRE(R <= 65535, PCNN_EINVAL, "average_distance: %d rows exceed the 65535 rows one launch addresses (grid.y); split the batch", R);
   PCNN_REQUIRE(loss, PCNN_ENULL, "average_distance: loss is NULL");
   hipStream_t stream = (hipStream_t)stream_;
   if (R == 0) {

@@ -280,7 +280,8 @@ extern "C" int pcnn_fc_rows_fwd(const float* x, const float* wt, const float* bi
                "fc_rows: out_features must be a multiple of 64 (got %d)", out_features);
   if (rows_capacity == 0) return PCNN_OK;
   PCNN_REQUIRE(x && wt && bias && y, PCNN_ENULL, "fc_rows: NULL pointer");
-  PCNN_REQUIRE(aligned16(x) && aligned16(wt) && aligned16(y) && aligned16(addend), PCNN_EINVAL, "fc_rows: pointers must be 16-byte aligned");
+  PCNN_REQUIRE(aligned16(x) && aligned16(wt) && aligned16(y) && aligned16(addend) && aligned16(bias), PCNN_EINVAL,
+               "fc_rows: pointers (x, wt, bias, addend, y) must be 16-byte aligned");
   PCNN_REQUIRE((long long)rows_capacity * in_features < (1ll << 30) && (long long)out_features * in_features < (1ll << 30),
                PCNN_EINVAL, "fc_rows: operand larger than the 32-bit byte offsets of the kernel");
   hipStream_t stream = (hipStream_t)stream_;

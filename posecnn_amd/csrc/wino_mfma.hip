@@ -508,8 +508,8 @@ extern "C" int pcnn_winograd43_conv_fwd(const float* v, const float* ut, const f
   PCNN_REQUIRE(!pool || (H % 2 == 0 && W % 2 == 0), PCNN_EINVAL, "winograd43_conv: pooling needs even height/width");
   PCNN_REQUIRE(groups >= 1 && B % groups == 0, PCNN_EINVAL, "winograd43_conv: batch %d is not a multiple of groups %d", B, groups);
   PCNN_REQUIRE(v && ut && bias && y && (pool != 2 || y_pool), PCNN_ENULL, "winograd43_conv: NULL pointer");
-  PCNN_REQUIRE(aligned16(v) && aligned16(ut) && aligned16(y) && (pool != 2 || aligned16(y_pool)), PCNN_EINVAL,
-               "winograd43_conv: pointers must be 16-byte aligned");
+  PCNN_REQUIRE(aligned16(v) && aligned16(ut) && aligned16(bias) && aligned16(y) && (pool != 2 || aligned16(y_pool)), PCNN_EINVAL,
+               "winograd43_conv: pointers (v, ut, bias, y, y_pool) must be 16-byte aligned");
   hipStream_t stream = (hipStream_t)stream_;
   const int Ht = (H + 3) / 4, Wt = (W + 3) / 4;
   const long long T = (long long)B * Ht * Wt;

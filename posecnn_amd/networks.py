@@ -2,11 +2,15 @@
 
 This mirrors the reference's op surface — same layer names, argument order and defaults as
 lib/networks/network.py:159-222,303-310,321-340,361-445,474-506 and the same `setup()` chain as
-lib/networks/vgg16_convs.py:79-212 — but executes eagerly on PyTorch-ROCm: the dense contractions
-(13 conv3x3, the 1x1 heads, fc6-8) go to MIOpen / hipBLASLt (MFMA), the custom layers go to the
-hand-written gfx950 kernels behind libposecnn_hip.so (posecnn_amd.ops). All activations are NHWC
-(`[B,H,W,C]` contiguous), exactly what the custom kernels index; convolutions see them as
-channels-last NCHW views, so there is no layout copy anywhere on the path.
+lib/networks/vgg16_convs.py:79-212 — but executes eagerly on PyTorch-ROCm tensors and streams. On the
+default inference path every dense contraction runs in the library's own gfx950 kernels behind
+libposecnn_hip.so (posecnn_amd.ops): the 3x3 trunk as Winograd F(4x4,3x3) on the fp32 matrix cores
+(csrc/winograd.hip, wino_mfma.hip, conv_first.hip), the 1x1 heads and fc6-8 on the row kernels of
+csrc/fc_mfma.hip, next to the five custom layers. MIOpen / hipBLASLt are only reached
+by the trainable training graph and by the non-default switches (`strict_numerics`, `fused_heads=False`,
+`winograd_min_channels = 0`). All activations are NHWC (`[B,H,W,C]` contiguous), exactly what the custom
+kernels index; library convolutions see them as channels-last NCHW views, so there is no layout copy
+anywhere on the path.
 
 TF1 -> PyTorch semantics (SURVEY.md §8a "Semantics ..."):
   conv       tf.nn.conv2d 'SAME' stride 1 + bias + ReLU unless relu=False      (network.py:159-188)
@@ -568,7 +572,7 @@ class Network(object):
         cache = getattr(self, "_argmax_cache", None)
         if cache is not None and cache[0] is input:
             return cache[1]
-        return ops.softmax_argmax(input, want_prob=False)[1] if False else torch.argmax(input, dim=3).to(torch.int32)
+        return torch.argmax(input, dim=3).to(torch.int32)   # tf.argmax: first maximum
 
     # ---- custom layers (gfx950 kernels) ------------------------------------------------------------
     @layer
@@ -616,8 +620,19 @@ class vgg16_convs(Network):
     def __init__(self, input_format, num_classes, num_units, scales, threshold_label, vote_threshold,
                  vertex_reg_2d=False, vertex_reg_3d=False, pose_reg=False, adaptation=False, trainable=True,
                  is_train=True, device="cuda", seed=3, init="he", with_losses=None, fused_heads=True,
-                 want_prob=True, fused_pool=True):
+                 want_prob=True, fused_pool=True, strict_numerics=False):
         Network.__init__(self, device=device, seed=seed, init=init, trainable=trainable)
+        # strict_numerics: every 3x3 layer as a direct f32 convolution (library kernels) instead of Winograd
+        # F(4x4,3x3). Both are exact in real arithmetic and f32 throughout; they differ in summation order
+        # and Winograd's transform constants amplify rounding ~3x (DESIGN.md §4 has the measured end-to-end
+        # distributions against a float64 trunk). bench.py runs the default (Winograd) and says so.
+        self.strict_numerics = bool(strict_numerics)
+        if self.strict_numerics:
+            self.winograd_min_channels = 0
+        # validation aid (tests/parity_study.py): None, or a torch dtype — the trunk is then evaluated as nine
+        # shifted GEMMs per layer in that dtype (float64: the real-arithmetic reference; float32: a direct
+        # convolution whose summation order is known), activations kept in that dtype between layers
+        self.reference_trunk = None
         # conv -> max_pool pairs whose un-pooled activation nobody else consumes: one kernel does
         # bias + ReLU + 2x2 max from the raw convolution output (conv4_3 feeds score_conv4 and
         # roi_pool, so pool4 stays a plain max_pool)
@@ -782,7 +797,10 @@ class vgg16_convs(Network):
                 v = ops.conv3x3_c3_winograd43(x, packed[0][0], packed[0][1], True, groups=2)
             else:
                 v = ops.winograd_input(y, 4)
-            mode = 0 if pool is None else (2 if name in self.dual_pool else 1)
+            # conv4_3 is read un-pooled by score_conv4 and roi_pool AND pooled by pool4: the kernel writes
+            # both (mode 2) whatever `dual_pool` / `fused_pool` say; the other conv -> pool pairs keep only
+            # the pooled tensor (mode 1)
+            mode = 0 if pool is None else (2 if name == "conv4_3" else 1)
             out = ops.winograd43_conv(v, wt, bias, B2, h, w_, True, pool=mode, groups=2)
             if mode == 2:
                 full, y = out
@@ -791,8 +809,6 @@ class vgg16_convs(Network):
             if name in ("conv4_3", "conv5_3"):
                 self.layers[name], self.layers[name + "_p"] = full[:B], full[B:]
             if pool is not None:
-                if mode == 0:
-                    y = _nhwc(F.max_pool2d(_nchw(y), 2, 2))
                 h, w_ = h // 2, w_ // 2
                 if pool == "pool4":
                     self.layers["pool4"], self.layers["pool4_p"] = y[:B], y[B:]
@@ -814,8 +830,42 @@ class vgg16_convs(Network):
         fl = sum(2.0 * 36 * tiles(div[n[4]]) * ci * co for n, ci, co, _ in self.TRUNK if ci != 3)
         return {"wino43_mfma_kernel": towers * fl}
 
+    def _trunk_reference(self, dtype):
+        """The VGG16 tower(s) (vgg16_convs.py:36-67) as plain tensor algebra in `dtype`, image by image:
+        conv3x3 'SAME' = sum over the 9 taps of [H*W, Cin] x [Cin, Cout] products of the zero-padded input,
+        + bias, ReLU, 2x2 max-pool — no Winograd, no library convolution, activations never leave `dtype`
+        until conv4_3 / pool4 / conv5_3 are handed to the heads as f32. Slow by design (validation only)."""
+        towers = [("", "data")] + ([("_p", "data_p")] if self.input_format == "RGBD" else [])
+        for sfx, src in towers:
+            x = self.get_output(src)
+            vars_ = [(w.detach().to(dtype), b.detach().to(dtype)) for w, b in self._trunk_vars(sfx)]
+            keep = {"conv4_3": [], "pool4": [], "conv5_3": []}
+            for n in range(x.shape[0]):
+                y = x[n:n + 1].to(dtype)
+                for (name, ci, co, pool), (w, b) in zip(self.TRUNK, vars_):
+                    _, h, w_, _ = y.shape
+                    yp = F.pad(y, (0, 0, 1, 1, 1, 1))
+                    acc = None
+                    for ky in range(3):
+                        for kx in range(3):
+                            t_ = yp[:, ky:ky + h, kx:kx + w_, :].reshape(-1, ci) @ w[:, :, ky, kx].t()
+                            acc = t_ if acc is None else acc + t_
+                    y = torch.relu(acc + b).view(1, h, w_, co)
+                    if name in keep:
+                        keep[name].append(y.to(torch.float32))
+                    if pool is not None:
+                        y = y.view(1, h // 2, 2, w_ // 2, 2, co).amax(dim=(2, 4))
+                        if pool in keep:
+                            keep[pool].append(y.to(torch.float32))
+            for k, v in keep.items():
+                self.layers[k + sfx] = torch.cat(v, dim=0).contiguous()
+        return self
+
     def setup(self):
         t = self.trainable
+        if self.reference_trunk is not None:
+            self._trunk_reference(self.reference_trunk)
+            return self._setup_heads()
         if self._can_group_towers():
             self._trunk_grouped()
             return self._setup_heads()

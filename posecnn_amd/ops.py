@@ -36,6 +36,12 @@ def _dev(t, name, dtype):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _aligned16(t):
+    """The float4 loads of the MFMA / reduction kernels need 16-byte aligned bases; a view that starts
+    mid-allocation (e.g. one row of a packed bias table) is copied — the C-ABI itself rejects it (EINVAL)."""
+    return t if t.data_ptr() % 16 == 0 else t.clone(memory_format=torch.contiguous_format)
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
@@ -478,7 +484,7 @@ def winograd43_conv(v, ut, bias, B, H, W, relu=True, pool=0, groups=1):
     returns (y, y_pool)). `groups`: image b uses filter set b // (B // groups)."""
     v = _dev(v, "v", torch.float32)
     ut = _dev(ut, "ut", torch.float32)
-    bias = _dev(bias, "bias", torch.float32)
+    bias = _aligned16(_dev(bias, "bias", torch.float32))
     Cin = v.shape[2]
     if ut.dim() == 3:
         ut = ut.unsqueeze(0)
@@ -505,7 +511,7 @@ def fc_rows(x, wt, bias, relu=True, num_rows=None, addend=None):
     [K, N] transposed), K % 64 == 0, N % 64 == 0. One fp32-MFMA kernel, no host synchronisation."""
     x = _dev(x, "x", torch.float32)
     wt = _dev(wt, "wt", torch.float32)
-    bias = _dev(bias, "bias", torch.float32)
+    bias = _aligned16(_dev(bias, "bias", torch.float32))
     if x.dim() != 2 or wt.dim() != 2 or wt.shape[1] != x.shape[1] or bias.numel() != wt.shape[0]:
         raise ValueError("x must be [M, K], wt [N, K], bias [N]")
     M, K = x.shape

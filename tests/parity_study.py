@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""End-to-end numerics study of the trunk (VERDICT r2 "Next" #1): how far do detections move when the
+same 480x640 RGB-D frames go through differently computed VGG16 trunks?
+
+  float64    the real-arithmetic reference: nine shifted GEMMs per layer in float64 (vgg16_convs._trunk_reference)
+  taps_f32   the same algebra in float32 — a direct convolution whose summation order is known
+  library    F.conv2d (MIOpen picks the algorithm; `strict_numerics=True` / winograd_min_channels = 0)
+  winograd   the product default: F(4x4,3x3) on the fp32 matrix cores (csrc/wino_mfma.hip)
+
+Everything behind the trunk (heads, softmax/argmax, Hough voting, RoI pooling, fc6-8) is the same f32
+kernel sequence in every run, so differences are the trunk's rounding and what the pipeline makes of it.
+Per path, against float64: label flips, detections that moved to another Hough cell, max |d box|,
+max |d quaternion|, the distribution of |d translation|, and the Hough voters of each detection that
+changed side of the hard inlier test (hough_voting_gpu_op.cu.cc:269-294) — counted by re-evaluating the
+canonical predicate (SURVEY.md §8a HOUGH) in torch on each run's own vertex field.
+
+TEST INFRASTRUCTURE (imported by tests/test_gpu_round3.py; `python tests/parity_study.py --frames 64
+--out profiles/r03_parity_study.json` writes the table DESIGN.md §4 quotes). Needs a GPU.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from posecnn_amd import config, synth  # noqa: E402
+
+F = np.float32
+PATHS = ("float64", "taps_f32", "library", "winograd")
+
+
+def _rgbd_inputs(rng, B, H, W):
+    im = rng.integers(0, 256, (B, H, W, 3)).astype(F)
+    depth = rng.integers(0, 3000, (B, H, W, 1)).astype(F)
+    data = (im - config.PIXEL_MEANS).astype(F)
+    data_p = (np.tile(np.clip(depth / 2000.0, 0, 1) * 255, (1, 1, 1, 3)) - config.PIXEL_MEANS).astype(F)   # test.py:70-74
+    return data, data_p
+
+
+def _project_box_thr(ext_c, d, fx, fy, px, py):
+    """PROJECT_BOX of SURVEY.md §8a (hough_voting_gpu_op.cu.cc:84-120) for a vector of depths d (torch f32)."""
+    import torch
+    hx, hy, hz = (float(np.float32(float(e) * 0.5)) for e in ext_c)
+    xs, ys = [], []
+    for sx in (-1.0, 1.0):
+        for sy in (-1.0, 1.0):
+            for sz in (-1.0, 1.0):
+                Z = sz * hz + d
+                xs.append(fx * ((sx * hx) / Z) + px)
+                ys.append(fy * ((sy * hy) / Z) + py)
+    xs, ys = torch.stack(xs), torch.stack(ys)
+    w = xs.max(0).values - xs.min(0).values + 1.0
+    h = ys.max(0).values - ys.min(0).values + 1.0
+    return torch.maximum(w, h) * 0.6
+
+
+def voters(label_n, vertex_n, c, cx, cy, ext, K, skip=10):
+    """(pixel indices sampled for class c, inlier mask at cell (cx, cy), depths) — the vote predicate of
+    compute_hough_kernel restated op by op in torch f32 (no FMA; exp is torch's, which only matters within
+    1 ulp of the window edge)."""
+    import torch
+    W = label_n.shape[1]
+    idx = torch.nonzero(label_n.reshape(-1) == c).reshape(-1)[::skip]
+    x, y = idx % W, idx // W
+    f = vertex_n[y, x]
+    u, v, d = f[:, 3 * c], f[:, 3 * c + 1], torch.exp(f[:, 3 * c + 2])
+    dx, dy = (cx - x).to(torch.float32), (cy - y).to(torch.float32)
+    cosv = (u * dx + v * dy) / (torch.sqrt(u * u + v * v) * torch.sqrt(dx * dx + dy * dy))
+    thr = _project_box_thr(ext[c], d, float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]))
+    inl = (cosv > 0.9) & (dx.abs() < thr) & (dy.abs() < thr)
+    return idx, inl, d
+
+
+def run_study(device, n_frames=32, batch=4, H=480, W=640, C=22, seed=2024, paths=PATHS, n_obj=5, log=None):
+    import torch
+    from posecnn_amd import fcn
+    from posecnn_amd.networks import vgg16_convs
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    net = vgg16_convs("RGBD", C, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True, trainable=False,
+                      is_train=False, seed=3, init="he", with_losses=False, device=device)
+    synth.init_planted_heads(net)
+    K = config.DEMO_INTRINSICS.copy()
+    K[:2] *= W / 640.0
+    ext = config.LOV_EXTENTS[:C]
+    pts = T(synth.make_model_points(C, 256))
+    rng = np.random.default_rng(seed)
+    acc = {p: {"label_flips": 0, "pixels": 0, "detections": 0, "missing_or_extra": 0, "cell_moved": 0, "box": [], "quat": [],
+               "trans": [], "votes": [], "changed": [], "bound_excess": [], "conv5_3_rel_err": 0.0, "max_prob_diff": 0.0}
+           for p in paths if p != "float64"}
+
+    def run(path, data, data_p, planted):
+        net.reference_trunk = {"float64": torch.float64, "taps_f32": torch.float32}.get(path)
+        net.winograd_min_channels = 0 if path == "library" else 64
+        with torch.no_grad():
+            det = fcn.im_segment_batch(net, data, K, ext, pts, config.LOV_SYMMETRY[:C], data_p=data_p, planted=planted)
+            n = int(det.count.item())
+            out = {"label": det.label_2d.clone(), "rows": det.rows[:n].cpu().numpy(), "prob": net.get_output("prob_normalized").clone(),
+                   "conv5_3": net.get_output("conv5_3").clone(), "vertex": net.get_output("vertex_pred").clone()}
+        net.reference_trunk = None
+        net.winograd_min_channels = 64
+        return out
+
+    for b0 in range(0, n_frames, batch):
+        B = min(batch, n_frames - b0)
+        data, data_p = _rgbd_inputs(rng, B, H, W)
+        planted_np, _ = synth.make_planted_batch(1000 + b0, B, H=H, W=W, C=C, K=K, n_obj=n_obj)
+        planted = {k: T(v) for k, v in planted_np.items()}
+        data, data_p = T(data), T(data_p)
+        ref = run("float64", data, data_p, planted)
+        rkey = {(int(r[0]), int(r[1])): r for r in ref["rows"]}
+        for p in acc:
+            got = run(p, data, data_p, planted)
+            a = acc[p]
+            a["label_flips"] += int((got["label"] != ref["label"]).sum())
+            a["pixels"] += ref["label"].numel()
+            a["max_prob_diff"] = max(a["max_prob_diff"], float((got["prob"] - ref["prob"]).abs().max()))
+            a["conv5_3_rel_err"] = max(a["conv5_3_rel_err"], float((got["conv5_3"] - ref["conv5_3"]).abs().max() / ref["conv5_3"].abs().max()))
+            gkey = {(int(r[0]), int(r[1])): r for r in got["rows"]}
+            a["missing_or_extra"] += len(set(gkey) ^ set(rkey))
+            for key in sorted(set(gkey) & set(rkey)):
+                g, r = gkey[key], rkey[key]
+                n, c = key
+                a["detections"] += 1
+                # the winning cell: the box is centre -/+ extent, the centre an integer cell
+                gc = (int(round((g[2] + g[4]) / 2)), int(round((g[3] + g[5]) / 2)))
+                rc = (int(round((r[2] + r[4]) / 2)), int(round((r[3] + r[5]) / 2)))
+                if gc != rc:
+                    a["cell_moved"] += 1
+                    continue   # a different (equally voted) cell: counted, not part of the distributions
+                a["box"].append(float(np.abs(g[2:6] - r[2:6]).max()))
+                a["quat"].append(float(np.abs(g[7:11] - r[7:11]).max()))
+                a["trans"].append(float(np.abs(g[11:14] - r[11:14]).max()))
+                # voters of that cell under each run's own field, on the reference's label map
+                _, ig, dg = voters(ref["label"][n], got["vertex"][n], c, rc[0], rc[1], ext, K)
+                _, ir, dr = voters(ref["label"][n], ref["vertex"][n], c, rc[0], rc[1], ext, K)
+                changed = int((ig != ir).sum())
+                nv = int(ir.sum())
+                a["votes"].append(nv)
+                a["changed"].append(changed)
+                # |d mean depth| <= changed * spread / voters (+ rounding of the sequential f32 sum)
+                both = ig | ir
+                spread = float((dr[both].max() - dr[both].min())) if bool(both.any()) else 0.0
+                scale = max(abs(float(r[11] / r[13])), abs(float(r[12] / r[13])), 1.0) if r[13] != 0 else 1.0
+                bound = scale * (changed * spread / max(min(nv, int(ig.sum())), 1)) + 2e-5
+                a["bound_excess"].append(float(np.abs(g[11:14] - r[11:14]).max()) - bound)
+        if log:
+            log("frames %d..%d done" % (b0, b0 + B - 1))
+
+    out = {"frames": n_frames, "height": H, "width": W, "classes": C, "objects_per_frame": n_obj, "reference": "float64 trunk (nine shifted GEMMs per layer)", "paths": {}}
+    for p, a in acc.items():
+        tr, ch = np.asarray(a["trans"]), np.asarray(a["changed"])
+        q = lambda v, x: float(np.quantile(v, x)) if len(v) else None
+        out["paths"][p] = {
+            "label_flips": a["label_flips"], "pixels": a["pixels"], "max_prob_diff": a["max_prob_diff"],
+            "conv5_3_rel_err": a["conv5_3_rel_err"], "detections_compared": a["detections"],
+            "detections_missing_or_extra": a["missing_or_extra"], "winning_cell_moved": a["cell_moved"],
+            "max_box_diff_px": max(a["box"]) if a["box"] else None, "max_quat_diff": max(a["quat"]) if a["quat"] else None,
+            "trans_diff_median": q(tr, 0.5), "trans_diff_p90": q(tr, 0.9), "trans_diff_p99": q(tr, 0.99),
+            "trans_diff_max": float(tr.max()) if len(tr) else None,
+            "voters_total": int(np.sum(a["votes"])), "voters_changed_total": int(ch.sum()) if len(ch) else 0,
+            "detections_with_changed_voters": int((ch > 0).sum()) if len(ch) else 0,
+            "trans_diff_max_when_no_voter_changed": float(tr[ch == 0].max()) if len(tr) and (ch == 0).any() else None,
+            "trans_diff_max_when_voters_changed": float(tr[ch > 0].max()) if len(tr) and (ch > 0).any() else None,
+            "max_excess_over_voter_bound": max(a["bound_excess"]) if a["bound_excess"] else None,
+        }
+    return out
+
+
+def main():
+    import torch
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    res = run_study(torch.device("cuda:0"), a.frames, a.batch, log=lambda m: print(m, file=sys.stderr, flush=True))
+    txt = json.dumps(res, indent=1)
+    print(txt)
+    if a.out:
+        os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+        with open(a.out, "w") as f:
+            f.write(txt + "\n")
+
+
+if __name__ == "__main__":
+    main()

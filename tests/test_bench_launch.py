@@ -43,6 +43,16 @@ def test_gpus2_self_spawns_two_ranks_and_gathers_on_gloo():
     out = _json_line(r.stdout)
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["process_group"] is True
     assert out["detections_gathered_per_step"] == 6   # 3 rows from each of the 2 ranks
+    assert out["ranks_seen"] == 2 and out["batches_in_flight"] == 2   # --streams 2 (default): two collectives in flight, same order on every rank
+
+
+def test_gpus2_single_lane_and_three_lanes():
+    for lanes in (1, 3):
+        r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "5", "--warmup", "0", "--dry-run", "--streams", str(lanes)],
+                           env=_env(), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out = _json_line(r.stdout)
+        assert out["ranks_seen"] == 2 and out["batches_in_flight"] == lanes and out["detections_gathered_per_step"] == 6
 
 
 def test_under_a_launcher_env_is_respected():

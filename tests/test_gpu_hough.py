@@ -358,7 +358,8 @@ def test_linemod_stress_size_960x1280(gpu):
     scale with the image (lib/fcn/test.py:130-131). Parity with the oracle at the full size."""
     H, W, C = 960, 1280, 14
     K = config.DEMO_INTRINSICS.copy(); K[:2] *= W / 640.0
-    ext = np.vstack([np.zeros((1, 3), F), np.linspace(0.08, 0.25, (C - 1) * 3).reshape(C - 1, 3).astype(F)])
+    ext = config.LINEMOD_EXTENTS      # data/LINEMOD/extents.txt, first 13 objects (checked against the file in test_datasets.py)
+    assert ext.shape == (C, 3)
     label, vertex, fr = synth.make_batch(500, 1, H=H, W=W, C=C, n_obj=4, extents=ext, K=K)
     meta = config.make_meta_data(K)[None]
     got = both(gpu, label, vertex, ext, meta)

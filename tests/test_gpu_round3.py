@@ -1,0 +1,282 @@
+"""GPU tests added in round 3 (VERDICT r2 "Next" #1, #4):
+  * the trunk numerics study — 32 full-size RGB-D frames through a float64 trunk, a direct f32 trunk with a
+    known summation order, the library's convolutions and the Winograd-MFMA default; asserts the MEASURED
+    bounds and the mechanism behind the translation outliers (voters crossing the hard
+    inlier test), instead of the 5e-3 / 2e-2 escape hatches of round 2;
+  * `datasets.run_evaluation` — the test_net_single_frame loop (lib/fcn/test.py:1154-1467) executed end to end
+    on a 5-frame YCB-Video-layout tree built from the demo depth/label fixtures;
+  * backproject at the shape `bench.py --config linemod` runs it on (960x1280x64, C = 14, k = 3);
+  * the grouped RGB-D trunk with fused_pool=False;
+  * the softmax head against an independent float64 softmax.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from posecnn_amd import config, synth
+from test_gpu_ops import N, T, backproject_case, same
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# ---- trunk numerics: the end-to-end parity statement ---------------------------------------------------
+def test_trunk_numerics_study_32_full_size_frames(gpu, capsys):
+    """north_star: label maps bit-exact, quaternions / translations within 1e-4 — given IDENTICAL dense-layer
+    outputs the custom kernels are bit-exact (test_gpu_hough / test_gpu_ops). The dense layers are f32 in a
+    different summation order than TF/cuDNN's (unknowable), so the end-to-end statement is
+    statistical: every f32 trunk (direct or Winograd) against the float64 trunk on 32 frames of 480x640."""
+    import parity_study
+    res = parity_study.run_study(gpu, n_frames=32, batch=4)
+    with capsys.disabled():
+        print("\ntrunk numerics study (vs float64 trunk):")
+        for p, r in res["paths"].items():
+            print("  %-9s" % p, {k: (round(v, 8) if isinstance(v, float) else v) for k, v in r.items()})
+    for p, r in res["paths"].items():
+        assert r["detections_compared"] >= 32 * 4 and r["detections_missing_or_extra"] == 0, (p, r)
+        # labels: at most a few near-tie pixels in 9.8 M
+        assert r["label_flips"] <= 1e-5 * r["pixels"], (p, r)
+        # quaternions go through RoI pooling + fc6-8 on near-identical features
+        assert r["max_quat_diff"] < 1e-4, (p, r)
+        # translations: identical voters -> identical mean depth up to the rounding of the field itself ...
+        if r["trans_diff_max_when_no_voter_changed"] is not None:
+            assert r["trans_diff_max_when_no_voter_changed"] < 1e-4, (p, r)
+        # ... and a detection whose voters changed moves by at most (changed / voters) x depth spread
+        assert r["max_excess_over_voter_bound"] <= 0.0, (p, r)
+        assert r["trans_diff_median"] < 1e-4, (p, r)
+    w, d = res["paths"]["winograd"], res["paths"]["taps_f32"]
+    # Winograd is in the same class as a direct f32 convolution: same mechanism, same order of magnitude
+    assert w["conv5_3_rel_err"] < 2e-5 and d["conv5_3_rel_err"] < 2e-5, (w, d)
+    assert w["trans_diff_max"] < 5e-3 and d["trans_diff_max"] < 5e-3, (w, d)
+
+
+def test_grouped_trunk_does_not_depend_on_fused_pool(gpu):
+    """with fused_pool=False (or a cleared dual_pool) the grouped RGB-D trunk registered the
+    POOLED conv4_3 under 'conv4_3'. conv4_3 must be the un-pooled tensor whatever the pooling switches say."""
+    import torch
+    from posecnn_amd import fcn
+    from posecnn_amd.networks import vgg16_convs
+    B, H, W = 2, 96, 128
+    rng = np.random.default_rng(4)
+    data = T(gpu, rng.standard_normal((B, H, W, 3)).astype(F) * 50)
+    data_p = T(gpu, rng.standard_normal((B, H, W, 3)).astype(F) * 50)
+    K = config.DEMO_INTRINSICS.copy(); K[:2] *= W / 640.0
+    pts = T(gpu, synth.make_model_points(22, 64))
+    outs = []
+    for fused_pool in (True, False):
+        net = vgg16_convs("RGBD", 22, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True, trainable=False,
+                          is_train=False, seed=3, init="he", with_losses=False, device=gpu, fused_pool=fused_pool)
+        synth.init_planted_heads(net)
+        planted_np, _ = synth.make_planted_batch(9, B, H=H, W=W, K=K, n_obj=2)
+        with torch.no_grad():
+            det = fcn.im_segment_batch(net, data, K, config.LOV_EXTENTS, pts, config.LOV_SYMMETRY, data_p=data_p,
+                                       planted={k: T(gpu, v) for k, v in planted_np.items()})
+        assert tuple(net.get_output("conv4_3").shape) == (B, H // 8, W // 8, 512)
+        assert tuple(net.get_output("pool4").shape) == (B, H // 16, W // 16, 512)
+        outs.append((N(net.get_output("conv4_3_p")), N(net.get_output("pool4")), N(det.rows), N(det.label_2d)))
+    for a, b, name in zip(outs[0], outs[1], ("conv4_3_p", "pool4", "rows", "label_2d")):
+        same(a, b, name)
+
+
+def test_softmax_head_against_independent_float64_softmax(gpu):
+    """kernel, C oracle and numpy reference share the canonical exp sequence, so bit-equality
+    among them cannot see a defect in that sequence. Independent anchor: float64 softmax of the same scores."""
+    from posecnn_amd import ops
+    rng = np.random.default_rng(77)
+    x = (rng.standard_normal((2, 60, 80, 22)) * 6).astype(F)
+    x[0, 0, 0, :] = 0.0                      # all-equal scores: 1/22 each, argmax 0
+    x[0, 0, 1, :] = -1e30; x[0, 0, 1, 7] = 3   # one live class
+    prob, label = ops.softmax_argmax(T(gpu, x), want_prob=True)
+    xd = x.astype(np.float64)
+    e = np.exp(xd - xd.max(-1, keepdims=True))
+    want = e / e.sum(-1, keepdims=True)
+    got = N(prob).astype(np.float64)
+    assert np.abs(got - want).max() < 4e-7, np.abs(got - want).max()          # a few f32 ulp of a value <= 1
+    assert np.abs(got.sum(-1) - 1.0).max() < 2e-6
+    assert np.array_equal(N(label), xd.argmax(-1).astype(np.int32))
+    # relative accuracy of small probabilities (the hard_label threshold compares them): <= 8 ulp
+    m = want > 1e-30
+    assert (np.abs(got[m] - want[m]) / want[m]).max() < 8 * 2.0 ** -23
+
+
+def test_misaligned_bias_views(gpu):
+    """the split-K / Cin-split reduction kernels read the bias as float4. A bias that is a view
+    at a 4-byte offset must work through ops.* (copied) and be refused by the C-ABI itself (EINVAL, no fault)."""
+    import ctypes
+    import torch
+    from posecnn_amd import _lib, ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    M, K_, N_ = 5, 25088, 128                      # 5 live rows -> the split-K path
+    x = torch.randn((M, K_), generator=g).to(gpu)
+    w = (torch.randn((K_, N_), generator=g) / K_ ** 0.5).to(gpu)
+    bfull = torch.randn((N_ + 1,), generator=g).to(gpu)
+    bias = bfull[1:]
+    assert bias.data_ptr() % 16 == 4
+    cnt = torch.tensor([M], dtype=torch.int32, device=gpu)
+    y = ops.fc_rows(x, w.t().contiguous(), bias, True, num_rows=cnt)
+    ref = torch.relu(x.double() @ w.double() + bias.double())
+    assert float((y.double() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+    wt = w.t().contiguous()
+    out = torch.empty((M, N_), device=gpu)
+    rc = _lib.lib().pcnn_fc_rows_fwd(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(wt.data_ptr()), ctypes.c_void_p(bias.data_ptr()),
+                                     M, K_, N_, 1, ctypes.c_void_p(cnt.data_ptr()), ctypes.c_void_p(0), ctypes.c_void_p(out.data_ptr()),
+                                     ctypes.c_void_p(0), 0, ctypes.c_void_p(torch.cuda.current_stream(gpu).cuda_stream))
+    assert rc == _lib.PCNN_EINVAL
+
+
+# ---- the evaluation loop, executed -----------------------------------------------------------
+def _write_demo_tree(root):
+    """A YCB-Video-layout tree (lov.py:57-135) from tests/golden/demo_frames.npz (the reference's own demo depth
+    images + a deterministic segmentation of them) and lov_models.npz (real model points / extents):
+    colour = the depth image as grey levels, `-meta.mat` poses = identity rotation at the blob's centroid and
+    median depth. Returns per frame [(cls, cx, cy, z)]."""
+    import scipy.io
+    from PIL import Image
+    fr = np.load(os.path.join(GOLD, "demo_frames.npz"))
+    md = np.load(os.path.join(GOLD, "lov_models.npz"))
+    os.makedirs(os.path.join(root, "data", "0048"))
+    np.savetxt(os.path.join(root, "extents.txt"), md["extents"][1:], fmt="%.6f")
+    for i, c in enumerate(config.LOV_CLASSES[1:]):
+        os.makedirs(os.path.join(root, "models", c))
+        np.savetxt(os.path.join(root, "models", c, "points.xyz"), md["points"][i + 1], fmt="%.6f")
+    K = config.DEMO_INTRINSICS
+    names, objects = [], []
+    for f in range(fr["depth"].shape[0]):
+        depth, label = fr["depth"][f], fr["label"][f]
+        name = "0048/%06d" % (f + 1)
+        names.append(name)
+        grey = np.clip(depth.astype(np.float64) / 20000.0 * 255, 0, 255).astype(np.uint8)
+        Image.fromarray(np.stack([grey, grey // 2, 255 - grey], axis=-1)).save(os.path.join(root, "data", name + "-color.png"))
+        Image.fromarray(depth).save(os.path.join(root, "data", name + "-depth.png"))
+        Image.fromarray(label).save(os.path.join(root, "data", name + "-label.png"))
+        objs = []
+        for c in [int(c) for c in np.unique(label) if c]:
+            ys, xs = np.nonzero(label == c)
+            z = float(np.median(depth[ys, xs])) / config.DEMO_FACTOR_DEPTH
+            objs.append((c, float(np.round(xs.mean())), float(np.round(ys.mean())), z))
+        poses = np.zeros((3, 4, len(objs)))
+        for j, (c, cx, cy, z) in enumerate(objs):
+            poses[:, :3, j] = np.eye(3)
+            poses[:, 3, j] = ((cx - K[0, 2]) / K[0, 0] * z, (cy - K[1, 2]) / K[1, 1] * z, z)
+        scipy.io.savemat(os.path.join(root, "data", name + "-meta.mat"),
+                         {"intrinsic_matrix": K, "factor_depth": np.array([[config.DEMO_FACTOR_DEPTH]]), "poses": poses,
+                          "cls_indexes": np.array([[o[0]] for o in objs])})
+        objects.append(objs)
+    with open(os.path.join(root, "keyframe.txt"), "w") as fh:
+        fh.write("\n".join(names) + "\n")
+    return objects
+
+
+def test_run_evaluation_executes_the_test_net_loop(gpu, tmp_path):
+    """lib/fcn/test.py:1154-1467 (`test_net_single_frame`): frame -> pad_im(16) -> im_segment_single_frame ->
+    un-padded labels, NMS'd rois + poses -> imdb.evaluate_result -> evaluate_segmentations, on real depth frames.
+    The network has random weights; a planted 1/8-resolution scene derived from each frame's OWN ground truth makes
+    the heads emit that frame's label map and a vertex field that points at the ground-truth centres,
+    so the evaluator must find high IoU and millimetre translation errors — which only happens if the reader,
+    the blob construction, the single-frame driver, NMS, the pose combine and the evaluator all line up."""
+    import torch
+    from posecnn_amd import datasets, fcn
+    from posecnn_amd.networks import vgg16_convs
+    objects = _write_demo_tree(str(tmp_path))
+    ds = datasets.YCBVideo(str(tmp_path), "keyframe")
+    assert len(ds) == 5
+    K = config.DEMO_INTRINSICS
+
+    class planted_net(vgg16_convs):
+        scene = None
+
+        def run(self, feed, planted=None):
+            return vgg16_convs.run(self, feed, planted=self.scene)
+
+    net = planted_net("RGBD", 22, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True, trainable=False,
+                      is_train=False, seed=3, init="he", with_losses=False, device=gpu)
+    synth.init_planted_heads(net)
+
+    def scene_of(i):
+        label = ds.frame(i)["label"]
+        low = label[4::8, 4::8]
+        h, w = low.shape
+        yy, xx = np.mgrid[0:h, 0:w]
+        yy, xx = yy * 8 + 3.5, xx * 8 + 3.5
+        s = np.zeros((1, h, w, 64), F)
+        for c in range(22):
+            s[0, ..., c] = 30.0 * (low == c)
+        v = np.zeros((1, h, w, 128), F)
+        for c, cx, cy, z in objects[i]:
+            ang = np.arctan2(cy - yy, cx - xx)
+            v[0, ..., 3 * c], v[0, ..., 3 * c + 1], v[0, ..., 3 * c + 2] = 30.0 * np.cos(ang), 30.0 * np.sin(ang), np.log(z)
+        return {"add_score": T(gpu, s), "add_score_vertex": T(gpu, v)}
+
+    class one_frame_at_a_time(object):       # run_evaluation pulls frames in order: plant frame i's scene before it runs
+        classes, extents, num_classes, points = ds.classes, ds.extents, ds.num_classes, ds.points
+
+        def __len__(self):
+            return len(ds)
+
+        def frame(self, i):
+            net.scene = scene_of(i)
+            return ds.frame(i)
+
+    _, points_all = ds.points
+    mat_dir = tmp_path / "mats"
+    mat_dir.mkdir()
+    with torch.no_grad():
+        ev = datasets.run_evaluation(net, one_frame_at_a_time(), points_all, config.LOV_SYMMETRY, device=gpu, mat_dir=str(mat_dir))
+    s = ev.summary()
+    assert s["frames"] == 5 and ev.hist.sum() == 5 * 480 * 640
+    # every ground-truth object was counted, class by class
+    want_all = np.zeros(22)
+    for objs in objects:
+        for c, _, _, _ in objs:
+            want_all[c] += 1
+    assert s["poses_all"] == want_all[1:].tolist() and want_all.sum() >= 20
+    # segmentation: the planted 1/8-resolution scene reproduces the ground truth up to 8-pixel block borders
+    big = [c for c in range(1, 22) if ev.hist[c].sum() > 5 * 3000]
+    assert len(big) >= 4 and all(s["per_class_iu"][config.LOV_CLASSES[c]] > 0.6 for c in big), s["per_class_iu"]
+    assert s["overall_accuracy"] > 0.9
+    # poses: re-run frame 0 by hand and check what evaluate_result saw
+    net.scene = scene_of(0)
+    fr = ds.frame(0)
+    with torch.no_grad():
+        labels, probs, vertex_pred, rois, poses = fcn.im_segment_single_frame(
+            net, fcn.pad_im(fr["color"], 16), fcn.pad_im(fr["depth"], 16), fr["meta"], ds.extents, points_all,
+            config.LOV_SYMMETRY, 22, device=gpu)
+    assert labels.shape == (480, 640) and probs.shape == (480, 640, 22) and vertex_pred.shape == (480, 640, 66)
+    import scipy.io
+    m = scipy.io.loadmat(str(mat_dir / "000000.mat"))
+    assert np.array_equal(m["labels"], labels) and np.array_equal(m["rois"], rois) and np.array_equal(m["poses"], poses)
+    detected = {int(r[1]): p for r, p in zip(rois, poses)}
+    seen = 0
+    for c, cx, cy, z in objects[0]:
+        if (labels == c).sum() <= 500 or c not in detected:
+            continue
+        seen += 1
+        t = detected[c][4:7]
+        want_t = np.array([(cx - K[0, 2]) / K[0, 0] * z, (cy - K[1, 2]) / K[1, 1] * z, z])
+        assert np.abs(t - want_t).max() < 0.02, (c, t, want_t)        # Hough centre within a few cells, depth = planted log z
+        e = ev.pose_error(c, detected[c], fr["meta"]["poses"][:, :, [o[0] for o in objects[0]].index(c)])
+        assert e["translation_error"] < 0.03
+    assert seen >= 3
+    rep = ev.write_reports(str(tmp_path / "report"))
+    assert rep["frames"] == 5 and os.path.exists(str(tmp_path / "report" / "confusion_matrix.txt"))
+
+
+# ---- configs[4]: backproject at the shape the LINEMOD preset runs ------------------------------------------
+def test_backproject_at_the_linemod_bench_shape(gpu):
+    """backprojecting_op_gpu.cu.cc:17-126 at 960x1280 inputs, 64 data channels, C = 14 class channels, k = 3
+    (7x7 window), G = 64 — `bench.py --config linemod` runs this shape (G = 128 there) through
+    backproject_fused_kernel; bit-exact against the oracle."""
+    from posecnn_amd import ops
+    rng = np.random.default_rng(31)
+    B, H, W, Cd, Cl, G, k = 1, 960, 1280, 64, 14, 64, 3
+    data, label, depth, meta, label3d = backproject_case(rng, B, H, W, Cd, Cl, G)
+    m4 = meta.reshape(B, 1, 1, 48)
+    td, tl, tf = ops.backproject(T(gpu, data), T(gpu, label), T(gpu, depth), T(gpu, m4), T(gpu, label3d), G, k, 0.05)
+    wd, wl, wf = oracle.backproject(data, label, depth, meta, label3d, G, k, 0.05)
+    assert 0.02 < wf.mean() < 0.98          # both branches (surface hit / miss) are exercised
+    same(N(td), wd, "top_data")
+    same(N(tf), wf, "top_flag")
+    same(N(tl), wl, "top_label")
