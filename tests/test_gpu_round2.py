@@ -186,7 +186,7 @@ def test_winograd_mfma_trunk_at_full_size_against_direct_convolutions(gpu, capsy
                                        data_p=T(gpu, data_p), planted=planted)
             n = int(det.count.item())
             outs[mode] = (N(det.label_2d), N(net.get_output("prob_normalized")), N(det.rows[:n]),
-                          N(net.get_output("conv5_3")), N(net.get_output("conv4_3_p")))
+                          N(net.get_output("conv5_3")), N(net.get_output("conv4_3_p")), N(net.get_output("fc8")[:n]))
     net.winograd_min_channels = 64
     a, b = outs["winograd_mfma"], outs["direct"]
     flips = int((a[0] != b[0]).sum())
@@ -199,10 +199,17 @@ def test_winograd_mfma_trunk_at_full_size_against_direct_convolutions(gpu, capsy
     report["max_box_diff_px"] = float(np.abs(a[2][:, 2:6] - b[2][:, 2:6]).max())
     report["max_quat_diff"] = float(np.abs(a[2][:, 7:11] - b[2][:, 7:11]).max())
     report["max_trans_diff"] = float(np.abs(a[2][:, 11:] - b[2][:, 11:]).max())
-    # translations come out of the Hough layer's hard inlier test (mean depth over the voters of the winning
-    # cell, .cu.cc:269-294): a 1e-6 change of the vertex field can move single voters across the 0.9
-    # threshold, which shifts the mean by O(1/voters) — millimetres, whatever computed the dense layers
-    assert report["max_quat_diff"] < 1e-4 and report["max_trans_diff"] < 5e-3, report
+    report["max_trans_rel_diff"] = float((np.abs(a[2][:, 11:] - b[2][:, 11:]).max(1) / np.abs(b[2][:, 11:]).max(1)).max())
+    report["fc8_absmax"] = float(np.abs(b[5]).max())
+    report["fc8_abs_diff"] = float(np.abs(a[5] - b[5]).max())
+    report["depth_max_m"] = float(b[2][:, 13].max())
+    # What the round-3 study (tests/parity_study.py) established: no voter crosses the hard inlier
+    # test; a translation is mean(exp(z)) over identical voters, so it agrees RELATIVELY to the vertex field's
+    # error (~1e-5 here, where the random-weight field reaches 45 and junk detections sit at exp(5) metres —
+    # the millimetres round 2 saw were 3e-6 of 270 m); quaternions are tanh(fc8) with fc8 ~ 1500 on these weights.
+    assert np.array_equal(a[2][:, 2:7], b[2][:, 2:7]), report                       # boxes and vote counts: identical
+    assert report["max_trans_rel_diff"] < 1e-4, report
+    assert report["fc8_abs_diff"] < 1e-5 * report["fc8_absmax"] and report["max_quat_diff"] <= 1.01 * report["fc8_abs_diff"] + 1e-7, report
     with capsys.disabled():
         print("\nfull-size winograd-MFMA vs direct:", report)
 
@@ -351,9 +358,20 @@ def test_batch_pipeline_rgbd_matches_cpu_reference(gpu, train):
     og = np.lexsort((g_rois[:, 1], g_rois[:, 0])); oc = np.lexsort((ref["final_rois"][:, 1], ref["final_rois"][:, 0]))
     gr, gp, cr, cp = g_rois[og], g_poses[og], ref["final_rois"][oc], ref["final_poses"][oc]
     assert np.array_equal(gr[:, :2], cr[:, :2])
-    assert np.abs(gr[:, 2:6] - cr[:, 2:6]).max() < (1e-3 if agree == 1.0 else 4.0)
-    assert np.abs(gp[:, 4:] - cp[:, 4:]).max() < (1e-4 if agree == 1.0 else 2e-2)     # translations
-    assert np.abs(gp[:, :4] - cp[:, :4]).max() < 1e-4                                  # quaternions
+    # (round 3) the branch is printed and the all-labels-equal case asserts what the numerics study measured:
+    # identical boxes, translations to 1e-4 of |t|. A flipped label pixel changes the class' pixel list and with it
+    # WHICH pixels skip_pixels samples (every 10th in index order from the flip on) — a different, equally valid
+    # voter set: the bounds for that case are the Hough layer's sampling noise, not rounding.
+    rel_t = float((np.abs(gp[:, 4:] - cp[:, 4:]).max(1) / np.maximum(np.abs(cp[:, 4:]).max(1), 1e-6)).max())
+    box_d = float(np.abs(gr[:, 2:6] - cr[:, 2:6]).max())
+    quat_d = float(np.abs(gp[:, :4] - cp[:, :4]).max())
+    print("\nrgbd pipeline vs cpu restatement [train=%s]: labels %s (agreement %.6f), box diff %.3g px, rel trans diff %.3g, quat diff %.3g"
+          % (train, "IDENTICAL" if agree == 1.0 else "differ", agree, box_d, rel_t, quat_d))
+    if agree == 1.0:
+        assert box_d < 1e-3 and rel_t < 1e-4
+    else:
+        assert box_d < 4.0 and rel_t < 2e-2
+    assert quat_d < 1e-3                      # tanh(fc8), |fc8| ~ 1e3 with random weights (see the study)
     n = int(det.count.item()) * (9 if train else 1)
     w_gpu = net.get_output("poses_weight")[:n].cpu().numpy()
     loss_gpu = float(net.get_output("loss_pose"))
