@@ -179,6 +179,7 @@ def run_study(device, n_frames=32, batch=4, H=480, W=640, C=22, seed=2024, paths
         tr, ch = np.asarray(a["trans"]), np.asarray(a["changed"])
         rt, pl, dp = np.asarray(a["rel_trans"]), np.asarray(a["planted"], dtype=bool), np.asarray(a["depth"])
         vt = np.asarray(a["votes"])
+        sup = vt >= 100
         q = lambda v, x: float(np.quantile(v, x)) if len(v) else None
         out["paths"][p] = {
             "label_flips": a["label_flips"], "pixels": a["pixels"], "max_prob_diff": a["max_prob_diff"],
@@ -188,11 +189,15 @@ def run_study(device, n_frames=32, batch=4, H=480, W=640, C=22, seed=2024, paths
             "trans_diff_median": q(tr, 0.5), "trans_diff_p90": q(tr, 0.9), "trans_diff_p99": q(tr, 0.99),
             "trans_diff_max": float(tr.max()) if len(tr) else None,
             "trans_rel_diff_median": q(rt, 0.5), "trans_rel_diff_p99": q(rt, 0.99), "trans_rel_diff_max": float(rt.max()) if len(rt) else None,
-            "planted_objects": int(pl.sum()), "planted_trans_diff_max": float(tr[pl].max()) if pl.any() else None,
-            "planted_trans_rel_diff_max": float(rt[pl].max()) if pl.any() else None,
-            "planted_depth_max_m": float(dp[pl].max()) if pl.any() else None, "planted_min_votes": int(vt[pl].min()) if pl.any() else None,
-            "junk_detections": int((~pl).sum()), "junk_depth_max_m": float(dp[~pl].max()) if (~pl).any() else None,
-            "junk_max_votes": int(vt[~pl].max()) if (~pl).any() else None,
+            # "supported": >= 100 voters agree on the cell — the planted objects as the Hough layer sees them. The rest are
+            # classes with > 500 label pixels whose votes do not agree (planted objects reduced to slivers by occlusion, noise
+            # classes): 0-2 votes, "depths" of exp(5).
+            "supported_detections": int(sup.sum()), "supported_trans_diff_max": float(tr[sup].max()) if sup.any() else None,
+            "supported_trans_rel_diff_max": float(rt[sup].max()) if sup.any() else None,
+            "supported_depth_max_m": float(dp[sup].max()) if sup.any() else None,
+            "unsupported_detections": int((~sup).sum()), "unsupported_depth_max_m": float(dp[~sup].max()) if (~sup).any() else None,
+            "unsupported_max_votes": int(vt[~sup].max()) if (~sup).any() else None,
+            "unsupported_trans_diff_max": float(tr[~sup].max()) if (~sup).any() else None,
             "vertex_field_abs_err": a["field_abs_err"], "vertex_field_absmax": a["field_absmax"], "vertex_field_rel_err": a["field_rel_err"],
             "fc8_rel_err_max": max(a["fc8_rel"]) if a["fc8_rel"] else None, "fc8_abs_err_max": max(a.get("fc8_abs", [0.0])),
             "fc8_absmax_median": q(np.asarray(a["fc8_scale"]), 0.5),

@@ -199,7 +199,7 @@ def test_winograd_mfma_trunk_at_full_size_against_direct_convolutions(gpu, capsy
     report["max_box_diff_px"] = float(np.abs(a[2][:, 2:6] - b[2][:, 2:6]).max())
     report["max_quat_diff"] = float(np.abs(a[2][:, 7:11] - b[2][:, 7:11]).max())
     report["max_trans_diff"] = float(np.abs(a[2][:, 11:] - b[2][:, 11:]).max())
-    report["max_trans_rel_diff"] = float((np.abs(a[2][:, 11:] - b[2][:, 11:]).max(1) / np.abs(b[2][:, 11:]).max(1)).max())
+    report["max_trans_rel_diff"] = float((np.abs(a[2][:, 11:] - b[2][:, 11:]).max(1) / np.maximum(np.abs(b[2][:, 11:]).max(1), 1e-6)).max())
     report["fc8_absmax"] = float(np.abs(b[5]).max())
     report["fc8_abs_diff"] = float(np.abs(a[5] - b[5]).max())
     report["depth_max_m"] = float(b[2][:, 13].max())
