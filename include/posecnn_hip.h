@@ -343,6 +343,45 @@ int pcnn_fc_rows_fwd(const float* x, const float* wt, const float* bias, int row
                      int in_features, int out_features, int relu, const int32_t* num_rows_dev,
                      const float* addend, float* y, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same layer when only a handful of rows exist (the single-frame loop of lib/fcn/test.py:1867-1888: one image,
+ * <= 21 detections): at <= 32 rows fc6 is a 411 MB weight stream, not a GEMM. Waves pull their weight rows straight
+ * from HBM into registers (no LDS ring, no barriers), the rows ride along as the A operand of the fp32 MFMA, K is
+ * split over grid.y and the LAST workgroup of a column group sums the partial products in ascending order
+ * (deterministic), adds the bias and applies the activation — one launch.
+ *   x f32 [rows_capacity <= 32][in_features % 16 == 0];  wt f32 [out_features][in_features] (any out_features >= 1:
+ *   fc8's 4 * num_classes included);  activation 0 none, 1 ReLU (`relu_layer`), 2 tanh: y_act = tanh(y), y stays
+ *   linear (fc8 -> poses_tanh, vgg16_convs.py:192-193; y_act may be NULL)
+ *   num_rows_dev device int32[1] or NULL;  rows at or past it are written as zeros
+ *   workspace / counters: pcnn_fc_skinny_workspace_bytes gives the bytes and the number of int32 tickets; the
+ *   tickets must be ZERO on entry and are zero again on exit (zero them once; no other launch may share them
+ *   concurrently). */
+int pcnn_fc_skinny_workspace_bytes(int rows_capacity, int in_features, int out_features, size_t* bytes,
+                                   int* num_counters);
+int pcnn_fc_skinny_fwd(const float* x, const float* wt, const float* bias, int rows_capacity, int in_features,
+                       int out_features, int activation, const int32_t* num_rows_dev, float* y, float* y_act,
+                       void* workspace, size_t workspace_bytes, int32_t* counters, int num_counters, void* stream);
+
+/* The 1/8-resolution part of a PoseCNN head in one launch (vgg16_convs.py:128-142 label head, :151-163 vertex head,
+ * in the commuted order DESIGN.md §3.2 "fused_heads" explains):
+ *   add_out = score4 + deconv_{kernel,stride}(score5) [+ planted]     (`add_score` / `dropout` at keep_prob 1)
+ *   z       = add_out . W                                             (the 1x1 `score` / `vertex_pred` product, no bias)
+ *   score4 f32 [B,h,w,units];  score5 f32 [B,h/stride,w/stride,units];  planted f32 [B,h,w,units] or NULL
+ *   weights_t f32 [units][out_channels] (the TF variable [1,1,units,out] as it is);  z f32 [B,h,w,out_channels]
+ * The deconv is the fixed bilinear filter of network.py:141-157 in the canonical tap order of csrc/bilinear.h
+ * (same bits as pcnn_deconv_bilinear_fwd); the product accumulates k ascending with fused multiply-adds. */
+int pcnn_head_lowres_fwd(const float* score4, const float* score5, const float* planted, const float* weights_t,
+                         int batch, int height, int width, int units, int out_channels, int kernel, int stride,
+                         float* add_out, float* z, void* stream);
+
+/* lib/fcn/test.py:197-211 on the device, minus the NMS: detection rows for the host / the all-gather.
+ *   det_rows[i] = rois[i s][0:7] | poses_tanh[i s][4 c : 4 c + 4] | top_pose[i s][4:7],  c = int(rois[i s][1]) clamped
+ *   to [0, num_classes), for i s < *num_rows_dev; zeros after.  s = row_stride: 9 in training mode (the un-jittered
+ *   first row of each group, hough_voting_gpu_op.cu.cc:440-466), else 1.  det_count[0] = *num_rows_dev / s.
+ *   rois f32 [rows][7], poses_tanh f32 [rows][4 num_classes], top_pose f32 [rows][7], det_rows f32 [ceil(rows/s)][14] */
+int pcnn_det_assemble_fwd(const float* rois, const float* poses_tanh, const float* top_pose,
+                          const int32_t* num_rows_dev, int rows, int row_stride, int num_classes, float* det_rows,
+                          int32_t* det_count, void* stream);
+
 /* pcnn_winograd43_output_fwd writing BOTH the activation y f32 [B,H,W,C] and its 2x2 max-pool y_pool f32
  * [B,H/2,W/2,C] in one pass (conv4_3 -> pool4, whose un-pooled output score_conv4 and roi_pool read too). */
 int pcnn_winograd43_output_both_fwd(const float* m, const float* bias, int batch, int height, int width,

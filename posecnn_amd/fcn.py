@@ -203,18 +203,14 @@ def im_segment_batch(net, data, K, extents, points, symmetry, data_p=None, plant
         (net.feed("pool_score")
             .fc(4096, height=7, width=7, channel=512, name="fc6")
             .fc(4096, num_in=4096, name="fc7")
-            .fc(4 * net.num_classes, relu=False, name="fc8")
-            .tanh(name="poses_tanh"))
+            .fc_tanh(4 * net.num_classes, name="fc8", tanh_name="poses_tanh"))
     finally:
         net.rows_count = None
     poses_tanh = net.get_output("poses_tanh")
-    # poses[i,:4] = poses_tanh[i, 4c:4c+4]  (lib/fcn/test.py:206-211), on the device
-    cls = rois[:, 1].long().clamp(min=0)
-    idx = (4 * cls).unsqueeze(1) + torch.arange(4, device=dev).unsqueeze(0)
-    quat = torch.gather(poses_tanh, 1, idx)
-    valid = (torch.arange(cap, device=dev) < count).unsqueeze(1)
-    rows = torch.cat([rois, torch.where(valid, quat, top_pose[:, :4]), top_pose[:, 4:]], dim=1)
-    rows = torch.where(valid, rows, torch.zeros_like(rows))
+    # poses[i,:4] = poses_tanh[i, 4c:4c+4] (lib/fcn/test.py:206-211) and the detection rows box7 | quat4 | trans3, on
+    # the device; training mode emits 9 rows per maximum (the box + 8 jitters, .cu.cc:440-466) — the detection
+    # product is the un-jittered first row of each group
+    det_rows, det_count = ops.det_assemble(rois, poses_tanh, top_pose, count, row_stride=9 if is_train else 1)
     net.layers.update({"rois": rois, "poses_init": top_pose, "poses_tanh": poses_tanh,
                        "poses_target": top_target, "poses_weight": top_weight})
     if with_losses:
@@ -229,11 +225,7 @@ def im_segment_batch(net, data, K, extents, points, symmetry, data_p=None, plant
         net.layers["poses_pred"] = pred
         net.layers["loss_pose"] = ops.average_distance_loss(pred, top_target, top_weight, feed["points"],
                                                             feed["symmetry"], 0.01, num_rows=count)[0]
-    if is_train:
-        # training mode emits 9 rows per maximum (the box + 8 jitters, .cu.cc:440-466); the detection
-        # product is the un-jittered first row of each group
-        return Detections(rows[0::9], count // 9, label_2d)
-    return Detections(rows, count.clone(), label_2d)
+    return Detections(det_rows, det_count, label_2d)
 
 
 def finalize_batch(det_rows, count):

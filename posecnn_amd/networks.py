@@ -165,6 +165,8 @@ class Network(object):
         self.defer_act = frozenset()  # conv layers whose bias + ReLU is left to the following max_pool
         self.dual_pool = frozenset()  # ... and those whose un-pooled output other layers read too (Winograd only)
         self.rows_count = None        # device int32[1]: true row count of capacity-sized ROI rows fed to `fc` (or None)
+        self.fc_skinny = True         # <= 32 capacity rows: fc6-8 on the weight-streaming kernel (csrc/fc_skinny.hip)
+        self.small_heads = True       # 1/8-resolution head algebra (deconv + add + 1x1) in one launch (csrc/heads_small.hip)
 
     # ---- plumbing ------------------------------------------------------------------------------
     def setup(self):
@@ -498,17 +500,44 @@ class Network(object):
         w = self.make_var(name + "/weights", (dim, num_out), self._weight_init(dim), trainable)
         b = self.make_var(name + "/biases", (num_out,), lambda s: torch.zeros(s), trainable)
         rows = getattr(self, "rows_count", None)
+        if self._fc_skinny_ok(feed_in, dim, w):
+            # a handful of rows (the single-frame loop): the layer is a weight stream — csrc/fc_skinny.hip
+            return ops.fc_skinny(feed_in.contiguous(), self._fc_wt(name, w), b, "relu" if relu else "none", num_rows=rows)
         if (rows is not None and feed_in.is_cuda and dim % 64 == 0 and dim >= 128 and num_out % 64 == 0
                 and not (torch.is_grad_enabled() and (w.requires_grad or feed_in.requires_grad))):
             # capacity-sized rows behind the sync-free Hough layer: only the first *rows_count rows exist
-            key = (w.data_ptr(), w._version)
-            hit = self._wino_u.get(("fc", name))
-            if hit is None or hit[0] != key:
-                hit = (key, w.detach().t().contiguous())
-                self._wino_u[("fc", name)] = hit
-            return ops.fc_rows(feed_in.contiguous(), hit[1], b, relu, num_rows=rows)
+            return ops.fc_rows(feed_in.contiguous(), self._fc_wt(name, w), b, relu, num_rows=rows)
         y = torch.addmm(b, feed_in, w)
         return F.relu(y) if relu else y
+
+    def _fc_wt(self, name, w):
+        """The TF weight variable [in, out] transposed to [out, in] (K contiguous rows for the kernels), cached."""
+        key = (w.data_ptr(), w._version)
+        hit = self._wino_u.get(("fc", name))
+        if hit is None or hit[0] != key:
+            hit = (key, w.detach().t().contiguous())
+            self._wino_u[("fc", name)] = hit
+        return hit[1]
+
+    def _fc_skinny_ok(self, feed_in, dim, w):
+        return (self.fc_skinny and getattr(self, "rows_count", None) is not None and feed_in.is_cuda and feed_in.dim() == 2
+                and 1 <= feed_in.shape[0] <= ops.SKINNY_MAX_ROWS and dim % 16 == 0
+                and not (torch.is_grad_enabled() and (w.requires_grad or feed_in.requires_grad)))
+
+    def fc_tanh(self, num_out, name, tanh_name, num_in=-1):
+        """`.fc(num_out, relu=False, name=name).tanh(name=tanh_name)` (fc8 -> poses_tanh, vgg16_convs.py:192-193);
+        on the few-row path both come out of one launch."""
+        x = self.inputs[0]
+        if isinstance(x, tuple):
+            x = x[0]
+        dim = int(x.shape[-1]) if num_in == -1 else int(num_in)
+        w = self.make_var(name + "/weights", (dim, num_out), self._weight_init(dim), True)
+        b = self.make_var(name + "/biases", (num_out,), lambda s: torch.zeros(s), True)
+        if x.dim() == 2 and self._fc_skinny_ok(x, dim, w):
+            y, t = ops.fc_skinny(x.contiguous(), self._fc_wt(name, w), b, "tanh", num_rows=self.rows_count)
+            self.layers[name], self.layers[tanh_name] = y, t
+            return self.feed(t)
+        return self.fc(num_out, relu=False, name=name, num_in=num_in).tanh(name=tanh_name)
 
     # ---- element-wise -----------------------------------------------------------------------------
     @layer
@@ -909,16 +938,48 @@ class vgg16_convs(Network):
                  .conv(3, 3, 512, 1, 1, name='conv5_3_p', c_i=512, trainable=t))
         return self._setup_heads()
 
+    def _small_head(self, s5, s4, up_name, add_name, drop_name, plant_key, conv_name, c_o, c_i):
+        """`deconv(4,4,·,2,2)(s5) -> add(s4, ·) [-> plant] -> dropout(1.0)` and the bias-free 1x1 product `conv_name` of
+        the fused-heads form, as ONE launch (ops.head_lowres). Registers the same layer names; the up-sampled
+        tensor itself is only built if somebody fetches it. Returns (z, bias) like _conv1x1_lowres, or None when
+        the launch does not apply (CPU checker, training graph, dropout active, loaded deconv filter)."""
+        a, b5 = self.layers.get(s4), self.layers.get(s5)
+        if not (self.small_heads and self.fused_heads and isinstance(a, torch.Tensor) and isinstance(b5, torch.Tensor)
+                and a.is_cuda and a.dim() == 4 and a.shape[1] % 2 == 0 and a.shape[2] % 2 == 0
+                and (self.keep_prob_queue is None or float(self.keep_prob_queue) >= 1.0)
+                and (up_name + "/weights") not in self.vars
+                and not (torch.is_grad_enabled() and self.trainable)):
+            return None
+        w = self.make_var(conv_name + "/weights", (c_o, c_i, 1, 1),
+                          lambda s: self._weight_init(c_i)(s).contiguous(memory_format=torch.channels_last))
+        b = self.make_var(conv_name + "/biases", (c_o,), lambda s: torch.zeros(s))
+        key = (w.data_ptr(), w._version)
+        hit = self._head_wt.get(("lowres", conv_name))
+        if hit is None or hit[0] != key:
+            hit = (key, w.detach().reshape(c_o, c_i).t().contiguous())     # [units, out]: the TF variable [1,1,in,out] as it is
+            self._head_wt[("lowres", conv_name)] = hit
+        planted = self.planted.get(plant_key) if self.planted is not None else None
+        add, z = ops.head_lowres(a, b5, hit[1], planted=planted, kernel=4, stride=2)
+        self.layers[up_name] = _Lazy(lambda: self._deconv_bilinear(b5, 4, 2))
+        self.layers[add_name] = add
+        self.layers[drop_name] = add
+        self.feed(add)
+        return z, b
+
     def _setup_heads(self):
         towers = ('', '_p') if self.input_format == 'RGBD' else ('',)
-        (self._head_conv1x1(['conv5_3' + t for t in towers], self.num_units, 'score_conv5')
-             .deconv(4, 4, self.num_units, 2, 2, name='upscore_conv5', trainable=False))
+        self._head_conv1x1(['conv5_3' + t for t in towers], self.num_units, 'score_conv5')
         self._head_conv1x1(['conv4_3' + t for t in towers], self.num_units, 'score_conv4')
+        small = self._small_head('score_conv5', 'score_conv4', 'upscore_conv5', 'add_score', 'dropout', 'add_score',
+                                 'score', self.num_classes, self.num_units)
+        if small is None:
+            (self.feed('score_conv5')
+                 .deconv(4, 4, self.num_units, 2, 2, name='upscore_conv5', trainable=False))
 
-        (self.feed('score_conv4', 'upscore_conv5')
-             .add(name='add_score')
-             ._plant('add_score', 'add_score')
-             .dropout(self.keep_prob_queue, name='dropout'))
+            (self.feed('score_conv4', 'upscore_conv5')
+                 .add(name='add_score')
+                 ._plant('add_score', 'add_score')
+                 .dropout(self.keep_prob_queue, name='dropout'))
 
         if self.fused_heads:
             # deconv and the 1x1 `score` conv are both linear and act on different axes, so
@@ -926,7 +987,7 @@ class vgg16_convs(Network):
             # included): run the 64->C contraction at 1/8 resolution (64x fewer MACs) and let one
             # gfx950 kernel do deconv + bias + ReLU + softmax + argmax without ever writing the
             # [B,480,640,64] `upscore` or the full-resolution `score` to HBM.
-            z, b = self._conv1x1_lowres(self.get_output('dropout'), 'score', self.num_classes, self.num_units)
+            z, b = small if small is not None else self._conv1x1_lowres(self.get_output('dropout'), 'score', self.num_classes, self.num_units)
             k, s = int(16 * self.scale), int(8 * self.scale)
             score, prob, label = self._upscore_softmax_argmax(z, b, k, s, relu=True, want_score=self.with_losses,
                                                              want_prob=self.want_prob)
@@ -956,20 +1017,24 @@ class vgg16_convs(Network):
                  .hard_label(threshold=self.threshold_label, name='gt_label_weight'))
 
         if self.vertex_reg:
-            (self._head_conv1x1(['conv5_3'], 128, 'score_conv5_vertex', relu=False)
-                 .deconv(4, 4, 128, 2, 2, name='upscore_conv5_vertex', trainable=False))
+            self._head_conv1x1(['conv5_3'], 128, 'score_conv5_vertex', relu=False)
             self._head_conv1x1(['conv4_3'], 128, 'score_conv4_vertex', relu=False)
+            small_v = self._small_head('score_conv5_vertex', 'score_conv4_vertex', 'upscore_conv5_vertex', 'add_score_vertex',
+                                       'dropout_vertex', 'add_score_vertex', 'vertex_pred', 3 * self.num_classes, 128)
+            if small_v is None:
+                (self.feed('score_conv5_vertex')
+                     .deconv(4, 4, 128, 2, 2, name='upscore_conv5_vertex', trainable=False))
 
-            (self.feed('score_conv4_vertex', 'upscore_conv5_vertex')
-                 .add(name='add_score_vertex')
-                 ._plant('add_score_vertex', 'add_score_vertex')
-                 .dropout(self.keep_prob_queue, name='dropout_vertex'))
+                (self.feed('score_conv4_vertex', 'upscore_conv5_vertex')
+                     .add(name='add_score_vertex')
+                     ._plant('add_score_vertex', 'add_score_vertex')
+                     .dropout(self.keep_prob_queue, name='dropout_vertex'))
             if self.fused_heads:
                 # same commutation as the label head: 128->3C at 1/8 resolution, then one
                 # interpolation pass writes vertex_pred (+ bias); `upscore_vertex` is never built
                 # and the Hough layer interpolates just the pixels it samples, so `vertex_pred`
                 # itself (81 MB/frame) is only materialised if somebody fetches it.
-                zv, bv = self._conv1x1_lowres(self.get_output('dropout_vertex'), 'vertex_pred', 3 * self.num_classes, 128)
+                zv, bv = small_v if small_v is not None else self._conv1x1_lowres(self.get_output('dropout_vertex'), 'vertex_pred', 3 * self.num_classes, 128)
                 kv, sv = int(16 * self.scale), int(8 * self.scale)
                 self.layers['vertex_pred_lowres'] = zv
                 self.layers['vertex_pred_bias'] = bv

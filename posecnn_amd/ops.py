@@ -529,6 +529,84 @@ def fc_rows(x, wt, bias, relu=True, num_rows=None, addend=None):
     return y
 
 
+_tickets = {}
+
+
+def _ticket_buffer(device, n):
+    """int32 ticket counters of the split-K kernels that finish in their last workgroup: zero on entry, zero on
+    exit (the kernel resets them), so one zero-filled buffer per stream serves every launch on that stream."""
+    k = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _tickets.get(k)
+    if buf is None or buf.numel() < n:
+        buf = torch.zeros(max(int(n), 256), dtype=torch.int32, device=device)
+        _tickets[k] = buf
+    return buf
+
+
+SKINNY_MAX_ROWS = 32
+
+
+def fc_skinny(x, wt, bias, activation="none", num_rows=None):
+    """`Network.fc` for <= 32 rows (the single-frame loop): y = act(x @ wt.T + bias) as one weight-streaming
+    launch (csrc/fc_skinny.hip). x [M <= 32, K % 16 == 0], wt [N, K] (the TF weight transposed), bias [N].
+    activation "none" | "relu" | "tanh"; "tanh" returns (linear, tanh(linear)) — fc8 and poses_tanh."""
+    x = _dev(x, "x", torch.float32)
+    wt = _dev(wt, "wt", torch.float32)
+    bias = _dev(bias, "bias", torch.float32)
+    if x.dim() != 2 or wt.dim() != 2 or wt.shape[1] != x.shape[1] or bias.numel() != wt.shape[0]:
+        raise ValueError("x must be [M, K], wt [N, K], bias [N]")
+    act = {"none": 0, "relu": 1, "tanh": 2}[activation]
+    M, K = x.shape
+    N = wt.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    y2 = torch.empty((M, N), dtype=torch.float32, device=x.device) if act == 2 else None
+    nr = _dev(num_rows, "num_rows", torch.int32) if num_rows is not None else None
+    nbytes, ncnt = ctypes.c_size_t(), ctypes.c_int()
+    check("pcnn_fc_skinny_workspace_bytes", lib().pcnn_fc_skinny_workspace_bytes(M, K, N, ctypes.byref(nbytes), ctypes.byref(ncnt)))
+    ws = _ws(x.device, "fc_skinny").get(nbytes.value, x.device)
+    cnt = _ticket_buffer(x.device, ncnt.value)
+    check("pcnn_fc_skinny_fwd", lib().pcnn_fc_skinny_fwd(_ptr(x), _ptr(wt), _ptr(bias), M, K, N, act, _ptr(nr), _ptr(y), _ptr(y2),
+                                                        _ptr(ws), nbytes.value, _ptr(cnt), cnt.numel(), _stream(x)))
+    return (y, y2) if act == 2 else y
+
+
+def head_lowres(score4, score5, weights_t, planted=None, kernel=4, stride=2):
+    """add = score4 + deconv_{kernel,stride}(score5) [+ planted]; z = add . weights_t (1x1 conv, no bias) in one
+    launch. score4 [B,h,w,U], score5 [B,h/stride,w/stride,U], weights_t [U, Cout] -> (add [B,h,w,U], z [B,h,w,Cout])."""
+    score4 = _dev(score4, "score4", torch.float32)
+    score5 = _dev(score5, "score5", torch.float32)
+    weights_t = _dev(weights_t, "weights_t", torch.float32)
+    pl = _dev(planted, "planted", torch.float32) if planted is not None else None
+    B, h, w, U = score4.shape
+    if (tuple(score5.shape) != (B, h // stride, w // stride, U) or weights_t.dim() != 2 or weights_t.shape[0] != U
+            or (pl is not None and tuple(pl.shape) != tuple(score4.shape))):
+        raise ValueError("score4 [B,h,w,U], score5 [B,h/s,w/s,U], weights_t [U,Cout], planted like score4")
+    Cout = weights_t.shape[1]
+    add = torch.empty_like(score4)
+    z = torch.empty((B, h, w, Cout), dtype=torch.float32, device=score4.device)
+    check("pcnn_head_lowres_fwd", lib().pcnn_head_lowres_fwd(_ptr(score4), _ptr(score5), _ptr(pl), _ptr(weights_t), B, h, w, U, Cout,
+                                                            int(kernel), int(stride), _ptr(add), _ptr(z), _stream(score4)))
+    return add, z
+
+
+def det_assemble(rois, poses_tanh, top_pose, num_rows, row_stride=1):
+    """lib/fcn/test.py:206-211 on the device: rows [ceil(R / stride), 14] = box7 | quaternion of the row's class |
+    translation, zeros past the device-side count; count [1] int32 = *num_rows // stride."""
+    rois = _dev(rois, "rois", torch.float32)
+    poses_tanh = _dev(poses_tanh, "poses_tanh", torch.float32)
+    top_pose = _dev(top_pose, "top_pose", torch.float32)
+    nr = _dev(num_rows, "num_rows", torch.int32)
+    R = rois.shape[0]
+    if rois.dim() != 2 or rois.shape[1] != 7 or tuple(top_pose.shape) != (R, 7) or poses_tanh.shape[0] != R or poses_tanh.shape[1] % 4:
+        raise ValueError("rois [R,7], top_pose [R,7], poses_tanh [R,4C]")
+    n_out = (R + row_stride - 1) // row_stride
+    rows = torch.empty((n_out, 14), dtype=torch.float32, device=rois.device)
+    count = torch.empty((1,), dtype=torch.int32, device=rois.device)
+    check("pcnn_det_assemble_fwd", lib().pcnn_det_assemble_fwd(_ptr(rois), _ptr(poses_tanh), _ptr(top_pose), _ptr(nr), R, int(row_stride),
+                                                              poses_tanh.shape[1] // 4, _ptr(rows), _ptr(count), _stream(rois)))
+    return rows, count
+
+
 def conv3x3_winograd(x, u, bias, relu=True, pool=False, tile=2):
     """3x3 / stride 1 / SAME convolution + bias [+ ReLU] [+ 2x2 max-pool] as Winograd F(tile x tile, 3x3):
     input transform (gfx950 kernel) -> (tile+2)^2 fp32 GEMMs (library, MFMA) -> output transform

@@ -295,3 +295,86 @@ def test_backproject_at_the_linemod_bench_shape(gpu):
     same(N(td), wd, "top_data")
     same(N(tf), wf, "top_flag")
     same(N(tl), wl, "top_label")
+
+
+# ---- BASELINE configs[1]: the few-row pose branch and the small head kernels -------------------------------------
+@pytest.mark.parametrize("M,K,N,count,act", [(5, 25088, 4096, 5, "relu"), (21, 4096, 4096, 17, "relu"), (21, 4096, 88, 4, "tanh"),
+                                             (21, 4096, 88, 21, "tanh"), (1, 256, 40, None, "none"), (16, 1024, 130, 0, "relu"),
+                                             (32, 2064, 200, 32, "none"), (7, 25088, 256, 3, "relu")])
+def test_fc_skinny_matches_float64_and_is_deterministic(gpu, M, K, N, count, act):
+    """`Network.fc` at <= 32 rows (csrc/fc_skinny.hip): rows below the device-side count equal act(x @ W + b) up to f32
+    roundoff against float64, rows at or past it are exact zeros whatever the buffer held (NaN poison), two runs
+    give the same bits (fixed-order split-K sum in the last workgroup), and the ticket counters are back at zero."""
+    import torch
+    from posecnn_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
+    x = torch.randn((M, K), generator=g).to(gpu)
+    w = (torch.randn((K, N), generator=g) / K ** 0.5).to(gpu)
+    b = torch.randn((N,), generator=g).to(gpu)
+    n = M if count is None else count
+    if n < M:
+        x[n:] = float("nan")
+    cnt = None if count is None else torch.tensor([count], dtype=torch.int32, device=gpu)
+    wt = w.t().contiguous()
+    out = ops.fc_skinny(x, wt, b, act, num_rows=cnt)
+    out2 = ops.fc_skinny(x, wt, b, act, num_rows=cnt)
+    y, t = out if act == "tanh" else (out, None)
+    y2, t2 = out2 if act == "tanh" else (out2, None)
+    same(y.cpu().numpy(), y2.cpu().numpy(), "run-to-run")
+    ref = x[:n].double() @ w.double() + b.double()
+    if act == "relu":
+        ref = torch.relu(ref)
+    if n:
+        scale = max(1.0, float(ref.abs().max()))
+        assert float((y[:n].double() - ref).abs().max()) < 2e-5 * scale
+    assert not y[n:].cpu().numpy().view(np.uint32).any()
+    if act == "tanh":
+        same(t.cpu().numpy(), t2.cpu().numpy(), "tanh run-to-run")
+        if n:
+            assert float((t[:n].double() - torch.tanh(y[:n].double())).abs().max()) < 3e-7
+        assert not t[n:].cpu().numpy().view(np.uint32).any()
+    assert all(int(v.abs().max()) == 0 for v in ops._tickets.values())
+
+
+def test_head_lowres_equals_the_op_sequence_it_replaces(gpu):
+    """csrc/heads_small.hip: add_score = score_conv4 + deconv(4,2)(score_conv5) [+ planted] must carry the bits of
+    pcnn_deconv_bilinear_fwd + two framework adds; the 1x1 product is checked against float64."""
+    import torch
+    from posecnn_amd import ops
+    rng = np.random.default_rng(12)
+    for (B, h, w, U, Cout, plant) in ((2, 60, 80, 64, 22, True), (1, 60, 80, 128, 66, False), (3, 6, 10, 64, 5, True), (1, 2, 2, 8, 3, False)):
+        a = T(gpu, rng.standard_normal((B, h, w, U)).astype(F))
+        b5 = T(gpu, rng.standard_normal((B, h // 2, w // 2, U)).astype(F))
+        pl = T(gpu, rng.standard_normal((B, h, w, U)).astype(F)) if plant else None
+        wt = T(gpu, (rng.standard_normal((U, Cout)) / U ** 0.5).astype(F))
+        add, z = ops.head_lowres(a, b5, wt, planted=pl)
+        want = a + ops.deconv_bilinear(b5, 4, 2)
+        if plant:
+            want = want + pl
+        same(N(add), N(want), "add_score %s" % ((B, h, w, U),))
+        zr = want.double().reshape(-1, U) @ wt.double()
+        assert float((z.double().reshape(-1, Cout) - zr).abs().max()) < 1e-5 * max(1.0, float(zr.abs().max()))
+
+
+@pytest.mark.parametrize("stride", [1, 9])
+def test_det_assemble_equals_the_host_pose_combine(gpu, stride):
+    """lib/fcn/test.py:206-211: poses[i, :4] = poses_tanh[i, 4c : 4c+4]; rows past the count are zero; training mode
+    keeps the first row of every group of 9."""
+    import torch
+    from posecnn_amd import ops
+    rng = np.random.default_rng(3)
+    C, R, n = 22, 27, 18
+    rois = rng.standard_normal((R, 7)).astype(F)
+    rois[:, 1] = rng.integers(0, C, R)
+    rois[5, 1] = -1                       # clamped to class 0
+    pt = rng.standard_normal((R, 4 * C)).astype(F)
+    tp = rng.standard_normal((R, 7)).astype(F)
+    rows, count = ops.det_assemble(T(gpu, rois), T(gpu, pt), T(gpu, tp), torch.tensor([n], dtype=torch.int32, device=gpu), row_stride=stride)
+    want = np.zeros(((R + stride - 1) // stride, 14), F)
+    for i in range(want.shape[0]):
+        ri = i * stride
+        if ri < n:
+            c = max(int(rois[ri, 1]), 0)
+            want[i] = np.concatenate([rois[ri], pt[ri, 4 * c:4 * c + 4], tp[ri, 4:]])
+    same(N(rows), want, "rows")
+    assert int(count) == n // stride
