@@ -15,8 +15,8 @@
 //     under an 85 us stream). x (<= 32 x K floats) is L2-resident and shared through L1 by the 4 waves of a
 //     workgroup, which work on the same K slice;
 //   * split-K over grid.y fills the chip (2048+ waves, ~20 KB in flight each); the partial products meet in a
-//     fixed-order sum performed by the LAST workgroup of each column group (ticket counter + __threadfence; the
-//     counter returns to zero) — deterministic, and one launch instead of two;
+//     fixed-order sum performed by the LAST workgroup of each column group (ticket counter; partials exchanged
+//     through agent-scope atomic stores / loads; the counter returns to zero) — deterministic, one launch;
 //   * epilogue in that last workgroup: + bias, then none / ReLU / tanh (fc8 -> poses_tanh, vgg16_convs.py:192-193:
 //     the linear output is kept as well), rows at or past the device-side count are written as zeros.
 //
@@ -34,15 +34,60 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int SK_NBW = 2;          // 16-column blocks per wave
 constexpr int SK_WAVES = 4;        // waves per workgroup (same K slice, consecutive column blocks)
 constexpr int SK_COLS = 16 * SK_NBW * SK_WAVES;   // 128 output columns per workgroup
-constexpr int SK_U = 4;            // K steps (of 16) per load group
 
-__device__ __forceinline__ v4f ldg_nt(const float* p)
+// (a non-temporal hint on this load measured 2.0 TB/s against 3+ without: a wave's load instruction covers 64 of a
+//  line's 128 bytes, the next K step the other 64 — streamed lines were fetched from HBM twice)
+__device__ __forceinline__ v4f ldg_w(const float* p)
 {
-  return __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+  return *reinterpret_cast<const v4f*>(p);
 }
 
-// MB = 16-row blocks of x (1 or 2). act: 0 none, 1 ReLU, 2 tanh (y2 = tanh(y), y = linear)
-template <int MB>
+// The K loop of one wave over its slice [ks0, ks1) of 16-float steps, for ML live row blocks: two groups of SK_U steps
+// in flight (registers), MFMAs of group g under the loads of group g + 1. A clamped step (past the slice end) is loaded
+// again and its MFMAs are skipped — at most SK_U - 1 redundant loads per wave instead of a remainder loop.
+template <int ML, int SK_U>
+__device__ __forceinline__ void sk_loop(const float* const* xp, const float* const* wp, int ks0, int ks1, v4f (*acc)[SK_NBW])
+{
+  v4f a[2][SK_U][ML], b[2][SK_U][SK_NBW];
+  const int ngroups = (ks1 - ks0 + SK_U - 1) / SK_U;
+  if (ngroups <= 0) return;
+#define SK_LOAD(BUF, G)                                                                     \
+  _Pragma("unroll") for (int u = 0; u < SK_U; u++) {                                         \
+    const int st = min(ks0 + (G) * SK_U + u, ks1 - 1);                                       \
+    _Pragma("unroll") for (int j = 0; j < SK_NBW; j++) b[BUF][u][j] = ldg_w(wp[j] + 16 * st); \
+    _Pragma("unroll") for (int mb = 0; mb < ML; mb++) a[BUF][u][mb] = *reinterpret_cast<const v4f*>(xp[mb] + 16 * st); \
+  }
+#define SK_MATH(BUF, G)                                                                     \
+  _Pragma("unroll") for (int u = 0; u < SK_U; u++) {                                         \
+    if (ks0 + (G) * SK_U + u < ks1) {   /* wave-uniform */                                   \
+      _Pragma("unroll") for (int i = 0; i < 4; i++)                                          \
+        _Pragma("unroll") for (int j = 0; j < SK_NBW; j++)                                   \
+          _Pragma("unroll") for (int mb = 0; mb < ML; mb++)                                  \
+            acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[BUF][u][mb][i], b[BUF][u][j][i], acc[mb][j], 0, 0, 0); \
+    }                                                                                       \
+  }
+  SK_LOAD(0, 0);
+  int g = 0;
+  for (; g + 2 <= ngroups - 1; g += 2) {
+    SK_LOAD(1, g + 1);
+    SK_MATH(0, g);
+    SK_LOAD(0, g + 2);
+    SK_MATH(1, g + 1);
+  }
+  // 1 or 2 groups left: g (in buffer 0) and possibly g + 1
+  if (g + 1 < ngroups) {
+    SK_LOAD(1, g + 1);
+    SK_MATH(0, g);
+    SK_MATH(1, g + 1);
+  } else {
+    SK_MATH(0, g);
+  }
+#undef SK_LOAD
+#undef SK_MATH
+}
+
+// MB = 16-row blocks of x the buffer can hold (1 or 2). act: 0 none, 1 ReLU, 2 tanh (y2 = tanh(y), y = linear)
+template <int MB, int SK_U>
 __global__ __launch_bounds__(64 * SK_WAVES) void fc_skinny_kernel(
     const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias, float* __restrict__ y,
     float* __restrict__ y2, int K, int N, int Mcap, int act, const int* __restrict__ num_rows_dev,
@@ -74,48 +119,10 @@ __global__ __launch_bounds__(64 * SK_WAVES) void fc_skinny_kernel(
     for (int j = 0; j < SK_NBW; j++) acc[mb][j] = (v4f){0.f, 0.f, 0.f, 0.f};
 
   if (count > 0) {
-    v4f a[2][SK_U][MB], b[2][SK_U][SK_NBW];
-    // group g of this slice = K steps ks0 + SK_U g ... (clamped to the slice: a clamped step is loaded again and
-    // its MFMAs are skipped below — simpler than a remainder loop and at most 3 redundant loads per wave)
-    const int ngroups = (ks1 - ks0 + SK_U - 1) / SK_U;
-#define SK_LOAD(BUF, G)                                                                   \
-    _Pragma("unroll") for (int u = 0; u < SK_U; u++) {                                     \
-      const int st = min(ks0 + (G) * SK_U + u, ks1 - 1);                                   \
-      _Pragma("unroll") for (int j = 0; j < SK_NBW; j++) b[BUF][u][j] = ldg_nt(wp[j] + 16 * st); \
-      _Pragma("unroll") for (int mb = 0; mb < MB; mb++)                                    \
-        if (mb == 0 || two) a[BUF][u][mb] = *reinterpret_cast<const v4f*>(xp[mb] + 16 * st); \
-    }
-#define SK_MATH(BUF, G)                                                                   \
-    _Pragma("unroll") for (int u = 0; u < SK_U; u++) {                                     \
-      const bool live = ks0 + (G) * SK_U + u < ks1;   /* wave-uniform */                    \
-      if (live) {                                                                         \
-        _Pragma("unroll") for (int i = 0; i < 4; i++)                                      \
-          _Pragma("unroll") for (int j = 0; j < SK_NBW; j++) {                             \
-            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[BUF][u][0][i], b[BUF][u][j][i], acc[0][j], 0, 0, 0); \
-            if (MB > 1 && two) acc[MB - 1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[BUF][u][MB - 1][i], b[BUF][u][j][i], acc[MB - 1][j], 0, 0, 0); \
-          }                                                                               \
-      }                                                                                   \
-    }
-    if (ngroups > 0) {
-      SK_LOAD(0, 0);
-      int g = 0;
-      for (; g + 2 <= ngroups - 1; g += 2) {
-        SK_LOAD(1, g + 1);
-        SK_MATH(0, g);
-        SK_LOAD(0, g + 2);
-        SK_MATH(1, g + 1);
-      }
-      // 1 or 2 groups left: g (loaded in buffer 0) and possibly g + 1
-      if (g + 1 < ngroups) {
-        SK_LOAD(1, g + 1);
-        SK_MATH(0, g);
-        SK_MATH(1, g + 1);
-      } else {
-        SK_MATH(0, g);
-      }
-    }
-#undef SK_LOAD
-#undef SK_MATH
+    // the loop is specialised on the LIVE row blocks: a frame with <= 16 detections in a 21-row buffer runs the
+    // one-block loop (branch-free bodies, half the operand registers in use)
+    if (MB > 1 && two) sk_loop<MB, SK_U>(xp, wp, ks0, ks1, acc);
+    else sk_loop<1, SK_U>(xp, wp, ks0, ks1, acc);
   }
 
   // partial products: lane holds D[m = 4 q + e][n = r] of each block
@@ -127,49 +134,81 @@ __global__ __launch_bounds__(64 * SK_WAVES) void fc_skinny_kernel(
       for (int j = 0; j < SK_NBW; j++)
 #pragma unroll
         for (int e = 0; e < 4; e++)
-          part[((size_t)s * (16 * MB) + 16 * mb + 4 * q + e) * Npad + n0 + 16 * j + r] = acc[mb][j][e];
+          __hip_atomic_store(&part[((size_t)s * (16 * MB) + 16 * mb + 4 * q + e) * Npad + n0 + 16 * j + r], acc[mb][j][e],
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 
   // ticket: the last workgroup of this column group sums the S partials in ascending order
+  // Coherence across the 8 XCDs (one L2 each) without cache-wide operations. A release fence at agent scope writes
+  // the XCD's whole L2 back, an acquire invalidates it: one __threadfence() per thread (first version) meant ~2000
+  // L2 invalidations during the launch and HALVED the stream rate (fc6 205 us); one release per workgroup still cost
+  // ~0.3 us each (119 us). The partials are therefore written with agent-scope atomic stores (sc1: written through to
+  // the coherence point) and read back with agent-scope atomic loads (sc1: never served from a stale line); the
+  // wait + barrier orders every wave's stores before the ticket. No fence, no invalidate.
   __shared__ int s_last;
-  __threadfence();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    const int old = atomicAdd(&counters[blockIdx.x], 1);
+    const int old = __hip_atomic_fetch_add(&counters[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = old == S - 1;
-    if (old == S - 1) counters[blockIdx.x] = 0;   // leave the counter as we found it
+    if (old == S - 1) __hip_atomic_store(&counters[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // leave the counter as we found it
   }
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
   // 256 threads over (column, row parity): thread handles column c = tid & 127, rows m = h, h + 2, ...
-  const int c = tid & (SK_COLS - 1), h = tid >> 7;
+  const int c = tid & (SK_COLS - 1), h = tid / SK_COLS;
   const int n = blockIdx.x * SK_COLS + c;
   if (n >= N) return;
   const float bv = bias[n];
   const int rows = 16 * MB;
-  for (int m = h; m < Mcap; m += 2) {
-    float v = 0.f, v2 = 0.f;
-    if (m < count && m < rows) {
-      float sum = 0.f;
-      for (int ks = 0; ks < S; ks++) sum += __builtin_nontemporal_load(&part[((size_t)ks * rows + m) * Npad + n]);
-      v = sum + bv;
-      if (act == 1) v = v > 0.f ? v : 0.f;
-      if (act == 2) v2 = tanhf(v);
+  // two rows at a time, the partials fetched 16 per row in one batch (32 independent loads in flight per thread: the
+  // partials come from other XCDs' workgroups, i.e. from memory, ~1 us each if taken one by one); the SUM stays
+  // sequential in ascending slice order
+  for (int m0 = h; m0 < Mcap; m0 += 4) {
+    float sum[2] = {0.f, 0.f};
+    const int m1 = m0 + 2;
+    const bool l0 = m0 < count, l1 = m1 < count && m1 < Mcap;
+    if (l0) {
+      for (int ks0 = 0; ks0 < S; ks0 += 16) {
+        float p0[16], p1[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+          const int ks = min(ks0 + u, S - 1);
+          p0[u] = __hip_atomic_load(&part[((size_t)ks * rows + m0) * Npad + n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          p1[u] = l1 ? __hip_atomic_load(&part[((size_t)ks * rows + m1) * Npad + n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+          if (ks0 + u < S) { sum[0] += p0[u]; sum[1] += p1[u]; }
+      }
     }
-    y[(size_t)m * N + n] = v;
-    if (act == 2 && y2) y2[(size_t)m * N + n] = v2;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int m = m0 + 2 * t;
+      if (m >= Mcap) break;
+      float v = 0.f, v2 = 0.f;
+      if (m < count) {
+        v = sum[t] + bv;
+        if (act == 1) v = v > 0.f ? v : 0.f;
+        if (act == 2) v2 = tanhf(v);
+      }
+      y[(size_t)m * N + n] = v;
+      if (act == 2 && y2) y2[(size_t)m * N + n] = v2;
+    }
   }
 }
 
-// split: enough waves to fill the chip with deep load queues, at least 8 K steps (128 floats) per slice
+// split: enough waves to fill the chip with deep load queues, at least 16 K steps (256 floats) per slice
 int sk_splits(int K, int N)
 {
   const int KS = K / 16;
   const int groups = (N + SK_COLS - 1) / SK_COLS;
-  int S = std::max(1, 512 / groups);           // ~512 workgroups = 2048 waves = 8 per CU
-  S = std::min(S, std::max(1, KS / 8));
+  // ONE 4-wave workgroup per CU: the launch is a single round of equal workgroups, so any count that is not a
+  // multiple of the 256 CUs leaves CUs idle or gives some of them two (measured on fc6: 256 workgroups 82 us,
+  // 192 -> 100, 320 -> 131, 512 -> 90, 1024 -> 98, 128 -> 131; 256 workgroups of 8 waves: 88)
+  int S = std::max(1, 256 / groups);
+  S = std::min(S, std::max(1, KS / 16));
   return std::min(S, 64);
 }
 
@@ -209,11 +248,10 @@ extern "C" int pcnn_fc_skinny_fwd(const float* x, const float* wt, const float* 
   const int KS = in_features / 16;
   const int per = (KS + S - 1) / S;
   float* part = static_cast<float*>(workspace);
-  if (rows_capacity > 16)
-    PCNN_LAUNCH(fc_skinny_kernel<2>, dim3(groups, S), dim3(64 * SK_WAVES), 0, stream, x, wt, bias, y, y_act, in_features,
-                out_features, rows_capacity, activation, num_rows_dev, part, counters, per);
-  else
-    PCNN_LAUNCH(fc_skinny_kernel<1>, dim3(groups, S), dim3(64 * SK_WAVES), 0, stream, x, wt, bias, y, y_act, in_features,
-                out_features, rows_capacity, activation, num_rows_dev, part, counters, per);
+#define SK_GO(MBV) PCNN_LAUNCH((fc_skinny_kernel<MBV, 2>), dim3(groups, S), dim3(64 * SK_WAVES), 0, stream, x, wt, bias, y, y_act, in_features, \
+                out_features, rows_capacity, activation, num_rows_dev, part, counters, per)
+  // (groups of 2 K steps: 66 / 80 VGPRs; groups of 4 need 114 / 140 and measured 5-10 % slower)
+  if (rows_capacity > 16) SK_GO(2); else SK_GO(1);
+#undef SK_GO
   return check_launch("fc_skinny_fwd");
 }

@@ -43,6 +43,20 @@ void profile_end(hipStream_t stream);
   } while (0)
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- data exchanged between workgroups INSIDE one launch (split-K partials summed by the last workgroup) -------------
+// gfx950 has one L2 per XCD and they are only made coherent at kernel boundaries. Inside a kernel, a value another
+// XCD's workgroup must see is stored with agent scope (sc1: written through to the level all XCDs share) and loaded
+// with agent scope (sc1: never served from a line another XCD may have overwritten) — no cache-wide write-back /
+// invalidate, which a release / acquire FENCE at agent scope would cost (measured in csrc/fc_skinny.hip).
+__device__ __forceinline__ void store_coherent(float* p, float v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float load_coherent(const float* p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---- exact f32 primitives --------------------------------------------------------------------
