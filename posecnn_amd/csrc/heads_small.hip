@@ -25,24 +25,29 @@ __global__ __launch_bounds__(256) void head_lowres_kernel(
     const float* __restrict__ wT, float* __restrict__ add_out, float* __restrict__ z, int B, int h, int w, int U,
     int Cout, int k, int s)
 {
-  extern __shared__ float smem[];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tL = smem;                  // [HL_PX][U]
   float* wL = smem + HL_PX * U;      // [U][Cout]
+  __shared__ Taps s_ty[HL_PX], s_tx[HL_PX];   // the interpolation taps of a pixel: once per pixel (double arithmetic), not per element
+  __shared__ int s_img[HL_PX];
   const int tid = threadIdx.x;
   const long long total = (long long)B * h * w;
   const long long gp0 = (long long)blockIdx.x * HL_PX;
   const int h5 = h / s, w5 = w / s, pad = (k - s) / 2;
+  if (tid < HL_PX) {
+    const long long gp = gp0 + tid < total ? gp0 + tid : total - 1;
+    s_tx[tid] = make_taps((int)(gp % w), k, s, pad, w5);
+    s_ty[tid] = make_taps((int)((gp / w) % h), k, s, pad, h5);
+    s_img[tid] = (int)(gp / ((long long)w * h));
+  }
   for (int i = tid; i < U * Cout; i += 256) wL[i] = wT[i];
+  __syncthreads();
   for (int idx = tid; idx < HL_PX * U; idx += 256) {
     const int p = idx / U, c = idx - p * U;
     const long long gp = gp0 + p;
     float t = 0.f;
     if (gp < total) {
-      const int x = (int)(gp % w);
-      const int y = (int)((gp / w) % h);
-      const int bi = (int)(gp / ((long long)w * h));
-      const Taps ty = make_taps(y, k, s, pad, h5), tx = make_taps(x, k, s, pad, w5);
-      const float up = bilinear_at(b5 + (size_t)bi * h5 * w5 * U, ty, tx, w5, U, c);
+      const float up = bilinear_at(b5 + (size_t)s_img[p] * h5 * w5 * U, s_ty[p], s_tx[p], w5, U, c);
       t = a[gp * U + c] + up;                       // add_score = score_conv4 + upscore_conv5   (tf.add_n order)
       if (planted) t = t + planted[gp * U + c];     // bench aid: the planted scene
       add_out[gp * U + c] = t;
@@ -50,18 +55,21 @@ __global__ __launch_bounds__(256) void head_lowres_kernel(
     tL[idx] = t;
   }
   __syncthreads();
-  // z[p][co] = sum_k t[p][k] W[k][co], k ascending; a thread owns 4 pixels x 1 output channel
+  // z[p][co] = sum_k t[p][k] W[k][co], k ascending; a thread owns 4 pixels x 1 output channel and walks K four at a
+  // time (one 128-bit LDS read per pixel — all lanes of a pixel quad read the same address: a broadcast)
   const int items = (HL_PX / 4) * Cout;
   for (int it = tid; it < items; it += 256) {
     const int pq = it / Cout, co = it - pq * Cout;
     const float* t0 = tL + (4 * pq) * U;
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-    for (int kk = 0; kk < U; kk++) {
-      const float wv = wL[kk * Cout + co];
-      acc0 = __builtin_fmaf(t0[kk], wv, acc0);
-      acc1 = __builtin_fmaf(t0[U + kk], wv, acc1);
-      acc2 = __builtin_fmaf(t0[2 * U + kk], wv, acc2);
-      acc3 = __builtin_fmaf(t0[3 * U + kk], wv, acc3);
+    for (int kk = 0; kk < U; kk += 4) {
+      const float4 x0 = *reinterpret_cast<const float4*>(t0 + kk), x1 = *reinterpret_cast<const float4*>(t0 + U + kk);
+      const float4 x2 = *reinterpret_cast<const float4*>(t0 + 2 * U + kk), x3 = *reinterpret_cast<const float4*>(t0 + 3 * U + kk);
+      const float w0 = wL[kk * Cout + co], w1 = wL[(kk + 1) * Cout + co], w2 = wL[(kk + 2) * Cout + co], w3 = wL[(kk + 3) * Cout + co];
+      acc0 = __builtin_fmaf(x0.x, w0, acc0); acc0 = __builtin_fmaf(x0.y, w1, acc0); acc0 = __builtin_fmaf(x0.z, w2, acc0); acc0 = __builtin_fmaf(x0.w, w3, acc0);
+      acc1 = __builtin_fmaf(x1.x, w0, acc1); acc1 = __builtin_fmaf(x1.y, w1, acc1); acc1 = __builtin_fmaf(x1.z, w2, acc1); acc1 = __builtin_fmaf(x1.w, w3, acc1);
+      acc2 = __builtin_fmaf(x2.x, w0, acc2); acc2 = __builtin_fmaf(x2.y, w1, acc2); acc2 = __builtin_fmaf(x2.z, w2, acc2); acc2 = __builtin_fmaf(x2.w, w3, acc2);
+      acc3 = __builtin_fmaf(x3.x, w0, acc3); acc3 = __builtin_fmaf(x3.y, w1, acc3); acc3 = __builtin_fmaf(x3.z, w2, acc3); acc3 = __builtin_fmaf(x3.w, w3, acc3);
     }
     const long long gp = gp0 + 4 * pq;
     if (gp < total) z[gp * Cout + co] = acc0;
@@ -101,12 +109,13 @@ extern "C" int pcnn_head_lowres_fwd(const float* score4, const float* score5, co
                                     const float* weights_t, int B, int h, int w, int units, int out_channels,
                                     int kernel, int stride, float* add_out, float* z, void* stream_)
 {
-  PCNN_REQUIRE(B >= 1 && h >= 1 && w >= 1 && units >= 1 && out_channels >= 1, PCNN_EINVAL, "head_lowres: bad shape");
+  PCNN_REQUIRE(B >= 1 && h >= 1 && w >= 1 && units >= 4 && units % 4 == 0 && out_channels >= 1, PCNN_EINVAL,
+               "head_lowres: bad shape (units must be a multiple of 4, got %d)", units);
   PCNN_REQUIRE(stride >= 1 && kernel >= stride && (kernel - stride) % 2 == 0 && kernel <= 2 * stride && h % stride == 0 && w % stride == 0,
                PCNN_EINVAL, "head_lowres: need stride <= kernel <= 2 stride, (kernel - stride) even, %dx%d divisible by the stride %d", h, w, stride);
   PCNN_REQUIRE(score4 && score5 && weights_t && add_out && z, PCNN_ENULL, "head_lowres: NULL pointer");
   const size_t lds = sizeof(float) * ((size_t)HL_PX * units + (size_t)units * out_channels);
-  PCNN_REQUIRE(lds <= 64 * 1024, PCNN_EINVAL, "head_lowres: %d units x %d outputs exceed the kernel's 64 KB of LDS", units, out_channels);
+  PCNN_REQUIRE(lds <= 60 * 1024, PCNN_EINVAL, "head_lowres: %d units x %d outputs exceed the kernel's 64 KB of LDS", units, out_channels);
   hipStream_t stream = (hipStream_t)stream_;
   const long long total = (long long)B * h * w;
   const long long blocks = (total + HL_PX - 1) / HL_PX;

@@ -167,6 +167,7 @@ class Network(object):
         self.rows_count = None        # device int32[1]: true row count of capacity-sized ROI rows fed to `fc` (or None)
         self.fc_skinny = True         # <= 32 capacity rows: fc6-8 on the weight-streaming kernel (csrc/fc_skinny.hip)
         self.small_heads = True       # 1/8-resolution head algebra (deconv + add + 1x1) in one launch (csrc/heads_small.hip)
+        self.small_heads_max_pixels = 2 * 60 * 80
 
     # ---- plumbing ------------------------------------------------------------------------------
     def setup(self):
@@ -946,6 +947,10 @@ class vgg16_convs(Network):
         a, b5 = self.layers.get(s4), self.layers.get(s5)
         if not (self.small_heads and self.fused_heads and isinstance(a, torch.Tensor) and isinstance(b5, torch.Tensor)
                 and a.is_cuda and a.dim() == 4 and a.shape[1] % 2 == 0 and a.shape[2] % 2 == 0
+                # a latency tool: one launch instead of five wins while the launch is what costs (1 frame: 54 vs 88 us for both
+                # heads); the product itself runs on the vector ALUs, and from a few frames on the library's MFMA 1x1
+                # convolution is faster (16 frames: 237 vs 165 us, tools/bench_heads_small.py)
+                and a.shape[0] * a.shape[1] * a.shape[2] <= self.small_heads_max_pixels
                 and (self.keep_prob_queue is None or float(self.keep_prob_queue) >= 1.0)
                 and (up_name + "/weights") not in self.vars
                 and not (torch.is_grad_enabled() and self.trainable)):
