@@ -416,6 +416,38 @@ int pcnn_smooth_l1_vertex_bwd(const float* pred, const float* target, const floa
                               float* grad_pred, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Depth-based pose refinement, first slice: the projective point-to-plane ICP that
+ * Synthesizer::refinePose runs per object (lib/synthesize/synthesize.cpp:2020-2026 -> df::icp,
+ * lib/kinect_fusion/src/optimization/icp.cpp:20-106 with the per-pixel kernel icp.cu:25-136), called from
+ * lib/fcn/test.py:1925-1933 through Synthesizer::solveICP. The OpenGL renderer that produces the predicted maps,
+ * the kd-tree hypothesis scoring and the nlopt stage of solveICP are outside this slice.
+ *
+ * pcnn_icp_backproject_fwd: synthesize.cpp:2139-2155 + df backproject (src/image/backprojection.cu:10-27, Poly3 camera
+ *   with k = 0): vertex_map[y][x] = ((x - px)/fx d, (y - py)/fy d, d), d = depth[y][x] / factor_depth where
+ *   label[y][x] == obj_id (label NULL: everywhere), else 0.   depth uint16 [H][W], label int32 [H][W] or NULL,
+ *   vertex_map f32 [H][W][3].
+ * pcnn_icp_refine_fwd: df::icp for num_objects independent problems in one call.
+ *   live_vertices f32 [N][H][W][3] (the backprojected, masked depth); pred_vertices / pred_normals f32
+ *   [N][H][W][pred_channels] (3 or 4 floats per pixel as the renderer's RGB(A) float textures; a predicted depth
+ *   outside [z_near, z_far] — the render's background — marks a pixel without model surface)
+ *   per iteration, per pixel (x, y) of the predicted maps: p = update * pred_vertex; (u, v) = round(project(p));
+ *   skipped unless 2 < u < W-3, 2 < v < H-3, live depth in range, -ray.normal >= 0.1, |n.(live - p)| <= max_error;
+ *   J = (1/live_z) [n^T | (p x n)^T], r = (1/live_z) n.(live - p); solve (sum J^T J) x = sum J^T r;
+ *   update = exp(x) * update.                 update f64 [N][12] (row-major 3x4, starts at the identity)
+ *   stats f32 [N][iterations][2] = (inliers, sum r^2) before each step, or NULL.
+ *   Reductions in a fixed order (256-pixel halving trees in f32, blocks ascending in f64), solve / exp in f64:
+ *   bit-identical to oracle_icp_refine. No host synchronisation between iterations.
+ * ------------------------------------------------------------------------------------------ */
+int pcnn_icp_backproject_fwd(const uint16_t* depth, const int32_t* label, int height, int width, int obj_id,
+                             float factor_depth, float fx, float fy, float px, float py, float* vertex_map,
+                             void* stream);
+int pcnn_icp_refine_workspace_bytes(int num_objects, int height, int width, size_t* bytes);
+int pcnn_icp_refine_fwd(const float* live_vertices, const float* pred_vertices, const float* pred_normals,
+                        int num_objects, int height, int width, int pred_channels, float fx, float fy, float px,
+                        float py, float z_near, float z_far, float max_error, int iterations, double* update,
+                        float* stats, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Kernel timing diagnostics (off by default; the reference's only instrumentation is the
  * wall-clock Timer of lib/utils/timer.py:10-32 around im_segment).
  * While enabled, every kernel launch of this library is bracketed by hipEventRecord on the launch

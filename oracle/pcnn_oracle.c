@@ -1143,3 +1143,200 @@ int oracle_hough_cpu_kernel(const int* label, const float* vertex, const float* 
   free(hs); free(dxs); free(dys);
   return rows;
 }
+
+/* ================================================================================================== */
+/* Depth-based pose refinement, first slice: the projective point-to-plane ICP core.   */
+/*                                                                                                      */
+/* Follows lib/kinect_fusion/src/optimization/icp.cu:25-136 (`icpKernel`: one Jacobian row + residual    */
+/* per pixel of the PREDICTED vertex / normal maps), lib/kinect_fusion/src/optimization/icp.cpp:20-106   */
+/* (`df::icp`: numIterations x { reduce J^T J / J^T r, LDLT solve, update = exp(solution),              */
+/* accumulated = update * accumulated }), include/df/optimization/linearSystems.h:181-203 (the sum),     */
+/* include/df/camera/poly3.h (projection with k1 = k2 = k3 = 0, as lib/synthesize/synthesize.cpp:2060-  */
+/* 2069 builds the model) and the masked depth -> vertex-map step of Synthesizer::solveICP               */
+/* (lib/synthesize/synthesize.cpp:2139-2155 + src/image/backprojection.cu:10-27). Called from            */
+/* Synthesizer::refinePose (synthesize.cpp:2020-2026), i.e. lib/fcn/test.py:1925-1933.                   */
+/*                                                                                                      */
+/* PARITY UNPINNED: df::icp needs Eigen, Sophus, thrust and CUDA (none present) and the reference holds  */
+/* no test vectors for it. The restatement is anchored statement by statement on icpKernel and pinned    */
+/* only by hand-derived known answers (tests/test_icp.py). Canonical choices where the reference is      */
+/* unspecified or order dependent:                                                                      */
+/*   - thrust::transform_reduce has no defined order -> pixels in raster order in blocks of 256, a        */
+/*     halving tree (i += i + 128, 64, ... 1) in f32 inside a block, blocks added in ascending order in   */
+/*     f64;                                                                                             */
+/*   - the 6x6 solve and the pose bookkeeping are float in the reference (Eigen LDLT with pivoting,       */
+/*     Sophus::SE3f): here LDL^T without pivoting, exp and the accumulated update in f64, with sin/cos    */
+/*     replaced by fixed 10-term Taylor polynomials in theta^2 (pure + and *: identical bits on every     */
+/*     IEEE machine); the kernel sees the accumulated update rounded to f32 like an SE3f;                */
+/*   - a singular system (no inlier) leaves the update unchanged.                                       */
+/* ================================================================================================== */
+#define ICP_BLOCK 256
+#define ICP_NSUM 29 /* 21 upper-triangular J^T J (row-major), 6 J^T r, inlier count, sum r^2 */
+
+/* solveICP :2139-2155 (depth of the object's pixels, 0 elsewhere) + backprojectKernel + Poly3 unproject, k = 0 */
+int oracle_icp_backproject(const uint16_t* depth, const int* label, int H, int W, int obj_id, float factor,
+                           float fx, float fy, float px, float py, float* vertex_map)
+{
+  for (int y = 0; y < H; y++)
+    for (int x = 0; x < W; x++) {
+      const long i = (long)y * W + x;
+      const float d = (label == NULL || label[i] == obj_id) ? (float)depth[i] / factor : 0.f;
+      vertex_map[3 * i + 0] = ((float)x - px) / fx * d;
+      vertex_map[3 * i + 1] = ((float)y - py) / fy * d;
+      vertex_map[3 * i + 2] = d;
+    }
+  return 0;
+}
+
+/* icpKernel :25-136 for one pixel; returns 1 and fills J[6], r when the pixel contributes */
+static int icp_pixel(const float* live, const float* pv, const float* pn, int W, int H, const float* T /* [12] */,
+                     float fx, float fy, float px, float py, float znear, float zfar, float max_error, float* J, float* r)
+{
+  const float border = 2.f, ray_norm_dot_threshold = 0.1f;
+  const float pdepth = pv[2];
+  if (!(pdepth >= znear) || pdepth > zfar) return 0;                 /* :60 (NaN background of the render: skipped) */
+  const float ux = ((T[0] * pv[0] + T[1] * pv[1]) + T[2] * pv[2]) + T[3];
+  const float uy = ((T[4] * pv[0] + T[5] * pv[1]) + T[6] * pv[2]) + T[7];
+  const float uz = ((T[8] * pv[0] + T[9] * pv[1]) + T[10] * pv[2]) + T[11];   /* :67 */
+  const float projx = ux / uz * fx + px, projy = uy / uz * fy + py;           /* :69, poly3.h project with k = 0 */
+  if (!(projx == projx) || !(projy == projy) || fabsf(projx) > 1e8f || fabsf(projy) > 1e8f) return 0;   /* (int conversion of NaN / huge values is UB) */
+  const int u = (int)(projx + 0.5f), v = (int)(projy + 0.5f);                  /* :78-79 */
+  if (((float)u <= border) || ((float)u >= (float)(W - 1) - border) || ((float)v <= border) || ((float)v >= (float)(H - 1) - border)) return 0;   /* :81 */
+  const float* lv = live + 3 * ((long)v * W + u);
+  const float ldepth = lv[2];
+  if (!(ldepth >= znear) || ldepth > zfar) return 0;                 /* :92 */
+  const float nrm = sqrtf((ux * ux + uy * uy) + uz * uz);
+  const float rx = ux / nrm, ry = uy / nrm, rz = uz / nrm;          /* :100 */
+  const float dotrn = (rx * pn[0] + ry * pn[1]) + rz * pn[2];
+  if (!(-dotrn >= ray_norm_dot_threshold)) return 0;                 /* :104 */
+  const float ex = lv[0] - ux, ey = lv[1] - uy, ez = lv[2] - uz;
+  const float error = (pn[0] * ex + pn[1] * ey) + pn[2] * ez;        /* :111 */
+  if (!(fabsf(error) <= max_error)) return 0;                        /* :115 */
+  const float w = 1.f / ldepth;                                      /* :122 */
+  const float wx = w * pn[0], wy = w * pn[1], wz = w * pn[2];        /* weightSqrt * n^T, then x [I | -[p]x] (:124-130) */
+  J[0] = wx; J[1] = wy; J[2] = wz;
+  J[3] = wy * (-uz) + wz * uy;
+  J[4] = wx * uz + wz * (-ux);
+  J[5] = wx * (-uy) + wy * ux;
+  *r = w * error;
+  return 1;
+}
+
+static void icp_exp_se3(const double* xi, double* U /* [12] */)
+{
+  /* Sophus::SE3::exp: xi = (upsilon, omega); R = I + A W + B W^2, t = (I + B W + C W^2) upsilon,
+     A = sin(th)/th, B = (1 - cos th)/th^2, C = (th - sin th)/th^3 as 10-term Taylor series in th^2 (Horner) */
+  const double wx = xi[3], wy = xi[4], wz = xi[5];
+  const double t2 = (wx * wx + wy * wy) + wz * wz;
+  static const double fa[10] = {1.0, 6.0, 120.0, 5040.0, 362880.0, 39916800.0, 6227020800.0, 1307674368000.0, 355687428096000.0, 121645100408832000.0};              /* (2k+1)! */
+  static const double fb[10] = {2.0, 24.0, 720.0, 40320.0, 3628800.0, 479001600.0, 87178291200.0, 20922789888000.0, 6402373705728000.0, 2432902008176640000.0};        /* (2k+2)! */
+  static const double fc[10] = {6.0, 120.0, 5040.0, 362880.0, 39916800.0, 6227020800.0, 1307674368000.0, 355687428096000.0, 121645100408832000.0, 51090942171709440000.0}; /* (2k+3)! */
+  double A = 0, B = 0, C = 0;
+  for (int k = 9; k >= 0; k--) {
+    const double s = (k & 1) ? -1.0 : 1.0;
+    A = A * t2 + s / fa[k];
+    B = B * t2 + s / fb[k];
+    C = C * t2 + s / fc[k];
+  }
+  const double Wm[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+  double W2[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) W2[3 * i + j] = (Wm[3 * i] * Wm[j] + Wm[3 * i + 1] * Wm[3 + j]) + Wm[3 * i + 2] * Wm[6 + j];
+  for (int i = 0; i < 3; i++) {
+    double t = 0;
+    for (int j = 0; j < 3; j++) {
+      const double id = i == j ? 1.0 : 0.0;
+      U[4 * i + j] = (id + A * Wm[3 * i + j]) + B * W2[3 * i + j];
+      const double V = (id + B * Wm[3 * i + j]) + C * W2[3 * i + j];
+      t = t + V * xi[j];
+    }
+    U[4 * i + 3] = t;
+  }
+}
+
+/* one Gauss-Newton solve + pose bookkeeping (icp.cpp:58-100); returns 0 when the system is singular */
+static int icp_solve_update(const double* S /* [ICP_NSUM] */, double* T /* [12], in/out */)
+{
+  double A[6][6], b[6], L[6][6], d[6], y[6], x[6];
+  int q = 0;
+  for (int i = 0; i < 6; i++)
+    for (int j = i; j < 6; j++) { A[i][j] = A[j][i] = S[q]; q++; }
+  for (int i = 0; i < 6; i++) b[i] = S[21 + i];
+  for (int j = 0; j < 6; j++) {
+    double dj = A[j][j];
+    for (int k = 0; k < j; k++) dj = dj - (L[j][k] * L[j][k]) * d[k];
+    if (!(dj > 1e-300) || !(dj < 1e300)) return 0;
+    d[j] = dj;
+    for (int i = j + 1; i < 6; i++) {
+      double v = A[i][j];
+      for (int k = 0; k < j; k++) v = v - (L[i][k] * L[j][k]) * d[k];
+      L[i][j] = v / dj;
+    }
+  }
+  for (int i = 0; i < 6; i++) { double v = b[i]; for (int k = 0; k < i; k++) v = v - L[i][k] * y[k]; y[i] = v; }
+  for (int i = 0; i < 6; i++) y[i] = y[i] / d[i];
+  for (int i = 5; i >= 0; i--) { double v = y[i]; for (int k = i + 1; k < 6; k++) v = v - L[k][i] * x[k]; x[i] = v; }
+  double U[12], N[12];
+  icp_exp_se3(x, U);
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) N[4 * i + j] = (U[4 * i] * T[j] + U[4 * i + 1] * T[4 + j]) + U[4 * i + 2] * T[8 + j];
+    N[4 * i + 3] = ((U[4 * i] * T[3] + U[4 * i + 1] * T[7]) + U[4 * i + 2] * T[11]) + U[4 * i + 3];
+  }
+  memcpy(T, N, sizeof(N));
+  return 1;
+}
+
+/* df::icp for N independent (live, predicted) map triples. pred_* have `pc` (3 or 4) floats per pixel.
+   update_out [N][12] f64 (row-major 3x4 accumulated update), stats_out [N][iterations][2] f32 (inliers, sum r^2) or NULL */
+int oracle_icp_refine(const float* live, const float* pred_v, const float* pred_n, int N, int H, int W, int pc,
+                      float fx, float fy, float px, float py, float znear, float zfar, float max_error,
+                      int iterations, double* update_out, float* stats_out)
+{
+  const long P = (long)H * W;
+  const long nblocks = (P + ICP_BLOCK - 1) / ICP_BLOCK;
+  float* buf = (float*)malloc(sizeof(float) * ICP_NSUM * ICP_BLOCK);
+  if (!buf) return -1;
+  for (int n = 0; n < N; n++) {
+    double T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    const float* lv = live + 3 * P * n;
+    const float* pv = pred_v + (long)pc * P * n;
+    const float* pn = pred_n + (long)pc * P * n;
+    for (int it = 0; it < iterations; it++) {
+      float Tf[12];
+      for (int i = 0; i < 12; i++) Tf[i] = (float)T[i];
+      double S[ICP_NSUM];
+      for (int q = 0; q < ICP_NSUM; q++) S[q] = 0.0;
+      for (long b = 0; b < nblocks; b++) {
+        int any = 0;
+        memset(buf, 0, sizeof(float) * ICP_NSUM * ICP_BLOCK);
+        for (int t = 0; t < ICP_BLOCK; t++) {
+          const long p = b * ICP_BLOCK + t;
+          if (p >= P) break;
+          float J[6], r;
+          if (!icp_pixel(lv, pv + pc * p, pn + pc * p, W, H, Tf, fx, fy, px, py, znear, zfar, max_error, J, &r)) continue;
+          any = 1;
+          int q = 0;
+          for (int i = 0; i < 6; i++)
+            for (int j = i; j < 6; j++) buf[(q++) * ICP_BLOCK + t] = J[i] * J[j];
+          for (int i = 0; i < 6; i++) buf[(21 + i) * ICP_BLOCK + t] = J[i] * r;
+          buf[27 * ICP_BLOCK + t] = 1.f;
+          buf[28 * ICP_BLOCK + t] = r * r;
+        }
+        if (!any) continue;   /* all zeros: adds nothing */
+        for (int q = 0; q < ICP_NSUM; q++) {
+          float* a = buf + q * ICP_BLOCK;
+          for (int s = ICP_BLOCK / 2; s >= 1; s >>= 1)
+            for (int t = 0; t < s; t++) a[t] = a[t] + a[t + s];
+          S[q] = S[q] + (double)a[0];
+        }
+      }
+      if (stats_out) {
+        stats_out[((long)n * iterations + it) * 2 + 0] = (float)S[27];
+        stats_out[((long)n * iterations + it) * 2 + 1] = (float)S[28];
+      }
+      icp_solve_update(S, T);
+    }
+    memcpy(update_out + 12 * n, T, sizeof(T));
+  }
+  free(buf);
+  return 0;
+}

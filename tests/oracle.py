@@ -241,3 +241,31 @@ def upscore_softmax_argmax(z, bias, k, s, relu=True):
     score = deconv_bilinear(z, k, s, bias=bias, relu=relu)
     prob, label = softmax_argmax(score)
     return score, prob, label
+
+
+# ---- depth-based pose refinement ---------------------------------------------------------------
+def icp_backproject(depth, label, obj_id, K, factor):
+    depth = np.ascontiguousarray(depth, dtype=np.uint16)
+    H, W = depth.shape
+    lab = None if label is None else _i32(label)
+    out = np.empty((H, W, 3), np.float32)
+    L = lib()
+    L.oracle_icp_backproject.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_void_p]
+    L.oracle_icp_backproject(_p(depth), _p(lab), H, W, int(obj_id), float(factor), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), _p(out))
+    return out
+
+
+def icp_refine(live, pred_v, pred_n, K, depth_range=(0.25, 6.0), max_error=0.01, iterations=8):
+    """oracle_icp_refine: live [N,H,W,3], pred_* [N,H,W,3|4] -> (update f64 [N,3,4], stats f32 [N,iterations,2])"""
+    live, pred_v, pred_n = _f32(live), _f32(pred_v), _f32(pred_n)
+    N, H, W, _ = live.shape
+    pc = pred_v.shape[3]
+    upd = np.empty((N, 3, 4), np.float64)
+    stats = np.zeros((N, max(iterations, 1), 2), np.float32)
+    L = lib()
+    L.oracle_icp_refine.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float,
+                                    c_float, c_float, c_float, c_int, c_void_p, c_void_p]
+    rc = L.oracle_icp_refine(_p(live), _p(pred_v), _p(pred_n), N, H, W, pc, float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]),
+                             float(depth_range[0]), float(depth_range[1]), float(max_error), int(iterations), _p(upd), _p(stats))
+    assert rc == 0
+    return upd, stats
