@@ -1167,7 +1167,7 @@ int oracle_hough_cpu_kernel(const int* label, const float* vertex, const float* 
 /*     Sophus::SE3f): here LDL^T without pivoting, exp and the accumulated update in f64, with sin/cos    */
 /*     replaced by fixed 10-term Taylor polynomials in theta^2 (pure + and *: identical bits on every     */
 /*     IEEE machine); the kernel sees the accumulated update rounded to f32 like an SE3f;                */
-/*   - a singular system (no inlier) leaves the update unchanged.                                       */
+/*   - a pivot that is not clearly positive drops its variable (no inlier at all: the update is unchanged). */
 /* ================================================================================================== */
 #define ICP_BLOCK 256
 #define ICP_NSUM 29 /* 21 upper-triangular J^T J (row-major), 6 J^T r, inlier count, sum r^2 */
@@ -1253,7 +1253,7 @@ static void icp_exp_se3(const double* xi, double* U /* [12] */)
   }
 }
 
-/* one Gauss-Newton solve + pose bookkeeping (icp.cpp:58-100); returns 0 when the system is singular */
+/* one Gauss-Newton solve + pose bookkeeping (icp.cpp:58-100) */
 static int icp_solve_update(const double* S /* [ICP_NSUM] */, double* T /* [12], in/out */)
 {
   double A[6][6], b[6], L[6][6], d[6], y[6], x[6];
@@ -1261,19 +1261,27 @@ static int icp_solve_update(const double* S /* [ICP_NSUM] */, double* T /* [12],
   for (int i = 0; i < 6; i++)
     for (int j = i; j < 6; j++) { A[i][j] = A[j][i] = S[q]; q++; }
   for (int i = 0; i < 6; i++) b[i] = S[21 + i];
+  /* LDL^T without pivoting. A pivot that is not clearly positive (below 1e-10 of the largest diagonal entry: a direction
+     the visible surface does not constrain — e.g. sliding along the only two faces in view — or no inlier at all) is
+     dropped: that variable stays 0 instead of the solve blowing up (Eigen's pivoted LDLT of the reference does the
+     equivalent for a rank-deficient system). */
+  double maxdiag = 0.0;
+  int skip[6];
+  for (int i = 0; i < 6; i++) if (A[i][i] > maxdiag) maxdiag = A[i][i];
+  const double tol = 1e-10 * maxdiag;
   for (int j = 0; j < 6; j++) {
     double dj = A[j][j];
     for (int k = 0; k < j; k++) dj = dj - (L[j][k] * L[j][k]) * d[k];
-    if (!(dj > 1e-300) || !(dj < 1e300)) return 0;
-    d[j] = dj;
+    skip[j] = !(dj > tol) || !(dj < 1e300);
+    d[j] = skip[j] ? 0.0 : dj;
     for (int i = j + 1; i < 6; i++) {
       double v = A[i][j];
       for (int k = 0; k < j; k++) v = v - (L[i][k] * L[j][k]) * d[k];
-      L[i][j] = v / dj;
+      L[i][j] = skip[j] ? 0.0 : v / dj;
     }
   }
   for (int i = 0; i < 6; i++) { double v = b[i]; for (int k = 0; k < i; k++) v = v - L[i][k] * y[k]; y[i] = v; }
-  for (int i = 0; i < 6; i++) y[i] = y[i] / d[i];
+  for (int i = 0; i < 6; i++) y[i] = skip[i] ? 0.0 : y[i] / d[i];
   for (int i = 5; i >= 0; i--) { double v = y[i]; for (int k = i + 1; k < 6; k++) v = v - L[k][i] * x[k]; x[i] = v; }
   double U[12], N[12];
   icp_exp_se3(x, U);

@@ -191,19 +191,25 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(
   for (int i = 0; i < 6; i++)
     for (int j = i; j < 6; j++) { A[i][j] = A[j][i] = S[q]; q++; }
   for (int i = 0; i < 6; i++) b[i] = S[21 + i];
+  // LDL^T without pivoting; a pivot below 1e-10 of the largest diagonal entry (an unconstrained direction, or no
+  // inlier at all) is dropped: that variable stays 0 (see oracle/pcnn_oracle.c)
+  double maxdiag = 0.0;
+  int skip[6];
+  for (int i = 0; i < 6; i++) if (A[i][i] > maxdiag) maxdiag = A[i][i];
+  const double tol = 1e-10 * maxdiag;
   for (int j = 0; j < 6; j++) {
     double dj = A[j][j];
     for (int k = 0; k < j; k++) dj = dj - (L[j][k] * L[j][k]) * d[k];
-    if (!(dj > 1e-300) || !(dj < 1e300)) return;   // singular (no inlier): the update stays as it is
-    d[j] = dj;
+    skip[j] = !(dj > tol) || !(dj < 1e300);
+    d[j] = skip[j] ? 0.0 : dj;
     for (int i = j + 1; i < 6; i++) {
       double v = A[i][j];
       for (int k = 0; k < j; k++) v = v - (L[i][k] * L[j][k]) * d[k];
-      L[i][j] = v / dj;
+      L[i][j] = skip[j] ? 0.0 : v / dj;
     }
   }
   for (int i = 0; i < 6; i++) { double v = b[i]; for (int k = 0; k < i; k++) v = v - L[i][k] * y[k]; y[i] = v; }
-  for (int i = 0; i < 6; i++) y[i] = y[i] / d[i];
+  for (int i = 0; i < 6; i++) y[i] = skip[i] ? 0.0 : y[i] / d[i];
   for (int i = 5; i >= 0; i--) { double v = y[i]; for (int k = i + 1; k < 6; k++) v = v - L[k][i] * x[k]; x[i] = v; }
   double U[12], Nn[12];
   double* T = state + 12 * n;

@@ -108,7 +108,7 @@ def test_refine_poses_driver(gpu):
     H, W = 240, 320
     K = config.DEMO_INTRINSICS.copy(); K[:2] *= W / 640.0
     half = {3: (0.09, 0.07, 0.05), 5: (0.05, 0.05, 0.08)}
-    T_true = {3: S.pose(S.rot([0.3, 1, 0.2], 0.7), [-0.08, 0.02, 0.7]), 5: S.pose(S.rot([1, 0.2, 0.4], 1.1), [0.1, -0.03, 0.8])}
+    T_true = {3: S.pose(S.rot([0.3, 1, 0.2], 0.7), [-0.08, 0.02, 0.7]), 5: S.pose(S.rot([0.3, 1, 0.2], 0.9), [0.1, -0.03, 0.8])}     # (three faces in view each: a well-posed problem)
     depth = np.zeros((H, W), np.uint16); label = np.zeros((H, W), np.int32)
     for cls in (3, 5):
         v, _, hit = S.render_box(T_true[cls], half[cls], K, H, W)
