@@ -481,8 +481,9 @@ int wino43_cin_split(long long nbt, int ncb, int Cin)
   // Measured round 3 on one frame (tools/bench_wino_mfma.py --batch 1 --groups 1, conv4_2: 80 workgroups of 288 stages):
   // S = 1 186 us, 2 111, 4 107, 8 129 (the reduction reads S partial outputs); conv3_x (152 workgroups) 104 us split or
   // not. A 6-deep LDS ring (prefetch distance 5, one workgroup per CU) made every small launch SLOWER (conv4_2 107 -> 126,
-  // conv5_x 66 -> 82): a lone workgroup keeps its MFMA pipe ~65 % busy whatever the prefetch depth — what a small launch
-  // lacks is a second workgroup per CU, not operand cover.
+  // conv5_x 66 -> 82), and with one workgroup per CU ring depths 3 / 4 / 5 time the same (conv4_2, S = 1: 184 / 186 / 188 us;
+  // S = 2: 111 / 114 / 113): a lone workgroup keeps its MFMA pipe ~65 % busy whatever the prefetch depth — what a small
+  // launch lacks is a second workgroup per CU, not operand cover.
   if (nbt * ncb >= 128) return 1;   // (152 workgroups — batch-1 conv3_x — measured slower split in two: the partials cost more than they buy)
   while (S < 8 && nbt * ncb * S * 2 <= 512 && NK % (2 * S) == 0) S *= 2;
   return S;
