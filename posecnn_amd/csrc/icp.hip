@@ -17,8 +17,8 @@
 //   icp_solve_kernel   one wave per object: partial rows added in ascending block order in f64 (29 lanes, coalesced),
 //                      LDL^T solve, update = exp(solution), accumulated = update * accumulated — all in f64 by lane 0;
 //                      the state stays in the workspace, the next iteration's terms kernel reads it from there.
-// Arithmetic is the canonical restatement of oracle/pcnn_oracle.c (same expression trees, same reduction order, sin/cos
-// replaced by fixed Taylor polynomials), so the result is bit-identical to the oracle.
+// Arithmetic follows the canonical statement the CPU checker implements as well (same expression trees, same reduction
+// order, sin/cos replaced by fixed Taylor polynomials), so the result is bit-identical to it (tests/test_gpu_icp.py).
 #include <algorithm>
 
 #include "pcnn_device.h"
@@ -192,7 +192,8 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(
     for (int j = i; j < 6; j++) { A[i][j] = A[j][i] = S[q]; q++; }
   for (int i = 0; i < 6; i++) b[i] = S[21 + i];
   // LDL^T without pivoting; a pivot below 1e-10 of the largest diagonal entry (an unconstrained direction, or no
-  // inlier at all) is dropped: that variable stays 0 (see oracle/pcnn_oracle.c)
+  // inlier at all) is dropped: that variable stays 0 instead of the solve blowing up
+  // (Eigen's pivoted LDLT of the reference does the equivalent for a rank-deficient system)
   double maxdiag = 0.0;
   int skip[6];
   for (int i = 0; i < 6; i++) if (A[i][i] > maxdiag) maxdiag = A[i][i];

@@ -37,13 +37,13 @@ def test_respawn_command_shape():
 
 
 def test_gpus2_self_spawns_two_ranks_and_gathers_on_gloo():
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--streams", "2"],
                        env=_env(), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     out = _json_line(r.stdout)
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["process_group"] is True
     assert out["detections_gathered_per_step"] == 6   # 3 rows from each of the 2 ranks
-    assert out["ranks_seen"] == 2 and out["batches_in_flight"] == 2   # --streams 2 (default): two collectives in flight, same order on every rank
+    assert out["ranks_seen"] == 2 and out["batches_in_flight"] == 2   # --streams 2: two collectives in flight, issued in the same order on every rank
 
 
 def test_gpus2_single_lane_and_three_lanes():
