@@ -470,7 +470,7 @@ def main(argv=None):
     # HBM traffic of the kernel from PMC counters: collected offline in separate --pmc passes (they
     # cannot share a run with the timed region) at this same workload; see profiles/README.md
     traffic, traffic_src = None, None
-    for name in ("r02_hough_pmc.json", "r01_hough_pmc.json"):
+    for name in ("r03_hough_pmc.json", "r02_hough_pmc.json", "r01_hough_pmc.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             ent = pmc.get(vote_name) or pmc.get("hv_vote_kernel")
@@ -560,6 +560,9 @@ def main(argv=None):
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": hv["avg_us"], "launches": hv["calls"],
                      "note": "Hough voting is VALU/LDS bound, not HBM bound (SURVEY.md §8d): compulsory traffic is ~2 MB/frame",
                      "hough_sequence_us": hough_us, "hough_GBps_whole_sequence": alg_bytes / (hough_us * 1e-6) / 1e9 if hough_us else None,
+                     "frac_whole_sequence": alg_bytes / (hough_us * 1e-6) / 1e9 / HBM_PEAK_GBPS if hough_us else None,
+                     "sequence_note": "SURVEY.md §8d defines the Hough-vote rate over the whole launch sequence (hist + scatter + vote + select + emit); "
+                                      "`frac` above is the vote kernel alone",
                      "pair_predicates_equiv_per_launch": pairs,
                      "pair_predicates_equiv_per_s": pairs / (hv["avg_us"] * 1e-6) if hv["calls"] else None},
         "roofline_other": others,

@@ -11,8 +11,9 @@
 //   hv_scatter  deterministic ranks (ascending pixel index, as a serial run of
 //               compute_arrays_kernel :174-187 would produce) from histogram prefixes + wave
 //               ballots; every skip-th pixel of each class that passes label_threshold becomes a
-//               32-byte record {x, y, thr(d), 1/|uv|, u, v, |uv|, d}: everything the inner loop
-//               of compute_hough_kernel :269-285 recomputes per (cell, pixel) pair, hoisted.
+//               48-byte record {x, y, thr(d), 1/|uv| ; u, v, |uv|, d ; ra, rb, g, mode}: everything the
+//               inner loop of compute_hough_kernel :269-285 recomputes per (cell, pixel) pair, hoisted,
+//               plus the two interval roots and the mode of the pixel's vote cone.
 //   hv_vote     interval formulation on bands of 4 Hough rows (two waves per row): the records that can
 //               reach a band are a contiguous range of the class' y-sorted list (64-ary search);
 //               a record's vote cone cut by a row is one dx-interval -> +1 / -1 in the row's LDS
