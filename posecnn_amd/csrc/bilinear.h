@@ -40,6 +40,25 @@ __device__ __forceinline__ Taps make_taps(int o, int k, int s, int pad, int n_in
   return T;
 }
 
+// make_taps with the k tap values bilinear_tap(t, k), t = 0 .. k-1, read from a table (LDS) instead of being evaluated in
+// double precision per call: same integers, same f32 weights.
+__device__ __forceinline__ Taps make_taps_tab(int o, int k, int s, int pad, int n_in, const float* tab)
+{
+  Taps T;
+  const int a = o + pad;
+  int lo = (a - k + 1 + s - 1) / s;
+  if (a - k + 1 < 0) lo = -((k - 1 - a) / s);
+  int hi = a / s;
+  if (lo < 0) lo = 0;
+  if (hi > n_in - 1) hi = n_in - 1;
+  T.i0 = lo;
+  T.n = hi - lo + 1;
+  if (T.n < 0) T.n = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) T.w[j] = j < T.n ? tab[a - s * (lo + j)] : 0.f;
+  return T;
+}
+
 // One output element of deconv(in)[+ bias] for channel c at output pixel (oy, ox); `inb` points at
 // the image's [H, W, C] low-resolution plane. Same arithmetic as deconv_bilinear_kernel.
 __device__ __forceinline__ float bilinear_at(const float* __restrict__ inb, const Taps& ty,

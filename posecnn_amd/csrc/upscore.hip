@@ -348,6 +348,175 @@ __global__ __launch_bounds__(UP_SEG) void upscore_softmax_argmax_kernel(
   }
 }
 
+// ---- the same epilogue for a class count known at compile time (even: 22 YCB-Video, 14 / 16 LINEMOD) --------------
+// The generic kernel above guards every channel operation with `c < C` and indexes its score array in a runtime loop
+// (the 22 divisions ran out of scratch memory): 2 223 VALU instructions per pixel, VALU-bound at 0.22 of the HBM rate.
+// With C a template parameter everything unrolls, the scores stay in registers as float2 pairs, LDS is read 8 bytes at
+// a time and the interpolation, the bias add and the exponential's polynomial are packed-f32 instructions
+// (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per instruction, no contraction). Same expression trees, same
+// order, same bits as the generic kernel and the CPU checker. Measured (16 frames, tools/bench_ops.py --ops upscore;
+// counters tools/pmc_label_head.sh): 2 223 -> 1 188 VALU instructions per pixel-wave changed NOTHING (258 us) — nor did
+// replacing the per-thread double-precision tap evaluation by a 16-entry LDS table; what did (258 -> 228 us) was
+// unrolling the tap loops so that the tap arrays are not indexed dynamically: they had been living in scratch memory
+// (52 bytes per lane), a chain of private-segment loads in front of every pixel. Now 36 % of the wave cycles sit in
+// s_waitcnt and 34 % wait for issue with 5.5 waves per SIMD (LDS-limited): latency-bound at 0.25 of the HBM rate.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// exp_softmax_f32 (pcnn_device.h) on two values at once; branch-free: the sub-normal scaling step multiplies by 1.0f
+// where it does not apply (exact), a NaN argument is passed through by a final select
+__device__ __forceinline__ f2 exp_softmax_f32x2(f2 x0)
+{
+  f2 x;
+  x.x = fminf(fmaxf(x0.x, -104.f), 88.f);
+  x.y = fminf(fmaxf(x0.y, -104.f), 88.f);
+  const f2 t = x * 1.44269502f;
+  f2 kf;
+  kf.x = __builtin_rintf(t.x);
+  kf.y = __builtin_rintf(t.y);
+  f2 r = x - kf * 0.693145752f;
+  r = r - kf * 1.42860677e-06f;
+  f2 p = (f2){1.98412698e-04f, 1.98412698e-04f};
+  p = p * r + 1.38888889e-03f;
+  p = p * r + 8.33333377e-03f;
+  p = p * r + 4.16666679e-02f;
+  p = p * r + 1.66666672e-01f;
+  p = p * r + 0.5f;
+  p = p * r + 1.0f;
+  p = p * r + 1.0f;
+  const int k0 = (int)kf.x, k1 = (int)kf.y;
+  const bool s0 = k0 < -126, s1 = k1 < -126;
+  f2 sc, m2;
+  sc.x = __int_as_float((k0 + (s0 ? 64 + 127 : 127)) << 23);
+  sc.y = __int_as_float((k1 + (s1 ? 64 + 127 : 127)) << 23);
+  m2.x = s0 ? 5.42101086e-20f : 1.0f;   // 2^-64
+  m2.y = s1 ? 5.42101086e-20f : 1.0f;
+  f2 y = (p * sc) * m2;
+  if (x0.x != x0.x) y.x = x0.x;
+  if (x0.y != x0.y) y.y = x0.y;
+  return y;
+}
+
+template <int C>
+__global__ __launch_bounds__(UP_SEG) void upscore_softmax_argmax_fixed_kernel(
+    const float* __restrict__ z, const float* __restrict__ bias, float* __restrict__ score_out,
+    float* __restrict__ prob, int* __restrict__ label, int H, int W, int k, int s, int relu, int nseg, int s_out_off)
+{
+  static_assert(C % 2 == 0 && C >= 2, "even class counts");
+  constexpr int C2 = C / 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int pad = (k - s) / 2;
+  const int Ho = H * s, Wo = W * s;
+  const int seg = blockIdx.x % nseg;
+  const int oy = (blockIdx.x / nseg) % Ho;
+  const int b = blockIdx.x / (nseg * Ho);
+  const int ox0 = seg * UP_SEG;
+  const int npx = min(UP_SEG, Wo - ox0);
+  const int tid = threadIdx.x;
+
+  // the k tap weights once per workgroup (evaluated in double like make_deconv_filter), then integer arithmetic + lookups
+  __shared__ float s_tab[64];
+  if (tid < k) s_tab[tid] = bilinear_tap(tid, k);
+  __syncthreads();
+  const Taps ty = make_taps_tab(oy, k, s, pad, H, s_tab);
+  const Taps tfirst = make_taps_tab(ox0, k, s, pad, W, s_tab);
+  const Taps tlast = make_taps_tab(ox0 + npx - 1, k, s, pad, W, s_tab);
+  const int cx0 = tfirst.i0;
+  const int ncx = tlast.i0 + (tlast.n > 0 ? tlast.n : 1) - cx0;
+  float* s_z = smem;                       // [ty.n][ncx][C]
+  float* s_out = smem + s_out_off;         // [UP_SEG][C]
+  const int rowlen = ncx * C;              // even: copied as float2
+#pragma unroll
+  for (int ry = 0; ry < 4; ry++)
+    if (ry < ty.n) {
+      const f2* src = reinterpret_cast<const f2*>(z + (((long long)b * H + ty.i0 + ry) * W + cx0) * C);
+      f2* dst = reinterpret_cast<f2*>(s_z + ry * rowlen);
+      for (int i = tid; i < rowlen / 2; i += UP_SEG) dst[i] = src[i];
+    }
+  __syncthreads();
+
+  const int ox = ox0 + tid;
+  f2 e[C2];
+  int best = 0;
+  if (tid < npx) {
+    const Taps tx = make_taps_tab(ox, k, s, pad, W, s_tab);
+#pragma unroll
+    for (int c = 0; c < C2; c++) e[c] = (f2){0.f, 0.f};
+    // (unrolled over the <= 4 x 4 taps with guards: runtime loop bounds would index the tap arrays dynamically, which
+    //  puts them in scratch memory — a chain of ~1 us private-segment loads in front of every pixel)
+#pragma unroll
+    for (int jy = 0; jy < 4; jy++)
+      if (jy < ty.n) {
+#pragma unroll
+        for (int jx = 0; jx < 4; jx++)
+          if (jx < tx.n) {
+            const float w = ty.w[jy] * tx.w[jx];
+            const f2* zc = reinterpret_cast<const f2*>(s_z + (jy * ncx + (tx.i0 + jx - cx0)) * C);
+#pragma unroll
+            for (int c = 0; c < C2; c++) e[c] = e[c] + w * zc[c];
+          }
+      }
+    const f2* b2 = reinterpret_cast<const f2*>(bias);
+#pragma unroll
+    for (int c = 0; c < C2; c++) {
+      f2 v = e[c] + b2[c];
+      if (relu) {
+        v.x = v.x > 0.f ? v.x : 0.f;
+        v.y = v.y > 0.f ? v.y : 0.f;
+      }
+      e[c] = v;
+    }
+  }
+  if (score_out) {
+    if (tid < npx) {
+      f2* so = reinterpret_cast<f2*>(s_out + tid * C);
+#pragma unroll
+      for (int c = 0; c < C2; c++) so[c] = e[c];
+    }
+    __syncthreads();
+    float* o = score_out + (((long long)b * Ho + oy) * Wo + ox0) * C;
+    for (int i = tid; i < npx * C; i += UP_SEG) o[i] = s_out[i];
+    __syncthreads();
+  }
+  if (tid < npx) {
+    float m = e[0].x;
+#pragma unroll
+    for (int c = 0; c < C2; c++) { m = fmaxf(m, e[c].x); m = fmaxf(m, e[c].y); }
+    float sum = 0.f;
+    const f2 m2 = (f2){m, m};
+#pragma unroll
+    for (int c = 0; c < C2; c++) {
+      e[c] = exp_softmax_f32x2(e[c] - m2);
+      sum += e[c].x;
+      sum += e[c].y;
+    }
+    float bestp = div_rn(e[0].x, sum);
+#pragma unroll
+    for (int c = 0; c < C2; c++) {
+      const float p0 = div_rn(e[c].x, sum), p1 = div_rn(e[c].y, sum);
+      e[c] = (f2){p0, p1};
+      if (p0 > bestp) { bestp = p0; best = 2 * c; }
+      if (p1 > bestp) { bestp = p1; best = 2 * c + 1; }
+    }
+    label[((long long)b * Ho + oy) * Wo + ox] = best;
+  }
+  if (prob) {
+    if (tid < npx) {
+      f2* so = reinterpret_cast<f2*>(s_out + tid * C);
+#pragma unroll
+      for (int c = 0; c < C2; c++) so[c] = e[c];
+    }
+    __syncthreads();
+    float* o = prob + (((long long)b * Ho + oy) * Wo + ox0) * C;
+    const int nfl = npx * C;
+    if (((nfl | (UP_SEG * C)) & 3) == 0 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+      for (int i = tid * 4; i < nfl; i += UP_SEG * 4)
+        *reinterpret_cast<float4*>(o + i) = *reinterpret_cast<const float4*>(s_out + i);
+    } else {
+      for (int i = tid; i < nfl; i += UP_SEG) o[i] = s_out[i];
+    }
+  }
+}
+
 int validate(int B, int H, int W, int C, int k, int s)
 {
   PCNN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && C >= 1, PCNN_EINVAL, "deconv: bad shape %dx%dx%dx%d", B, H, W, C);
@@ -438,6 +607,7 @@ extern "C" int pcnn_upscore_softmax_argmax_fwd(const float* z, const float* bias
   int st = validate(B, H, W, C, k, s);
   if (st != PCNN_OK) return st;
   PCNN_REQUIRE(C <= PCNN_MAX_CLASSES, PCNN_EINVAL, "upscore_softmax_argmax: num_classes must be <= %d (got %d)", PCNN_MAX_CLASSES, C);
+  PCNN_REQUIRE(k <= 64, PCNN_EINVAL, "upscore_softmax_argmax: kernel size must be <= 64 (got %d)", k);
   PCNN_REQUIRE(z && bias && label, PCNN_ENULL, "upscore_softmax_argmax: NULL pointer");
   hipStream_t stream = (hipStream_t)stream_;
   const int Wo = W * s, Ho = H * s;
@@ -449,7 +619,14 @@ extern "C" int pcnn_upscore_softmax_argmax_fwd(const float* z, const float* bias
   const int s_out_off = (rows * ncx_max * C + 3) / 4 * 4;
   const size_t sh = sizeof(float) * ((size_t)s_out_off + (size_t)UP_SEG * C);
   PCNN_REQUIRE(sh <= 160 * 1024, PCNN_EINVAL, "upscore_softmax_argmax: tile does not fit LDS");
-  if (C <= 24)
+  // class counts known at compile time (even; 8-byte aligned operands): the unrolled packed-f32 kernel
+  const bool al8 = ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(bias)) & 7) == 0 && s_out_off % 2 == 0;
+#define UP_FIXED(CC) PCNN_LAUNCH(upscore_softmax_argmax_fixed_kernel<CC>, dim3((unsigned)blocks), dim3(UP_SEG), sh, stream, z, bias, score_out, prob, label, H, W, k, s, relu, nseg, s_out_off)
+  if (al8 && C == 22) UP_FIXED(22);
+  else if (al8 && C == 14) UP_FIXED(14);
+  else if (al8 && C == 16) UP_FIXED(16);
+#undef UP_FIXED
+  else if (C <= 24)
     PCNN_LAUNCH(upscore_softmax_argmax_kernel<24>, dim3((unsigned)blocks), dim3(UP_SEG), sh, stream, z, bias, score_out, prob, label, H, W, C, k, s, relu, nseg, s_out_off);
   else
     PCNN_LAUNCH(upscore_softmax_argmax_kernel<64>, dim3((unsigned)blocks), dim3(UP_SEG), sh, stream, z, bias, score_out, prob, label, H, W, C, k, s, relu, nseg, s_out_off);

@@ -378,3 +378,28 @@ def test_det_assemble_equals_the_host_pose_combine(gpu, stride):
             want[i] = np.concatenate([rois[ri], pt[ri, 4 * c:4 * c + 4], tp[ri, 4:]])
     same(N(rows), want, "rows")
     assert int(count) == n // stride
+
+
+@pytest.mark.parametrize("C", [22, 14, 16])
+def test_label_head_fixed_class_count_kernel_on_extreme_scores(gpu, C):
+    """The unrolled packed-f32 label head (upscore_softmax_argmax_fixed_kernel<C>) must carry the bits of the generic kernel
+    and the oracle everywhere the exponential does something special: arguments below -87.3 (sub-normal results, the two-step
+    scaling), the clamp at -104, ties, and NaN / inf scores."""
+    from posecnn_amd import ops
+    rng = np.random.default_rng(C)
+    B, h, w = 2, 9, 11
+    z = (rng.standard_normal((B, h, w, C)) * 4).astype(F)
+    z[0, 2, 3, :] = 0.0                                   # ties everywhere: argmax 0
+    z[0, 4, :, 1] = 95.0                                  # one huge class: the others land at exp(-95 ...): sub-normal
+    z[0, 5, :, 2] = 120.0; z[0, 5, :, 3] = -120.0         # past the clamp
+    z[1, 1, 1, 4] = np.nan
+    z[1, 6, 2, 5] = np.inf
+    z[1, 7, 7, :] = -1e30
+    bias = rng.standard_normal(C).astype(F)
+    for relu in (True, False):
+        score, prob, label = ops.upscore_softmax_argmax(T(gpu, z), T(gpu, bias), 16, 8, relu=relu, want_score=True)
+        ws, wp, wl = oracle.upscore_softmax_argmax(z, bias, 16, 8, relu)
+        same(N(score), ws, "score relu=%s" % relu)
+        same(N(prob), wp, "prob relu=%s" % relu)
+        same(N(label), wl, "label relu=%s" % relu)
+    assert (wp[0, 4 * 8 + 4] < 1e-38).any() and (wp[0, 4 * 8 + 4] > 0).any()      # sub-normal probabilities were exercised
