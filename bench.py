@@ -49,11 +49,10 @@ def parse_args(argv=None):
     ap.add_argument("--resident-inputs", action="store_true", help="A/B: frames already in HBM (no H2D in the timed region)")
     ap.add_argument("--latency", action="store_true", help="per-frame synchronous loop; reports p50/p99 latency")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (see posecnn_amd/pipeline.py)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="HIP streams the batches alternate over. Default 1. With 2, batch i+1's trunk overlaps batch i's heads / Hough / "
-                         "RoI tail (+1 %% on this workload) — but round 3 found that with two queues active a batch occasionally "
-                         "differs from the one-stream run (tools/debug_streams.py: fc7 rows, once a Hough row; independent of the "
-                         "network object, of split-K and of the LDS ring depth), so concurrent batches are NOT a supported mode")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the batches alternate over: with 2, batch i+1's trunk overlaps batch i's heads / Hough / RoI tail "
+                         "(+1 %% on this workload). Round 3 found and fixed the race this mode used to expose (an s_waitcnt vmcnt(0) "
+                         "missing in front of the barrier that recycles the MFMA kernels' LDS ring; tools/debug_streams.py)")
     ap.add_argument("--backproject-grid", type=int, default=None,
                     help="also run the backprojecting layer on each batch's head features (G^3 voxels per frame); "
                          "default 128 for --config linemod (configs[4] names it), 0 = off otherwise")

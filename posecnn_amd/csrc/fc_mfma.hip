@@ -180,7 +180,14 @@ __global__ __launch_bounds__(512, 4) void fc_rows_mfma_kernel(
   }
   __builtin_amdgcn_sched_barrier(0);
   FC_MFMA1(ya0, ya1, yb, 0) FC_MFMA1(ya0, ya1, yb, 1)
-  __syncthreads();   // drains the two parked prefetches and every LDS read before the buffers are recycled
+  // Every wave's outstanding DMA must have LANDED before anybody recycles the ring as the epilogue's staging buffer.
+  // The DMA instructions are inline asm, invisible to the compiler's s_waitcnt insertion, so __syncthreads() alone
+  // is a bare s_barrier here (checked in the ISA): a parked prefetch of ANOTHER wave could land after this wave had
+  // written its output rows into the same LDS — output rows replaced by operand rows, a few times in a thousand
+  // launches on an idle GPU, a few per hundred with a second stream competing for memory (round 3,
+  // tools/debug_streams.py). The wait has to be explicit and in front of the barrier.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();   // ... and every LDS read is done: the buffers can be recycled
 #undef FC_DMA
 #undef FC_READ
 #undef FC_DSREAD

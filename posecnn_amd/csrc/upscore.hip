@@ -271,10 +271,12 @@ __global__ __launch_bounds__(UP_SEG) void upscore_softmax_argmax_kernel(
   float* s_out = smem + s_out_off;         // [UP_SEG][C]
   // a row's ncx cells x C channels are one contiguous run of z: straight copies, no index arithmetic per element
   const int rowlen = ncx * C;
-  for (int ry = 0; ry < ty.n; ry++) {
-    const float* src = z + (((long long)b * H + ty.i0 + ry) * W + cx0) * C;
-    for (int i = tid; i < rowlen; i += UP_SEG) s_z[ry * rowlen + i] = src[i];
-  }
+#pragma unroll
+  for (int ry = 0; ry < 4; ry++)      // (constant indices into the tap structs: see the note on scratch memory below)
+    if (ry < ty.n) {
+      const float* src = z + (((long long)b * H + ty.i0 + ry) * W + cx0) * C;
+      for (int i = tid; i < rowlen; i += UP_SEG) s_z[ry * rowlen + i] = src[i];
+    }
   __syncthreads();
 
   const int ox = ox0 + tid;
@@ -284,13 +286,18 @@ __global__ __launch_bounds__(UP_SEG) void upscore_softmax_argmax_kernel(
     const Taps tx = make_taps(ox, k, s, pad, W);
 #pragma unroll
     for (int c = 0; c < CMAX; c++) e[c] = 0.f;
-    for (int jy = 0; jy < ty.n; jy++)
-      for (int jx = 0; jx < tx.n; jx++) {
-        const float w = ty.w[jy] * tx.w[jx];
-        const float* zc = s_z + (jy * ncx + (tx.i0 + jx - cx0)) * C;
 #pragma unroll
-        for (int c = 0; c < CMAX; c++)
-          if (c < C) e[c] = e[c] + w * zc[c];
+    for (int jy = 0; jy < 4; jy++)
+      if (jy < ty.n) {
+#pragma unroll
+        for (int jx = 0; jx < 4; jx++)
+          if (jx < tx.n) {
+            const float w = ty.w[jy] * tx.w[jx];
+            const float* zc = s_z + (jy * ncx + (tx.i0 + jx - cx0)) * C;
+#pragma unroll
+            for (int c = 0; c < CMAX; c++)
+              if (c < C) e[c] = e[c] + w * zc[c];
+          }
       }
 #pragma unroll
     for (int c = 0; c < CMAX; c++)

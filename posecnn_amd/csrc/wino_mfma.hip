@@ -307,6 +307,10 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
   __builtin_amdgcn_sched_barrier(0);
   WM_MFMA(ya0, ya1, yb, acc[5]);
   WM_FOLD(5);
+  // all waves' parked prefetch DMAs have landed before the ring becomes the epilogue's staging buffer: the DMAs are
+  // inline asm, so the compiler's __syncthreads() is a bare s_barrier without the vmcnt(0) it would need (see
+  // csrc/fc_mfma.hip: the same omission corrupted output rows there)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 #undef WM_STAGE
 #undef WM_READ

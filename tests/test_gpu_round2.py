@@ -274,9 +274,55 @@ def test_hipgraph_replay_equals_the_eager_step(gpu, B, fmt, train):
                 same(N(got).reshape(-1), N(want).reshape(-1), "%s of frame set %d" % (name, j))
 
 
-# (round 3) test_batches_on_alternating_streams_equal_the_serial_run was removed: with more repetitions it fails a few
-# batches in a hundred — on the round-2 tree as well — so two batches in flight on two HIP streams is not a supported
-# mode any more (bench.py --streams defaults to 1; tools/debug_streams.py reproduces and localises the mismatch).
+def test_batches_on_alternating_streams_equal_the_serial_run(gpu):
+    """bench.py --streams 2: consecutive batches go to different HIP streams so that one batch's trunk
+    overlaps the other's heads / Hough / RoI tail. Everything a batch touches is stream-local (allocator
+    pools, library workspaces keyed by stream), so the detections must equal the one-stream run bit for bit.
+
+    Round 3: with 3 repetitions this test passed while the kernels under it had a race — the MFMA kernels recycled their
+    LDS ring as the epilogue's staging buffer behind a bare s_barrier, without waiting for the other waves' in-flight
+    operand DMAs (inline asm, invisible to the compiler's s_waitcnt insertion): a few batches per hundred came out with
+    operand rows in place of fc7 output rows once a second stream competed for memory (tools/debug_streams.py). Fixed in
+    csrc/fc_mfma.hip / csrc/wino_mfma.hip; the test now runs 8 rounds and compares the pose branch's tensors too."""
+    import torch
+    from posecnn_amd import fcn
+    from posecnn_amd.networks import vgg16_convs
+    B, H, W = 2, 240, 320
+    net = vgg16_convs("RGBD", 22, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True, trainable=False,
+                      is_train=True, seed=3, init="he", with_losses=False, device=gpu)
+    synth.init_planted_heads(net)
+    K = config.DEMO_INTRINSICS.copy(); K[:2] *= W / 640.0
+    rng = np.random.default_rng(5)
+    pts = T(gpu, synth.make_model_points(22, 256))
+    batches = []
+    for i in range(4):
+        data, data_p = _rgbd_inputs(rng, B, H, W)
+        planted_np, scenes = synth.make_planted_batch(40 + i, B, H=H, W=W, K=K, n_obj=3)
+        batches.append((T(gpu, data), T(gpu, data_p), {k: T(gpu, v) for k, v in planted_np.items()},
+                        T(gpu, synth.make_gt_poses(scenes, K, seed=i))))
+
+    def one(b):
+        det = fcn.im_segment_batch(net, b[0], K, config.LOV_EXTENTS, pts, config.LOV_SYMMETRY, data_p=b[1], planted=b[2],
+                                   with_losses=True, gt_poses=b[3])
+        return det.rows.clone(), det.count.clone(), net.get_output("loss_pose").clone(), net.get_output("fc7").clone(), net.get_output("poses_tanh").clone()
+
+    with torch.no_grad():
+        serial = [one(b) for b in batches]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(device=gpu), torch.cuda.Stream(device=gpu)]
+        got = []
+        for rep in range(8):                       # many rounds: the two streams really run concurrently
+            for i, b in enumerate(batches):
+                with torch.cuda.stream(streams[i % 2]):
+                    got.append(one(b))
+        torch.cuda.synchronize()
+    for j, (rows, count, loss, fc7, ptanh) in enumerate(got):
+        want = serial[j % len(batches)]
+        assert int(count) == int(want[1]) and int(count) > 0
+        same(N(rows), N(want[0]), "rows of batch %d" % j)
+        same(N(loss).reshape(-1), N(want[2]).reshape(-1), "loss_pose of batch %d" % j)
+        same(N(fc7), N(want[3]), "fc7 of batch %d" % j)
+        same(N(ptanh), N(want[4]), "poses_tanh of batch %d" % j)
 
 
 @pytest.mark.parametrize("train", [False, True])

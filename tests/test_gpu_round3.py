@@ -403,3 +403,41 @@ def test_label_head_fixed_class_count_kernel_on_extreme_scores(gpu, C):
         same(N(prob), wp, "prob relu=%s" % relu)
         same(N(label), wl, "label relu=%s" % relu)
     assert (wp[0, 4 * 8 + 4] < 1e-38).any() and (wp[0, 4 * 8 + 4] > 0).any()      # sub-normal probabilities were exercised
+
+
+def test_new_entries_reject_bad_arguments(gpu):
+    """Error conventions of the round-3 entries (validate, return negative codes, never fault): the Python layer
+    raises ValueError for InvalidArgument / NULL, like the reference's OP_REQUIRES."""
+    import torch
+    from posecnn_amd import icp, ops
+    x = torch.zeros((33, 64), device=gpu); w = torch.zeros((8, 64), device=gpu); b = torch.zeros(8, device=gpu)
+    with pytest.raises(ValueError, match="1..32"):
+        ops.fc_skinny(x, w, b)                                   # more than 32 rows belong to fc_rows
+    with pytest.raises(ValueError, match="multiple of 16"):
+        ops.fc_skinny(torch.zeros((4, 40), device=gpu), torch.zeros((8, 40), device=gpu), b)
+    with pytest.raises(ValueError):
+        ops.fc_skinny(x[:4], w, torch.zeros(9, device=gpu))      # bias / weight mismatch
+    with pytest.raises(KeyError):
+        ops.fc_skinny(x[:4], w, b, activation="gelu")
+    a = torch.zeros((1, 6, 8, 16), device=gpu)
+    with pytest.raises(ValueError):
+        ops.head_lowres(a, torch.zeros((1, 3, 4, 8), device=gpu), torch.zeros((16, 5), device=gpu))     # channel mismatch
+    with pytest.raises(ValueError, match="multiple of 4"):
+        ops.head_lowres(torch.zeros((1, 6, 8, 6), device=gpu), torch.zeros((1, 3, 4, 6), device=gpu), torch.zeros((6, 5), device=gpu))
+    with pytest.raises(ValueError):
+        ops.det_assemble(torch.zeros((4, 6), device=gpu), torch.zeros((4, 88), device=gpu), torch.zeros((4, 7), device=gpu),
+                         torch.zeros(1, dtype=torch.int32, device=gpu))
+    live = torch.zeros((1, 16, 16, 3), device=gpu)
+    with pytest.raises(ValueError):
+        icp.icp(live, torch.zeros((1, 16, 16, 5), device=gpu), torch.zeros((1, 16, 16, 5), device=gpu), config.DEMO_INTRINSICS)
+    with pytest.raises(ValueError):
+        icp.icp(live, torch.zeros((1, 16, 16, 3), device=gpu), torch.zeros((1, 16, 16, 3), device=gpu), config.DEMO_INTRINSICS, max_error=-1.0)
+    # zero iterations: the identity; zero objects: an empty result, nothing launched
+    u = icp.icp(live, torch.zeros((1, 16, 16, 3), device=gpu), torch.zeros((1, 16, 16, 3), device=gpu), config.DEMO_INTRINSICS, iterations=0)
+    assert np.array_equal(u.cpu().numpy()[0], np.hstack([np.eye(3), np.zeros((3, 1))]))
+    u0 = icp.icp(live[:0], torch.zeros((0, 16, 16, 3), device=gpu), torch.zeros((0, 16, 16, 3), device=gpu), config.DEMO_INTRINSICS)
+    assert tuple(u0.shape) == (0, 3, 4)
+    with pytest.raises(ValueError):
+        icp.backproject(torch.zeros((4, 4), dtype=torch.uint16, device=gpu), None, 0, config.DEMO_INTRINSICS, 0.0)   # factor_depth must be positive
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.fc_skinny(torch.zeros((4, 64)), w, b)                 # no CPU path

@@ -1,9 +1,15 @@
 #!/usr/bin/env python
 """Diagnostic (round 3): batches issued alternately on two HIP streams versus the same batches on one stream.
-Prints every tensor of the pose branch that differs, with the rows affected. Observed on MI355X / ROCm 7.2: a few
-batches per hundred differ (fc7 output rows of single waves' operand rows, once a Hough row) — also with one network
-object per stream (`two_nets`), without split-K, and with a 3-deep LDS ring in fc_rows; never on one stream. Hence
-bench.py --streams defaults to 1.      python tools/debug_streams.py [two_nets]"""
+Prints every tensor of the pose branch that differs, with the rows affected.
+
+History: on the round-2 kernels a few batches per hundred differed (fc7 output rows = the operand rows of single waves'
+DMA instructions, once a Hough row) — with one network object per stream (`two_nets`) too, without split-K rarely, with a
+3-deep ring in fc_rows too; never on one stream in this script, once in ~10 full test-suite runs on one stream. Cause: the
+MFMA kernels (fc_rows_mfma_kernel, wino43_mfma_kernel) recycle their LDS operand ring as the epilogue's staging buffer
+behind `__syncthreads()`, which is a bare s_barrier there — the operand DMAs are inline asm, invisible to the compiler's
+s_waitcnt insertion — so another wave's parked prefetch could land on top of freshly staged output rows. With an explicit
+`s_waitcnt vmcnt(0)` in front of that barrier: 0 mismatching tensors in 4 x 24 batches.
+    python tools/debug_streams.py [two_nets]"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
