@@ -490,14 +490,14 @@ def main(argv=None):
     towers = 2 if a.input == "RGBD" else 1
     hbm = {
         "hard_label_fwd_kernel": 4.0 * B * H * W * (2 + C),
-        "upscore_softmax_argmax_kernel": 4.0 * B * H * W * (C + 1) + act(8, C),
+        "upscore_softmax_argmax": 4.0 * B * H * W * (C + 1) + act(8, C),     # (generic kernel or the compile-time-C instance)
     }
     hbm.update(net.hbm_table(B, H, W)) if hasattr(net, "hbm_table") else None
     if G3 > 0:   # writes data + flag [G^3, 64] and label [G^3, C], reads label_3d [G^3, C]
         hbm["backproject_fused_kernel"] = 4.0 * B * G3 ** 3 * (2 * 64 + 2 * C)
 
     def us(k):  # per step, all template instances of a kernel together
-        t = sum(v["avg_us"] * v["calls"] for n, v in kern.items() if n == k or n.startswith(k + "<"))
+        t = sum(v["avg_us"] * v["calls"] for n, v in kern.items() if n == k or n.startswith(k + "<") or n.startswith(k + "_kernel") or n.startswith(k + "_fixed_kernel"))
         return t / a.steps if t else None
     others = []
     for k, byt in hbm.items():

@@ -3,6 +3,7 @@ set -x
 O=/root/repo/gpurun_out/${1:-r3p}; mkdir -p $O
 cd /root/repo
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --streams 1 --no-cpu-baseline > $O/bench_streams1.json 2> $O/bench_streams1.err
 python bench.py --graph --no-cpu-baseline > $O/bench_graph.json 2> $O/bench_graph.err
 python bench.py --latency --batch 1 --input COLOR --losses test --no-cpu-baseline --graph --steps 100 > $O/bench_latency_b1.json 2> $O/bench_latency_b1.err
 python bench.py --config linemod --no-cpu-baseline > $O/bench_linemod.json 2> $O/bench_linemod.err
