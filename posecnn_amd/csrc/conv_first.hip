@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_bias_relu_kernel(
 // (csrc/winograd.hip), so V is bit-identical to the unfused pair.
 constexpr int FW_TILES = 4;
 constexpr int FW_COLS = 4 * FW_TILES + 2;   // 18 patch columns
-constexpr int FW_INF = (FW_COLS + 2) * CF_CIN;
+constexpr int FW_INF = (FW_COLS + 6) * CF_CIN;   // 20 window columns + 4 of slack for the last (partial) pixel quad of a row
 
 __device__ __forceinline__ void fw_bt6(const f4* d, f4* r)
 {
@@ -140,56 +140,56 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wino43_kernel(
       val = x[(((size_t)b * H + iy) * W + ix) * CF_CIN + (j % CF_CIN)];
     s_in[r][j] = val;
   }
-  const int quad = lane & 15, slot = lane >> 4;
-  const int c0 = cg * 64 + quad * 4;
   {
-    f4 wq[27];
+    // phase 1: the 6 x FW_COLS patch as quads of horizontally adjacent pixels x PAIRS of output channels: a lane keeps
+    // 27 x 2 filter taps (54 VGPRs; the earlier pixel-pair x channel-quad form kept 27 x 4 = 108 and ran at 3 waves
+    // per SIMD, latency-bound with 43 % of its wave cycles in s_waitcnt), reads the 18 window floats a quad shares per
+    // filter row (4.5 LDS reads per pixel instead of 6; all 32 lanes of a half-wave read the same address: broadcast)
+    // and runs four independent FMA chains. Same per-pixel order (ky, kx, ci ascending) -> same bits.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const int half = lane >> 5, cp = lane & 31;
+    const int c0 = cg * 64 + cp * 2;
+    f2 wq[27];
 #pragma unroll
-    for (int t = 0; t < 27; t++) wq[t] = *reinterpret_cast<const f4*>(w + (size_t)t * Cout + c0);
-    const f4 bq = *reinterpret_cast<const f4*>(bias + c0);
+    for (int t = 0; t < 27; t++) wq[t] = *reinterpret_cast<const f2*>(w + (size_t)t * Cout + c0);
+    const f2 bq = *reinterpret_cast<const f2*>(bias + c0);
     __syncthreads();
-    // phase 1: the 6 x FW_COLS patch as pairs of horizontally adjacent pixels, 16 pairs per iteration (4 waves x
-    // 4 slots): a pair shares 6 of its 9 window floats per filter row (12 LDS reads instead of 18) and gives the
-    // lane two independent FMA chains; each pixel still sums (ky, kx, ci) ascending, as the stand-alone kernel does
-    constexpr int NPAIR = FW_COLS / 2;
-    static_assert(FW_COLS % 2 == 0, "pixel pairs");
-    for (int it = 0; it < (6 * NPAIR + 15) / 16; it++) {
-      const int p = it * 16 + wave * 4 + slot;
-      if (p < 6 * NPAIR) {
-        const int r = p / NPAIR, cx = 2 * (p - r * NPAIR);
+    constexpr int NQUAD = (FW_COLS + 3) / 4;   // 5 per patch row, the last one half empty
+    for (int it = 0; it < (6 * NQUAD + 7) / 8; it++) {
+      const int p = it * 8 + wave * 2 + half;
+      if (p < 6 * NQUAD) {
+        const int r = p / NQUAD, cx = 4 * (p - r * NQUAD);
         const int yy = py0 + r, xx = px0 + cx;
-        f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        f2 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = (f2){0.f, 0.f};
         const bool rowok = yy >= 0 && yy < H;
-        const bool ok0 = rowok && xx >= 0 && xx < W, ok1 = rowok && xx + 1 >= 0 && xx + 1 < W;
-        if (ok0 || ok1) {
+        if (rowok) {
 #pragma unroll
           for (int ky = 0; ky < 3; ky++) {
-            const float* win = &s_in[r + ky][cx * CF_CIN];   // 12 floats: columns cx-1 .. cx+2
-            float wv[12];
+            const float* win = &s_in[r + ky][cx * CF_CIN];   // 18 floats: columns cx-1 .. cx+4
+            float wv[18];
 #pragma unroll
-            for (int j = 0; j < 12; j++) wv[j] = win[j];
+            for (int j = 0; j < 18; j++) wv[j] = win[j];
 #pragma unroll
-            for (int j = 0; j < 9; j++) {
-              const f4 v0 = {wv[j], wv[j], wv[j], wv[j]};
-              const f4 v1 = {wv[j + 3], wv[j + 3], wv[j + 3], wv[j + 3]};
-              acc0 = __builtin_elementwise_fma(wq[ky * 9 + j], v0, acc0);
-              acc1 = __builtin_elementwise_fma(wq[ky * 9 + j], v1, acc1);
-            }
+            for (int j = 0; j < 9; j++)
+#pragma unroll
+              for (int q = 0; q < 4; q++) {
+                const f2 v = {wv[j + 3 * q], wv[j + 3 * q]};
+                acc[q] = __builtin_elementwise_fma(wq[ky * 9 + j], v, acc[q]);
+              }
           }
-          acc0 = acc0 + bq;
-          acc1 = acc1 + bq;
-          if (relu) {
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-              acc0[e] = acc0[e] > 0.f ? acc0[e] : 0.f;
-              acc1[e] = acc1[e] > 0.f ? acc1[e] : 0.f;
-            }
-          }
-          if (!ok0) acc0 = (f4){0.f, 0.f, 0.f, 0.f};
-          if (!ok1) acc1 = (f4){0.f, 0.f, 0.f, 0.f};
         }
-        *reinterpret_cast<f4*>(&s_y[r][cx][quad * 4]) = acc0;
-        *reinterpret_cast<f4*>(&s_y[r][cx + 1][quad * 4]) = acc1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          f2 a = acc[q] + bq;
+          if (relu) {
+            a.x = a.x > 0.f ? a.x : 0.f;
+            a.y = a.y > 0.f ? a.y : 0.f;
+          }
+          if (!(rowok && xx + q >= 0 && xx + q < W)) a = (f2){0.f, 0.f};   // outside the image: conv1_2's zero padding
+          if (cx + q < FW_COLS) *reinterpret_cast<f2*>(&s_y[r][cx + q][cp * 2]) = a;
+        }
       }
     }
   }
