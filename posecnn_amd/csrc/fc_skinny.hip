@@ -104,10 +104,13 @@ __global__ __launch_bounds__(64 * SK_WAVES) void fc_skinny_kernel(
   const int ks0 = min(KS, s * steps_per_slice), ks1 = min(KS, ks0 + steps_per_slice);
   const bool two = MB > 1 && count > 16;     // wave-uniform: the second row block exists
 
-  // per-lane row pointers (rows / columns past the end are clamped: their products are never stored)
+  // per-lane row pointers. Rows past the LIVE count are clamped to the last live row (their products are never
+  // stored): the lanes of the dead rows then share one address, and a frame with 5 detections in a 21-row buffer
+  // pulls 5 rows of x through L2 instead of 16
+  const int last_row = max(count, 1) - 1;
   const float* xp[MB];
 #pragma unroll
-  for (int mb = 0; mb < MB; mb++) xp[mb] = x + (size_t)min(16 * mb + r, Mcap - 1) * K + 4 * q;
+  for (int mb = 0; mb < MB; mb++) xp[mb] = x + (size_t)min(16 * mb + r, last_row) * K + 4 * q;
   const float* wp[SK_NBW];
 #pragma unroll
   for (int j = 0; j < SK_NBW; j++) wp[j] = wt + (size_t)min(n0 + 16 * j + r, N - 1) * K + 4 * q;
