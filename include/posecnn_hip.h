@@ -419,8 +419,7 @@ int pcnn_smooth_l1_vertex_bwd(const float* pred, const float* target, const floa
  * Depth-based pose refinement, first slice: the projective point-to-plane ICP that
  * Synthesizer::refinePose runs per object (lib/synthesize/synthesize.cpp:2020-2026 -> df::icp,
  * lib/kinect_fusion/src/optimization/icp.cpp:20-106 with the per-pixel kernel icp.cu:25-136), called from
- * lib/fcn/test.py:1925-1933 through Synthesizer::solveICP. The OpenGL renderer that produces the predicted maps,
- * the kd-tree hypothesis scoring and the nlopt stage of solveICP are outside this slice.
+ * lib/fcn/test.py:1925-1933 through Synthesizer::solveICP (the rest of solveICP: next block).
  *
  * pcnn_icp_backproject_fwd: synthesize.cpp:2139-2155 + df backproject (src/image/backprojection.cu:10-27, Poly3 camera
  *   with k = 0): vertex_map[y][x] = ((x - px)/fx d, (y - py)/fy d, d), d = depth[y][x] / factor_depth where
@@ -435,7 +434,7 @@ int pcnn_smooth_l1_vertex_bwd(const float* pred, const float* target, const floa
  *   J = (1/live_z) [n^T | (p x n)^T], r = (1/live_z) n.(live - p); solve (sum J^T J) x = sum J^T r;
  *   update = exp(x) * update.                 update f64 [N][12] (row-major 3x4, starts at the identity)
  *   stats f32 [N][iterations][2] = (inliers, sum r^2) before each step, or NULL.
- *   Reductions in a fixed order (256-pixel halving trees in f32, blocks ascending in f64), solve / exp in f64:
+ *   Reductions in a fixed order (256-pixel halving trees in f32; block sums in f64, 8 contiguous segments ascending), solve / exp in f64:
  *   bit-identical to oracle_icp_refine. No host synchronisation between iterations.
  * ------------------------------------------------------------------------------------------ */
 int pcnn_icp_backproject_fwd(const uint16_t* depth, const int32_t* label, int height, int width, int obj_id,
@@ -446,6 +445,49 @@ int pcnn_icp_refine_fwd(const float* live_vertices, const float* pred_vertices, 
                         int num_objects, int height, int width, int pred_channels, float fx, float fy, float px,
                         float py, float z_near, float z_far, float max_error, int iterations, double* update,
                         float* stats, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Depth-based pose refinement, second slice: the rest of Synthesizer::solveICP (lib/synthesize/synthesize.cpp:2052-2380)
+ * except its nlopt stage (poseWithOpt :2529-2570, a Nelder-Mead polish between the translation estimate and the ICP
+ * hypotheses; nlopt is not available here).
+ *
+ * pcnn_render_mesh_fwd replaces the two OpenGL passes of solveICP / refinePose (:2104-2136, :1972-1991; shaders
+ *   lib/kinect_fusion/shaders/vertsAndNorms.{vert,frag}, canonicalVerts.{vert,frag}; projection :2088 = pixel centres at
+ *   integer (u, v), u = fx X / Z + px): a triangle mesh rendered at num_poses poses in one call.
+ *   vertices f32 [Nv][3] (object frame), normals f32 [Nv][3] or NULL, faces int32 [Nf][3], poses f32 [N][12] (row-major
+ *   3x4, camera <- object; device memory like everything else).
+ *   out_vertices f32 [N][H][W][4] = (camera-frame surface point, 1), out_normals f32 [N][H][W][4] = (per-vertex normals
+ *   rotated and normalised per vertex, interpolated, 0), out_canonical f32 [N][H][W][3] = object-frame surface point with
+ *   canon_x_offset (the model index, synthesize.cpp:270) added to x; each may be NULL; NaN where no surface is hit
+ *   (the reference clears to NaN, :2113). Perspective-correct interpolation, z-buffer on (depth, face index), depth
+ *   kept in [z_near, z_far]; triangles with a vertex in front of z_near are dropped. Deterministic and bit-identical to
+ *   oracle_render_mesh. workspace: 8 bytes per pixel and pose (pcnn_render_mesh_workspace_bytes), 8-byte aligned.
+ * pcnn_icp_center_fwd (:2157-2207): over the pixels with label == obj_id, live depth > 0 and a rendered canonical
+ *   vertex m (x - round(x) strips the model index): mask = 1 (the (depth point, model point) pairs of the scoring step);
+ *   those with |n.(d - v)| < max_error add (d - m) to the translation estimate.
+ *   sums f64 [5] = (sum dx, sum dy, sum dz, count, valid pairs); mask uint8 [H][W]. Fixed-order reduction like pcnn_icp_refine_fwd.
+ * pcnn_icp_score_fwd (:2302-2343, the SegICP score): for each hypothesis pose (f32 [M][12]) every model point of the mask,
+ *   moved by the pose, marks its nearest depth point strictly inside `radius` (0.01 in the reference; ties to the lower
+ *   pixel index); hits int32 [M] = distinct marked depth points (the reference's score times the number of model points).
+ *   The reference searches a kd-tree built on the host; here the depth points are still an image, so the search is a window
+ *   around the projection (exact: a point within r of (X, Y, Z) projects within fx r (1 + |X/Z|) / (Z - r) pixels).
+ *   workspace: one bit per pixel and hypothesis (pcnn_icp_score_workspace_bytes).
+ * ------------------------------------------------------------------------------------------ */
+int pcnn_render_mesh_workspace_bytes(int num_poses, int height, int width, size_t* bytes);
+int pcnn_render_mesh_fwd(const float* vertices, const float* normals, const int32_t* faces, int num_vertices,
+                         int num_faces, const float* poses, int num_poses, int height, int width, float fx, float fy,
+                         float px, float py, float z_near, float z_far, float canon_x_offset, float* out_vertices,
+                         float* out_normals, float* out_canonical, void* workspace, size_t workspace_bytes,
+                         void* stream);
+int pcnn_icp_center_workspace_bytes(int height, int width, size_t* bytes);
+int pcnn_icp_center_fwd(const int32_t* label, const float* live_vertices, const float* canonical,
+                        const float* pred_vertices, const float* pred_normals, int pred_channels, int height, int width,
+                        int obj_id, float max_error, double* sums, uint8_t* mask, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int pcnn_icp_score_workspace_bytes(int num_hypotheses, int height, int width, size_t* bytes);
+int pcnn_icp_score_fwd(const float* live_vertices, const float* canonical, const uint8_t* mask, int height, int width,
+                       const float* hypotheses, int num_hypotheses, float fx, float fy, float px, float py, float radius,
+                       int32_t* hits, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Kernel timing diagnostics (off by default; the reference's only instrumentation is the

@@ -1161,8 +1161,8 @@ int oracle_hough_cpu_kernel(const int* label, const float* vertex, const float* 
 /* only by hand-derived known answers (tests/test_icp.py). Canonical choices where the reference is      */
 /* unspecified or order dependent:                                                                      */
 /*   - thrust::transform_reduce has no defined order -> pixels in raster order in blocks of 256, a        */
-/*     halving tree (i += i + 128, 64, ... 1) in f32 inside a block, blocks added in ascending order in   */
-/*     f64;                                                                                             */
+/*     halving tree (i += i + 128, 64, ... 1) in f32 inside a block; the block sums added in f64 in 8      */
+/*     contiguous segments (ascending inside a segment, then the segments ascending);                    */
 /*   - the 6x6 solve and the pose bookkeeping are float in the reference (Eigen LDLT with pivoting,       */
 /*     Sophus::SE3f): here LDL^T without pivoting, exp and the accumulated update in f64, with sin/cos    */
 /*     replaced by fixed 10-term Taylor polynomials in theta^2 (pure + and *: identical bits on every     */
@@ -1293,6 +1293,26 @@ static int icp_solve_update(const double* S /* [ICP_NSUM] */, double* T /* [12],
   return 1;
 }
 
+/* the canonical f64 sum of per-block f32 partial rows [nblocks][nq]: ICP_NSEG contiguous segments of
+   ceil(nblocks / ICP_NSEG) blocks, each added in ascending block order, then the segment sums in ascending order */
+#define ICP_NSEG 8
+static void icp_segmented_sums(const float* rows, long nblocks, int nq, double* S)
+{
+  const long L = (nblocks + ICP_NSEG - 1) / ICP_NSEG;
+  for (int q = 0; q < nq; q++) {
+    double seg[ICP_NSEG];
+    for (int sg = 0; sg < ICP_NSEG; sg++) {
+      const long b0 = sg * L, b1 = (b0 + L < nblocks) ? b0 + L : nblocks;
+      double acc = 0.0;
+      for (long b = b0; b < b1; b++) acc = acc + (double)rows[b * nq + q];
+      seg[sg] = acc;
+    }
+    double s = seg[0];
+    for (int sg = 1; sg < ICP_NSEG; sg++) s = s + seg[sg];
+    S[q] = s;
+  }
+}
+
 /* df::icp for N independent (live, predicted) map triples. pred_* have `pc` (3 or 4) floats per pixel.
    update_out [N][12] f64 (row-major 3x4 accumulated update), stats_out [N][iterations][2] f32 (inliers, sum r^2) or NULL */
 int oracle_icp_refine(const float* live, const float* pred_v, const float* pred_n, int N, int H, int W, int pc,
@@ -1302,7 +1322,8 @@ int oracle_icp_refine(const float* live, const float* pred_v, const float* pred_
   const long P = (long)H * W;
   const long nblocks = (P + ICP_BLOCK - 1) / ICP_BLOCK;
   float* buf = (float*)malloc(sizeof(float) * ICP_NSUM * ICP_BLOCK);
-  if (!buf) return -1;
+  float* rows = (float*)malloc(sizeof(float) * ICP_NSUM * (size_t)nblocks);
+  if (!buf || !rows) { free(buf); free(rows); return -1; }
   for (int n = 0; n < N; n++) {
     double T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     const float* lv = live + 3 * P * n;
@@ -1312,7 +1333,7 @@ int oracle_icp_refine(const float* live, const float* pred_v, const float* pred_
       float Tf[12];
       for (int i = 0; i < 12; i++) Tf[i] = (float)T[i];
       double S[ICP_NSUM];
-      for (int q = 0; q < ICP_NSUM; q++) S[q] = 0.0;
+      memset(rows, 0, sizeof(float) * ICP_NSUM * (size_t)nblocks);
       for (long b = 0; b < nblocks; b++) {
         int any = 0;
         memset(buf, 0, sizeof(float) * ICP_NSUM * ICP_BLOCK);
@@ -1329,14 +1350,15 @@ int oracle_icp_refine(const float* live, const float* pred_v, const float* pred_
           buf[27 * ICP_BLOCK + t] = 1.f;
           buf[28 * ICP_BLOCK + t] = r * r;
         }
-        if (!any) continue;   /* all zeros: adds nothing */
+        if (!any) continue;   /* all zeros: a zero row */
         for (int q = 0; q < ICP_NSUM; q++) {
           float* a = buf + q * ICP_BLOCK;
           for (int s = ICP_BLOCK / 2; s >= 1; s >>= 1)
             for (int t = 0; t < s; t++) a[t] = a[t] + a[t + s];
-          S[q] = S[q] + (double)a[0];
+          rows[b * ICP_NSUM + q] = a[0];
         }
       }
+      icp_segmented_sums(rows, nblocks, ICP_NSUM, S);
       if (stats_out) {
         stats_out[((long)n * iterations + it) * 2 + 0] = (float)S[27];
         stats_out[((long)n * iterations + it) * 2 + 1] = (float)S[28];
@@ -1346,5 +1368,257 @@ int oracle_icp_refine(const float* live, const float* pred_v, const float* pred_
     memcpy(update_out + 12 * n, T, sizeof(T));
   }
   free(buf);
+  free(rows);
+  return 0;
+}
+
+/* ================================================================================================== */
+/* solveICP around the iterations: predicted maps, translation estimate, hypothesis selection          */
+/* ================================================================================================== */
+/* Follows lib/synthesize/synthesize.cpp:2104-2136 + :1972-1991 (what the two GL renderers produce:     */
+/* shaders lib/kinect_fusion/shaders/vertsAndNorms.{vert,frag}, canonicalVerts.{vert,frag}; projection   */
+/* matrix :2088 = pixel centres at integer (u, v) of u = fx X / Z + px; canonical x + model index        */
+/* :266-271; NaN clear colour :2113), :2157-2207 (translation estimate), :2302-2343 (SegICP score).      */
+/*                                                                                                      */
+/* PARITY UNPINNED: OpenGL rasterisation (fixed-point snapping, fill rule, vendor interpolation) is not  */
+/* reproducible off the reference's GPU + driver, PCL/FLANN are absent and the reference holds no test    */
+/* vectors. The renderer is pinned to an analytic ray-caster (tests/test_icp.py); canonical choices:      */
+/*   - coverage: float edge functions evaluated from the lower-numbered vertex of an edge (both triangles */
+/*     sharing it see the same number), inclusive on both sides; visibility = minimum of (depth, face     */
+/*     index); triangles with a vertex in front of z_near are dropped, not clipped;                       */
+/*   - attributes: perspective-correct, weight_i = (e_i / area) / z_i normalised by their sum;            */
+/*   - sums of the translation estimate: blocks of 256 pixels in raster order, halving tree in f32,        */
+/*     block sums in f64 in 8 ascending segments like the ICP sums (the reference: sequential float);    */
+/*   - radius search: the nearest depth point strictly inside the radius, ties to the lower pixel index   */
+/*     (FLANN's order among equal distances is unspecified); the score counts distinct marked points      */
+/*     (the reference marks from an OpenMP loop: same count whatever the order).                         */
+
+typedef struct {
+  float u[3], v[3], z[3];
+  int flip[3];
+  int x0, x1, y0, y1;
+} RdTri;
+
+static void rd_transform(const float* T, const float* p, float* c)
+{
+  const float x = p[0], y = p[1], z = p[2];
+  c[0] = ((T[0] * x + T[1] * y) + T[2] * z) + T[3];
+  c[1] = ((T[4] * x + T[5] * y) + T[6] * z) + T[7];
+  c[2] = ((T[8] * x + T[9] * y) + T[10] * z) + T[11];
+}
+
+static float rd_edge(float au, float av, float bu, float bv, float x, float y)
+{
+  return (bu - au) * (y - av) - (bv - av) * (x - au);
+}
+
+static int rd_setup(const float* T, const float* vtx, const int* face, int W, int H, float fx, float fy, float px,
+                    float py, float znear, RdTri* t, float cam[3][3])
+{
+  const int idx[3] = {face[0], face[1], face[2]};
+  for (int k = 0; k < 3; k++) {
+    rd_transform(T, vtx + 3 * (size_t)idx[k], cam[k]);
+    t->z[k] = cam[k][2];
+    t->u[k] = cam[k][0] / cam[k][2] * fx + px;
+    t->v[k] = cam[k][1] / cam[k][2] * fy + py;
+  }
+  if (idx[0] == idx[1] || idx[1] == idx[2] || idx[0] == idx[2]) return 0;
+  for (int k = 0; k < 3; k++)
+    if (!(t->z[k] >= znear) || !(fabsf(t->u[k]) < 1e7f) || !(fabsf(t->v[k]) < 1e7f)) return 0;
+  t->flip[0] = idx[1] > idx[2];
+  t->flip[1] = idx[2] > idx[0];
+  t->flip[2] = idx[0] > idx[1];
+  const float umin = fminf(fminf(t->u[0], t->u[1]), t->u[2]), umax = fmaxf(fmaxf(t->u[0], t->u[1]), t->u[2]);
+  const float vmin = fminf(fminf(t->v[0], t->v[1]), t->v[2]), vmax = fmaxf(fmaxf(t->v[0], t->v[1]), t->v[2]);
+  const int cx0 = (int)ceilf(umin), cx1 = (int)floorf(umax), cy0 = (int)ceilf(vmin), cy1 = (int)floorf(vmax);
+  t->x0 = cx0 > 0 ? cx0 : 0;
+  t->x1 = cx1 < W - 1 ? cx1 : W - 1;
+  t->y0 = cy0 > 0 ? cy0 : 0;
+  t->y1 = cy1 < H - 1 ? cy1 : H - 1;
+  return t->x0 <= t->x1 && t->y0 <= t->y1;
+}
+
+static int rd_weights(const RdTri* t, float x, float y, float* w, float* s)
+{
+  float e[3];
+  e[0] = t->flip[0] ? -rd_edge(t->u[2], t->v[2], t->u[1], t->v[1], x, y) : rd_edge(t->u[1], t->v[1], t->u[2], t->v[2], x, y);
+  e[1] = t->flip[1] ? -rd_edge(t->u[0], t->v[0], t->u[2], t->v[2], x, y) : rd_edge(t->u[2], t->v[2], t->u[0], t->v[0], x, y);
+  e[2] = t->flip[2] ? -rd_edge(t->u[1], t->v[1], t->u[0], t->v[0], x, y) : rd_edge(t->u[0], t->v[0], t->u[1], t->v[1], x, y);
+  const int pos = e[0] >= 0.f && e[1] >= 0.f && e[2] >= 0.f;
+  const int neg = e[0] <= 0.f && e[1] <= 0.f && e[2] <= 0.f;
+  if (!(pos || neg)) return 0;
+  const float area = (e[0] + e[1]) + e[2];
+  if (area == 0.f) return 0;
+  w[0] = e[0] / area / t->z[0];
+  w[1] = e[1] / area / t->z[1];
+  w[2] = e[2] / area / t->z[2];
+  *s = (w[0] + w[1]) + w[2];
+  return *s > 0.f;
+}
+
+static float rd_nan(void)
+{
+  union { uint32_t u; float f; } c;
+  c.u = 0x7fc00000u;
+  return c.f;
+}
+
+/* vertices [Nv,3], normals [Nv,3] (or NULL), faces [Nf,3], poses [N,12] f32 (row-major 3x4 camera <- object).
+   out_v / out_n [N,H,W,4], out_c [N,H,W,3] (each optional); NaN where nothing is hit */
+int oracle_render_mesh(const float* vtx, const float* nrm, const int* faces, int nv, int nf, const float* poses, int N,
+                       int H, int W, float fx, float fy, float px, float py, float znear, float zfar, float canon_x_offset,
+                       float* out_v, float* out_n, float* out_c)
+{
+  (void)nv;
+  const long P = (long)H * W;
+  uint64_t* zbuf = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)P);
+  if (!zbuf) return -1;
+  const float qnan = rd_nan();
+  for (int n = 0; n < N; n++) {
+    const float* T = poses + 12 * (size_t)n;
+    for (long i = 0; i < P; i++) zbuf[i] = ~(uint64_t)0;
+    for (int f = 0; f < nf; f++) {
+      RdTri t;
+      float cam[3][3];
+      if (!rd_setup(T, vtx, faces + 3 * (size_t)f, W, H, fx, fy, px, py, znear, &t, cam)) continue;
+      for (int y = t.y0; y <= t.y1; y++)
+        for (int x = t.x0; x <= t.x1; x++) {
+          float w[3], s;
+          if (!rd_weights(&t, (float)x, (float)y, w, &s)) continue;
+          const float z = ((w[0] * t.z[0] + w[1] * t.z[1]) + w[2] * t.z[2]) / s;
+          if (!(z >= znear) || !(z <= zfar)) continue;
+          union { float f; uint32_t u; } c;
+          c.f = z;
+          const uint64_t key = ((uint64_t)c.u << 32) | (uint32_t)f;
+          if (key < zbuf[(long)y * W + x]) zbuf[(long)y * W + x] = key;
+        }
+    }
+    for (long i = 0; i < P; i++) {
+      const uint64_t key = zbuf[i];
+      float ov[3] = {qnan, qnan, qnan}, on[3] = {qnan, qnan, qnan}, oc[3] = {qnan, qnan, qnan};
+      const int hit = key != ~(uint64_t)0;
+      if (hit) {
+        const int* face = faces + 3 * (size_t)(uint32_t)(key & 0xffffffffu);
+        RdTri t;
+        float cam[3][3], w[3], s;
+        rd_setup(T, vtx, face, W, H, fx, fy, px, py, znear, &t, cam);
+        if (rd_weights(&t, (float)(i % W), (float)(i / W), w, &s)) {
+          for (int k = 0; k < 3; k++) ov[k] = ((w[0] * cam[0][k] + w[1] * cam[1][k]) + w[2] * cam[2][k]) / s;
+          if (out_n) {
+            float vn[3][3];
+            for (int j = 0; j < 3; j++) {
+              const float* p = nrm + 3 * (size_t)face[j];
+              const float a = p[0], b = p[1], c = p[2];
+              const float rx = (T[0] * a + T[1] * b) + T[2] * c;
+              const float ry = (T[4] * a + T[5] * b) + T[6] * c;
+              const float rz = (T[8] * a + T[9] * b) + T[10] * c;
+              const float len = sqrtf((rx * rx + ry * ry) + rz * rz);
+              const int ok = len > 0.f;
+              vn[j][0] = ok ? rx / len : rx;
+              vn[j][1] = ok ? ry / len : ry;
+              vn[j][2] = ok ? rz / len : rz;
+            }
+            for (int k = 0; k < 3; k++) on[k] = ((w[0] * vn[0][k] + w[1] * vn[1][k]) + w[2] * vn[2][k]) / s;
+          }
+          if (out_c)
+            for (int k = 0; k < 3; k++) {
+              const float off = k == 0 ? canon_x_offset : 0.f;
+              const float a0 = vtx[3 * (size_t)face[0] + k] + off, a1 = vtx[3 * (size_t)face[1] + k] + off,
+                          a2 = vtx[3 * (size_t)face[2] + k] + off;
+              oc[k] = ((w[0] * a0 + w[1] * a1) + w[2] * a2) / s;
+            }
+        }
+      }
+      const size_t o = (size_t)n * P + i;
+      if (out_v) { out_v[4 * o] = ov[0]; out_v[4 * o + 1] = ov[1]; out_v[4 * o + 2] = ov[2]; out_v[4 * o + 3] = hit ? 1.f : qnan; }
+      if (out_n) { out_n[4 * o] = on[0]; out_n[4 * o + 1] = on[1]; out_n[4 * o + 2] = on[2]; out_n[4 * o + 3] = hit ? 0.f : qnan; }
+      if (out_c) { out_c[3 * o] = oc[0]; out_c[3 * o + 1] = oc[1]; out_c[3 * o + 2] = oc[2]; }
+    }
+  }
+  free(zbuf);
+  return 0;
+}
+
+#define ICP_NCEN 5
+/* synthesize.cpp:2157-2207. sums[5] = sum (d - m).xyz over the agreeing pixels, their count, number of valid pairs; mask [H*W] */
+int oracle_icp_center(const int* label, const float* live, const float* canon, const float* pred_v, const float* pred_n, int pc,
+                      int H, int W, int obj_id, float max_error, double* sums, uint8_t* mask)
+{
+  const long P = (long)H * W;
+  const long nblocks = (P + ICP_BLOCK - 1) / ICP_BLOCK;
+  float buf[ICP_NCEN][ICP_BLOCK];
+  float* rows = (float*)malloc(sizeof(float) * ICP_NCEN * (size_t)nblocks);
+  if (!rows) return -1;
+  for (long b = 0; b < nblocks; b++) {
+    memset(buf, 0, sizeof(buf));
+    for (int t = 0; t < ICP_BLOCK; t++) {
+      const long p = b * ICP_BLOCK + t;
+      if (p >= P) break;
+      int valid = 0;
+      if (label[p] == obj_id) {
+        const float dx = live[3 * p], dy = live[3 * p + 1], dz = live[3 * p + 2];
+        if (dz > 0.f) {                                                   /* :2166 */
+          const float cx = canon[3 * p], vy = canon[3 * p + 1], vz = canon[3 * p + 2];
+          const float vx = cx - roundf(cx);                                /* :2168 */
+          if (vx == vx && vy == vy && vz == vz) {                          /* :2172 */
+            valid = 1;
+            const float* pv = pred_v + p * pc;
+            const float* pn = pred_n + p * pc;
+            const float error = (pn[0] * (dx - pv[0]) + pn[1] * (dy - pv[1])) + pn[2] * (dz - pv[2]);   /* :2177 */
+            if (fabsf(error) < max_error) {                                /* :2178 */
+              buf[0][t] = dx - vx; buf[1][t] = dy - vy; buf[2][t] = dz - vz; buf[3][t] = 1.f;
+            }
+            buf[4][t] = 1.f;
+          }
+        }
+      }
+      mask[p] = (uint8_t)valid;
+    }
+    for (int q = 0; q < ICP_NCEN; q++) {
+      float* a = buf[q];
+      for (int s = ICP_BLOCK / 2; s >= 1; s >>= 1)
+        for (int t = 0; t < s; t++) a[t] = a[t] + a[t + s];
+      rows[b * ICP_NCEN + q] = a[0];
+    }
+  }
+  icp_segmented_sums(rows, nblocks, ICP_NCEN, sums);
+  free(rows);
+  return 0;
+}
+
+/* synthesize.cpp:2302-2343 by exhaustive search. hyps [M,12] f32; hits [M] = number of distinct depth points that are
+   the nearest one (strictly inside `radius`) of some model point moved by the hypothesis */
+int oracle_icp_score(const float* live, const float* canon, const uint8_t* mask, int H, int W, const float* hyps, int M,
+                     float radius, int* hits)
+{
+  const long P = (long)H * W;
+  uint8_t* flags = (uint8_t*)malloc((size_t)P);
+  if (!flags) return -1;
+  const float r2 = radius * radius;
+  for (int m = 0; m < M; m++) {
+    const float* T = hyps + 12 * (size_t)m;
+    memset(flags, 0, (size_t)P);
+    int score = 0;
+    for (long p = 0; p < P; p++) {
+      if (!mask[p]) continue;
+      const float cx = canon[3 * p];
+      const float mx = cx - roundf(cx), my = canon[3 * p + 1], mz = canon[3 * p + 2];
+      const float qx = ((T[0] * mx + T[1] * my) + T[2] * mz) + T[3];
+      const float qy = ((T[4] * mx + T[5] * my) + T[6] * mz) + T[7];
+      const float qz = ((T[8] * mx + T[9] * my) + T[10] * mz) + T[11];
+      if (!(qx == qx) || !(qy == qy) || !(qz == qz)) continue;
+      float best = r2;
+      long bi = -1;
+      for (long i = 0; i < P; i++) {
+        if (!mask[i]) continue;
+        const float ex = live[3 * i] - qx, ey = live[3 * i + 1] - qy, ez = live[3 * i + 2] - qz;
+        const float d2 = (ex * ex + ey * ey) + ez * ez;
+        if (d2 < best) { best = d2; bi = i; }
+      }
+      if (bi >= 0 && !flags[bi]) { flags[bi] = 1; score++; }
+    }
+    hits[m] = score;
+  }
+  free(flags);
   return 0;
 }

@@ -2,9 +2,10 @@
 // behind Synthesizer::refinePose / solveICP (lib/synthesize/synthesize.cpp:2020-2026, :2052-2380; called from
 // lib/fcn/test.py:1925-1933), i.e. df::icp (lib/kinect_fusion/src/optimization/icp.cpp:20-106) with its per-pixel
 // kernel (src/optimization/icp.cu:25-136) and the masked depth -> vertex map step (synthesize.cpp:2139-2155 +
-// src/image/backprojection.cu:10-27). The OpenGL renderer that produces the predicted vertex / normal maps, the
-// PCL kd-tree hypothesis scoring and the nlopt refinement around it are NOT part of this slice: the entry takes the
-// predicted maps as inputs, exactly like df::icp does.
+// src/image/backprojection.cu:10-27), plus the two host-side steps of solveICP around the iterations — the translation
+// estimate (synthesize.cpp:2157-2225) and the SegICP scoring of the refined hypotheses (:2302-2343, PCL kd-tree in the
+// reference) — as kernels. The predicted maps come from csrc/render.hip (OpenGL in the reference); the nlopt polish
+// (poseWithOpt) is not reproduced.
 //
 // The reference runs, per iteration and per object: one kernel writing a 28-byte Jacobian/residual record for EVERY
 // pixel of the frame (8.6 MB), cudaDeviceSynchronize, a thrust::transform_reduce over all of them, a second
@@ -14,7 +15,7 @@
 //                      the 29 sums a pixel contributes to (21 J^T J, 6 J^T r, inlier count, sum r^2) are reduced
 //                      in LDS by a halving tree per 256-pixel block (blocks without a single contributing pixel —
 //                      ~95 % of a frame — skip the tree) into one partial row per block;
-//   icp_solve_kernel   one wave per object: partial rows added in ascending block order in f64 (29 lanes, coalesced),
+//   icp_solve_kernel   one workgroup per object: partial rows added in f64 in a fixed order (8 segments x 29 columns),
 //                      LDL^T solve, update = exp(solution), accumulated = update * accumulated — all in f64 by lane 0;
 //                      the state stays in the workspace, the next iteration's terms kernel reads it from there.
 // Arithmetic follows the canonical statement the CPU checker implements as well (same expression trees, same reduction
@@ -168,19 +169,50 @@ __device__ void icp_exp_se3(const double* xi, double* U)
   }
 }
 
+// The canonical sum of the per-block partial rows (f32) in f64: ICP_NSEG contiguous segments of ceil(nblocks / ICP_NSEG)
+// blocks, each added up in ascending block order, then the segment sums in ascending order. (One lane walking all 1200
+// rows of a 480x640 frame one dependent load at a time cost 267 us per ICP iteration — 2/3 of the whole refinement;
+// 8 segments x 8 loads in flight: a few us.)   256 threads: thread = (segment t >> 5, column t & 31), NQ <= 32 columns.
+constexpr int ICP_NSEG = 8;
+
+template <int NQ>
+__device__ __forceinline__ void icp_segmented_sums(const float* __restrict__ rows, int nblocks, double* S /* shared [NQ] */,
+                                                   double (*seg)[32] /* shared [ICP_NSEG][32] */)
+{
+  const int t = threadIdx.x, q = t & 31, sg = t >> 5;
+  const int L = (nblocks + ICP_NSEG - 1) / ICP_NSEG;
+  const int b0 = sg * L, b1 = min(nblocks, b0 + L);
+  double acc = 0.0;
+  if (q < NQ) {
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = rows[(long long)(b + u) * NQ + q];
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc = acc + (double)v[u];
+    }
+    for (; b < b1; b++) acc = acc + (double)rows[(long long)b * NQ + q];
+  }
+  seg[sg][q] = acc;
+  __syncthreads();
+  if (t < NQ) {
+    double s = seg[0][t];
+#pragma unroll
+    for (int k = 1; k < ICP_NSEG; k++) s = s + seg[k][t];
+    S[t] = s;
+  }
+  __syncthreads();
+}
+
 // icp.cpp:58-100 on the device: sums -> 6x6 solve -> exp -> accumulated update
-__global__ __launch_bounds__(64) void icp_solve_kernel(
+__global__ __launch_bounds__(256) void icp_solve_kernel(
     const float* __restrict__ partial, int nblocks, double* __restrict__ state, float* __restrict__ stats, int it, int iterations)
 {
   __shared__ double S[ICP_NSUM];
+  __shared__ double seg[ICP_NSEG][32];
   const int n = blockIdx.x, t = threadIdx.x;
-  if (t < ICP_NSUM) {
-    const float* src = partial + (long long)n * nblocks * ICP_NSUM + t;
-    double acc = 0.0;
-    for (int b = 0; b < nblocks; b++) acc = acc + (double)src[(long long)b * ICP_NSUM];
-    S[t] = acc;
-  }
-  __syncthreads();
+  icp_segmented_sums<ICP_NSUM>(partial + (long long)n * nblocks * ICP_NSUM, nblocks, S, seg);
   if (t != 0) return;
   if (stats) {
     stats[((long long)n * iterations + it) * 2 + 0] = (float)S[27];
@@ -220,6 +252,172 @@ __global__ __launch_bounds__(64) void icp_solve_kernel(
     Nn[4 * i + 3] = ((U[4 * i] * T[3] + U[4 * i + 1] * T[7]) + U[4 * i + 2] * T[11]) + U[4 * i + 3];
   }
   for (int i = 0; i < 12; i++) T[i] = Nn[i];
+}
+
+// ---- solveICP around the iterations: translation estimate and hypothesis selection (synthesize.cpp:2157-2262, :2302-2343) ----
+constexpr int ICP_NCEN = 5;   // sum (d - m).x, .y, .z over the pixels that agree with the render, their count, valid pixels
+
+// synthesize.cpp:2157-2207: pixels of the object with a depth reading and a rendered canonical vertex are the
+// (depth point, model point) pairs of the rest of solveICP (mask = 1); those whose depth point lies within max_error of
+// the rendered surface along its normal vote for the translation with (depth point - model point).
+__global__ __launch_bounds__(ICP_BLOCK) void icp_center_kernel(
+    const int* __restrict__ label, const float* __restrict__ live, const float* __restrict__ canon,
+    const float* __restrict__ pred_v, const float* __restrict__ pred_n, int pc, long long P, int obj_id, float max_error,
+    unsigned char* __restrict__ mask, float* __restrict__ partial)
+{
+  __shared__ float red[ICP_NCEN][ICP_BLOCK];
+  const int t = threadIdx.x;
+  const long long p = (long long)blockIdx.x * ICP_BLOCK + t;
+  float c[ICP_NCEN] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  if (p < P) {
+    bool valid = false;
+    if (label[p] == obj_id) {
+      const float dx = live[3 * p], dy = live[3 * p + 1], dz = live[3 * p + 2];
+      if (dz > 0.f) {
+        const float cx = canon[3 * p], vy = canon[3 * p + 1], vz = canon[3 * p + 2];
+        const float vx = cx - roundf(cx);        // the model index rides in the integer part of x (synthesize.cpp:270-271, :2173)
+        if (vx == vx && vy == vy && vz == vz) {
+          valid = true;
+          const float* pv = pred_v + p * pc;
+          const float* pn = pred_n + p * pc;
+          const float error = (pn[0] * (dx - pv[0]) + pn[1] * (dy - pv[1])) + pn[2] * (dz - pv[2]);
+          if (fabsf(error) < max_error) {
+            c[0] = dx - vx; c[1] = dy - vy; c[2] = dz - vz; c[3] = 1.f;
+          }
+          c[4] = 1.f;
+        }
+      }
+    }
+    mask[p] = valid ? 1 : 0;
+  }
+#pragma unroll
+  for (int q = 0; q < ICP_NCEN; q++) red[q][t] = c[q];
+  __syncthreads();
+  for (int s = ICP_BLOCK / 2; s >= 1; s >>= 1) {
+    if (t < s) {
+#pragma unroll
+      for (int q = 0; q < ICP_NCEN; q++) red[q][t] = red[q][t] + red[q][t + s];
+    }
+    __syncthreads();
+  }
+  if (t < ICP_NCEN) partial[(long long)blockIdx.x * ICP_NCEN + t] = red[t][0];
+}
+
+__global__ __launch_bounds__(256) void icp_center_sum_kernel(const float* __restrict__ partial, int nblocks, double* __restrict__ sums)
+{
+  __shared__ double S[ICP_NCEN];
+  __shared__ double seg[ICP_NSEG][32];
+  icp_segmented_sums<ICP_NCEN>(partial, nblocks, S, seg);
+  if (threadIdx.x < ICP_NCEN) sums[threadIdx.x] = S[threadIdx.x];
+}
+
+// synthesize.cpp:2302-2343 (the SegICP score): every model point, moved by the hypothesis, looks for its NEAREST depth
+// point within `radius` (pcl::KdTreeFLANN::radiusSearch returns its hits sorted by distance; [0] is used) and marks it;
+// the score is the number of distinct marked depth points. The reference builds a kd-tree per object on the host and
+// marks from an OpenMP loop (a race on flags[]); the distinct count does not depend on the order. Here the depth points
+// are still in image order, so the search is a window around the projection of the moved model point: a point within
+// r of (X, Y, Z) projects within fx r (1 + |X/Z|) / (Z - r) pixels of it — an exact search, ties to the lower pixel index.
+// At 0.7 m a 1 cm radius is a 41 x 41 pixel window (1 681 candidates; the first version scanned all of them: 0.5 ms per
+// object); but the nearest point is almost always a pixel or two from the projection. So the window is shrunk first: a
+// 5 x 5, then a 13 x 13 probe around the projection yields an upper bound b on the nearest squared distance, and every
+// point at least that close lies in the window of radius sqrt(b) — typically 7 x 7. The final scan runs over that window
+// in raster order from scratch (strict <, so ties still go to the lower pixel index): same result as the exhaustive search.
+struct IcpWin { int x0, x1, y0, y1; };
+
+__device__ __forceinline__ IcpWin icp_window(float qx, float qy, float qz, float rad, float fx, float fy, float px, float py, int H, int W,
+                                             bool& none)
+{
+  IcpWin w = {0, W - 1, 0, H - 1};
+  none = false;
+  if (qz > 2.f * rad) {
+    const float uc = qx / qz * fx + px, vc = qy / qz * fy + py;
+    const float hw = fabsf(fx) * rad * (1.f + fabsf(qx / qz)) / (qz - rad) + 2.f;
+    const float hh = fabsf(fy) * rad * (1.f + fabsf(qy / qz)) / (qz - rad) + 2.f;
+    if (!(fabsf(uc) < 1e8f) || !(fabsf(vc) < 1e8f) || !(hw < 1e8f) || !(hh < 1e8f)) { none = true; return w; }   // nowhere near the image
+    w.x0 = max(0, (int)floorf(uc - hw)); w.x1 = min(W - 1, (int)ceilf(uc + hw));
+    w.y0 = max(0, (int)floorf(vc - hh)); w.y1 = min(H - 1, (int)ceilf(vc + hh));
+  }
+  return w;
+}
+
+// nearest masked depth point inside the window with d2 < best (strict), raster order; |dz| >= radius cannot qualify
+// (then d2 >= dz^2 >= radius^2 also in rounded arithmetic: squares and sums of non-negatives are monotone)
+constexpr int ICP_CH = 8;
+__device__ __forceinline__ void icp_scan(const float* __restrict__ live, const unsigned char* __restrict__ mask, int W, IcpWin w,
+                                         float qx, float qy, float qz, float radius, float& best, long long& bi)
+{
+  // ICP_CH candidates of a row at a time: their 4 ICP_CH loads are issued together, unconditionally (one candidate per trip
+  // with its dependent loads — mask, z, then x and y, L2 hits each — made a thread with a full 41 x 41 window take 0.4 ms).
+  // Measured alternatives: 16 per trip, or x / y fetched only after the depth test: both 6 % slower.
+  for (int y = w.y0; y <= w.y1; y++) {
+    const long long base = (long long)y * W;
+    for (int x = w.x0; x <= w.x1; x += ICP_CH) {
+      unsigned char mk[ICP_CH];
+      float vx[ICP_CH], vy[ICP_CH], vz[ICP_CH];
+#pragma unroll
+      for (int u = 0; u < ICP_CH; u++) {
+        const long long i = base + min(x + u, w.x1);
+        mk[u] = mask[i];
+        vx[u] = live[3 * i]; vy[u] = live[3 * i + 1]; vz[u] = live[3 * i + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < ICP_CH; u++) {
+        if (x + u > w.x1 || !mk[u]) continue;
+        const float ez = vz[u] - qz;
+        if (!(fabsf(ez) < radius)) continue;
+        const float ex = vx[u] - qx, ey = vy[u] - qy;
+        const float d2 = (ex * ex + ey * ey) + ez * ez;
+        if (d2 < best) { best = d2; bi = base + x + u; }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void icp_score_kernel(
+    const float* __restrict__ live, const float* __restrict__ canon, const unsigned char* __restrict__ mask, int H, int W,
+    const float* __restrict__ hyps, float fx, float fy, float px, float py, float radius, unsigned* __restrict__ flags,
+    int nwords, int* __restrict__ hits)
+{
+  const long long P = (long long)H * W;
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int m = blockIdx.y;
+  if (p >= P || !mask[p]) return;
+  const float* T = hyps + 12 * (size_t)m;
+  const float cx = canon[3 * p];
+  const float mx = cx - roundf(cx), my = canon[3 * p + 1], mz = canon[3 * p + 2];
+  const float qx = ((T[0] * mx + T[1] * my) + T[2] * mz) + T[3];
+  const float qy = ((T[4] * mx + T[5] * my) + T[6] * mz) + T[7];
+  const float qz = ((T[8] * mx + T[9] * my) + T[10] * mz) + T[11];
+  if (!(qx == qx) || !(qy == qy) || !(qz == qz)) return;
+  bool none;
+  IcpWin full = icp_window(qx, qy, qz, radius, fx, fy, px, py, H, W, none);
+  if (none) return;
+  const float r2 = radius * radius;
+  if (qz > 2.f * radius) {
+    // probes around the projection: an upper bound on the nearest squared distance, if anything is close at all
+    const int uc = (int)rintf(qx / qz * fx + px), vc = (int)rintf(qy / qz * fy + py);
+    float bound = r2;
+    long long dummy = -1;
+#pragma unroll
+    for (int half = 2; half <= 6; half += 4) {
+      if (bound < r2) break;
+      IcpWin pw = {max(full.x0, uc - half), min(full.x1, uc + half), max(full.y0, vc - half), min(full.y1, vc + half)};
+      icp_scan(live, mask, W, pw, qx, qy, qz, radius, bound, dummy);
+    }
+    if (bound < r2) {
+      const float rb = sqrt_rn(bound) * 1.0001f + 1e-7f;      // >= the distance of the probe's best point
+      bool n2;
+      const IcpWin sw = icp_window(qx, qy, qz, fminf(rb, radius), fx, fy, px, py, H, W, n2);
+      if (!n2) { full.x0 = max(full.x0, sw.x0); full.x1 = min(full.x1, sw.x1); full.y0 = max(full.y0, sw.y0); full.y1 = min(full.y1, sw.y1); }
+    }
+  }
+  float best = r2;
+  long long bi = -1;
+  icp_scan(live, mask, W, full, qx, qy, qz, radius, best, bi);
+  if (bi < 0) return;
+  const unsigned bit = 1u << (bi & 31);
+  const unsigned old = atomicOr(&flags[(size_t)m * nwords + (bi >> 5)], bit);
+  if (!(old & bit)) atomicAdd(&hits[m], 1);
 }
 
 size_t icp_ws_bytes(int N, int H, int W)
@@ -273,7 +471,67 @@ extern "C" int pcnn_icp_refine_fwd(const float* live_vertices, const float* pred
   for (int it = 0; it < iterations; it++) {
     PCNN_LAUNCH(icp_terms_kernel, dim3(nblocks, num_objects), dim3(ICP_BLOCK), 0, stream, live_vertices, pred_vertices, pred_normals,
                 update, P, height, width, pred_channels, fx, fy, px, py, z_near, z_far, max_error, partial, nblocks);
-    PCNN_LAUNCH(icp_solve_kernel, dim3(num_objects), dim3(64), 0, stream, partial, nblocks, update, stats, it, iterations);
+    PCNN_LAUNCH(icp_solve_kernel, dim3(num_objects), dim3(256), 0, stream, partial, nblocks, update, stats, it, iterations);
   }
   return check_launch("icp_refine_fwd");
+}
+
+extern "C" int pcnn_icp_center_workspace_bytes(int height, int width, size_t* bytes)
+{
+  PCNN_REQUIRE(bytes, PCNN_ENULL, "icp_center_workspace_bytes: NULL output");
+  PCNN_REQUIRE(height >= 1 && width >= 1, PCNN_EINVAL, "icp_center_workspace_bytes: bad shape");
+  *bytes = align_up(sizeof(float) * (size_t)(((long long)height * width + ICP_BLOCK - 1) / ICP_BLOCK) * ICP_NCEN, 256);
+  return PCNN_OK;
+}
+
+extern "C" int pcnn_icp_center_fwd(const int32_t* label, const float* live_vertices, const float* canonical,
+                                   const float* pred_vertices, const float* pred_normals, int pred_channels, int height,
+                                   int width, int obj_id, float max_error, double* sums, uint8_t* mask, void* workspace,
+                                   size_t workspace_bytes, void* stream_)
+{
+  PCNN_REQUIRE(height >= 1 && width >= 1, PCNN_EINVAL, "icp_center: bad shape %dx%d", height, width);
+  PCNN_REQUIRE(pred_channels == 3 || pred_channels == 4, PCNN_EINVAL, "icp_center: predicted maps carry 3 or 4 floats per pixel (got %d)", pred_channels);
+  PCNN_REQUIRE(label && live_vertices && canonical && pred_vertices && pred_normals && sums && mask && workspace, PCNN_ENULL, "icp_center: NULL pointer");
+  size_t need = 0;
+  pcnn_icp_center_workspace_bytes(height, width, &need);
+  PCNN_REQUIRE(workspace_bytes >= need, PCNN_EWORKSPACE, "icp_center: workspace too small (%zu < %zu)", workspace_bytes, need);
+  hipStream_t stream = (hipStream_t)stream_;
+  const long long P = (long long)height * width;
+  const int nblocks = (int)((P + ICP_BLOCK - 1) / ICP_BLOCK);
+  float* partial = static_cast<float*>(workspace);
+  PCNN_LAUNCH(icp_center_kernel, dim3(nblocks), dim3(ICP_BLOCK), 0, stream, label, live_vertices, canonical, pred_vertices,
+              pred_normals, pred_channels, P, obj_id, max_error, mask, partial);
+  PCNN_LAUNCH(icp_center_sum_kernel, dim3(1), dim3(256), 0, stream, partial, nblocks, sums);
+  return check_launch("icp_center_fwd");
+}
+
+extern "C" int pcnn_icp_score_workspace_bytes(int num_hypotheses, int height, int width, size_t* bytes)
+{
+  PCNN_REQUIRE(bytes, PCNN_ENULL, "icp_score_workspace_bytes: NULL output");
+  PCNN_REQUIRE(num_hypotheses >= 0 && height >= 1 && width >= 1, PCNN_EINVAL, "icp_score_workspace_bytes: bad shape");
+  *bytes = sizeof(unsigned) * (size_t)num_hypotheses * (size_t)(((long long)height * width + 31) / 32);
+  return PCNN_OK;
+}
+
+extern "C" int pcnn_icp_score_fwd(const float* live_vertices, const float* canonical, const uint8_t* mask, int height, int width,
+                                  const float* hypotheses, int num_hypotheses, float fx, float fy, float px, float py,
+                                  float radius, int32_t* hits, void* workspace, size_t workspace_bytes, void* stream_)
+{
+  PCNN_REQUIRE(height >= 1 && width >= 1 && num_hypotheses >= 0, PCNN_EINVAL, "icp_score: bad shape %dx%d, %d hypotheses", height, width, num_hypotheses);
+  PCNN_REQUIRE(num_hypotheses <= 65535, PCNN_EINVAL, "icp_score: at most 65535 hypotheses per call");
+  PCNN_REQUIRE(radius > 0 && fx != 0 && fy != 0, PCNN_EINVAL, "icp_score: radius must be positive, focal lengths non-zero");
+  if (num_hypotheses == 0) return PCNN_OK;
+  PCNN_REQUIRE(live_vertices && canonical && mask && hypotheses && hits && workspace, PCNN_ENULL, "icp_score: NULL pointer");
+  size_t need = 0;
+  pcnn_icp_score_workspace_bytes(num_hypotheses, height, width, &need);
+  PCNN_REQUIRE(workspace_bytes >= need, PCNN_EWORKSPACE, "icp_score: workspace too small (%zu < %zu)", workspace_bytes, need);
+  hipStream_t stream = (hipStream_t)stream_;
+  const long long P = (long long)height * width;
+  const int nwords = (int)((P + 31) / 32);
+  int st = zero_async(workspace, need, stream, "icp_score");
+  if (st == PCNN_OK) st = zero_async(hits, sizeof(int32_t) * (size_t)num_hypotheses, stream, "icp_score");
+  if (st != PCNN_OK) return st;
+  PCNN_LAUNCH(icp_score_kernel, dim3((unsigned)((P + 255) / 256), num_hypotheses), dim3(256), 0, stream, live_vertices, canonical, mask,
+              height, width, hypotheses, fx, fy, px, py, radius, static_cast<unsigned*>(workspace), nwords, hits);
+  return check_launch("icp_score_fwd");
 }

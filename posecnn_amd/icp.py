@@ -1,16 +1,21 @@
-"""Depth-based pose refinement, first slice: the projective point-to-plane ICP core of
-`Synthesizer::solveICP` / `refinePose` (lib/synthesize/synthesize.cpp:2052-2380, :1969-2029 -> `df::icp`,
-lib/kinect_fusion/src/optimization/icp.cpp:20-106), which lib/fcn/test.py:1925-1933 calls after the network when
-`cfg.TEST.POSE_REFINE` is set:
+"""Depth-based pose refinement: `Synthesizer::solveICP` (lib/synthesize/synthesize.cpp:2052-2380), which
+lib/fcn/test.py:1925-1933 calls after the network when `cfg.TEST.POSE_REFINE` is set:
 
     synthesizer.icp_python(labels_icp, im_depth, parameters, height, width, num_roi, channel_roi,
                            rois_icp, poses, poses_new, poses_icp, error_threshold)
 
-What is here: the masked depth -> vertex-map step and the ICP iterations (gfx950 kernels behind
-`pcnn_icp_backproject_fwd` / `pcnn_icp_refine_fwd`, all objects of a frame in one call, no host round trip between
-iterations), and `refine_poses`, the per-frame driver with the reference's argument meaning. What is NOT here: the
-OpenGL renderer that turns (mesh, pose) into the predicted vertex / normal maps — `refine_poses` takes it as a
-callable —, the PCL kd-tree scoring of the 11 depth hypotheses and the nlopt stage (synthesize.cpp:2237-2343).
+`Synthesizer` below keeps that call (same argument meaning, results written into `poses_new` / `poses_icp`). Per ROI with a
+class id > 0 and >= 400 label pixels, all on the GPU (gfx950 kernels of libposecnn_hip.so):
+
+    render the mesh at the network's pose            pcnn_render_mesh_fwd     (the reference: two OpenGL passes, :2104-2136)
+    masked depth -> live vertex map                  pcnn_icp_backproject_fwd (:2139-2155)
+    translation from depth vs. rendered surface      pcnn_icp_center_fwd      (:2157-2225)  -> poses_new
+    8 depth hypotheses, each: render + 8 ICP steps   pcnn_render_mesh_fwd + pcnn_icp_refine_fwd, the 8 in ONE call each (:2272-2300)
+    SegICP score of the 8 refined hypotheses         pcnn_icp_score_fwd       (:2302-2343)  -> poses_icp = best
+
+NOT here: the Nelder-Mead polish between the translation estimate and the hypotheses (`poseWithOpt`, :2226-2235, :2529-2570
+— nlopt; `polish` is the hook) and assimp: meshes are Wavefront OBJ read by `Mesh.load_obj` (positions, faces, optional
+normals; smooth normals are generated like aiProcess_GenSmoothNormals when the file has none).
 """
 import ctypes
 
@@ -59,6 +64,153 @@ def icp(live_vertices, pred_vertices, pred_normals, K, depth_range=(Z_NEAR, Z_FA
                                     float(K[0, 2]), float(K[1, 2]), float(depth_range[0]), float(depth_range[1]), float(max_error),
                                     int(iterations), ops._ptr(update), ops._ptr(stats), ops._ptr(ws), nbytes.value, ops._stream(live)))
     return (update, stats) if want_stats else update
+
+
+def _pose34(q_t):
+    T = np.zeros((3, 4))
+    T[:, :3] = quat2mat(np.asarray(q_t[:4], dtype=np.float64))
+    T[:, 3] = q_t[4:7]
+    return T
+
+
+def _compose(U, T):
+    """U * T for 3x4 rigid transforms (Sophus: update * T_co, synthesize.cpp:2025)"""
+    out = np.zeros((3, 4))
+    out[:, :3] = U[:, :3] @ T[:, :3]
+    out[:, 3] = U[:, :3] @ T[:, 3] + U[:, 3]
+    return out
+
+
+class Mesh:
+    """One object model as the reference keeps it after `loadTexturedMesh` + `initializeBuffers`
+    (synthesize.cpp:197-320): positions, per-vertex normals, triangle indices — on the GPU."""
+
+    def __init__(self, vertices, faces, normals=None, device="cuda"):
+        v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
+        f = np.ascontiguousarray(faces, dtype=np.int32).reshape(-1, 3)
+        if f.size and (f.min() < 0 or f.max() >= len(v)):
+            raise ValueError("face index out of range (0..%d)" % (len(v) - 1))
+        n = self.smooth_normals(v, f) if normals is None else np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
+        if n.shape != v.shape:
+            raise ValueError("one normal per vertex")
+        self.vertices_np, self.faces_np, self.normals_np = v, f, n
+        dev = torch.device(device)
+        self.vertices = torch.from_numpy(v).to(dev)
+        self.faces = torch.from_numpy(f).to(dev)
+        self.normals = torch.from_numpy(n).to(dev)
+
+    @staticmethod
+    def smooth_normals(v, f):
+        """aiProcess_GenSmoothNormals (synthesize.cpp:199): face normals (v1-v0) x (v2-v0), un-normalised — i.e. area
+        weighted —, summed over the faces around a vertex and normalised."""
+        v = v.astype(np.float64)
+        fn = np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]])
+        n = np.zeros_like(v)
+        for k in range(3):
+            np.add.at(n, f[:, k], fn)
+        ln = np.linalg.norm(n, axis=1, keepdims=True)
+        return (n / np.maximum(ln, 1e-30)).astype(np.float32)
+
+    @classmethod
+    def load_obj(cls, path, device="cuda"):
+        """Wavefront OBJ: `v`, `vn`, `f` records (polygons are fanned into triangles; `a/b/c` index triples: when every
+        corner's normal index equals its position index the file's normals are used, else smooth normals are generated).
+        Vertices are NOT merged (assimp's JoinIdenticalVertices only matters for the generated normals of duplicated
+        positions, which OBJ exports of the YCB / LINEMOD models do not have)."""
+        vs, vns, faces, nidx_ok = [], [], [], True
+        with open(path) as fh:
+            for line in fh:
+                t = line.split()
+                if not t:
+                    continue
+                if t[0] == "v":
+                    vs.append([float(x) for x in t[1:4]])
+                elif t[0] == "vn":
+                    vns.append([float(x) for x in t[1:4]])
+                elif t[0] == "f":
+                    idx = []
+                    for c in t[1:]:
+                        parts = c.split("/")
+                        vi = int(parts[0])
+                        vi = vi - 1 if vi > 0 else len(vs) + vi
+                        if len(parts) >= 3 and parts[2]:
+                            ni = int(parts[2])
+                            ni = ni - 1 if ni > 0 else len(vns) + ni
+                            nidx_ok = nidx_ok and ni == vi
+                        else:
+                            nidx_ok = False
+                        idx.append(vi)
+                    for k in range(1, len(idx) - 1):
+                        faces.append([idx[0], idx[k], idx[k + 1]])
+        normals = np.asarray(vns, dtype=np.float32) if (nidx_ok and len(vns) == len(vs) and vns) else None
+        return cls(np.asarray(vs, dtype=np.float32), np.asarray(faces, dtype=np.int32), normals, device)
+
+
+def render(mesh, poses, K, height, width, depth_range=(Z_NEAR, Z_FAR), model_index=0, want=("vertices", "normals")):
+    """The predicted maps of `refinePose` / `solveICP` (synthesize.cpp:1972-1991, :2104-2136) for N poses in one call.
+    poses [N,3,4] (camera <- object; numpy or torch). Returns a dict with the requested maps: "vertices" / "normals"
+    f32 [N,H,W,4], "canonical" f32 [N,H,W,3] (object-frame point, x + model_index); NaN where no surface is hit."""
+    dev = mesh.vertices.device
+    P = torch.as_tensor(np.asarray(poses, dtype=np.float32) if not isinstance(poses, torch.Tensor) else poses, dtype=torch.float32).to(dev)
+    P = P.reshape(-1, 12).contiguous()
+    N = P.shape[0]
+    out = {}
+    for key, ch in (("vertices", 4), ("normals", 4), ("canonical", 3)):
+        out[key] = torch.empty((N, height, width, ch), dtype=torch.float32, device=dev) if key in want else None
+    nbytes = ctypes.c_size_t()
+    check("pcnn_render_mesh_workspace_bytes", lib().pcnn_render_mesh_workspace_bytes(N, height, width, ctypes.byref(nbytes)))
+    ws = ops._ws(dev, "render").get(nbytes.value, dev)
+    check("pcnn_render_mesh_fwd",
+          lib().pcnn_render_mesh_fwd(ops._ptr(mesh.vertices), ops._ptr(mesh.normals), ops._ptr(mesh.faces), mesh.vertices.shape[0],
+                                     mesh.faces.shape[0], ops._ptr(P), N, height, width, float(K[0, 0]), float(K[1, 1]), float(K[0, 2]),
+                                     float(K[1, 2]), float(depth_range[0]), float(depth_range[1]), float(model_index),
+                                     ops._ptr(out["vertices"]), ops._ptr(out["normals"]), ops._ptr(out["canonical"]), ops._ptr(ws),
+                                     nbytes.value, ops._stream(mesh.vertices)))
+    return {k: v for k, v in out.items() if v is not None}
+
+
+def center(label, live_vertices, canonical, pred_vertices, pred_normals, obj_id, max_error=ERROR_THRESHOLD):
+    """synthesize.cpp:2157-2207: returns (sums f64 [5] = sum (d - m).xyz over the pixels whose depth point agrees with the
+    render, their count, number of valid (depth point, model point) pairs; mask uint8 [H,W] of those pairs)."""
+    lab = ops._dev(label, "label", torch.int32)
+    live = ops._dev(live_vertices, "live_vertices", torch.float32)
+    can = ops._dev(canonical, "canonical", torch.float32)
+    pv = ops._dev(pred_vertices, "pred_vertices", torch.float32)
+    pn = ops._dev(pred_normals, "pred_normals", torch.float32)
+    H, W = lab.shape
+    if live.shape != (H, W, 3) or can.shape != (H, W, 3) or pv.shape[:2] != (H, W) or pv.shape != pn.shape or pv.shape[2] not in (3, 4):
+        raise ValueError("label [H,W], live / canonical [H,W,3], pred_* [H,W,3|4]")
+    sums = torch.empty((5,), dtype=torch.float64, device=lab.device)
+    mask = torch.empty((H, W), dtype=torch.uint8, device=lab.device)
+    nbytes = ctypes.c_size_t()
+    check("pcnn_icp_center_workspace_bytes", lib().pcnn_icp_center_workspace_bytes(H, W, ctypes.byref(nbytes)))
+    ws = ops._ws(lab.device, "icp_center").get(nbytes.value, lab.device)
+    check("pcnn_icp_center_fwd",
+          lib().pcnn_icp_center_fwd(ops._ptr(lab), ops._ptr(live), ops._ptr(can), ops._ptr(pv), ops._ptr(pn), int(pv.shape[2]), H, W,
+                                    int(obj_id), float(max_error), ops._ptr(sums), ops._ptr(mask), ops._ptr(ws), nbytes.value,
+                                    ops._stream(lab)))
+    return sums, mask
+
+
+def score(live_vertices, canonical, mask, hypotheses, K, radius=0.01):
+    """synthesize.cpp:2302-2343: int32 [M] = distinct depth points marked by the model points moved by each hypothesis
+    (hypotheses [M,3,4]); the reference's score is this divided by the number of model points."""
+    live = ops._dev(live_vertices, "live_vertices", torch.float32)
+    can = ops._dev(canonical, "canonical", torch.float32)
+    msk = ops._dev(mask, "mask", torch.uint8)
+    H, W = msk.shape
+    hyp = torch.as_tensor(np.asarray(hypotheses, dtype=np.float32) if not isinstance(hypotheses, torch.Tensor) else hypotheses,
+                          dtype=torch.float32).to(live.device).reshape(-1, 12).contiguous()
+    M = hyp.shape[0]
+    hits = torch.empty((M,), dtype=torch.int32, device=live.device)
+    nbytes = ctypes.c_size_t()
+    check("pcnn_icp_score_workspace_bytes", lib().pcnn_icp_score_workspace_bytes(M, H, W, ctypes.byref(nbytes)))
+    ws = ops._ws(live.device, "icp_score").get(max(nbytes.value, 4), live.device)
+    check("pcnn_icp_score_fwd",
+          lib().pcnn_icp_score_fwd(ops._ptr(live), ops._ptr(can), ops._ptr(msk), H, W, ops._ptr(hyp), M, float(K[0, 0]), float(K[1, 1]),
+                                   float(K[0, 2]), float(K[1, 2]), float(radius), ops._ptr(hits), ops._ptr(ws), nbytes.value,
+                                   ops._stream(live)))
+    return hits
 
 
 def mat2quat(R):
@@ -119,3 +271,86 @@ def refine_poses(labels, depth, K, factor_depth, rois, poses, render_fn, iterati
         out[i, :4] = mat2quat(R)
         out[i, 4:] = t
     return out
+
+
+HYPOTHESIS_DZ = (0.0, -0.02, -0.01, 0.01, 0.02, 0.03, 0.04, 0.05)    # synthesize.cpp:2252-2270
+
+
+class Synthesizer:
+    """The slice of `libsynthesizer.Synthesizer` the test loop uses (lib/fcn/test.py:1863-1865, :1925-1933):
+    `Synthesizer(model_file, pose_file)`, `setup(width, height)`, `icp_python(...)`. `model_file` lists one OBJ path per
+    line (synthesize.cpp:147-160; class id c uses line c - 1); `meshes` passes `Mesh` objects directly instead."""
+
+    def __init__(self, model_file=None, pose_file=None, meshes=None, device="cuda", polish=None):
+        self.model_file, self.pose_file, self.device = model_file, pose_file, torch.device(device)
+        self.meshes = list(meshes) if meshes is not None else None
+        self.polish = polish          # optional callable(T_co [3,4], context dict) -> T_co: the reference's nlopt stage
+        self.width = self.height = None
+        self.last = []                # per processed ROI: hits / pairs of each hypothesis and the chosen one
+
+    def setup(self, width, height):
+        self.width, self.height = int(width), int(height)
+        if self.meshes is None:
+            if not self.model_file:
+                raise ValueError("Synthesizer needs model_file or meshes")
+            with open(self.model_file) as fh:
+                self.meshes = [Mesh.load_obj(line.strip(), self.device) for line in fh if line.strip()]
+
+    def icp_python(self, labelmap, depth, parameters, height, width, num_roi, channel_roi, rois, poses, outputs, outputs_icp,
+                   maxError, iterations=8, min_pixels=400, radius=0.01):
+        """`Synthesizer::icp_python` -> `solveICP`. parameters = (fx, fy, px, py, znear, zfar, factor_depth);
+        labelmap int32 [H,W]; depth uint16 [H,W]; rois [num_roi, channel_roi] (class id in column 1); poses [num_roi,7]
+        (quaternion wxyz, translation); outputs / outputs_icp f32 [num_roi,7] are filled in place (rows of skipped ROIs
+        untouched): outputs = pose with the depth-based translation, outputs_icp = best refined hypothesis."""
+        if self.meshes is None:
+            self.setup(width, height)
+        fx, fy, px, py, znear, zfar, factor = [float(x) for x in np.asarray(parameters).reshape(-1)[:7]]
+        K = np.array([[fx, 0, px], [0, fy, py], [0, 0, 1]], dtype=np.float64)
+        dev = self.device
+        labels_np = np.ascontiguousarray(labelmap, dtype=np.int32).reshape(height, width)
+        labels_t = torch.from_numpy(labels_np).to(dev)
+        depth_t = depth.to(dev) if isinstance(depth, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(depth, dtype=np.uint16).reshape(height, width)).to(dev)
+        rois = np.asarray(rois).reshape(num_roi, channel_roi)
+        poses = np.asarray(poses, dtype=np.float64).reshape(num_roi, 7)
+        counts = np.bincount(labels_np.reshape(-1).clip(min=0), minlength=len(self.meshes) + 2)
+        self.last = []
+        for i in range(num_roi):
+            obj = int(rois[i, 1])
+            if obj <= 0:                                   # :2096
+                continue
+            if obj > len(self.meshes):
+                raise ValueError("ROI %d: class id %d has no model (%d loaded)" % (i, obj, len(self.meshes)))
+            if counts[obj] < min_pixels:                   # :2152 (the reference leaves the row as it was)
+                continue
+            mesh = self.meshes[obj - 1]
+            T_co = _pose34(poses[i])
+            maps = render(mesh, T_co[None], K, height, width, (znear, zfar), model_index=obj - 1, want=("vertices", "normals", "canonical"))
+            live = backproject(depth_t, labels_t, obj, K, factor)
+            sums, mask = center(labels_t, live, maps["canonical"][0], maps["vertices"][0], maps["normals"][0], obj, maxError)
+            sums = sums.cpu().numpy()
+            c = int(sums[3])
+            Tz = T_co[2, 3]
+            if c > 0:                                      # :2215-2236
+                Tz = float(np.float32(sums[2]) / np.float32(c))
+                rx = poses[i, 4] / poses[i, 6] if poses[i, 6] else 0.0
+                ry = poses[i, 5] / poses[i, 6] if poses[i, 6] else 0.0
+                T_co[:, 3] = (rx * Tz, ry * Tz, Tz)
+                if self.polish is not None:
+                    T_co = np.asarray(self.polish(T_co.copy(), {"obj": obj, "live": live, "labels": labels_t, "K": K, "mesh": mesh}), dtype=np.float64)
+                    Tz = T_co[2, 3]
+            outputs[i, :4] = mat2quat(T_co[:, :3])
+            outputs[i, 4:7] = T_co[:, 3]
+            hyps = np.repeat(T_co[None], len(HYPOTHESIS_DZ), 0)
+            hyps[:, 2, 3] = Tz + np.asarray(HYPOTHESIS_DZ)
+            pm = render(mesh, hyps, K, height, width, (znear, zfar), want=("vertices", "normals"))
+            live_n = live.unsqueeze(0).expand(len(hyps), -1, -1, -1).contiguous()
+            upd = icp(live_n, pm["vertices"], pm["normals"], K, (znear, zfar), maxError, iterations).cpu().numpy()
+            hyps = np.stack([_compose(U, T) for U, T in zip(upd, hyps)])
+            pairs = int(sums[4])
+            choose, hits = 0, None
+            if pairs > 0:                                  # :2302-2343
+                hits = score(live, maps["canonical"][0], mask, hyps, K, radius).cpu().numpy()
+                choose = int(np.argmax(hits))              # first maximum (`score > max_score`, :2336)
+            self.last.append({"roi": i, "obj": obj, "pairs": pairs, "agree": c, "hits": hits, "choose": choose})
+            outputs_icp[i, :4] = mat2quat(hyps[choose][:, :3])
+            outputs_icp[i, 4:7] = hyps[choose][:, 3]

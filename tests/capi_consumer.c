@@ -45,6 +45,17 @@ int main(void)
     CHECK(pcnn_fc_rows_workspace_bytes(76800, 512, 64, &head) == PCNN_OK && head == 0);
     CHECK(pcnn_fc_rows_fwd(NULL, NULL, NULL, 16, 100, 64, 1, NULL, NULL, NULL, NULL, 0, NULL) == PCNN_EINVAL);
   }
+  /* pose refinement (Synthesizer::solveICP): workspace rules and host-side argument checks of the render / centre / score entries */
+  {
+    size_t zb = 0, cw = 0, sw = 0;
+    CHECK(pcnn_render_mesh_workspace_bytes(8, 480, 640, &zb) == PCNN_OK && zb == 8u * 480u * 640u * 8u);
+    CHECK(pcnn_icp_center_workspace_bytes(480, 640, &cw) == PCNN_OK && cw >= 1200u * 5u * 4u);
+    CHECK(pcnn_icp_score_workspace_bytes(8, 480, 640, &sw) == PCNN_OK && sw == 8u * 9600u * 4u);
+    CHECK(pcnn_render_mesh_fwd(NULL, NULL, NULL, 3, 1, NULL, 1, 480, 640, 1066.f, 1067.f, 313.f, 241.f, 0.f, 6.f, 0.f, NULL, NULL, NULL, NULL, 0, NULL) == PCNN_EINVAL);
+    CHECK(pcnn_render_mesh_fwd(NULL, NULL, NULL, 3, 1, NULL, 1, 480, 640, 1066.f, 1067.f, 313.f, 241.f, 0.25f, 6.f, 0.f, NULL, NULL, NULL, NULL, 0, NULL) == PCNN_ENULL);
+    CHECK(pcnn_icp_center_fwd(NULL, NULL, NULL, NULL, NULL, 5, 480, 640, 1, 0.01f, NULL, NULL, NULL, 0, NULL) == PCNN_EINVAL);
+    CHECK(pcnn_icp_score_fwd(NULL, NULL, NULL, 480, 640, NULL, 8, 1066.f, 1067.f, 313.f, 241.f, -1.f, NULL, NULL, 0, NULL) == PCNN_EINVAL);
+  }
   printf("capi_consumer ok: abi %d, hough workspace %zu / %zu / %zu bytes\n", pcnn_abi_version(), small, big, wide);
   return 0;
 }

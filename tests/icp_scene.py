@@ -64,3 +64,102 @@ def scene(T_true, T_init, half, K, H, W, factor=10000.0, obj_id=3, noise=0.0, rn
     label = np.where(hit, obj_id, 0).astype(np.int32)
     pv, pn, _ = render_box(T_init, half, K, H, W)
     return depth, label, pv, pn
+
+
+# ---- triangle meshes for the renderer tests ---------------------------------------------------------------------------
+def box_mesh(half):
+    """12 triangles, 24 vertices (one quad per face so that the per-vertex normals are the face normals)"""
+    hx, hy, hz = half
+    verts, norms, faces = [], [], []
+    for axis in range(3):
+        for sgn in (-1.0, 1.0):
+            a, b = (axis + 1) % 3, (axis + 2) % 3
+            base = len(verts)
+            for sa, sb in ((-1, -1), (1, -1), (1, 1), (-1, 1)):
+                p = [0.0, 0.0, 0.0]
+                p[axis] = sgn * half[axis]
+                p[a] = sa * half[a]
+                p[b] = sb * half[b]
+                verts.append(p)
+                n = [0.0, 0.0, 0.0]
+                n[axis] = sgn
+                norms.append(n)
+            faces += [[base, base + 1, base + 2], [base, base + 2, base + 3]]
+    return np.asarray(verts, np.float32), np.asarray(norms, np.float32), np.asarray(faces, np.int32)
+
+
+def icosphere(radius=1.0, subdivisions=2, scale=(1.0, 1.0, 1.0)):
+    """Subdivided icosahedron (20 * 4^s faces) scaled per axis into an ellipsoid; returns (vertices, unit-sphere normals, faces).
+    (For the ellipsoid the true normal is n ~ p / scale^2; callers that need it compute it from the vertices.)"""
+    t = (1.0 + 5 ** 0.5) / 2
+    v = [[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t], [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]]
+    f = [[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6], [7, 1, 8],
+         [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10], [8, 6, 7], [9, 8, 1]]
+    v = [np.asarray(p, np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(subdivisions):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = v[a] + v[b]
+                v.append(m / np.linalg.norm(m))
+                cache[key] = len(v) - 1
+            return cache[key]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [[a, ab, ca], [b, bc, ab], [c, ca, bc], [ab, bc, ca]]
+        f = nf
+    v = np.asarray(v)
+    sc = np.asarray(scale, np.float64) * radius
+    n = v / sc
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    return (v * sc).astype(np.float32), n.astype(np.float32), np.asarray(f, np.int32)
+
+
+def depth_scene_from_mesh(render_fn, T_true, K, H, W, factor=10000.0, obj_id=3):
+    """depth (uint16) + label of a mesh at T_true through `render_fn(pose[1,3,4]) -> vertices [1,H,W,4]`"""
+    v = np.asarray(render_fn(T_true[None]))[0]
+    hit = np.isfinite(v[..., 2])
+    z = np.where(hit, v[..., 2], 0.0).astype(np.float64)
+    depth = np.clip(np.round(z * factor), 0, 65535).astype(np.uint16)
+    label = np.where(hit, obj_id, 0).astype(np.int32)
+    return depth, label
+
+
+HYPOTHESIS_DZ = (0.0, -0.02, -0.01, 0.01, 0.02, 0.03, 0.04, 0.05)    # synthesize.cpp:2252-2270
+
+
+def solve_icp_reference(label, depth, K, factor, obj, T_co, mesh, max_error=0.01, iterations=8, depth_range=(0.25, 6.0), radius=0.01,
+                        q_t=None):
+    """Synthesizer::solveICP for ONE object on the CPU checker (oracle_*), without the nlopt stage:
+    render -> masked backprojection -> translation estimate -> 8 depth hypotheses x (render + ICP) -> SegICP score.
+    T_co: the network's pose (3x4, camera <- object); q_t: the same as (quaternion, translation) when the caller wants the
+    rx, ry of synthesize.cpp:2209-2214 taken from it. Returns a dict (T_new, T_icp, hits, choose, pairs, agree)."""
+    import oracle
+    v, n, f = mesh
+    H, W = label.shape
+    T_co = np.array(T_co, dtype=np.float64)
+    maps = oracle.render_mesh(v, n, f, T_co[None], K, H, W, depth_range, model_index=obj - 1)
+    live = oracle.icp_backproject(depth, label, obj, K, factor)
+    sums, mask = oracle.icp_center(label, live, maps["canonical"][0], maps["vertices"][0], maps["normals"][0], obj, max_error)
+    c = int(sums[3])
+    t_in = T_co[:, 3].copy() if q_t is None else np.asarray(q_t[4:7], dtype=np.float64)
+    Tz = T_co[2, 3]
+    if c > 0:
+        Tz = float(np.float32(sums[2]) / np.float32(c))
+        rx = t_in[0] / t_in[2] if t_in[2] else 0.0
+        ry = t_in[1] / t_in[2] if t_in[2] else 0.0
+        T_co[:, 3] = (rx * Tz, ry * Tz, Tz)
+    T_new = T_co.copy()
+    hyps = np.repeat(T_co[None], len(HYPOTHESIS_DZ), 0)
+    hyps[:, 2, 3] = Tz + np.asarray(HYPOTHESIS_DZ)
+    pm = oracle.render_mesh(v, n, f, hyps, K, H, W, depth_range, want=("vertices", "normals"))
+    upd, _ = oracle.icp_refine(np.repeat(live[None], len(hyps), 0), pm["vertices"], pm["normals"], K, depth_range, max_error, iterations)
+    hyps = np.stack([compose(U, T) for U, T in zip(upd, hyps)])
+    pairs = int(sums[4])
+    choose, hits = 0, None
+    if pairs > 0:
+        hits = oracle.icp_score(live, maps["canonical"][0], mask, hyps, radius)
+        choose = int(np.argmax(hits))
+    return {"T_new": T_new, "T_icp": hyps[choose], "hyps": hyps, "hits": hits, "choose": choose, "pairs": pairs, "agree": c}

@@ -269,3 +269,48 @@ def icp_refine(live, pred_v, pred_n, K, depth_range=(0.25, 6.0), max_error=0.01,
                              float(depth_range[0]), float(depth_range[1]), float(max_error), int(iterations), _p(upd), _p(stats))
     assert rc == 0
     return upd, stats
+
+
+def render_mesh(vertices, normals, faces, poses, K, H, W, depth_range=(0.25, 6.0), model_index=0, want=("vertices", "normals", "canonical")):
+    """oracle_render_mesh: poses [N,3,4] -> dict of "vertices" / "normals" f32 [N,H,W,4], "canonical" f32 [N,H,W,3] (NaN = no surface)"""
+    v, f = _f32(vertices).reshape(-1, 3), _i32(faces).reshape(-1, 3)
+    n = None if normals is None else _f32(normals).reshape(-1, 3)
+    P = _f32(poses).reshape(-1, 12)
+    N = P.shape[0]
+    out = {"vertices": np.empty((N, H, W, 4), np.float32) if "vertices" in want else None,
+           "normals": np.empty((N, H, W, 4), np.float32) if "normals" in want else None,
+           "canonical": np.empty((N, H, W, 3), np.float32) if "canonical" in want else None}
+    L = lib()
+    L.oracle_render_mesh.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_float,
+                                     c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]
+    rc = L.oracle_render_mesh(_p(v), _p(n), _p(f), len(v), len(f), _p(P), N, H, W, float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]),
+                              float(depth_range[0]), float(depth_range[1]), float(model_index), _p(out["vertices"]), _p(out["normals"]), _p(out["canonical"]))
+    assert rc == 0
+    return {k: a for k, a in out.items() if a is not None}
+
+
+def icp_center(label, live, canonical, pred_v, pred_n, obj_id, max_error=0.01):
+    """oracle_icp_center -> (sums f64 [5], mask uint8 [H,W])"""
+    label, live, canonical, pred_v, pred_n = _i32(label), _f32(live), _f32(canonical), _f32(pred_v), _f32(pred_n)
+    H, W = label.shape
+    sums = np.empty((5,), np.float64)
+    mask = np.empty((H, W), np.uint8)
+    L = lib()
+    L.oracle_icp_center.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]
+    rc = L.oracle_icp_center(_p(label), _p(live), _p(canonical), _p(pred_v), _p(pred_n), pred_v.shape[2], H, W, int(obj_id), float(max_error), _p(sums), _p(mask))
+    assert rc == 0
+    return sums, mask
+
+
+def icp_score(live, canonical, mask, hypotheses, radius=0.01):
+    """oracle_icp_score (exhaustive nearest-neighbour search) -> int32 [M]"""
+    live, canonical = _f32(live), _f32(canonical)
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    H, W = mask.shape
+    hyp = _f32(hypotheses).reshape(-1, 12)
+    hits = np.empty((hyp.shape[0],), np.int32)
+    L = lib()
+    L.oracle_icp_score.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_float, c_void_p]
+    rc = L.oracle_icp_score(_p(live), _p(canonical), _p(mask), H, W, _p(hyp), hyp.shape[0], float(radius), _p(hits))
+    assert rc == 0
+    return hits
