@@ -447,9 +447,7 @@ int pcnn_icp_refine_fwd(const float* live_vertices, const float* pred_vertices, 
                         float* stats, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Depth-based pose refinement, second slice: the rest of Synthesizer::solveICP (lib/synthesize/synthesize.cpp:2052-2380)
- * except its nlopt stage (poseWithOpt :2529-2570, a Nelder-Mead polish between the translation estimate and the ICP
- * hypotheses; nlopt is not available here).
+ * Depth-based pose refinement, second slice: the rest of Synthesizer::solveICP (lib/synthesize/synthesize.cpp:2052-2380).
  *
  * pcnn_render_mesh_fwd replaces the two OpenGL passes of solveICP / refinePose (:2104-2136, :1972-1991; shaders
  *   lib/kinect_fusion/shaders/vertsAndNorms.{vert,frag}, canonicalVerts.{vert,frag}; projection :2088 = pixel centres at
@@ -472,7 +470,19 @@ int pcnn_icp_refine_fwd(const float* live_vertices, const float* pred_vertices, 
  *   The reference searches a kd-tree built on the host; here the depth points are still an image, so the search is a window
  *   around the projection (exact: a point within r of (X, Y, Z) projects within fx r (1 + |X/Z|) / (Z - r) pixels).
  *   workspace: one bit per pixel and hypothesis (pcnn_icp_score_workspace_bytes).
+ * pcnn_icp_polish_fwd (Synthesizer::poseWithOpt :2529-2570 with the objective optEnergy :2476-2526; refinePose case 0):
+ *   Nelder-Mead over an update pose x = (quaternion wxyz, translation) in the box (1,0,0,0,0,0,0) +- (0.1 x4, 0.01, 0.01, 0.1),
+ *   minimising the mean distance |x * pred_vertex - live_vertex| over the pixels with label == obj_id whose live and moved
+ *   depths lie inside (z_near, z_far); max_evaluations = 50 in the reference (>= 8: the initial simplex). pred_vertices is
+ *   the render at the pose the update multiplies from the left. update f64 [7] = the best vertex (quaternion NOT normalised,
+ *   like nlopt hands it back; the caller normalises as Sophus::SE3f does), info f64 [2] = (its energy, evaluations used).
+ *   nlopt itself is not available here: the algorithm is the published one of its nldrmd.c (Box's bound handling, alpha 1,
+ *   beta 0.5, gamma 2, delta 0.5, initial step (ub - lb) / 4) restated, not its bits. The whole optimisation is one launch of
+ *   one workgroup (simplex in LDS, an evaluation = a sweep of the label's bounding box); bit-identical to oracle_icp_polish.
  * ------------------------------------------------------------------------------------------ */
+int pcnn_icp_polish_fwd(const int32_t* label, const float* live_vertices, const float* pred_vertices, int pred_channels,
+                        int height, int width, int obj_id, float z_near, float z_far, int max_evaluations, double* update,
+                        double* info, void* stream);
 int pcnn_render_mesh_workspace_bytes(int num_poses, int height, int width, size_t* bytes);
 int pcnn_render_mesh_fwd(const float* vertices, const float* normals, const int32_t* faces, int num_vertices,
                          int num_faces, const float* poses, int num_poses, int height, int width, float fx, float fy,

@@ -1622,3 +1622,171 @@ int oracle_icp_score(const float* live, const float* canon, const uint8_t* mask,
   free(flags);
   return 0;
 }
+
+/* ================================================================================================== */
+/* solveICP's polish between the translation estimate and the hypotheses: Synthesizer::poseWithOpt      */
+/* (lib/synthesize/synthesize.cpp:2529-2570: nlopt LN_NELDERMEAD, 7 variables = quaternion wxyz +        */
+/* translation of an UPDATE applied on the left of T_co, box +-0.1 / +-0.01 (x, y) / +-0.1 (z) around    */
+/* (1,0,0,0,0,0,0), maxeval = 50) minimising optEnergy (:2476-2526): the mean distance between the       */
+/* moved predicted vertex and the depth point of the same pixel, over the object's label pixels.          */
+/*                                                                                                      */
+/* PARITY UNPINNED: nlopt is absent; what follows restates the published algorithm of nlopt's            */
+/* nldrmd.c (Nelder-Mead with Box's bound handling: a trial point outside the box is moved onto it;        */
+/* alpha = 1, beta = 0.5, gamma = 2, delta = 0.5; initial simplex x0 and x0 + step_i e_i with nlopt's      */
+/* default initial step (ub - lb) / 4) — NOT its code, and not its bits. Canonical choices:               */
+/*   - the energy: pixels of the label's bounding box in raster order dealt round-robin to 1024 partial    */
+/*     sums (f32 distance, int count), a halving tree over them, energy = sum / count in f32 (0 when       */
+/*     no pixel qualifies); the update's rotation from the un-normalised quaternion (2 / q.q form: no      */
+/*     sqrt), computed in f64 and rounded to f32 like an SE3f;                                           */
+/*   - ties in the simplex ordering: the lower vertex index counts as better.                             */
+#define NM_N 7
+#define NM_LANES 1024
+
+static void nm_update_matrix(const double* x, float* T /* [12] */)
+{
+  const double w = x[0], a = x[1], b = x[2], c = x[3];
+  const double n = ((w * w + a * a) + b * b) + c * c;
+  const double s = n > 0.0 ? 2.0 / n : 0.0;
+  const double R[9] = {1.0 - s * (b * b + c * c), s * (a * b - c * w), s * (a * c + b * w),
+                       s * (a * b + c * w), 1.0 - s * (a * a + c * c), s * (b * c - a * w),
+                       s * (a * c - b * w), s * (b * c + a * w), 1.0 - s * (a * a + b * b)};
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) T[4 * i + j] = (float)R[3 * i + j];
+    T[4 * i + 3] = (float)x[4 + i];
+  }
+}
+
+/* optEnergy :2476-2526 */
+static float nm_energy(const int* label, const float* live, const float* pred_v, int pc, int W, const int* box, int obj,
+                       float znear, float zfar, const double* x, float* part, int* cnt)
+{
+  float T[12];
+  nm_update_matrix(x, T);
+  const int bw = box[1] - box[0] + 1;
+  const long nb = (long)bw * (box[3] - box[2] + 1);
+  for (int t = 0; t < NM_LANES; t++) {
+    float acc = 0.f;
+    int c = 0;
+    for (long j = t; j < nb; j += NM_LANES) {
+      const long p = (long)(box[2] + j / bw) * W + (box[0] + j % bw);
+      if (label[p] != obj) continue;
+      const float* pv = pred_v + p * pc;
+      const float qx = ((T[0] * pv[0] + T[1] * pv[1]) + T[2] * pv[2]) + T[3];
+      const float qy = ((T[4] * pv[0] + T[5] * pv[1]) + T[6] * pv[2]) + T[7];
+      const float qz = ((T[8] * pv[0] + T[9] * pv[1]) + T[10] * pv[2]) + T[11];
+      const float vx = live[3 * p], vy = live[3 * p + 1], vz = live[3 * p + 2];
+      if (qx == qx && qy == qy && qz == qz && vz > znear && vz < zfar && qz > znear && qz < zfar) {   /* :2515 */
+        const float ex = qx - vx, ey = qy - vy, ez = qz - vz;
+        acc = acc + sqrtf((ex * ex + ey * ey) + ez * ez);
+        c++;
+      }
+    }
+    part[t] = acc;
+    cnt[t] = c;
+  }
+  for (int s = NM_LANES / 2; s >= 1; s >>= 1)
+    for (int t = 0; t < s; t++) { part[t] = part[t] + part[t + s]; cnt[t] = cnt[t] + cnt[t + s]; }
+  return cnt[0] ? part[0] / (float)cnt[0] : 0.f;
+}
+
+/* label int32 [H,W], live f32 [H,W,3], pred_v f32 [H,W,pc] (rendered at the pose the update will multiply).
+   x_out f64 [7] = best update found (quaternion wxyz NOT normalised, translation), info f64 [2] = (its energy, evaluations) */
+int oracle_icp_polish(const int* label, const float* live, const float* pred_v, int pc, int H, int W, int obj, float znear,
+                      float zfar, int maxeval, double* x_out, double* info)
+{
+  int box[4] = {W, -1, H, -1};
+  for (int y = 0; y < H; y++)
+    for (int x = 0; x < W; x++)
+      if (label[(long)y * W + x] == obj) {
+        if (x < box[0]) box[0] = x;
+        if (x > box[1]) box[1] = x;
+        if (y < box[2]) box[2] = y;
+        if (y > box[3]) box[3] = y;
+      }
+  const double x0[NM_N] = {1, 0, 0, 0, 0, 0, 0};
+  const double range[NM_N] = {0.1, 0.1, 0.1, 0.1, 0.01, 0.01, 0.1};      /* :2535-2557 */
+  double lb[NM_N], ub[NM_N], P[NM_N + 1][NM_N], f[NM_N + 1];
+  for (int i = 0; i < NM_N; i++) { lb[i] = x0[i] - range[i]; ub[i] = x0[i] + range[i]; }
+  float* part = (float*)malloc(sizeof(float) * NM_LANES);
+  int* cnt = (int*)malloc(sizeof(int) * NM_LANES);
+  if (!part || !cnt) { free(part); free(cnt); return -1; }
+  int evals = 0;
+  if (box[1] < box[0]) {            /* no pixel of the object: nothing to minimise */
+    memcpy(x_out, x0, sizeof(x0));
+    info[0] = 0.0; info[1] = 0.0;
+    free(part); free(cnt);
+    return 0;
+  }
+#define NM_EVAL(X) ((double)nm_energy(label, live, pred_v, pc, W, box, obj, znear, zfar, (X), part, cnt))
+  /* initial simplex: x0, x0 + step_i e_i, step = (ub - lb) / 4 (nlopt's default initial step for a centred start) */
+  for (int k = 0; k <= NM_N; k++) {
+    for (int i = 0; i < NM_N; i++) P[k][i] = x0[i];
+    if (k > 0) P[k][k - 1] = x0[k - 1] + (ub[k - 1] - lb[k - 1]) * 0.25;
+    f[k] = NM_EVAL(P[k]);
+    evals++;
+  }
+  while (evals < maxeval) {
+    /* best (lowest f, then lowest index), worst (highest f, then highest index), second worst */
+    int lo = 0, hi = 0, nh = -1;
+    for (int k = 1; k <= NM_N; k++) {
+      if (f[k] < f[lo]) lo = k;
+      if (f[k] >= f[hi]) hi = k;
+    }
+    for (int k = 0; k <= NM_N; k++)
+      if (k != hi && (nh < 0 || f[k] >= f[nh])) nh = k;
+    double c[NM_N], xr[NM_N], xe[NM_N];
+    for (int i = 0; i < NM_N; i++) {
+      double sacc = 0.0;
+      for (int k = 0; k <= NM_N; k++)
+        if (k != hi) sacc = sacc + P[k][i];
+      c[i] = sacc / (double)NM_N;
+    }
+#define NM_POINT(DST, COEF)                                          \
+    for (int i = 0; i < NM_N; i++) {                                 \
+      double v_ = c[i] + (COEF) * (c[i] - P[hi][i]);                 \
+      if (v_ < lb[i]) v_ = lb[i];                                    \
+      if (v_ > ub[i]) v_ = ub[i];                                    \
+      (DST)[i] = v_;                                                 \
+    }
+    NM_POINT(xr, 1.0);
+    const double fr = NM_EVAL(xr);
+    evals++;
+    if (fr < f[lo]) {                                   /* new best: try to expand */
+      if (evals < maxeval) {
+        NM_POINT(xe, 2.0);
+        const double fe = NM_EVAL(xe);
+        evals++;
+        if (fe < fr) { memcpy(P[hi], xe, sizeof(xe)); f[hi] = fe; }
+        else { memcpy(P[hi], xr, sizeof(xr)); f[hi] = fr; }
+      } else { memcpy(P[hi], xr, sizeof(xr)); f[hi] = fr; }
+    } else if (fr < f[nh]) {                            /* better than the second worst: accept */
+      memcpy(P[hi], xr, sizeof(xr)); f[hi] = fr;
+    } else {                                            /* contract: outside if the reflection beat the worst, else inside */
+      if (evals >= maxeval) { if (fr < f[hi]) { memcpy(P[hi], xr, sizeof(xr)); f[hi] = fr; } break; }
+      const double coef = fr < f[hi] ? 0.5 : -0.5;
+      NM_POINT(xe, coef);
+      const double fc = NM_EVAL(xe);
+      evals++;
+      const double fref = fr < f[hi] ? fr : f[hi];
+      if (fc < fref) { memcpy(P[hi], xe, sizeof(xe)); f[hi] = fc; }
+      else {                                            /* shrink towards the best vertex */
+        for (int k = 0; k <= NM_N && evals < maxeval; k++) {
+          if (k == lo) continue;
+          for (int i = 0; i < NM_N; i++) P[k][i] = P[lo][i] + 0.5 * (P[k][i] - P[lo][i]);
+          f[k] = NM_EVAL(P[k]);
+          evals++;
+        }
+      }
+    }
+  }
+  int lo = 0;
+  for (int k = 1; k <= NM_N; k++)
+    if (f[k] < f[lo]) lo = k;
+  memcpy(x_out, P[lo], sizeof(double) * NM_N);
+  info[0] = f[lo];
+  info[1] = (double)evals;
+  free(part); free(cnt);
+  return 0;
+#undef NM_EVAL
+#undef NM_POINT
+}

@@ -93,6 +93,7 @@ SIGNATURES = {
     "pcnn_icp_center_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, c_size_t, _P]),
     "pcnn_icp_score_workspace_bytes": (c_int, [c_int, c_int, c_int, POINTER(c_size_t)]),
     "pcnn_icp_score_fwd": (c_int, [_P, _P, _P, c_int, c_int, _P, c_int, c_float, c_float, c_float, c_float, c_float, _P, _P, c_size_t, _P]),
+    "pcnn_icp_polish_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, _P, _P, _P]),
     "pcnn_crc32c": (ctypes.c_uint32, [_P, c_size_t, ctypes.c_uint32]),
     "pcnn_profile_enable": (c_int, [c_int]),
     "pcnn_profile_reset": (c_int, []),

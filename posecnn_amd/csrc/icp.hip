@@ -420,6 +420,220 @@ __global__ __launch_bounds__(256) void icp_score_kernel(
   if (!(old & bit)) atomicAdd(&hits[m], 1);
 }
 
+// ---- solveICP's polish (Synthesizer::poseWithOpt, synthesize.cpp:2529-2570; objective optEnergy :2476-2526) ---------------
+// nlopt's Nelder-Mead over the 7 numbers of an update pose (quaternion wxyz + translation, box +-0.1 / +-0.01 / +-0.1 around
+// the identity, maxeval = 50), minimising the mean distance between the moved predicted vertex and the depth point of the
+// same pixel over the object's label pixels. In the reference every one of the 50 evaluations is a host loop over the label
+// pixels. Here the whole optimisation is ONE launch of one 1024-thread workgroup: the simplex lives in LDS, an evaluation is a
+// sweep of the label's bounding box (round-robin over the threads, halving tree) and nothing goes back to the host in between.
+// The algorithm is the published one of nlopt's nldrmd.c (Box's bound handling, alpha 1, beta 0.5, gamma 2, delta 0.5,
+// default initial step (ub - lb) / 4), restated — not its code, not its bits; the CPU checker restates the same statement
+// and the two agree bit for bit.
+constexpr int NM_N = 7;
+constexpr int NM_LANES = 1024;
+
+struct NmShared {
+  double P[NM_N + 1][NM_N], c[NM_N], xr[NM_N], xe[NM_N], lb[NM_N], ub[NM_N];
+  double f[NM_N + 1];        // (in LDS, not in registers: f[lo] / f[hi] are dynamically indexed — a private array went to scratch)
+  float T[12];
+  float part[NM_LANES];
+  int cnt[NM_LANES];
+  int box[4];
+};
+
+// optEnergy for the update x (LDS, 7 doubles): every thread returns the same value
+__device__ float nm_energy(NmShared& sh, const double* x, const int* __restrict__ label, const float* __restrict__ live,
+                           const float* __restrict__ pred_v, int pc, int W, int obj, float znear, float zfar)
+{
+  const int t = threadIdx.x;
+  __syncthreads();                       // x is complete, the previous tree is consumed
+  if (t == 0) {
+    const double w = x[0], a = x[1], b = x[2], c = x[3];
+    const double n = ((w * w + a * a) + b * b) + c * c;
+    const double s = n > 0.0 ? 2.0 / n : 0.0;
+    const double R[9] = {1.0 - s * (b * b + c * c), s * (a * b - c * w), s * (a * c + b * w),
+                         s * (a * b + c * w), 1.0 - s * (a * a + c * c), s * (b * c - a * w),
+                         s * (a * c - b * w), s * (b * c + a * w), 1.0 - s * (a * a + b * b)};
+    for (int i = 0; i < 3; i++) {
+      for (int j = 0; j < 3; j++) sh.T[4 * i + j] = (float)R[3 * i + j];
+      sh.T[4 * i + 3] = (float)x[4 + i];
+    }
+  }
+  __syncthreads();
+  float T[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) T[i] = sh.T[i];
+  const int bw = sh.box[1] - sh.box[0] + 1, bh = sh.box[3] - sh.box[2] + 1;
+  float acc = 0.f;
+  int c = 0;
+  // a thread's pixels are j = t, t + 1024, ... of the box in raster order: (row, column) advance by (1024 / bw, 1024 % bw)
+  // with a carry — no division per pixel (a 64-bit divide + modulo per pixel made an evaluation 18 us). 4 pixels per trip
+  // with all their loads in flight together: with a single workgroup on the chip every dependent load is an L2 round trip.
+  const int dq = NM_LANES / bw, dr = NM_LANES % bw;
+  int yy = t / bw, xx = t % bw;
+  constexpr int NB = 4;
+  while (yy < bh) {
+    int lab[NB], live_ok[NB];
+    float pvv[NB][3], lv[NB][3];
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+      live_ok[u] = yy < bh;
+      const int yc = live_ok[u] ? yy : bh - 1;
+      const long long p = (long long)(sh.box[2] + yc) * W + (sh.box[0] + xx);
+      lab[u] = label[p];
+      const float* pv = pred_v + p * pc;
+      pvv[u][0] = pv[0]; pvv[u][1] = pv[1]; pvv[u][2] = pv[2];
+      lv[u][0] = live[3 * p]; lv[u][1] = live[3 * p + 1]; lv[u][2] = live[3 * p + 2];
+      xx += dr; yy += dq;
+      if (xx >= bw) { xx -= bw; yy++; }
+    }
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+      if (!live_ok[u] || lab[u] != obj) continue;
+      const float p0 = pvv[u][0], p1 = pvv[u][1], p2 = pvv[u][2];
+      const float qx = ((T[0] * p0 + T[1] * p1) + T[2] * p2) + T[3];
+      const float qy = ((T[4] * p0 + T[5] * p1) + T[6] * p2) + T[7];
+      const float qz = ((T[8] * p0 + T[9] * p1) + T[10] * p2) + T[11];
+      const float vx = lv[u][0], vy = lv[u][1], vz = lv[u][2];
+      if (qx == qx && qy == qy && qz == qz && vz > znear && vz < zfar && qz > znear && qz < zfar) {
+        const float ex = qx - vx, ey = qy - vy, ez = qz - vz;
+        acc = acc + sqrt_rn((ex * ex + ey * ey) + ez * ez);
+        c++;
+      }
+    }
+  }
+  sh.part[t] = acc;
+  sh.cnt[t] = c;
+  __syncthreads();
+  for (int s = NM_LANES / 2; s >= 1; s >>= 1) {
+    if (t < s) { sh.part[t] = sh.part[t] + sh.part[t + s]; sh.cnt[t] = sh.cnt[t] + sh.cnt[t + s]; }
+    __syncthreads();
+  }
+  const float e = sh.cnt[0] ? sh.part[0] / (float)sh.cnt[0] : 0.f;
+  return e;
+}
+
+__global__ __launch_bounds__(NM_LANES) void icp_polish_kernel(
+    const int* __restrict__ label, const float* __restrict__ live, const float* __restrict__ pred_v, int pc, int H, int W,
+    int obj, float znear, float zfar, int maxeval, double* __restrict__ x_out, double* __restrict__ info)
+{
+  __shared__ NmShared sh;
+  const int t = threadIdx.x;
+  // bounding box of the object's label pixels
+  if (t == 0) { sh.box[0] = W; sh.box[1] = -1; sh.box[2] = H; sh.box[3] = -1; }
+  __syncthreads();
+  {
+    int x0 = W, x1 = -1, y0 = H, y1 = -1;
+    const long long P = (long long)H * W;
+    for (long long p = t; p < P; p += NM_LANES)
+      if (label[p] == obj) {
+        const int x = (int)(p % W), y = (int)(p / W);
+        x0 = min(x0, x); x1 = max(x1, x); y0 = min(y0, y); y1 = max(y1, y);
+      }
+    if (x1 >= 0) { atomicMin(&sh.box[0], x0); atomicMax(&sh.box[1], x1); atomicMin(&sh.box[2], y0); atomicMax(&sh.box[3], y1); }
+  }
+  __syncthreads();
+  const double x0v[NM_N] = {1, 0, 0, 0, 0, 0, 0};
+  const double range[NM_N] = {0.1, 0.1, 0.1, 0.1, 0.01, 0.01, 0.1};
+  if (sh.box[1] < sh.box[0]) {
+    if (t < NM_N) x_out[t] = x0v[t];
+    if (t == 0) { info[0] = 0.0; info[1] = 0.0; }
+    return;
+  }
+  if (t == 0)
+    for (int i = 0; i < NM_N; i++) { sh.lb[i] = x0v[i] - range[i]; sh.ub[i] = x0v[i] + range[i]; }
+  __syncthreads();
+  int evals = 0;
+  double* f = sh.f;      // written by thread 0 only; every reader sits behind a barrier
+#define NM_EVAL(X) ((double)nm_energy(sh, (X), label, live, pred_v, pc, W, obj, znear, zfar))
+#define NM_SETF(K, V) do { if (t == 0) f[(K)] = (V); } while (0)
+  for (int k = 0; k <= NM_N; k++) {
+    if (t == 0) {
+      for (int i = 0; i < NM_N; i++) sh.P[k][i] = x0v[i];
+      if (k > 0) sh.P[k][k - 1] = x0v[k - 1] + (sh.ub[k - 1] - sh.lb[k - 1]) * 0.25;
+    }
+    const double fk = NM_EVAL(sh.P[k]);
+    NM_SETF(k, fk);
+    evals++;
+  }
+  while (evals < maxeval) {
+    __syncthreads();
+    int lo = 0, hi = 0, nh = -1;
+    for (int k = 1; k <= NM_N; k++) {
+      if (f[k] < f[lo]) lo = k;
+      if (f[k] >= f[hi]) hi = k;
+    }
+    for (int k = 0; k <= NM_N; k++)
+      if (k != hi && (nh < 0 || f[k] >= f[nh])) nh = k;
+    const double flo = f[lo], fhi = f[hi], fnh = f[nh];
+    __syncthreads();
+    if (t == 0)
+      for (int i = 0; i < NM_N; i++) {
+        double sacc = 0.0;
+        for (int k = 0; k <= NM_N; k++)
+          if (k != hi) sacc = sacc + sh.P[k][i];
+        sh.c[i] = sacc / (double)NM_N;
+      }
+#define NM_POINT(DST, COEF)                                               \
+    if (t == 0)                                                           \
+      for (int i = 0; i < NM_N; i++) {                                    \
+        double v_ = sh.c[i] + (COEF) * (sh.c[i] - sh.P[hi][i]);           \
+        if (v_ < sh.lb[i]) v_ = sh.lb[i];                                 \
+        if (v_ > sh.ub[i]) v_ = sh.ub[i];                                 \
+        (DST)[i] = v_;                                                    \
+      }
+#define NM_TAKE(SRC, FV)                                                  \
+    do {                                                                  \
+      if (t == 0) { for (int i = 0; i < NM_N; i++) sh.P[hi][i] = (SRC)[i]; f[hi] = (FV); } \
+    } while (0)
+    NM_POINT(sh.xr, 1.0);
+    const double fr = NM_EVAL(sh.xr);
+    evals++;
+    if (fr < flo) {
+      if (evals < maxeval) {
+        NM_POINT(sh.xe, 2.0);
+        const double fe = NM_EVAL(sh.xe);
+        evals++;
+        if (fe < fr) NM_TAKE(sh.xe, fe); else NM_TAKE(sh.xr, fr);
+      } else {
+        NM_TAKE(sh.xr, fr);
+      }
+    } else if (fr < fnh) {
+      NM_TAKE(sh.xr, fr);
+    } else {
+      if (evals >= maxeval) { if (fr < fhi) NM_TAKE(sh.xr, fr); break; }
+      const double coef = fr < fhi ? 0.5 : -0.5;
+      NM_POINT(sh.xe, coef);
+      const double fc = NM_EVAL(sh.xe);
+      evals++;
+      const double fref = fr < fhi ? fr : fhi;
+      if (fc < fref) {
+        NM_TAKE(sh.xe, fc);
+      } else {
+        for (int k = 0; k <= NM_N && evals < maxeval; k++) {
+          if (k == lo) continue;
+          __syncthreads();
+          if (t == 0)
+            for (int i = 0; i < NM_N; i++) sh.P[k][i] = sh.P[lo][i] + 0.5 * (sh.P[k][i] - sh.P[lo][i]);
+          const double fk = NM_EVAL(sh.P[k]);
+          NM_SETF(k, fk);
+          evals++;
+        }
+      }
+    }
+  }
+#undef NM_SETF
+#undef NM_EVAL
+#undef NM_POINT
+#undef NM_TAKE
+  __syncthreads();
+  int lo = 0;
+  for (int k = 1; k <= NM_N; k++)
+    if (f[k] < f[lo]) lo = k;
+  if (t < NM_N) x_out[t] = sh.P[lo][t];
+  if (t == 0) { info[0] = f[lo]; info[1] = (double)evals; }
+}
+
 size_t icp_ws_bytes(int N, int H, int W)
 {
   const long long nblocks = ((long long)H * W + ICP_BLOCK - 1) / ICP_BLOCK;
@@ -534,4 +748,18 @@ extern "C" int pcnn_icp_score_fwd(const float* live_vertices, const float* canon
   PCNN_LAUNCH(icp_score_kernel, dim3((unsigned)((P + 255) / 256), num_hypotheses), dim3(256), 0, stream, live_vertices, canonical, mask,
               height, width, hypotheses, fx, fy, px, py, radius, static_cast<unsigned*>(workspace), nwords, hits);
   return check_launch("icp_score_fwd");
+}
+
+extern "C" int pcnn_icp_polish_fwd(const int32_t* label, const float* live_vertices, const float* pred_vertices, int pred_channels,
+                                   int height, int width, int obj_id, float z_near, float z_far, int max_evaluations, double* update,
+                                   double* info, void* stream_)
+{
+  PCNN_REQUIRE(height >= 1 && width >= 1, PCNN_EINVAL, "icp_polish: bad shape %dx%d", height, width);
+  PCNN_REQUIRE(pred_channels == 3 || pred_channels == 4, PCNN_EINVAL, "icp_polish: predicted maps carry 3 or 4 floats per pixel (got %d)", pred_channels);
+  PCNN_REQUIRE(max_evaluations >= 8, PCNN_EINVAL, "icp_polish: the initial simplex alone takes 8 evaluations (got max_evaluations = %d)", max_evaluations);
+  PCNN_REQUIRE(label && live_vertices && pred_vertices && update && info, PCNN_ENULL, "icp_polish: NULL pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  PCNN_LAUNCH(icp_polish_kernel, dim3(1), dim3(NM_LANES), 0, stream, label, live_vertices, pred_vertices, pred_channels, height, width,
+              obj_id, z_near, z_far, max_evaluations, update, info);
+  return check_launch("icp_polish_fwd");
 }

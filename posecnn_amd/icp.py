@@ -13,9 +13,11 @@ class id > 0 and >= 400 label pixels, all on the GPU (gfx950 kernels of libposec
     8 depth hypotheses, each: render + 8 ICP steps   pcnn_render_mesh_fwd + pcnn_icp_refine_fwd, the 8 in ONE call each (:2272-2300)
     SegICP score of the 8 refined hypotheses         pcnn_icp_score_fwd       (:2302-2343)  -> poses_icp = best
 
-NOT here: the Nelder-Mead polish between the translation estimate and the hypotheses (`poseWithOpt`, :2226-2235, :2529-2570
-— nlopt; `polish` is the hook) and assimp: meshes are Wavefront OBJ read by `Mesh.load_obj` (positions, faces, optional
-normals; smooth normals are generated like aiProcess_GenSmoothNormals when the file has none).
+    (between the two: re-render + Nelder-Mead polish     pcnn_icp_polish_fwd      (:2226-2235, poseWithOpt :2529-2570; nlopt's published
+     algorithm restated — nlopt itself is absent —, the whole optimisation in one launch))
+
+No assimp here: meshes are Wavefront OBJ read by `Mesh.load_obj` (positions, faces, optional normals; smooth normals are
+generated like aiProcess_GenSmoothNormals when the file has none).
 """
 import ctypes
 
@@ -213,6 +215,28 @@ def score(live_vertices, canonical, mask, hypotheses, K, radius=0.01):
     return hits
 
 
+def polish(label, live_vertices, pred_vertices, obj_id, depth_range=(Z_NEAR, Z_FAR), max_evaluations=50):
+    """`Synthesizer::poseWithOpt` (synthesize.cpp:2529-2570): Nelder-Mead over an update pose, minimising `optEnergy`
+    (:2476-2526). pred_vertices [H,W,3|4] = the render at the pose the update multiplies. Returns (update 3x4 float64 with the
+    quaternion normalised as Sophus::SE3f does at :2014-2016, energy, evaluations)."""
+    lab = ops._dev(label, "label", torch.int32)
+    live = ops._dev(live_vertices, "live_vertices", torch.float32)
+    pv = ops._dev(pred_vertices, "pred_vertices", torch.float32)
+    H, W = lab.shape
+    if live.shape != (H, W, 3) or pv.shape[:2] != (H, W) or pv.shape[2] not in (3, 4):
+        raise ValueError("label [H,W], live [H,W,3], pred_vertices [H,W,3|4]")
+    x = torch.empty((7,), dtype=torch.float64, device=lab.device)
+    info = torch.empty((2,), dtype=torch.float64, device=lab.device)
+    check("pcnn_icp_polish_fwd",
+          lib().pcnn_icp_polish_fwd(ops._ptr(lab), ops._ptr(live), ops._ptr(pv), int(pv.shape[2]), H, W, int(obj_id), float(depth_range[0]),
+                                    float(depth_range[1]), int(max_evaluations), ops._ptr(x), ops._ptr(info), ops._stream(lab)))
+    x, info = x.cpu().numpy(), info.cpu().numpy()
+    U = np.zeros((3, 4))
+    U[:, :3] = quat2mat(x[:4])
+    U[:, 3] = x[4:7]
+    return U, float(info[0]), int(info[1]), x
+
+
 def mat2quat(R):
     """Rotation matrix -> unit quaternion (w, x, y, z), w >= 0 (what Sophus::SE3f::unit_quaternion() hands to the
     output arrays of solveICP, synthesize.cpp:2366-2375)."""
@@ -281,10 +305,10 @@ class Synthesizer:
     `Synthesizer(model_file, pose_file)`, `setup(width, height)`, `icp_python(...)`. `model_file` lists one OBJ path per
     line (synthesize.cpp:147-160; class id c uses line c - 1); `meshes` passes `Mesh` objects directly instead."""
 
-    def __init__(self, model_file=None, pose_file=None, meshes=None, device="cuda", polish=None):
+    def __init__(self, model_file=None, pose_file=None, meshes=None, device="cuda", polish_evaluations=50):
         self.model_file, self.pose_file, self.device = model_file, pose_file, torch.device(device)
         self.meshes = list(meshes) if meshes is not None else None
-        self.polish = polish          # optional callable(T_co [3,4], context dict) -> T_co: the reference's nlopt stage
+        self.polish_evaluations = polish_evaluations      # `iterations = 50` of synthesize.cpp:2226; 0 skips the polish
         self.width = self.height = None
         self.last = []                # per processed ROI: hits / pairs of each hypothesis and the chosen one
 
@@ -335,8 +359,10 @@ class Synthesizer:
                 rx = poses[i, 4] / poses[i, 6] if poses[i, 6] else 0.0
                 ry = poses[i, 5] / poses[i, 6] if poses[i, 6] else 0.0
                 T_co[:, 3] = (rx * Tz, ry * Tz, Tz)
-                if self.polish is not None:
-                    T_co = np.asarray(self.polish(T_co.copy(), {"obj": obj, "live": live, "labels": labels_t, "K": K, "mesh": mesh}), dtype=np.float64)
+                if self.polish_evaluations:                 # refinePose(..., 50, maxError, 0), :2226-2232
+                    pv = render(mesh, T_co[None], K, height, width, (znear, zfar), want=("vertices",))["vertices"][0]
+                    U, energy, evals, _ = polish(labels_t, live, pv, obj, (znear, zfar), self.polish_evaluations)
+                    T_co = _compose(U, T_co)
                     Tz = T_co[2, 3]
             outputs[i, :4] = mat2quat(T_co[:, :3])
             outputs[i, 4:7] = T_co[:, 3]

@@ -55,6 +55,7 @@ int main(void)
     CHECK(pcnn_render_mesh_fwd(NULL, NULL, NULL, 3, 1, NULL, 1, 480, 640, 1066.f, 1067.f, 313.f, 241.f, 0.25f, 6.f, 0.f, NULL, NULL, NULL, NULL, 0, NULL) == PCNN_ENULL);
     CHECK(pcnn_icp_center_fwd(NULL, NULL, NULL, NULL, NULL, 5, 480, 640, 1, 0.01f, NULL, NULL, NULL, 0, NULL) == PCNN_EINVAL);
     CHECK(pcnn_icp_score_fwd(NULL, NULL, NULL, 480, 640, NULL, 8, 1066.f, 1067.f, 313.f, 241.f, -1.f, NULL, NULL, 0, NULL) == PCNN_EINVAL);
+    CHECK(pcnn_icp_polish_fwd(NULL, NULL, NULL, 4, 480, 640, 1, 0.25f, 6.f, 7, NULL, NULL, NULL) == PCNN_EINVAL);
   }
   printf("capi_consumer ok: abi %d, hough workspace %zu / %zu / %zu bytes\n", pcnn_abi_version(), small, big, wide);
   return 0;

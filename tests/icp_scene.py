@@ -130,10 +130,18 @@ def depth_scene_from_mesh(render_fn, T_true, K, H, W, factor=10000.0, obj_id=3):
 HYPOTHESIS_DZ = (0.0, -0.02, -0.01, 0.01, 0.02, 0.03, 0.04, 0.05)    # synthesize.cpp:2252-2270
 
 
+def quat2mat(q):
+    w, x, y, z = [float(v) for v in q]
+    s = 2.0 / (w * w + x * x + y * y + z * z)
+    return np.array([[1 - s * (y * y + z * z), s * (x * y - z * w), s * (x * z + y * w)],
+                     [s * (x * y + z * w), 1 - s * (x * x + z * z), s * (y * z - x * w)],
+                     [s * (x * z - y * w), s * (y * z + x * w), 1 - s * (x * x + y * y)]])
+
+
 def solve_icp_reference(label, depth, K, factor, obj, T_co, mesh, max_error=0.01, iterations=8, depth_range=(0.25, 6.0), radius=0.01,
-                        q_t=None):
-    """Synthesizer::solveICP for ONE object on the CPU checker (oracle_*), without the nlopt stage:
-    render -> masked backprojection -> translation estimate -> 8 depth hypotheses x (render + ICP) -> SegICP score.
+                        q_t=None, polish_evaluations=50):
+    """Synthesizer::solveICP for ONE object on the CPU checker (oracle_*):
+    render -> masked backprojection -> translation estimate -> Nelder-Mead polish -> 8 depth hypotheses x (render + ICP) -> SegICP score.
     T_co: the network's pose (3x4, camera <- object); q_t: the same as (quaternion, translation) when the caller wants the
     rx, ry of synthesize.cpp:2209-2214 taken from it. Returns a dict (T_new, T_icp, hits, choose, pairs, agree)."""
     import oracle
@@ -151,6 +159,11 @@ def solve_icp_reference(label, depth, K, factor, obj, T_co, mesh, max_error=0.01
         rx = t_in[0] / t_in[2] if t_in[2] else 0.0
         ry = t_in[1] / t_in[2] if t_in[2] else 0.0
         T_co[:, 3] = (rx * Tz, ry * Tz, Tz)
+        if polish_evaluations:
+            pv = oracle.render_mesh(v, n, f, T_co[None], K, H, W, depth_range, want=("vertices",))["vertices"][0]
+            x, _, _ = oracle.icp_polish(label, live, pv, obj, depth_range, polish_evaluations)
+            T_co = compose(pose(quat2mat(x[:4]), x[4:7]), T_co)
+            Tz = T_co[2, 3]
     T_new = T_co.copy()
     hyps = np.repeat(T_co[None], len(HYPOTHESIS_DZ), 0)
     hyps[:, 2, 3] = Tz + np.asarray(HYPOTHESIS_DZ)

@@ -314,3 +314,16 @@ def icp_score(live, canonical, mask, hypotheses, radius=0.01):
     rc = L.oracle_icp_score(_p(live), _p(canonical), _p(mask), H, W, _p(hyp), hyp.shape[0], float(radius), _p(hits))
     assert rc == 0
     return hits
+
+
+def icp_polish(label, live, pred_v, obj_id, depth_range=(0.25, 6.0), maxeval=50):
+    """oracle_icp_polish -> (x f64 [7] = update (quaternion wxyz un-normalised, translation), energy, evaluations)"""
+    label, live, pred_v = _i32(label), _f32(live), _f32(pred_v)
+    H, W = label.shape
+    x = np.empty((7,), np.float64)
+    info = np.empty((2,), np.float64)
+    L = lib()
+    L.oracle_icp_polish.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_void_p, c_void_p]
+    rc = L.oracle_icp_polish(_p(label), _p(live), _p(pred_v), pred_v.shape[2], H, W, int(obj_id), float(depth_range[0]), float(depth_range[1]), int(maxeval), _p(x), _p(info))
+    assert rc == 0
+    return x, float(info[0]), int(info[1])

@@ -126,6 +126,27 @@ def test_center_and_score_bit_identical(gpu, H, W):
              oracle.icp_score(live, maps["canonical"][0], want_m, hyps2, 0.3), "hits, 30 cm radius")
 
 
+@pytest.mark.parametrize("H,W,pc", [(480, 640, 4), (100, 131, 3)])
+def test_polish_bit_identical(gpu, H, W, pc):
+    """pcnn_icp_polish_fwd (one launch, simplex in LDS) against oracle_icp_polish: the best vertex, its energy and the number of
+    evaluations for budgets that stop in every branch (initial simplex only, mid-iteration, the reference's 50), an absent
+    object, 3- and 4-channel predicted maps."""
+    from posecnn_amd import icp
+    obj = 5
+    K, (v, n, f), T_true, _, depth, label = make_case(H, W, 0.0, obj)
+    T_est = S.pose(S.rot([0, 1, 0], 0.05) @ T_true[:, :3], T_true[:, 3] + np.array([0.004, -0.003, 0.02]))
+    live = oracle.icp_backproject(depth, label, obj, K, 10000.0)
+    pv = oracle.render_mesh(v, n, f, T_est[None], K, H, W, want=("vertices",))["vertices"][0][..., :pc].copy()
+    for budget in (8, 9, 10, 13, 20, 50, 120):
+        wx, we, wn = oracle.icp_polish(label, live, pv, obj, maxeval=budget)
+        U, ge, gn, gx = icp.polish(T(gpu, label), T(gpu, live), T(gpu, pv), obj, max_evaluations=budget)
+        assert gn == wn == budget and ge == we, (budget, gn, wn, ge, we)
+        assert np.array_equal(gx.view(np.uint64), wx.view(np.uint64)), (budget, gx, wx)
+    assert we < 0.5 * oracle.icp_polish(label, live, pv, obj, maxeval=8)[1]
+    U, ge, gn, gx = icp.polish(T(gpu, label), T(gpu, live), T(gpu, pv), 7)
+    assert gn == 0 and ge == 0 and np.array_equal(gx, [1, 0, 0, 0, 0, 0, 0]) and np.array_equal(U, np.hstack([np.eye(3), np.zeros((3, 1))]))
+
+
 def test_synthesizer_icp_python_equals_the_flow_on_the_checker(gpu):
     """lib/fcn/test.py:1925-1933 on a two-object frame + one ROI that is skipped (too few pixels) + a background ROI:
     outputs / outputs_icp of Synthesizer.icp_python against tests/icp_scene.solve_icp_reference, per hypothesis hit counts
@@ -219,4 +240,6 @@ def test_new_entries_reject_bad_arguments(gpu):
     assert L.pcnn_icp_center_fwd(p, p, p, p, p, 4, 4, 4, 1, 0.01, p, p, p, 4, z) < 0             # workspace
     assert L.pcnn_icp_score_fwd(p, p, p, 4, 4, p, 1, 100.0, 100.0, 2.0, 2.0, 0.0, p, p, 4096, z) < 0    # radius
     assert L.pcnn_icp_score_fwd(p, p, p, 4, 4, z, 1, 100.0, 100.0, 2.0, 2.0, 0.01, p, p, 4096, z) < 0   # NULL hypotheses
+    assert L.pcnn_icp_polish_fwd(p, p, p, 4, 4, 4, 1, 0.25, 6.0, 7, p, p, z) < 0                        # fewer evaluations than the initial simplex
+    assert L.pcnn_icp_polish_fwd(p, p, z, 4, 4, 4, 1, 0.25, 6.0, 50, p, p, z) < 0
     torch.cuda.synchronize()
