@@ -160,9 +160,12 @@ class Evaluator(object):
                 "rotation_error_deg": pose_error.re(RT[:3, :3], RT_gt[:3, :3]),
                 "translation_error": pose_error.te(RT[:, 3], RT_gt[:, 3])}
 
-    def evaluate_result(self, labels, rois, poses, gt_labels, meta_data, mat_path=None):
+    def evaluate_result(self, labels, rois, poses, gt_labels, meta_data, mat_path=None, poses_new=None, poses_icp=None):
         """One frame (lov.py:397-515): adds its confusion histogram and pose matches to the totals and
-        returns {'iou': {class: v}, 'poses': [{class, error, threshold, correct, ...}]}."""
+        returns {'iou': {class: v}, 'poses': [{class, error, threshold, correct, ...}]}. With the refined poses of
+        cfg.TEST.POSE_REFINE (`poses_refined` / `poses_icp` of the segmentation record, lov.py:381-382, :463-511) every
+        pose entry also carries error_new / error_icp (+ rotation / translation errors); the totals keep counting the
+        network's pose, as the reference does (:517-520)."""
         h = fast_hist(gt_labels, labels, self.n)
         self.hist += h
         inter = np.diag(h)
@@ -170,7 +173,10 @@ class Evaluator(object):
         out = {"iou": {self.classes[i]: float(inter[i] / union[i]) for i in np.where(union > 0)[0]}, "poses": []}
         if mat_path is not None:
             import scipy.io
-            scipy.io.savemat(mat_path, {"labels": labels, "rois": rois, "poses": poses}, do_compression=True)
+            rec = {"labels": labels, "rois": rois, "poses": poses}
+            if poses_new is not None:
+                rec.update({"poses_refined": poses_new, "poses_icp": poses_icp})          # lov.py:389
+            scipy.io.savemat(mat_path, rec, do_compression=True)
         poses_gt = np.asarray(meta_data["poses"])
         if poses_gt.ndim == 2:
             poses_gt = poses_gt.reshape(3, 4, 1)
@@ -186,6 +192,10 @@ class Evaluator(object):
                 e = self.pose_error(cj, poses[k], poses_gt[:, :, j])
                 e.update({"class": self.classes[cj], "threshold": float(self.threshold[cj]),
                           "correct": bool(e["error"] < self.threshold[cj])})
+                for tag, pp in (("new", poses_new), ("icp", poses_icp)):
+                    if pp is not None:
+                        e2 = self.pose_error(cj, pp[k], poses_gt[:, :, j])
+                        e.update({k2 + "_" + tag: v for k2, v in e2.items()})
                 if e["correct"]:
                     self.count_correct[cj] += 1
                 out["poses"].append(e)
@@ -223,10 +233,13 @@ class Evaluator(object):
         return s
 
 
-def run_evaluation(net, dataset, points_all, symmetry, device="cuda", max_frames=None, evaluator=None, mat_dir=None):
+def run_evaluation(net, dataset, points_all, symmetry, device="cuda", max_frames=None, evaluator=None, mat_dir=None,
+                   synthesizer=None):
     """The evaluation loop of lib/fcn/test.py:1867-1945 (`test_net_single_frame`) without the
-    visualisation / ICP branches: every frame of `dataset` -> pad to a multiple of 16 -> PoseCNN single
-    frame inference -> un-padded labels, ROIs, poses -> `Evaluator.evaluate_result`. Returns the evaluator."""
+    visualisation branch: every frame of `dataset` -> pad to a multiple of 16 -> PoseCNN single
+    frame inference -> un-padded labels, ROIs, poses -> [cfg.TEST.POSE_REFINE, :1896-1933: `synthesizer.icp_python` on the
+    un-padded labels and the depth image -> poses_refined, poses_icp] -> `Evaluator.evaluate_result`. `synthesizer`: a
+    `posecnn_amd.icp.Synthesizer` (None = POSE_REFINE off). Returns the evaluator."""
     from . import fcn
     if evaluator is None:
         evaluator = Evaluator(dataset.classes, dataset.extents, dataset.points[0])
@@ -239,5 +252,16 @@ def run_evaluation(net, dataset, points_all, symmetry, device="cuda", max_frames
             net, im, depth, fr["meta"], dataset.extents, points_all, symmetry, dataset.num_classes, device=device)
         labels = fcn.unpad_im(labels, 16, orig_shape=fr["color"].shape[:2])
         mat = None if mat_dir is None else os.path.join(mat_dir, "%06d.mat" % i)
-        evaluator.evaluate_result(labels, rois, poses, fr["label"], fr["meta"], mat_path=mat)
+        poses_new = poses_icp = None
+        if synthesizer is not None:                          # lib/fcn/test.py:1900-1933
+            Km = np.asarray(fr["meta"]["intrinsic_matrix"], dtype=np.float64)
+            parameters = np.array([Km[0, 0], Km[1, 1], Km[0, 2], Km[1, 2], 0.25, 6.0, float(np.asarray(fr["meta"]["factor_depth"]).reshape(-1)[0])],
+                                  dtype=np.float32)
+            poses_new = np.zeros((poses.shape[0], 7), dtype=np.float32)
+            poses_icp = np.zeros((poses.shape[0], 7), dtype=np.float32)
+            if rois.shape[0]:
+                lab = np.ascontiguousarray(labels, dtype=np.int32)
+                synthesizer.icp_python(lab, np.ascontiguousarray(fr["depth"], dtype=np.uint16), parameters, lab.shape[0], lab.shape[1],
+                                       rois.shape[0], rois.shape[1], rois, poses, poses_new, poses_icp, 0.01)
+        evaluator.evaluate_result(labels, rois, poses, fr["label"], fr["meta"], mat_path=mat, poses_new=poses_new, poses_icp=poses_icp)
     return evaluator

@@ -178,14 +178,10 @@ def _write_demo_tree(root):
     return objects
 
 
-def test_run_evaluation_executes_the_test_net_loop(gpu, tmp_path):
-    """lib/fcn/test.py:1154-1467 (`test_net_single_frame`): frame -> pad_im(16) -> im_segment_single_frame ->
-    un-padded labels, NMS'd rois + poses -> imdb.evaluate_result -> evaluate_segmentations, on real depth frames.
-    The network has random weights; a planted 1/8-resolution scene derived from each frame's OWN ground truth makes
-    the heads emit that frame's label map and a vertex field that points at the ground-truth centres (DESIGN §5),
-    so the evaluator must find high IoU and millimetre translation errors — which only happens if the reader,
-    the blob construction, the single-frame driver, NMS, the pose combine and the evaluator all line up."""
-    import torch
+def _planted_evaluation_setup(gpu, tmp_path):
+    """demo tree on disk + a random-weight network whose planted 1/8-resolution scene is derived from each frame's own ground
+    truth + a dataset wrapper that plants frame i's scene before handing the frame out"""
+    import torch  # noqa: F401
     from posecnn_amd import datasets, fcn
     from posecnn_amd.networks import vgg16_convs
     objects = _write_demo_tree(str(tmp_path))
@@ -228,11 +224,25 @@ def test_run_evaluation_executes_the_test_net_loop(gpu, tmp_path):
             net.scene = scene_of(i)
             return ds.frame(i)
 
+    return ds, net, one_frame_at_a_time(), objects, scene_of
+
+
+def test_run_evaluation_executes_the_test_net_loop(gpu, tmp_path):
+    """lib/fcn/test.py:1154-1467 (`test_net_single_frame`): frame -> pad_im(16) -> im_segment_single_frame ->
+    un-padded labels, NMS'd rois + poses -> imdb.evaluate_result -> evaluate_segmentations, on real depth frames.
+    The network has random weights; a planted 1/8-resolution scene derived from each frame's OWN ground truth makes
+    the heads emit that frame's label map and a vertex field that points at the ground-truth centres (DESIGN §5),
+    so the evaluator must find high IoU and millimetre translation errors — which only happens if the reader,
+    the blob construction, the single-frame driver, NMS, the pose combine and the evaluator all line up."""
+    import torch
+    from posecnn_amd import datasets, fcn
+    ds, net, wrapped, objects, scene_of = _planted_evaluation_setup(gpu, tmp_path)
+    K = config.DEMO_INTRINSICS
     _, points_all = ds.points
     mat_dir = tmp_path / "mats"
     mat_dir.mkdir()
     with torch.no_grad():
-        ev = datasets.run_evaluation(net, one_frame_at_a_time(), points_all, config.LOV_SYMMETRY, device=gpu, mat_dir=str(mat_dir))
+        ev = datasets.run_evaluation(net, wrapped, points_all, config.LOV_SYMMETRY, device=gpu, mat_dir=str(mat_dir))
     s = ev.summary()
     assert s["frames"] == 5 and ev.hist.sum() == 5 * 480 * 640
     # every ground-truth object was counted, class by class
@@ -277,6 +287,65 @@ def test_run_evaluation_executes_the_test_net_loop(gpu, tmp_path):
     assert seen >= 3
     rep = ev.write_reports(str(tmp_path / "report"))
     assert rep["frames"] == 5 and os.path.exists(str(tmp_path / "report" / "confusion_matrix.txt"))
+
+
+def test_run_evaluation_with_pose_refinement(gpu, tmp_path):
+    """cfg.TEST.POSE_REFINE (lib/fcn/test.py:1896-1933, lov.py:381-389, :463-511): the loop hands the un-padded labels, the
+    depth image and the network's rois / poses to `synthesizer.icp_python` and evaluates poses_refined / poses_icp next to the
+    network's pose. Real depth frames; the models are ellipsoids with the classes' extents (no YCB mesh exists offline), so
+    what is asserted is the plumbing: the loop's refined poses equal a direct call on the same inputs, they land in the .mat
+    record, every evaluated detection carries the three error triples, and the translation is the depth-based one exactly
+    when depth points agreed with the render (the refinement's accuracy is tested on synthetic scenes with known poses,
+    tests/test_gpu_icp_render.py)."""
+    import scipy.io
+    import torch
+    import icp_scene as S
+    from posecnn_amd import datasets, fcn, icp
+    ds, net, wrapped, objects, scene_of = _planted_evaluation_setup(gpu, tmp_path)
+    _, points_all = ds.points
+    meshes = []
+    for c in range(1, 22):
+        v, n, f = S.icosphere(1.0, 2)
+        v = (v * (ds.extents[c] / 2.0)).astype(F)
+        meshes.append(icp.Mesh(v, f, None, device=gpu))                # normals generated from the faces
+    syn = icp.Synthesizer(meshes=meshes, device=gpu)
+    syn.setup(640, 480)
+    mat_dir = tmp_path / "mats_refine"
+    mat_dir.mkdir()
+    with torch.no_grad():
+        ev = datasets.run_evaluation(net, wrapped, points_all, config.LOV_SYMMETRY, device=gpu, mat_dir=str(mat_dir), max_frames=2,
+                                     synthesizer=syn)
+    assert ev.summary()["frames"] == 2
+    m = scipy.io.loadmat(str(mat_dir / "000001.mat"))
+    assert m["poses_refined"].shape == m["poses"].shape == m["poses_icp"].shape and m["poses"].shape[1] == 7
+    # the same frame by hand
+    net.scene = scene_of(1)
+    fr = ds.frame(1)
+    with torch.no_grad():
+        labels, _, _, rois, poses = fcn.im_segment_single_frame(net, fcn.pad_im(fr["color"], 16), fcn.pad_im(fr["depth"], 16), fr["meta"], ds.extents,
+                                                                points_all, config.LOV_SYMMETRY, 22, device=gpu)
+    assert np.array_equal(m["rois"], rois) and np.array_equal(m["poses"], poses)
+    Km = np.asarray(fr["meta"]["intrinsic_matrix"], dtype=np.float64)
+    par = np.array([Km[0, 0], Km[1, 1], Km[0, 2], Km[1, 2], 0.25, 6.0, float(np.asarray(fr["meta"]["factor_depth"]).reshape(-1)[0])], F)
+    pn, pi = np.zeros_like(poses), np.zeros_like(poses)
+    lab = np.ascontiguousarray(labels, np.int32)
+    syn.icp_python(lab, np.ascontiguousarray(fr["depth"], np.uint16), par, 480, 640, rois.shape[0], rois.shape[1], rois, poses, pn, pi, 0.01)
+    assert np.array_equal(m["poses_refined"], pn) and np.array_equal(m["poses_icp"], pi)
+    assert len(syn.last) >= 2
+    for info in syn.last:
+        r = info["roi"]
+        assert np.isfinite(pn[r]).all() and np.isfinite(pi[r]).all() and abs(np.linalg.norm(pi[r, :4]) - 1) < 1e-5
+        if info["agree"] > 0:
+            # depth points agreed with the render: the depth-based translation sits on the object's depth pixels
+            zs = fr["depth"][labels == int(rois[r, 1])].astype(np.float64) / par[6]
+            zs = zs[zs > 0]
+            assert abs(pn[r, 6] - zs.mean()) < np.linalg.norm(ds.extents[int(rois[r, 1])]), (r, pn[r, 6], zs.mean())
+        else:
+            # (the random network's depth can put the model nowhere near the data — even in front of z_near, where nothing
+            #  is rendered: the reference then keeps the network's translation, synthesize.cpp:2238-2239)
+            assert np.allclose(pn[r, 4:], poses[r, 4:], atol=1e-6)
+    first = datasets.Evaluator(ds.classes, ds.extents, ds.points[0]).evaluate_result(labels, rois, poses, fr["label"], fr["meta"], poses_new=pn, poses_icp=pi)
+    assert first["poses"] and all(("error_new" in e and "error_icp" in e and "translation_error_icp" in e) for e in first["poses"])
 
 
 # ---- configs[4]: backproject at the shape the LINEMOD preset runs ------------------------------------------
