@@ -215,10 +215,10 @@ def score(live_vertices, canonical, mask, hypotheses, K, radius=0.01):
     return hits
 
 
-def polish(label, live_vertices, pred_vertices, obj_id, depth_range=(Z_NEAR, Z_FAR), max_evaluations=50):
+def polish_async(label, live_vertices, pred_vertices, obj_id, depth_range=(Z_NEAR, Z_FAR), max_evaluations=50):
     """`Synthesizer::poseWithOpt` (synthesize.cpp:2529-2570): Nelder-Mead over an update pose, minimising `optEnergy`
-    (:2476-2526). pred_vertices [H,W,3|4] = the render at the pose the update multiplies. Returns (update 3x4 float64 with the
-    quaternion normalised as Sophus::SE3f does at :2014-2016, energy, evaluations)."""
+    (:2476-2526), enqueued on the current stream. pred_vertices [H,W,3|4] = the render at the pose the update multiplies.
+    Returns device tensors (x f64 [7] = quaternion wxyz un-normalised + translation, info f64 [2] = energy, evaluations)."""
     lab = ops._dev(label, "label", torch.int32)
     live = ops._dev(live_vertices, "live_vertices", torch.float32)
     pv = ops._dev(pred_vertices, "pred_vertices", torch.float32)
@@ -230,11 +230,15 @@ def polish(label, live_vertices, pred_vertices, obj_id, depth_range=(Z_NEAR, Z_F
     check("pcnn_icp_polish_fwd",
           lib().pcnn_icp_polish_fwd(ops._ptr(lab), ops._ptr(live), ops._ptr(pv), int(pv.shape[2]), H, W, int(obj_id), float(depth_range[0]),
                                     float(depth_range[1]), int(max_evaluations), ops._ptr(x), ops._ptr(info), ops._stream(lab)))
+    return x, info
+
+
+def polish(label, live_vertices, pred_vertices, obj_id, depth_range=(Z_NEAR, Z_FAR), max_evaluations=50):
+    """polish_async + read-back: (update 3x4 float64 with the quaternion normalised as Sophus::SE3f does at :2014-2016,
+    energy, evaluations, raw x)."""
+    x, info = polish_async(label, live_vertices, pred_vertices, obj_id, depth_range, max_evaluations)
     x, info = x.cpu().numpy(), info.cpu().numpy()
-    U = np.zeros((3, 4))
-    U[:, :3] = quat2mat(x[:4])
-    U[:, 3] = x[4:7]
-    return U, float(info[0]), int(info[1]), x
+    return _pose34(x), float(info[0]), int(info[1]), x
 
 
 def mat2quat(R):
@@ -311,6 +315,7 @@ class Synthesizer:
         self.polish_evaluations = polish_evaluations      # `iterations = 50` of synthesize.cpp:2226; 0 skips the polish
         self.width = self.height = None
         self.last = []                # per processed ROI: hits / pairs of each hypothesis and the chosen one
+        self._streams = []            # one per object of a frame (created on first use)
 
     def setup(self, width, height):
         self.width, self.height = int(width), int(height)
@@ -338,6 +343,7 @@ class Synthesizer:
         poses = np.asarray(poses, dtype=np.float64).reshape(num_roi, 7)
         counts = np.bincount(labels_np.reshape(-1).clip(min=0), minlength=len(self.meshes) + 2)
         self.last = []
+        jobs = []
         for i in range(num_roi):
             obj = int(rois[i, 1])
             if obj <= 0:                                   # :2096
@@ -346,37 +352,69 @@ class Synthesizer:
                 raise ValueError("ROI %d: class id %d has no model (%d loaded)" % (i, obj, len(self.meshes)))
             if counts[obj] < min_pixels:                   # :2152 (the reference leaves the row as it was)
                 continue
-            mesh = self.meshes[obj - 1]
-            T_co = _pose34(poses[i])
-            maps = render(mesh, T_co[None], K, height, width, (znear, zfar), model_index=obj - 1, want=("vertices", "normals", "canonical"))
-            live = backproject(depth_t, labels_t, obj, K, factor)
-            sums, mask = center(labels_t, live, maps["canonical"][0], maps["vertices"][0], maps["normals"][0], obj, maxError)
-            sums = sums.cpu().numpy()
-            c = int(sums[3])
-            Tz = T_co[2, 3]
-            if c > 0:                                      # :2215-2236
-                Tz = float(np.float32(sums[2]) / np.float32(c))
-                rx = poses[i, 4] / poses[i, 6] if poses[i, 6] else 0.0
-                ry = poses[i, 5] / poses[i, 6] if poses[i, 6] else 0.0
-                T_co[:, 3] = (rx * Tz, ry * Tz, Tz)
-                if self.polish_evaluations:                 # refinePose(..., 50, maxError, 0), :2226-2232
-                    pv = render(mesh, T_co[None], K, height, width, (znear, zfar), want=("vertices",))["vertices"][0]
-                    U, energy, evals, _ = polish(labels_t, live, pv, obj, (znear, zfar), self.polish_evaluations)
-                    T_co = _compose(U, T_co)
-                    Tz = T_co[2, 3]
-            outputs[i, :4] = mat2quat(T_co[:, :3])
-            outputs[i, 4:7] = T_co[:, 3]
-            hyps = np.repeat(T_co[None], len(HYPOTHESIS_DZ), 0)
-            hyps[:, 2, 3] = Tz + np.asarray(HYPOTHESIS_DZ)
-            pm = render(mesh, hyps, K, height, width, (znear, zfar), want=("vertices", "normals"))
-            live_n = live.unsqueeze(0).expand(len(hyps), -1, -1, -1).contiguous()
-            upd = icp(live_n, pm["vertices"], pm["normals"], K, (znear, zfar), maxError, iterations).cpu().numpy()
-            hyps = np.stack([_compose(U, T) for U, T in zip(upd, hyps)])
-            pairs = int(sums[4])
-            choose, hits = 0, None
-            if pairs > 0:                                  # :2302-2343
-                hits = score(live, maps["canonical"][0], mask, hyps, K, radius).cpu().numpy()
-                choose = int(np.argmax(hits))              # first maximum (`score > max_score`, :2336)
-            self.last.append({"roi": i, "obj": obj, "pairs": pairs, "agree": c, "hits": hits, "choose": choose})
-            outputs_icp[i, :4] = mat2quat(hyps[choose][:, :3])
-            outputs_icp[i, 4:7] = hyps[choose][:, 3]
+            jobs.append({"i": i, "obj": obj, "mesh": self.meshes[obj - 1], "T": _pose34(poses[i])})
+        if not jobs:
+            return
+        # The objects of a frame are independent and most of the kernels are short or narrow (the polish is ONE workgroup for
+        # 0.7 ms): each object's chain runs on its own stream, phase by phase, so they overlap on the chip; the host reads a
+        # phase's few numbers back object by object while the others are still running.
+        cur = torch.cuda.current_stream(dev)
+        while len(self._streams) < len(jobs):
+            self._streams.append(torch.cuda.Stream(device=dev))
+        for job, st in zip(jobs, self._streams):
+            job["stream"] = st
+            st.wait_stream(cur)
+        dr = (znear, zfar)
+        for job in jobs:                                   # render at the network's pose, live vertex map, translation votes
+            with torch.cuda.stream(job["stream"]):
+                job["maps"] = render(job["mesh"], job["T"][None], K, height, width, dr, model_index=job["obj"] - 1,
+                                     want=("vertices", "normals", "canonical"))
+                job["live"] = backproject(depth_t, labels_t, job["obj"], K, factor)
+                job["sums_t"], job["mask"] = center(labels_t, job["live"], job["maps"]["canonical"][0], job["maps"]["vertices"][0],
+                                                    job["maps"]["normals"][0], job["obj"], maxError)
+        for job in jobs:                                   # :2209-2232: new translation, then the polish (re-render + Nelder-Mead)
+            with torch.cuda.stream(job["stream"]):
+                sums = job["sums_t"].cpu().numpy()
+                i, T_co = job["i"], job["T"]
+                job["agree"], job["pairs"], job["Tz"] = int(sums[3]), int(sums[4]), T_co[2, 3]
+                job["polish"] = None
+                if job["agree"] > 0:
+                    Tz = float(np.float32(sums[2]) / np.float32(job["agree"]))
+                    rx = poses[i, 4] / poses[i, 6] if poses[i, 6] else 0.0
+                    ry = poses[i, 5] / poses[i, 6] if poses[i, 6] else 0.0
+                    T_co[:, 3] = (rx * Tz, ry * Tz, Tz)
+                    job["Tz"] = Tz
+                    if self.polish_evaluations:
+                        pv = render(job["mesh"], T_co[None], K, height, width, dr, want=("vertices",))["vertices"][0]
+                        job["polish"] = polish_async(labels_t, job["live"], pv, job["obj"], dr, self.polish_evaluations)
+        for job in jobs:                                   # :2238-2300: outputs, the 8 depth hypotheses, 8 ICP iterations each
+            with torch.cuda.stream(job["stream"]):
+                i, T_co = job["i"], job["T"]
+                if job["polish"] is not None:
+                    x = job["polish"][0].cpu().numpy()
+                    T_co = _compose(_pose34(x), T_co)
+                    job["T"], job["Tz"] = T_co, T_co[2, 3]
+                outputs[i, :4] = mat2quat(T_co[:, :3])
+                outputs[i, 4:7] = T_co[:, 3]
+                hyps = np.repeat(T_co[None], len(HYPOTHESIS_DZ), 0)
+                hyps[:, 2, 3] = job["Tz"] + np.asarray(HYPOTHESIS_DZ)
+                pm = render(job["mesh"], hyps, K, height, width, dr, want=("vertices", "normals"))
+                live_n = job["live"].unsqueeze(0).expand(len(hyps), -1, -1, -1).contiguous()
+                job["hyps"] = hyps
+                job["upd_t"] = icp(live_n, pm["vertices"], pm["normals"], K, dr, maxError, iterations)
+        for job in jobs:                                   # :2302-2343: SegICP score of the refined hypotheses
+            with torch.cuda.stream(job["stream"]):
+                upd = job["upd_t"].cpu().numpy()
+                job["hyps"] = np.stack([_compose(U, T) for U, T in zip(upd, job["hyps"])])
+                job["hits_t"] = score(job["live"], job["maps"]["canonical"][0], job["mask"], job["hyps"], K, radius) if job["pairs"] > 0 else None
+        for job in jobs:
+            with torch.cuda.stream(job["stream"]):
+                choose, hits = 0, None
+                if job["hits_t"] is not None:
+                    hits = job["hits_t"].cpu().numpy()
+                    choose = int(np.argmax(hits))          # first maximum (`score > max_score`, :2336)
+                i = job["i"]
+                self.last.append({"roi": i, "obj": job["obj"], "pairs": job["pairs"], "agree": job["agree"], "hits": hits, "choose": choose})
+                outputs_icp[i, :4] = mat2quat(job["hyps"][choose][:, :3])
+                outputs_icp[i, 4:7] = job["hyps"][choose][:, 3]
+            cur.wait_stream(job["stream"])
