@@ -49,10 +49,12 @@ def parse_args(argv=None):
     ap.add_argument("--resident-inputs", action="store_true", help="A/B: frames already in HBM (no H2D in the timed region)")
     ap.add_argument("--latency", action="store_true", help="per-frame synchronous loop; reports p50/p99 latency")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (see posecnn_amd/pipeline.py)")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="HIP streams the batches alternate over: with 2, batch i+1's trunk overlaps batch i's heads / Hough / RoI tail "
-                         "(+1 %% on this workload). Round 3 found and fixed the race this mode used to expose (an s_waitcnt vmcnt(0) "
-                         "missing in front of the barrier that recycles the MFMA kernels' LDS ring; tools/debug_streams.py)")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="HIP streams the batches alternate over (default 2; 1 with --graph): with 2, batch i+1's trunk overlaps batch "
+                         "i's heads / Hough / RoI tail (+1 %% on this workload). Round 3 found and fixed the race this mode used to "
+                         "expose (an s_waitcnt vmcnt(0) missing in front of the barrier that recycles the MFMA kernels' LDS ring; "
+                         "tools/debug_streams.py). --graph --streams 2 is legal (each graph owns its scratch) but measured slower: "
+                         "689 vs 722 frames/s")
     ap.add_argument("--backproject-grid", type=int, default=None,
                     help="also run the backprojecting layer on each batch's head features (G^3 voxels per frame); "
                          "default 128 for --config linemod (configs[4] names it), 0 = off otherwise")
@@ -67,7 +69,10 @@ def parse_args(argv=None):
                     help="initialise RCCL and run the detection all-gather through it even at world size 1")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: launch / rendezvous / collective / JSON plumbing on gloo")
     ap.add_argument("--master-port", type=int, default=0)
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.streams is None:
+        a.streams = 1 if a.graph else 2
+    return a
 
 
 def respawn_command(a, argv):
@@ -317,11 +322,10 @@ def main(argv=None):
             last["backproject"] = top[0]
         return det
 
-    if a.graph and a.streams > 1:
-        # library workspaces (Hough, ADL, split-K / Cin-split partials) are keyed by the stream that is
-        # current when they are first requested; during capture that is torch's one capture stream, so two graphs
-        # would bake in the SAME scratch buffers and then replay concurrently. Graph replays therefore run on one stream.
-        a.streams = 1
+    # (--graph with --streams 2: every GraphedStep warms up and captures on a stream of its own, so the library scratch
+    #  it bakes in — keyed by stream — is private to it and the two device slots' graphs may replay concurrently
+    #  (tests/test_gpu_round3.py::test_two_graphs_replaying_concurrently_equal_the_eager_steps). It is not the default:
+    #  two whole-step graphs interleaving kernel by kernel measured 689 frames/s against 722 for one graph stream.)
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(max(1, a.streams) - 1)]
     multi = {"on": len(streams) > 1}
 

@@ -111,15 +111,20 @@ class GraphedStep:
 
     def __init__(self, fn, warmup=3, device=None):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):          # warm-up off the default stream: MIOpen find, workspaces, caches
+        # The step is warmed up AND captured on a stream of its own, kept alive with the graph: the library's scratch
+        # (Hough / ADL workspaces, split-K and Cin-split partials, ticket counters) is keyed by the stream that is current
+        # when it is requested (ops._ws), so every GraphedStep bakes in ITS OWN buffers and two of them can replay
+        # concurrently on two streams (bench.py --graph --streams 2). Captured on torch's shared capture stream, two
+        # graphs would share one set of scratch buffers — a race when they overlap.
+        self.side = torch.cuda.Stream(device=self.device)
+        self.side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.side):     # warm-up off the default stream: MIOpen find, workspaces, caches
             for _ in range(warmup):
                 fn()
-        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.current_stream(self.device).wait_stream(self.side)
         torch.cuda.synchronize(self.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=self.side):
             self.outputs = fn()
         torch.cuda.synchronize(self.device)
 

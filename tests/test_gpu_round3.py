@@ -348,6 +348,74 @@ def test_run_evaluation_with_pose_refinement(gpu, tmp_path):
     assert first["poses"] and all(("error_new" in e and "error_icp" in e and "translation_error_icp" in e) for e in first["poses"])
 
 
+def test_two_graphs_replaying_concurrently_equal_the_eager_steps(gpu):
+    """bench.py --graph --streams 2: one hipGraph per device slot, the two replayed concurrently on two
+    streams. Every GraphedStep warms up and captures on a stream of its own, so the library scratch it bakes in (keyed by
+    stream: Hough / ADL workspaces, fc6 split-K partials, Cin-split partials at batch 1) is private to it. 8 rounds of
+    overlapping replays on changing frame contents must reproduce the eager single-stream results bit for bit."""
+    import torch
+    from posecnn_amd import fcn, pipeline
+    from posecnn_amd.networks import vgg16_convs
+    from test_gpu_round2 import _rgbd_inputs
+    B, H, W = 1, 240, 320
+    net = vgg16_convs("RGBD", 22, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True, trainable=False,
+                      is_train=True, seed=3, init="he", with_losses=False, device=gpu)
+    synth.init_planted_heads(net)
+    K = config.DEMO_INTRINSICS.copy(); K[:2] *= W / 640.0
+    rng = np.random.default_rng(18)
+    pts = T(gpu, synth.make_model_points(22, 256))
+    frames = []
+    for i in range(4):
+        data, data_p = _rgbd_inputs(rng, B, H, W)
+        planted_np, scenes = synth.make_planted_batch(80 + i, B, H=H, W=W, K=K, n_obj=3)
+        frames.append((T(gpu, data), T(gpu, data_p), {k: T(gpu, v) for k, v in planted_np.items()}, T(gpu, synth.make_gt_poses(scenes, K, seed=i))))
+    slots = []
+    for k in range(2):
+        f = frames[k]
+        slots.append({"data": f[0].clone(), "data_p": f[1].clone(), "plant": {n_: v.clone() for n_, v in f[2].items()}, "gt": f[3].clone()})
+    feed = fcn._feed(net, slots[0]["data"], slots[0]["data_p"], K, config.LOV_EXTENTS, pts, config.LOV_SYMMETRY, 22, gpu)
+
+    def make_step(sl):
+        def step():
+            det = fcn.im_segment_batch(net, sl["data"], K, config.LOV_EXTENTS, pts, config.LOV_SYMMETRY, data_p=sl["data_p"],
+                                       planted=sl["plant"], feed_cache=feed, with_losses=True, gt_poses=sl["gt"])
+            return det.rows, det.count, det.label_2d, net.get_output("loss_pose"), net.get_output("fc7")
+        return step
+
+    def fill(sl, f):
+        sl["data"].copy_(f[0]); sl["data_p"].copy_(f[1]); sl["gt"].copy_(f[3])
+        for n_ in sl["plant"]:
+            sl["plant"][n_].copy_(f[2][n_])
+
+    with torch.no_grad():
+        eager = []
+        for f in frames:
+            fill(slots[0], f)
+            eager.append([t.clone() for t in make_step(slots[0])()])
+        torch.cuda.synchronize()
+        graphs = [pipeline.GraphedStep(make_step(sl), warmup=1, device=gpu) for sl in slots]
+        streams = [torch.cuda.Stream(device=gpu), torch.cuda.Stream(device=gpu)]
+        bad = 0
+        for rnd in range(8):
+            pick = [(rnd + k) % 4 for k in range(2)] if rnd % 2 else [(rnd + 2 * k + 1) % 4 for k in range(2)]
+            outs = []
+            for k in range(2):
+                with torch.cuda.stream(streams[k]):
+                    fill(slots[k], frames[pick[k]])
+                    outs.append([t.clone() for t in graphs[k].replay()])
+            torch.cuda.synchronize()
+            for k in range(2):
+                for got, want, name in zip(outs[k], eager[pick[k]], ("rows", "count", "label_2d", "loss_pose", "fc7")):
+                    g_, w_ = N(got).reshape(-1), N(want).reshape(-1)
+                    if name == "fc7":
+                        live = int(outs[k][1]) * 9
+                        g_, w_ = N(got)[:live].reshape(-1), N(want)[:live].reshape(-1)
+                    if not np.array_equal(g_.view(np.uint32) if g_.dtype.kind == "f" else g_, w_.view(np.uint32) if w_.dtype.kind == "f" else w_):
+                        bad += 1
+        assert bad == 0, "%d tensors differed between concurrent graph replays and the eager steps" % bad
+        assert int(eager[0][1]) > 0
+
+
 # ---- configs[4]: backproject at the shape the LINEMOD preset runs ------------------------------------------
 def test_backproject_at_the_linemod_bench_shape(gpu):
     """backprojecting_op_gpu.cu.cc:17-126 at 960x1280 inputs, 64 data channels, C = 14 class channels, k = 3
