@@ -39,10 +39,17 @@ __device__ __forceinline__ void quat_rot(float s, float u, float v, float w, flo
   r[8] = s * s - u * u - v * v + w * w;
 }
 
+// first class whose weight is positive (average_distance_loss_op_gpu.cu.cc:52-60), found by the whole wave at once:
+// lane l looks at classes l, l + 64, ...; a ballot picks the lowest (the serial form was a chain of up to C dependent
+// loads in front of every block). Must be called by all lanes of the wave.
 __device__ __forceinline__ int find_class(const float* __restrict__ weight, int n, int C)
 {
-  for (int c = 0; c < C; c++)
-    if (weight[(size_t)n * PCNN_POSE_CHANNELS * C + PCNN_POSE_CHANNELS * c] > 0) return c;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + lane_id();
+    const bool hit = c < C && weight[(size_t)n * PCNN_POSE_CHANNELS * C + PCNN_POSE_CHANNELS * c] > 0;
+    const unsigned long long m = __ballot(hit);
+    if (m) return c0 + __ffsll((long long)m) - 1;
+  }
   return -1;
 }
 
@@ -61,11 +68,9 @@ __global__ __launch_bounds__(ADL_THREADS) void adl_terms_kernel(
   const int R = num_rows_dev ? min(R_cap, num_rows_dev[0]) : R_cap;
   const int cls = n < R ? find_class(weight, n, C) : -1;
   float* tn = terms + (size_t)n * 5 * P;
-  if (cls < 0) {
-    if (p < P)
-      for (int k = 0; k < 5; k++) tn[(size_t)k * P + p] = 0.f;
-    return;
-  }
+  if (cls < 0) return;   // no target (or past the row count): adl_sum writes this row's zeros without reading any terms
+                         // (a train-mode buffer of 3024 rows holds ~470 with targets: 134 MB of zeros were written here
+                         //  and read back there)
   const int qi = n * PCNN_POSE_CHANNELS * C + PCNN_POSE_CHANNELS * cls;
   float rg[9], ru[9];
   quat_rot(target[qi], target[qi + 1], target[qi + 2], target[qi + 3], rg);
@@ -152,6 +157,10 @@ __global__ __launch_bounds__(64) void adl_sum_kernel(const float* __restrict__ t
   const int R = num_rows_dev ? min(R_cap, num_rows_dev[0]) : R_cap;
   const int cls = n < R ? find_class(weight, n, C) : -1;
   for (int c = lane; c < CH; c += 64) bottom_diff[(size_t)n * CH + c] = 0.f;
+  if (cls < 0) {         // every term of the row is +0 (never written by adl_terms): the sums are +0
+    if (lane == 0) loss_batch[n] = 0.f;
+    return;
+  }
   const float* tn = terms + (size_t)n * 5 * P;
   float acc = 0.f;
   for (int p0 = 0; p0 < P; p0 += TILE) {

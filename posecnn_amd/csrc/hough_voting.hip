@@ -1041,6 +1041,15 @@ __global__ __launch_bounds__(128) void hv_emit_kernel(
     int is_train)
 {
   extern __shared__ int s_off[];  // [B]: rows of the images in front (every block recomputes it)
+  // (batch, class) of the first HV_GT_LDS ground-truth rows: the target search below walks all num_gt rows per thread —
+  // 80 trips of two global loads each were 40 of this launch's 52 us
+  constexpr int HV_GT_LDS = 512;
+  __shared__ int s_gtkey[HV_GT_LDS][2];
+  if (is_train)
+    for (int i = threadIdx.x; i < min(num_gt, HV_GT_LDS); i += 128) {
+      s_gtkey[i][0] = (int)gt[i * 13 + 0];
+      s_gtkey[i][1] = (int)gt[i * 13 + 1];
+    }
   if (threadIdx.x == 0) {
     int acc = 0;
     if (cap > 0)
@@ -1086,8 +1095,9 @@ __global__ __launch_bounds__(128) void hv_emit_kernel(
   if (!is_train) return;
 
   for (int i = 0; i < num_gt; i++) {
-    int gt_batch = (int)gt[i * 13 + 0];
-    int gt_id = (int)gt[i * 13 + 1];
+    int gt_batch, gt_id;
+    if (i < HV_GT_LDS) { gt_batch = s_gtkey[i][0]; gt_id = s_gtkey[i][1]; }
+    else { gt_batch = (int)gt[i * 13 + 0]; gt_id = (int)gt[i * 13 + 1]; }
     if (cls == gt_id && n == gt_batch) {
       float overlap = compute_box_overlap(cls, extents, fx, fy, px, py, gt + i * 13, b + 2);
       if ((double)overlap > 0.2) {
