@@ -6,6 +6,7 @@ python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --streams 1 --no-cpu-baseline > $O/bench_streams1.json 2> $O/bench_streams1.err
 python bench.py --graph --no-cpu-baseline > $O/bench_graph.json 2> $O/bench_graph.err
 python bench.py --latency --batch 1 --input COLOR --losses test --no-cpu-baseline --graph --steps 100 > $O/bench_latency_b1.json 2> $O/bench_latency_b1.err
+python bench.py --latency --batch 1 --input COLOR --losses none --no-cpu-baseline --graph --steps 100 > $O/bench_latency_b1_inference.json 2> $O/bench_latency_b1_inference.err
 python bench.py --config linemod --no-cpu-baseline > $O/bench_linemod.json 2> $O/bench_linemod.err
 python bench.py --force-process-group --no-cpu-baseline > $O/bench_rccl_world1.json 2> $O/bench_rccl_world1.err
 python bench.py --input COLOR --losses test --resident-inputs --no-cpu-baseline > $O/bench_color_test_resident.json 2> $O/bench_color.err
@@ -23,5 +24,7 @@ python tools/bench_wino_mfma.py --no-library --batch 1 --groups 1 > $O/layers_mf
 python tools/bench_fc_skinny.py > $O/fc_skinny.json 2>&1
 python tools/bench_heads_small.py > $O/heads_small.json 2>&1
 python tools/bench_ops.py > $O/ops.json 2> $O/ops.err
+python tools/bench_icp.py > $O/icp.json 2> $O/icp.err
+python tools/bench_fc_rows.py > $O/fc_rows.txt 2>&1
 rm -rf $O/prof/*.db $O/pmc_*/ 2>/dev/null
 ls -la $O
