@@ -176,3 +176,18 @@ def solve_icp_reference(label, depth, K, factor, obj, T_co, mesh, max_error=0.01
         hits = oracle.icp_score(live, maps["canonical"][0], mask, hyps, radius)
         choose = int(np.argmax(hits))
     return {"T_new": T_new, "T_icp": hyps[choose], "hyps": hyps, "hits": hits, "choose": choose, "pairs": pairs, "agree": c}
+
+
+def random_sheet(seed, n_points=400, tilt=(0.4, -0.25), z0=0.8, half=0.12):
+    """A random Delaunay triangulation of a square sheet (slivers and all) in the plane z = z0 + tilt . (x, y): returns
+    (vertices f32 [n,3], faces int32 [m,3], hull test `inside(x, y, margin)`)."""
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform(-half, half, (n_points, 2))
+    pts[:4] = [[-half, -half], [half, -half], [half, half], [-half, half]]         # the hull is the square itself
+    tri = Delaunay(pts)
+    z = z0 + tilt[0] * pts[:, 0] + tilt[1] * pts[:, 1]
+    v = np.concatenate([pts, z[:, None]], axis=1).astype(np.float32)
+    f = tri.simplices.astype(np.int32)
+    f[::2] = f[::2, ::-1]                                                           # mixed windings
+    return v, f

@@ -57,6 +57,20 @@ def test_render_bit_identical_box_and_spheres(gpu):
     check_render(gpu, vm, np.concatenate([nb, ns]), np.concatenate([fb, fs + len(vb)]), poses, K, 480, 640, "mixed")
 
 
+def test_render_bit_identical_on_random_triangulations(gpu):
+    """400-point Delaunay sheets (slivers, mixed windings, shared edges at every angle) at three poses each: the atomicMin
+    z-buffer and the serial checker agree on every pixel bit for bit."""
+    rng = np.random.default_rng(2)
+    K = scaled_K(320)
+    for seed in range(3):
+        v, f = S.random_sheet(10 + seed, tilt=(0.0, 0.0), z0=0.0)
+        poses = np.stack([S.pose(S.rot(rng.standard_normal(3), rng.uniform(0, 1.2)), [rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05), rng.uniform(0.5, 0.9)])
+                          for _ in range(3)])
+        n = np.tile(np.array([[0, 0, -1.0]], F), (len(v), 1))
+        w = check_render(gpu, v, n, f, poses, K, 240, 320, "sheet %d" % seed)
+        assert np.isfinite(w["vertices"][..., 2]).sum() > 10000
+
+
 def test_render_edge_cases(gpu):
     """An object half outside the image, one straddling z_near (its near triangles are dropped), one past z_far, a degenerate
     and a repeated-index triangle, an empty mesh, zero poses."""

@@ -269,3 +269,26 @@ def test_polish_lowers_the_energy_and_respects_its_box_and_budget():
     # no pixel of the object: the identity, zero evaluations
     x, e, ne = oracle.icp_polish(label, live, pv, 6, maxeval=50)
     assert ne == 0 and e == 0 and np.array_equal(x, [1, 0, 0, 0, 0, 0, 0])
+
+
+def test_random_triangulations_are_watertight():
+    """The shared-edge rule: 400-point Delaunay triangulations of a tilted square sheet (mixed windings, slivers) leave no
+    hole — every pixel whose ray meets the sheet at least half a pixel inside its border is covered, and carries the plane's
+    depth; nothing outside the sheet's image is covered."""
+    H, W = 120, 160
+    K = small_K(W, H)
+    for seed in range(4):
+        v, f = S.random_sheet(seed)
+        out = oracle.render_mesh(v, None, f, IDENT[None], K, H, W, want=("vertices",))["vertices"][0]
+        hit = np.isfinite(out[..., 2])
+        ys, xs = np.mgrid[0:H, 0:W]
+        rx, ry = (xs - K[0, 2]) / K[0, 0], (ys - K[1, 2]) / K[1, 1]
+        # ray (rx, ry, 1) t meets z = z0 + a x + b y at t = z0 / (1 - a rx - b ry)
+        t = 0.8 / (1 - 0.4 * rx + 0.25 * ry)
+        px_, py_ = rx * t, ry * t
+        margin = 0.6 * t / K[0, 0]
+        inside = (np.abs(px_) < 0.12 - margin) & (np.abs(py_) < 0.12 - margin)
+        outside = (np.abs(px_) > 0.12 + margin) | (np.abs(py_) > 0.12 + margin)
+        assert inside.sum() > 4000 and hit[inside].all(), (seed, (~hit[inside]).sum())
+        assert not hit[outside].any()
+        assert np.abs(out[..., 2][inside] - t[inside]).max() < 5e-6
