@@ -9,12 +9,13 @@ class id > 0 and >= 400 label pixels, all on the GPU (gfx950 kernels of libposec
 
     render the mesh at the network's pose            pcnn_render_mesh_fwd     (the reference: two OpenGL passes, :2104-2136)
     masked depth -> live vertex map                  pcnn_icp_backproject_fwd (:2139-2155)
-    translation from depth vs. rendered surface      pcnn_icp_center_fwd      (:2157-2225)  -> poses_new
+    translation from depth vs. rendered surface      pcnn_icp_center_fwd      (:2157-2225)
+    re-render + Nelder-Mead polish of the pose       pcnn_icp_polish_fwd      (:2226-2235, poseWithOpt :2529-2570)  -> poses_new
     8 depth hypotheses, each: render + 8 ICP steps   pcnn_render_mesh_fwd + pcnn_icp_refine_fwd, the 8 in ONE call each (:2272-2300)
     SegICP score of the 8 refined hypotheses         pcnn_icp_score_fwd       (:2302-2343)  -> poses_icp = best
 
-    (between the two: re-render + Nelder-Mead polish     pcnn_icp_polish_fwd      (:2226-2235, poseWithOpt :2529-2570; nlopt's published
-     algorithm restated — nlopt itself is absent —, the whole optimisation in one launch))
+(nlopt is absent: the polish is its published Nelder-Mead restated, the whole optimisation in one launch.) The objects of a
+frame run phase by phase on their own streams.
 
 No assimp here: meshes are Wavefront OBJ read by `Mesh.load_obj` (positions, faces, optional normals; smooth normals are
 generated like aiProcess_GenSmoothNormals when the file has none).
