@@ -19,7 +19,6 @@ from posecnn_amd import _lib, config, icp  # noqa: E402
 
 def main():
     import icp_scene as S
-    import oracle
     dev = torch.device("cuda:0")
     H, W = 480, 640
     K = config.DEMO_INTRINSICS.copy()
