@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Pose refinement of one 640x480 frame (posecnn_amd.icp.Synthesizer.icp_python = Synthesizer::solveICP without nlopt):
+"""Pose refinement of one 640x480 frame (posecnn_amd.icp.Synthesizer.icp_python = Synthesizer::solveICP, its nlopt polish as the library's Nelder-Mead):
 5 objects, meshes of 81 920 triangles each (the size of a YCB `textured_simple.obj`), poses 2 cm off in depth.
 Prints one JSON object: wall time per frame and per object, per-kernel times from the library's own HIP-event profiler,
 and the same flow on the CPU checker for ONE object (tests/icp_scene.solve_icp_reference, bounded sample)."""
