@@ -295,9 +295,12 @@ def test_random_triangulations_are_watertight():
 
 
 def test_refinement_checker_under_address_and_ub_sanitizers():
-    """oracle/asan_driver.c: the pose-refinement functions of the checker in one translation unit with -fsanitize=address,
-    undefined, driven over odd-sized inputs (objects cut by the image border, zero faces, empty masks, every polish budget
-    from 8 to 40). Any out-of-bounds access, use-after-free, signed overflow or misaligned access aborts the driver."""
+    """oracle/asan_driver.c: the checker in one translation unit with -fsanitize=address,undefined ("ASAN build of
+    the CPU oracle"), driven over odd-sized inputs — pose refinement (objects cut by the image border, zero faces, empty
+    masks, every polish budget from 8 to 40), then Hough voting (train / test, both threshold branches), ROI pooling with
+    off-image / inverted / bad-batch ROIs and its backward, hard labels with ignore and out-of-range ids, softmax, both
+    deconvolutions, the pose loss with a symmetric class, the vertex loss. Any out-of-bounds access, use-after-free, signed
+    overflow or misaligned access aborts the driver."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
