@@ -348,6 +348,37 @@ def test_run_evaluation_with_pose_refinement(gpu, tmp_path):
     assert first["poses"] and all(("error_new" in e and "error_icp" in e and "translation_error_icp" in e) for e in first["poses"])
 
 
+def test_listener_callback_builds_the_posecnn_message(gpu, tmp_path):
+    """ros/listener.py:41-90 without ROS (posecnn_amd.listener.ImageListener): a (colour, depth) pair of the demo tree ->
+    the PoseCNNMsg fields, equal to what im_segment_single_frame returns for that frame; both publishers are called; a 32FC1
+    depth message gives the same result as its 16UC1 twin; an unsupported encoding is dropped."""
+    import torch
+    from posecnn_amd import fcn, listener
+    ds, net, wrapped, objects, scene_of = _planted_evaluation_setup(gpu, tmp_path)
+    fr = ds.frame(0)
+    net.scene = scene_of(0)
+    sent, sent_label, logged = [], [], []
+    li = listener.ImageListener(net, ds, fr["meta"], config.LOV_SYMMETRY, publish=sent.append, publish_label=sent_label.append, device=gpu,
+                                log=logged.append)
+    with torch.no_grad():
+        msg = li.callback(fr["color"], fr["depth"], "16UC1")
+        _, points_all = ds.points
+        labels, _, _, rois, poses = fcn.im_segment_single_frame(net, fcn.pad_im(fr["color"], 16), fcn.pad_im(fr["depth"], 16), fr["meta"], ds.extents,
+                                                                points_all, config.LOV_SYMMETRY, 22, device=gpu)
+        metres = fr["depth"].astype(np.float32) / 1000.0
+        msg32 = li.callback(fr["color"], metres, "32FC1")
+        assert li.callback(fr["color"], fr["depth"], "8UC1") is None and len(logged) == 1 and "Unsupported depth type" in logged[0]
+    K = np.asarray(fr["meta"]["intrinsic_matrix"])
+    assert (msg["height"], msg["width"], msg["roi_num"], msg["roi_channel"]) == (480, 640, rois.shape[0], 7) and rois.shape[0] >= 3
+    assert msg["fx"] == float(K[0, 0]) and msg["py"] == float(K[1, 2]) and msg["znear"] == 0.25 and msg["zfar"] == 6.0
+    assert np.array_equal(msg["label"], labels.astype(np.uint8)) and np.array_equal(msg["depth"], fr["depth"])
+    assert msg["rois"] == rois.astype(F).flatten().tolist() and msg["poses"] == poses.astype(F).flatten().tolist()
+    assert len(sent) == 2 and sent[0] is msg and len(sent_label) == 2 and sent_label[0].shape == (480, 640, 3)
+    assert np.array_equal(sent_label[0], listener.labels_to_image(labels))
+    # uint16(depth / 1000 * 1000) can differ from depth by one count: the RGB-D network sees a slightly different depth blob
+    assert msg32["roi_num"] == msg["roi_num"] and np.abs(np.asarray(msg32["depth"], np.int32) - fr["depth"]).max() <= 1
+
+
 def test_two_graphs_replaying_concurrently_equal_the_eager_steps(gpu):
     """bench.py --graph --streams 2: one hipGraph per device slot, the two replayed concurrently on two
     streams. Every GraphedStep warms up and captures on a stream of its own, so the library scratch it bakes in (keyed by

@@ -167,3 +167,17 @@ def test_upload_slots_are_adjacent_and_stack_as_a_view():
     assert pipeline.stacked_view(slot[0], slot[1][:, :3]) is None   # shape mismatch
     odd = pipeline.alloc_adjacent((torch.zeros(3, 5, 7, 3), torch.zeros(3, 5, 7, 3)), "cpu")   # 1260 B: padded to 256
     assert pipeline.stacked_view(odd[0], odd[1]) is None
+
+
+def test_listener_host_helpers():
+    """posecnn_amd.listener: the depth-message decoding of ros/listener.py:42-51 and imdb.labels_to_image (lov.py:348-364)."""
+    from posecnn_amd import listener
+    d32 = np.array([[0.5, 1.2345], [0.0, 6.5]], np.float32)
+    assert listener.depth_from_message(d32, "32FC1").tolist() == [[500, 1234], [0, 6500]]
+    d16 = np.array([[1, 2], [3, 65535]], np.uint16)
+    assert np.array_equal(listener.depth_from_message(d16, "16UC1"), d16) and listener.depth_from_message(d16, "8UC1") is None
+    labels = np.array([[0, 1, 21], [2, 22, 5]], np.int32)
+    img = listener.labels_to_image(labels)
+    assert img.dtype == np.uint8 and img.shape == (2, 3, 3)
+    assert img[0, 0].tolist() == [255, 255, 255] and img[0, 1].tolist() == [255, 0, 0] and img[0, 2].tolist() == [0, 0, 192]
+    assert img[1, 0].tolist() == [0, 255, 0] and img[1, 1].tolist() == [0, 0, 0] and img[1, 2].tolist() == [255, 0, 255]   # class 22: no colour -> black
