@@ -47,6 +47,9 @@ def parse_args(argv=None):
                          "targets (configs[2]); test: is_train=0 graph with the loss layers evaluated (no targets -> "
                          "ADL skips every row); none: pure inference")
     ap.add_argument("--resident-inputs", action="store_true", help="A/B: frames already in HBM (no H2D in the timed region)")
+    ap.add_argument("--raw-inputs", action="store_true",
+                    help="upload the frames as the sensor delivers them (uint8 BGR, uint16 depth: 0.9 + 0.6 MB per frame instead of "
+                         "2 x 3.7 MB of f32 blobs); the first trunk kernel forms the blobs of lib/fcn/test.py:56-74 itself, bit for bit")
     ap.add_argument("--latency", action="store_true", help="per-frame synchronous loop; reports p50/p99 latency")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (see posecnn_amd/pipeline.py)")
     ap.add_argument("--streams", type=int, default=None,
@@ -146,7 +149,7 @@ def dry_run(a, pdist):
     pdist.shutdown()
 
 
-def make_host_inputs(first, B, H, W, C, input_format, nbuf, extents, K, train):
+def make_host_inputs(first, B, H, W, C, input_format, nbuf, extents, K, train, raw=False):
     """nbuf distinct synthetic batches: image blobs as pinned host tensors (what feed_dict holds in
     lib/fcn/test.py:151-170), the planted 1/8-resolution scene and its gt poses as numpy."""
     import numpy as np
@@ -155,13 +158,18 @@ def make_host_inputs(first, B, H, W, C, input_format, nbuf, extents, K, train):
     g = torch.Generator(device="cpu").manual_seed(1234 + first)
     host, aux = [], []
     for i in range(nbuf):
-        im = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8).float()
-        data = (im - torch.from_numpy(config.PIXEL_MEANS)).contiguous()          # BGR - PIXEL_MEANS (test.py:60)
+        im8 = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+        im = im8.float()
+        data = (im - torch.from_numpy(config.PIXEL_MEANS)).float().contiguous()  # BGR - PIXEL_MEANS (test.py:60; float32 -= float64)
         data_p = None
         if input_format == "RGBD":
-            depth = torch.randint(0, 3000, (B, H, W, 1), generator=g).float()
+            depth_i = torch.randint(0, 3000, (B, H, W, 1), generator=g)
+            depth = depth_i.float()
             d = (torch.clamp(depth / 2000.0, 0, 1) * 255).expand(B, H, W, 3)     # test.py:70-74
-            data_p = (d - torch.from_numpy(config.PIXEL_MEANS)).contiguous()
+            data_p = (d - torch.from_numpy(config.PIXEL_MEANS)).float().contiguous()
+        if raw:   # the same frames before _get_image_blob: what a camera driver hands over
+            data = im8.contiguous()
+            data_p = None if data_p is None else torch.from_numpy(depth_i.numpy().astype(np.uint16).reshape(B, H, W))
         planted_np, scenes = synth.make_planted_batch(first + i * B, B, H=H, W=W, K=K, C=C, extents=extents)
         gt = synth.make_gt_poses(scenes, K, seed=first + i) if train else None
         host.append((pipeline.pin(data), pipeline.pin(data_p)))
@@ -187,11 +195,11 @@ def cpu_baseline(a, K, H, W, C, extents, symmetry, net_gpu, train, max_seconds=2
     out = None
     for i in range(max_frames + 1):
         im = torch.randint(0, 256, (1, H, W, 3), generator=g, dtype=torch.uint8).float()
-        data = (im - torch.from_numpy(config.PIXEL_MEANS)).numpy()
+        data = (im - torch.from_numpy(config.PIXEL_MEANS)).float().numpy()
         data_p = None
         if a.input == "RGBD":
             depth = torch.randint(0, 3000, (1, H, W, 1), generator=g).float()
-            data_p = ((torch.clamp(depth / 2000.0, 0, 1) * 255).expand(1, H, W, 3) - torch.from_numpy(config.PIXEL_MEANS)).numpy()
+            data_p = ((torch.clamp(depth / 2000.0, 0, 1) * 255).expand(1, H, W, 3) - torch.from_numpy(config.PIXEL_MEANS)).float().numpy()
         planted_np, scenes = synth.make_planted_batch(5000 + i, 1, H=H, W=W, K=K, C=C, extents=extents)
         gt = synth.make_gt_poses(scenes, K, seed=i) if train else None
         t0 = time.perf_counter()
@@ -272,7 +280,7 @@ def main(argv=None):
     # (with_losses=False: the graph itself adds no loss layers — the log-softmax `prob` feeds only loss_cls,
     # which nobody fetches here; im_segment_batch evaluates hard_label and average_distance_loss on request)
     synth.init_planted_heads(net)
-    host, aux = make_host_inputs(100000 * rank, B, H, W, C, a.input, a.nbuf, extents, K, train)
+    host, aux = make_host_inputs(100000 * rank, B, H, W, C, a.input, a.nbuf, extents, K, train, raw=a.raw_inputs)
     planted = [{k: torch.from_numpy(v).to(dev) for k, v in p.items()} for p, _, _ in aux]
     gts = [None if g is None else torch.from_numpy(g).to(dev) for _, g, _ in aux]
     pts = torch.from_numpy(synth.make_model_points(C, config.NUM_MODEL_POINTS, extents=extents)).to(dev)
@@ -541,7 +549,7 @@ def main(argv=None):
         workload += " + hard_label + average_distance_loss (%d rows with pose targets)" % adl_rows
     if G3 > 0:
         workload += " + upscore deconv + backproject into a %d^3 grid (%.1f GB of voxel features per step)" % (G3, 4.0 * B * G3 ** 3 * (2 * 64 + C) / 1e9)
-    workload += " + all-gather + D2H + NMS; inputs from %s" % ("HBM (resident)" if a.resident_inputs else "pinned host memory (H2D inside the timed region)")
+    workload += " + all-gather + D2H + NMS; inputs from %s" % ("HBM (resident)" if a.resident_inputs else ("pinned host memory as raw uint8 / uint16 frames (H2D inside the timed region; the blobs are formed in the first kernel)" if a.raw_inputs else "pinned host memory (H2D inside the timed region)"))
     out = {
         "metric": "%s frames/sec (%dx%d, %d classes)" % (name_of, W, H, C - 1),
         "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -550,7 +558,7 @@ def main(argv=None):
                                 "so the heads emit 5 objects/frame with known poses — DESIGN.md §5)",
         "config": {"workload": workload, "global_batch": B * world, "per_gpu_batch": B, "height": H, "width": W,
                    "num_classes": C, "input_format": a.input, "losses": a.losses,
-                   "inputs": "resident" if a.resident_inputs else "pinned-host",
+                   "inputs": "resident" if a.resident_inputs else ("pinned-host-raw" if a.raw_inputs else "pinned-host"),
                    "h2d_MB_per_step": None if a.resident_inputs else round(uploader.bytes_per_batch / 1e6, 1),
                    "parallelism": "dp%d (frames sharded, 1 all-gather of detections)" % world,
                    "detections_per_step": ndet / a.steps, "adl_rows_with_targets": adl_rows},

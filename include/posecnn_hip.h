@@ -278,6 +278,18 @@ int pcnn_conv3x3_c3_winograd43_fwd(const float* x, const float* weights, const f
                                    int height, int width, int out_channels, int groups, int relu,
                                    float* v, void* stream);
 
+/* The same, fed with the frames as the sensor delivers them instead of the f32 blobs of lib/fcn/test.py:56-74:
+ *   color_bgr uint8 [num_color][H][W][3] (OpenCV order) and / or depth uint16 [num_depth][H][W]; either count may be 0.
+ *   The blob values — (float)((double)bgr - pixel_means[c]) and (float)((double)(clip(depth / 2000, 0, 1) * 255) - pixel_means[c])
+ *   tiled over the 3 channels, i.e. numpy's float32 -= float64 of `_get_image_blob` — are formed while the kernel stages its
+ *   input window, so v is bit-identical to pcnn_conv3x3_c3_winograd43_fwd on the host-built blobs, while 0.9 MB (colour) /
+ *   0.6 MB (depth) per 640x480 frame cross PCIe instead of 3.7 MB each and the blobs never exist in HBM.
+ *   Colour frames come first in v's tile order and use filter set 0; depth frames follow and use the next set
+ *   (weights [sets][3,3,3,Cout], bias [sets][Cout], sets = (num_color > 0) + (num_depth > 0)). pixel_means: 3 doubles, HOST. */
+int pcnn_conv3x3_c3_winograd43_raw_fwd(const uint8_t* color_bgr, int num_color, const uint16_t* depth, int num_depth,
+                                       const double* pixel_means, const float* weights, const float* bias, int height,
+                                       int width, int out_channels, int relu, float* v, void* stream);
+
 /* Data transforms of a Winograd F(2x2,3x3) evaluation of `Network.conv` for the deep 3x3 / stride 1 /
  * SAME layers of the trunk (network.py:159-187; vgg16_convs.py:42-52). All f32.
  *   pcnn_winograd_input_fwd : x f32 [B,H,W,C] (H, W even, C % 4 == 0) -> v f32 [16][T][C],

@@ -49,8 +49,9 @@ LINEMOD_SYMMETRY = np.array([0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0], dtype=np
 DEMO_INTRINSICS = np.array([[1066.778, 0.0, 312.9869], [0.0, 1067.487, 241.3109], [0.0, 0.0, 1.0]], dtype=np.float64)
 DEMO_FACTOR_DEPTH = 10000.0
 
-# lib/fcn/config.py:242 (BGR order)
-PIXEL_MEANS = np.array([[[102.9801, 115.9465, 122.7717]]], dtype=np.float32)
+# lib/fcn/config.py:242 (BGR order). float64 like the reference's: `im_orig -= cfg.PIXEL_MEANS` on a float32 image is then
+# numpy's float32 -= float64, i.e. float32(double(x) - mean) — not x - float32(mean), which differs by up to 2.5e-6
+PIXEL_MEANS = np.array([[[102.9801, 115.9465, 122.7717]]], dtype=np.float64)
 
 NUM_MODEL_POINTS = 2620  # min over data/LOV/models/*/points.xyz (lov.py:141-158)
 

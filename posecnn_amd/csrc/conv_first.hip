@@ -112,10 +112,24 @@ __device__ __forceinline__ void fw_bt6(const f4* d, f4* r)
   r[5] = (4.f * d[1] - 5.f * d[3]) + d[5];
 }
 
+// RAW: the frames arrive as the sensor delivers them — colour uint8 BGR [Bc,H,W,3] and / or depth uint16 [Bd,H,W] — and
+// the network's input blobs (lib/fcn/test.py:56-74: BGR - PIXEL_MEANS; clip(depth / 2000, 0, 1) * 255 tiled to 3 channels
+// - PIXEL_MEANS, numpy's float32 -= float64 semantics) are formed while the input window is staged into LDS, value for value
+// what posecnn_amd.fcn._get_image_blob builds on the host: V is bit-identical to the blob path, 4x (colour) / 6x (depth)
+// fewer bytes cross PCIe and the 3.7 MB per frame f32 blobs never exist. Images [0, Bc) are colour (filter set 0),
+// [Bc, Bc + Bd) depth (the next filter set).
+struct RawFrames {
+  const unsigned char* color;
+  const unsigned short* depth;
+  int n_color;
+  double mean[3];
+};
+
+template <bool RAW>
 __global__ __launch_bounds__(256) void conv3x3_c3_wino43_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ v, int H, int W, int Cout, int relu, int Ht, int Wt, int nseg,
-    long long plane, int imgs_per_group)
+    long long plane, int imgs_per_group, RawFrames raw)
 {
   __shared__ float s_in[8][FW_INF];
   __shared__ __attribute__((aligned(16))) float s_y[6][FW_COLS][64];
@@ -127,17 +141,27 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wino43_kernel(
   const int tx0 = seg * FW_TILES;
   const int py0 = 4 * ty - 1, px0 = 4 * tx0 - 1;   // image coordinates of patch pixel (0, 0)
   // filter set of this image (groups: the colour and the depth tower in one launch)
-  const int grp = b / imgs_per_group;
+  const bool is_depth = RAW && (raw.color == nullptr || b >= raw.n_color);
+  const int grp = RAW ? ((raw.color != nullptr && is_depth) ? 1 : 0) : b / imgs_per_group;
   w += (size_t)grp * 27 * Cout;
   bias += (size_t)grp * Cout;
 
   // input window: rows py0-1 .. py0+6, columns px0-1 .. px0+34
   for (int i = tid; i < 8 * FW_INF; i += 256) {
     const int r = i / FW_INF, j = i - r * FW_INF;
-    const int iy = py0 - 1 + r, ix = px0 - 1 + j / CF_CIN;
+    const int iy = py0 - 1 + r, ix = px0 - 1 + j / CF_CIN, ch = j % CF_CIN;
     float val = 0.f;
-    if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-      val = x[(((size_t)b * H + iy) * W + ix) * CF_CIN + (j % CF_CIN)];
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+      if (!RAW) {
+        val = x[(((size_t)b * H + iy) * W + ix) * CF_CIN + ch];
+      } else if (!is_depth) {
+        val = (float)((double)raw.color[(((size_t)b * H + iy) * W + ix) * CF_CIN + ch] - raw.mean[ch]);
+      } else {
+        const int bd = b - (raw.color ? raw.n_color : 0);
+        const float t = fminf(fmaxf(div_rn((float)raw.depth[((size_t)bd * H + iy) * W + ix], 2000.f), 0.f), 1.f) * 255.f;
+        val = (float)((double)t - raw.mean[ch]);
+      }
+    }
     s_in[r][j] = val;
   }
   {
@@ -256,9 +280,37 @@ extern "C" int pcnn_conv3x3_c3_winograd43_fwd(const float* x, const float* weigh
   const long long blocks = (long long)B * Ht * nseg;
   PCNN_REQUIRE(blocks < (1ll << 31), PCNN_EINVAL, "conv3x3_c3_winograd43: grid too large");
   const long long plane = (long long)B * Ht * Wt * Cout;
-  PCNN_LAUNCH(conv3x3_c3_wino43_kernel, dim3((unsigned)blocks, Cout / 64), dim3(256), 0, stream, x,
-              weights, bias, v, H, W, Cout, relu, Ht, Wt, nseg, plane, B / groups);
+  const RawFrames none = {nullptr, nullptr, 0, {0.0, 0.0, 0.0}};
+  PCNN_LAUNCH((conv3x3_c3_wino43_kernel<false>), dim3((unsigned)blocks, Cout / 64), dim3(256), 0, stream, x,
+              weights, bias, v, H, W, Cout, relu, Ht, Wt, nseg, plane, B / groups, none);
   return check_launch("conv3x3_c3_winograd43_fwd");
+}
+
+extern "C" int pcnn_conv3x3_c3_winograd43_raw_fwd(const uint8_t* color_bgr, int num_color, const uint16_t* depth, int num_depth,
+                                                  const double* pixel_means, const float* weights, const float* bias, int H,
+                                                  int W, int Cout, int relu, float* v, void* stream_)
+{
+  PCNN_REQUIRE(num_color >= 0 && num_depth >= 0 && num_color + num_depth >= 1 && H >= 1 && W >= 1, PCNN_EINVAL,
+               "conv3x3_c3_winograd43_raw: bad shape (%d colour + %d depth frames of %dx%d)", num_color, num_depth, H, W);
+  PCNN_REQUIRE(Cout >= 64 && Cout % 64 == 0, PCNN_EINVAL,
+               "conv3x3_c3_winograd43_raw: output channels must be a multiple of 64 (got %d)", Cout);
+  PCNN_REQUIRE((num_color == 0 || color_bgr) && (num_depth == 0 || depth) && pixel_means && weights && bias && v, PCNN_ENULL,
+               "conv3x3_c3_winograd43_raw: NULL pointer");
+  PCNN_REQUIRE(aligned16(v) && aligned16(weights) && aligned16(bias), PCNN_EINVAL,
+               "conv3x3_c3_winograd43_raw: weights, bias and output must be 16-byte aligned");
+  PCNN_REQUIRE((reinterpret_cast<uintptr_t>(depth) & 1u) == 0, PCNN_EINVAL, "conv3x3_c3_winograd43_raw: depth must be 2-byte aligned");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int B = num_color + num_depth;
+  const int Ht = (H + 3) / 4, Wt = (W + 3) / 4;
+  const int nseg = (Wt + FW_TILES - 1) / FW_TILES;
+  const long long blocks = (long long)B * Ht * nseg;
+  PCNN_REQUIRE(blocks < (1ll << 31), PCNN_EINVAL, "conv3x3_c3_winograd43_raw: grid too large");
+  const long long plane = (long long)B * Ht * Wt * Cout;
+  const RawFrames raw = {num_color ? color_bgr : nullptr, num_depth ? depth : nullptr, num_color,
+                         {pixel_means[0], pixel_means[1], pixel_means[2]}};       // (host pointer: read here, passed by value)
+  PCNN_LAUNCH((conv3x3_c3_wino43_kernel<true>), dim3((unsigned)blocks, Cout / 64), dim3(256), 0, stream, (const float*)nullptr,
+              weights, bias, v, H, W, Cout, relu, Ht, Wt, nseg, plane, 1, raw);
+  return check_launch("conv3x3_c3_winograd43_raw_fwd");
 }
 
 extern "C" int pcnn_conv3x3_c3_fwd(const float* x, const float* weights, const float* bias, int B,

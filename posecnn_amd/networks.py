@@ -102,6 +102,31 @@ class _Lazy(object):
         self.fn = fn
 
 
+def raw_frame_blob(t):
+    """A raw frame tensor -> the network's f32 input blob with the arithmetic of lib/fcn/test.py:56-74 (fcn._get_image_blob):
+    uint8 BGR [B,H,W,3] -> float32(double(x) - PIXEL_MEANS); uint16 depth [B,H,W] -> clip(d / 2000, 0, 1) * 255 tiled to 3
+    channels, minus the means. Only the configurations that do not fuse conv1_1 into conv1_2's input transform need it —
+    the fused kernel forms these values itself (ops.conv3x3_c3_winograd43_raw)."""
+    from .config import PIXEL_MEANS
+    means = torch.from_numpy(np.asarray(PIXEL_MEANS, dtype=np.float64).reshape(1, 1, 1, 3)).to(t.device)
+    if t.dtype == torch.uint8:
+        return (t.to(torch.float64) - means).to(torch.float32).contiguous()
+    if t.dtype == torch.uint16:
+        d = (t.view(torch.int16).to(torch.int32) & 0xFFFF).to(torch.float64)
+        if d.dim() == 4:
+            d = d.reshape(d.shape[:3])
+        # numpy's float32 / 2000.0 is a correctly rounded f32 division; the framework's f32 division on the GPU is not
+        # (reciprocal multiply). A double division rounded to f32 is: d / 2000 with an integer d < 65536 is never within
+        # 2^-36 (relative) of an f32 rounding boundary, so the second rounding cannot flip it.
+        d = torch.clamp((d / 2000.0).to(torch.float32), 0, 1) * 255
+        return (d.unsqueeze(-1).to(torch.float64) - means).to(torch.float32).contiguous()
+    return t
+
+
+def _is_raw(t):
+    return isinstance(t, torch.Tensor) and t.dtype in (torch.uint8, torch.uint16)
+
+
 class _RawConv(object):
     """A convolution output before bias + ReLU, handed to a consumer that fuses them (max_pool).
     Fetching the layer by name materialises the activated tensor (in place) like any other."""
@@ -199,7 +224,7 @@ class Network(object):
                 m, B, H, W = raw.wino
                 raw.out = ops.winograd_output(m, raw.bias, B, H, W, raw.relu, pool=False, tile=self.winograd_tile)
             elif raw.first is not None:
-                raw.out = ops.conv3x3_c3(raw.first[0], raw.first[1], raw.bias, raw.relu)
+                raw.out = ops.conv3x3_c3(raw_frame_blob(raw.first[0]), raw.first[1], raw.bias, raw.relu)
             elif raw.gemm is not None:
                 v, ut, B, H, W = raw.gemm
                 raw.out = ops.winograd43_conv(v, ut, raw.bias, B, H, W, raw.relu, pool=0)
@@ -351,8 +376,9 @@ class Network(object):
         assert padding in ("SAME", "VALID")
         if isinstance(input, tuple):
             input = input[0]
+        raw_in = _is_raw(input)       # a frame as the sensor delivers it (uint8 BGR / uint16 depth): the blob has 3 channels
         if c_i == -1:
-            c_i = input.shape[-1]
+            c_i = 3 if raw_in else input.shape[-1]
         assert c_i % group == 0 and c_o % group == 0
         pending_first = input if isinstance(input, _RawConv) else None
         w = self.make_var(name + "/weights", (c_o, c_i // group, k_h, k_w),
@@ -367,7 +393,9 @@ class Network(object):
             # Winograd conv follows, that layer's input transform kernel does it on the fly
             if self.fuse_first_conv_into_winograd and self.winograd_tile == 4 and self.winograd_min_channels and input.is_cuda:
                 return _RawConv(None, b, relu, first=(input.contiguous(), w.permute(2, 3, 1, 0).contiguous()))
-            return self._conv_first(input, w, b, relu)
+            return self._conv_first(raw_frame_blob(input), w, b, relu)
+        if raw_in:
+            input = raw_frame_blob(input)
         wino_ok = (b is not None and (k_h, k_w, s_h, s_w, group) == (3, 3, 1, 1, 1) and padding == "SAME")
         if pending_first is not None:
             if (wino_ok and self.winograd_tile == 4 and self.winograd_min_channels
@@ -379,7 +407,12 @@ class Network(object):
                 if self.conv_timing is not None:
                     timing = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), 2.0 * B_ * H_ * W_ * c_i * 27)
                     timing[0].record()
-                v = ops.conv3x3_c3_winograd43(pending_first.first[0], pending_first.first[1], pending_first.bias, pending_first.relu)
+                x0 = pending_first.first[0]
+                if _is_raw(x0):
+                    v = ops.conv3x3_c3_winograd43_raw(x0 if x0.dtype == torch.uint8 else None, x0 if x0.dtype == torch.uint16 else None,
+                                                      pending_first.first[1], pending_first.bias, pending_first.relu)
+                else:
+                    v = ops.conv3x3_c3_winograd43(x0, pending_first.first[1], pending_first.bias, pending_first.relu)
                 return self._winograd43_tail(name, v, w, b, relu, B_, H_, W_, c_i, c_o, timing)
             input = self._activate(pending_first)
         if (wino_ok and input.is_cuda
@@ -784,11 +817,14 @@ class vgg16_convs(Network):
 
     def _can_group_towers(self):
         d = self.layers.get('data')
+        dp = self.layers.get('data_p')
+        same = isinstance(dp, torch.Tensor) and (dp.shape == d.shape if not _is_raw(d) else
+                                                 (dp.dtype == torch.uint16 and tuple(dp.shape[:3]) == tuple(d.shape[:3]))) if isinstance(d, torch.Tensor) else False
         return (self.grouped_towers and self.input_format == 'RGBD' and isinstance(d, torch.Tensor) and d.is_cuda
                 and self.winograd_mfma and self.winograd_tile == 4 and self.winograd_min_channels == 64
                 and self.fused_first_conv and self.fuse_first_conv_into_winograd
                 and not (torch.is_grad_enabled() and self.trainable)
-                and d.shape[1] % 16 == 0 and d.shape[2] % 16 == 0 and self.layers['data_p'].shape == d.shape)
+                and d.shape[1] % 16 == 0 and d.shape[2] % 16 == 0 and same)
 
     def _trunk_grouped(self):
         """Both VGG16 towers of an RGB-D network (vgg16_convs.py:36-52 and :53-67) as ONE launch
@@ -798,11 +834,17 @@ class vgg16_convs(Network):
         with half the launches and twice the workgroups per launch (conv5_x alone has only 160
         workgroups per tower for the 256 CUs). Registers conv4_3 / conv5_3 (+ '_p') and pool4."""
         d, dp = self.get_output('data'), self.get_output('data_p')
-        x = pipeline.stacked_view(d, dp)        # free when the uploader placed the blobs back to back
-        if x is None:
-            x = torch.cat([d, dp], dim=0)
-        B2, H, W, _ = x.shape
-        B = B2 // 2
+        raw = _is_raw(d)                        # uint8 colour + uint16 depth frames: the first kernel forms the blobs itself
+        if raw:
+            x = None
+            B, H, W = d.shape[:3]
+            B2 = 2 * B
+        else:
+            x = pipeline.stacked_view(d, dp)        # free when the uploader placed the blobs back to back
+            if x is None:
+                x = torch.cat([d, dp], dim=0)
+            B2, H, W, _ = x.shape
+            B = B2 // 2
         va, vb = self._trunk_vars(""), self._trunk_vars("_p")
         key = tuple((w.data_ptr(), w._version, b.data_ptr(), b._version) for w, b in va + vb)
         hit = self._wino_u.get("grouped")
@@ -824,7 +866,8 @@ class vgg16_convs(Network):
             if ci == 3:
                 continue   # conv1_1 is evaluated inside conv1_2's input transform
             if li == 1:
-                v = ops.conv3x3_c3_winograd43(x, packed[0][0], packed[0][1], True, groups=2)
+                v = (ops.conv3x3_c3_winograd43_raw(d, dp, packed[0][0], packed[0][1], True) if raw
+                     else ops.conv3x3_c3_winograd43(x, packed[0][0], packed[0][1], True, groups=2))
             else:
                 v = ops.winograd_input(y, 4)
             # conv4_3 is read un-pooled by score_conv4 and roi_pool AND pooled by pool4: the kernel writes
@@ -867,7 +910,7 @@ class vgg16_convs(Network):
         until conv4_3 / pool4 / conv5_3 are handed to the heads as f32. Slow by design (validation only)."""
         towers = [("", "data")] + ([("_p", "data_p")] if self.input_format == "RGBD" else [])
         for sfx, src in towers:
-            x = self.get_output(src)
+            x = raw_frame_blob(self.get_output(src))
             vars_ = [(w.detach().to(dtype), b.detach().to(dtype)) for w, b in self._trunk_vars(sfx)]
             keep = {"conv4_3": [], "pool4": [], "conv5_3": []}
             for n in range(x.shape[0]):

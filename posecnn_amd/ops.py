@@ -10,6 +10,8 @@ stream. There is no eager/PyTorch fallback: a missing library or a CPU tensor ra
 import ctypes
 from ctypes import c_size_t
 
+import numpy as np
+
 import torch
 
 from . import _lib
@@ -410,6 +412,40 @@ def conv3x3_c3_winograd43(x, weights, bias, relu=True, groups=1):
     check("pcnn_conv3x3_c3_winograd43_fwd",
           lib().pcnn_conv3x3_c3_winograd43_fwd(_ptr(x), _ptr(weights), _ptr(bias), B, H, W, Cout, int(groups),
                                                1 if relu else 0, _ptr(v), _stream(x)))
+    return v
+
+
+def conv3x3_c3_winograd43_raw(color_bgr, depth, weights, bias, relu=True, pixel_means=None):
+    """conv3x3_c3_winograd43 on the frames as the sensor delivers them: color_bgr uint8 [B,H,W,3] (or None), depth uint16
+    [B,H,W] (or None); the blobs of lib/fcn/test.py:56-74 are formed inside the kernel, bit for bit. Colour frames first
+    (filter set 0), depth frames after (next set): weights [sets,3,3,3,Cout], bias [sets,Cout]. Returns V [36, T, Cout]."""
+    from .config import PIXEL_MEANS
+    c = _dev(color_bgr, "color_bgr", torch.uint8) if color_bgr is not None else None
+    d = _dev(depth, "depth", torch.uint16) if depth is not None else None
+    if c is None and d is None:
+        raise ValueError("need colour and / or depth frames")
+    if c is not None and (c.dim() != 4 or c.shape[3] != 3):
+        raise ValueError("color_bgr must be uint8 [B,H,W,3]")
+    if d is not None and d.dim() == 4 and d.shape[3] == 1:
+        d = d.reshape(d.shape[:3])
+    if d is not None and d.dim() != 3:
+        raise ValueError("depth must be uint16 [B,H,W]")
+    H, W = (c.shape[1], c.shape[2]) if c is not None else (d.shape[1], d.shape[2])
+    if c is not None and d is not None and tuple(d.shape[1:]) != (H, W):
+        raise ValueError("colour and depth frames must have the same size")
+    nc, nd = (0 if c is None else c.shape[0]), (0 if d is None else d.shape[0])
+    sets = (nc > 0) + (nd > 0)
+    dev = (c if c is not None else d).device
+    weights = _dev(weights, "weights", torch.float32)
+    bias = _dev(bias, "bias", torch.float32)
+    Cout = weights.shape[-1]
+    if weights.numel() != sets * 27 * Cout or tuple(weights.shape[-4:]) != (3, 3, 3, Cout) or bias.numel() != sets * Cout:
+        raise ValueError("weights must be [sets,3,3,3,Cout] (ky,kx,ci,co) and bias [sets,Cout]")
+    means = (ctypes.c_double * 3)(*[float(x) for x in np.asarray(PIXEL_MEANS if pixel_means is None else pixel_means, dtype=np.float64).reshape(-1)[:3]])
+    v = torch.empty((36, (nc + nd) * ((H + 3) // 4) * ((W + 3) // 4), Cout), dtype=torch.float32, device=dev)
+    check("pcnn_conv3x3_c3_winograd43_raw_fwd",
+          lib().pcnn_conv3x3_c3_winograd43_raw_fwd(_ptr(c), nc, _ptr(d), nd, means, _ptr(weights), _ptr(bias), H, W, Cout,
+                                                   1 if relu else 0, _ptr(v), _stream(v)))
     return v
 
 

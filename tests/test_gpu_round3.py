@@ -348,6 +348,80 @@ def test_run_evaluation_with_pose_refinement(gpu, tmp_path):
     assert first["poses"] and all(("error_new" in e and "error_icp" in e and "translation_error_icp" in e) for e in first["poses"])
 
 
+@pytest.mark.parametrize("H,W", [(480, 640), (50, 70)])
+def test_raw_frame_first_conv_is_bit_identical_to_the_blob_path(gpu, H, W):
+    """pcnn_conv3x3_c3_winograd43_raw_fwd: uint8 BGR / uint16 depth frames in, the blobs of lib/fcn/test.py:56-74 formed
+    inside the kernel — V must equal the blob path on host-built blobs (fcn._get_image_blob: float32 -= float64 means, the
+    depth clip / scale / tile) bit for bit: both towers in one launch, colour only, depth only, ragged tiles."""
+    import torch
+    from posecnn_amd import fcn, ops
+    rng = np.random.default_rng(H)
+    B = 2
+    im8 = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    d16 = rng.integers(0, 3000, (B, H, W)).astype(np.uint16)
+    d16[0, :3, :5] = 65535
+    d16[1, -2:, :] = 0
+    blobs = [fcn._get_image_blob(im8[i], d16[i]) for i in range(B)]
+    data = np.concatenate([b[0] for b in blobs]).astype(F)
+    data_p = np.concatenate([b[1] for b in blobs]).astype(F)
+    w = (rng.standard_normal((2, 3, 3, 3, 64)) * 0.1).astype(F)
+    b = rng.standard_normal((2, 64)).astype(F)
+    tw, tb = T(gpu, w), T(gpu, b)
+    t8, t16 = T(gpu, im8), torch.from_numpy(d16).to(gpu)
+    want = ops.conv3x3_c3_winograd43(T(gpu, np.concatenate([data, data_p])), tw, tb, True, groups=2)
+    got = ops.conv3x3_c3_winograd43_raw(t8, t16, tw, tb, True)
+    same(N(got), N(want), "both towers")
+    same(N(ops.conv3x3_c3_winograd43_raw(t8, None, tw[:1].contiguous(), tb[:1].contiguous(), True)),
+         N(ops.conv3x3_c3_winograd43(T(gpu, data), tw[:1].contiguous(), tb[:1].contiguous(), True)), "colour only")
+    same(N(ops.conv3x3_c3_winograd43_raw(None, t16, tw[1:].contiguous(), tb[1:].contiguous(), False)),
+         N(ops.conv3x3_c3_winograd43(T(gpu, data_p), tw[1:].contiguous(), tb[1:].contiguous(), False)), "depth only, no ReLU")
+    # the framework-side conversion the non-fused configurations use gives the same blobs
+    from posecnn_amd.networks import raw_frame_blob
+    same(N(raw_frame_blob(t8)), data, "colour blob")
+    same(N(raw_frame_blob(t16)), data_p, "depth blob")
+    with pytest.raises(ValueError):
+        ops.conv3x3_c3_winograd43_raw(None, None, tw, tb)
+
+
+@pytest.mark.parametrize("fmt,strict", [("RGBD", False), ("COLOR", False), ("RGBD", True)])
+def test_network_on_raw_frames_equals_network_on_blobs(gpu, fmt, strict):
+    """`im_segment_batch` fed uint8 / uint16 frames (bench.py --raw-inputs) against the same frames as f32 blobs: grouped
+    RGB-D towers, a single colour tower, and the strict_numerics configuration (no fused first conv: the frames are turned
+    into blobs on the device first) — detections, label maps and fc7 bit for bit."""
+    import torch
+    from posecnn_amd import fcn
+    from posecnn_amd.networks import vgg16_convs
+    B, H, W = 2, 240, 320
+    net = vgg16_convs(fmt, 22, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True, trainable=False, is_train=False, seed=3,
+                      init="he", with_losses=False, device=gpu, strict_numerics=strict)
+    synth.init_planted_heads(net)
+    K = config.DEMO_INTRINSICS.copy(); K[:2] *= W / 640.0
+    rng = np.random.default_rng(3)
+    im8 = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    d16 = rng.integers(0, 3000, (B, H, W)).astype(np.uint16)
+    blobs = [fcn._get_image_blob(im8[i], d16[i]) for i in range(B)]
+    data = T(gpu, np.concatenate([b[0] for b in blobs]).astype(F))
+    data_p = T(gpu, np.concatenate([b[1] for b in blobs]).astype(F)) if fmt == "RGBD" else None
+    planted_np, _ = synth.make_planted_batch(7, B, H=H, W=W, K=K, n_obj=3)
+    planted = {k: T(gpu, v) for k, v in planted_np.items()}
+    pts = T(gpu, synth.make_model_points(22, 256))
+    outs = []
+    with torch.no_grad():
+        for (d_, dp_) in ((data, data_p), (T(gpu, im8), torch.from_numpy(d16).to(gpu) if fmt == "RGBD" else None)):
+            det = fcn.im_segment_batch(net, d_, K, config.LOV_EXTENTS, pts, config.LOV_SYMMETRY, data_p=dp_, planted=planted)
+            outs.append([N(det.rows), N(det.count), N(det.label_2d), N(net.get_output("fc7"))])
+    assert int(outs[0][1].reshape(-1)[0]) >= 3
+    for a_, b_, name in zip(outs[0], outs[1], ("rows", "count", "label_2d", "fc7")):
+        if not strict:
+            same(b_.reshape(-1), a_.reshape(-1), "%s (%s)" % (name, fmt))
+        elif name == "label_2d":
+            assert (a_ == b_).mean() > 0.9999
+        else:
+            # the library convolutions of this configuration are not run-to-run reproducible to the bit (the SAME blobs give
+            # conv5_3 2e-6 of its range apart in a second pass); the blobs themselves are compared bit for bit in the test above
+            assert np.abs(b_.astype(np.float64) - a_).max() <= 1e-5 * max(np.abs(a_).max(), 1.0), name
+
+
 def test_listener_callback_builds_the_posecnn_message(gpu, tmp_path):
     """ros/listener.py:41-90 without ROS (posecnn_amd.listener.ImageListener): a (colour, depth) pair of the demo tree ->
     the PoseCNNMsg fields, equal to what im_segment_single_frame returns for that frame; both publishers are called; a 32FC1

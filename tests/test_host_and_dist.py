@@ -40,6 +40,15 @@ def test_pad_unpad_and_image_blob():
     # depth tower: clip(d / 2000, 0, 1) * 255 - means (lib/fcn/test.py:70-74)
     assert np.allclose(blob_d[0, 0, 1], 127.5 - config.PIXEL_MEANS[0, 0])
     assert np.allclose(blob_d[0, 1, 1], 255 - config.PIXEL_MEANS[0, 0])
+    # the reference's means are float64 (lib/fcn/config.py:242), so `im_orig -= cfg.PIXEL_MEANS` on a float32 image is
+    # float32(double(x) - mean): for every byte value, and NOT the float32 - float32(mean) it is easy to write instead
+    assert config.PIXEL_MEANS.dtype == np.float64 and blob.dtype == np.float32 and blob_d.dtype == np.float32
+    allv = np.arange(256, dtype=np.uint8).reshape(16, 16, 1).repeat(3, axis=2)
+    b2, _, _ = fcn._get_image_blob(allv, None)
+    want = (allv.astype(np.float64) - config.PIXEL_MEANS).astype(np.float32)
+    assert np.array_equal(b2[0].view(np.uint32), want.view(np.uint32))
+    wrong = allv.astype(np.float32) - config.PIXEL_MEANS.astype(np.float32)
+    assert (b2[0] != wrong).mean() > 0.3
 
 
 def test_meta_data_layout():
