@@ -279,7 +279,7 @@ def main(argv=None):
                       trainable=False, is_train=train, device=dev, seed=3, init="he", with_losses=False)
     # (with_losses=False: the graph itself adds no loss layers — the log-softmax `prob` feeds only loss_cls,
     # which nobody fetches here; im_segment_batch evaluates hard_label and average_distance_loss on request)
-    synth.init_planted_heads(net)
+    synth.init_calibrated(net)
     host, aux = make_host_inputs(100000 * rank, B, H, W, C, a.input, a.nbuf, extents, K, train, raw=a.raw_inputs)
     planted = [{k: torch.from_numpy(v).to(dev) for k, v in p.items()} for p, _, _ in aux]
     gts = [None if g is None else torch.from_numpy(g).to(dev) for _, g, _ in aux]

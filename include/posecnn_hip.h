@@ -285,7 +285,9 @@ int pcnn_conv3x3_c3_winograd43_fwd(const float* x, const float* weights, const f
  *   input window, so v is bit-identical to pcnn_conv3x3_c3_winograd43_fwd on the host-built blobs, while 0.9 MB (colour) /
  *   0.6 MB (depth) per 640x480 frame cross PCIe instead of 3.7 MB each and the blobs never exist in HBM.
  *   Colour frames come first in v's tile order and use filter set 0; depth frames follow and use the next set
- *   (weights [sets][3,3,3,Cout], bias [sets][Cout], sets = (num_color > 0) + (num_depth > 0)). pixel_means: 3 doubles, HOST. */
+ *   (weights [sets][3,3,3,Cout], bias [sets][Cout], sets = (num_color > 0) + (num_depth > 0)). pixel_means: 3 finite doubles
+ *   behind a HOST pointer, read when the call is made and passed to the kernel by value (the caller may free or change them
+ *   as soon as the call returns; non-finite values are refused with PCNN_EINVAL). */
 int pcnn_conv3x3_c3_winograd43_raw_fwd(const uint8_t* color_bgr, int num_color, const uint16_t* depth, int num_depth,
                                        const double* pixel_means, const float* weights, const float* bias, int height,
                                        int width, int out_channels, int relu, float* v, void* stream);

@@ -729,14 +729,12 @@ int oracle_average_distance_bwd(const float* grad, const float* bottom_diff, int
 /* ------------------------------------------------------------------------------------------ */
 /* Backprojecting: BackprojectForward, backprojecting_op_gpu.cu.cc:17-126                       */
 /* ------------------------------------------------------------------------------------------ */
-int oracle_backproject(const float* data, const float* label, const float* depth,
-                       const float* meta, const float* label_3d, int B, int H, int W, int Cd,
-                       int Cl, int num_meta, int G, int ksize, float threshold, float* top_data,
-                       float* top_label, float* top_flag)
+/* one voxel of BackprojectForward; (td, tl, tf) point at this voxel's output rows */
+static void backproject_voxel(const float* data, const float* label, const float* depth, const float* meta,
+                              const float* label_3d, int H, int W, int Cd, int Cl, int num_meta, int G,
+                              int ksize, float threshold, long vox, float* td, float* tl, float* tf)
 {
-  const long nvox = (long)B * G * G * G;
-#pragma omp parallel for schedule(static)
-  for (long vox = 0; vox < nvox; vox++) {
+  {
     long t = vox;
     int w = (int)(t % G); t /= G;
     int h = (int)(t % G); t /= G;
@@ -757,9 +755,6 @@ int oracle_backproject(const float* data, const float* label, const float* depth
     float fpx = roundf(x1 / x3), fpy = roundf(x2 / x3);
     int px = fpx != fpx ? 0 : (fpx >= 2147483648.f ? INT32_MAX : (fpx <= -2147483648.f ? INT32_MIN : (int)fpx));
     int py = fpy != fpy ? 0 : (fpy >= 2147483648.f ? INT32_MAX : (fpy <= -2147483648.f ? INT32_MIN : (int)fpy));
-    float* td = top_data + vox * Cd;
-    float* tf = top_flag + vox * Cd;
-    float* tl = top_label + vox * Cl;
     for (int c = 0; c < Cd; c++) td[c] = 0;
     for (int c = 0; c < Cl; c++) tl[c] = 0;
     int count = 0;
@@ -787,6 +782,36 @@ int oracle_backproject(const float* data, const float* label, const float* depth
       for (int c = 0; c < Cl; c++) tl[c] /= count;
     }
   }
+}
+
+int oracle_backproject(const float* data, const float* label, const float* depth,
+                       const float* meta, const float* label_3d, int B, int H, int W, int Cd,
+                       int Cl, int num_meta, int G, int ksize, float threshold, float* top_data,
+                       float* top_label, float* top_flag)
+{
+  const long nvox = (long)B * G * G * G;
+#pragma omp parallel for schedule(static)
+  for (long vox = 0; vox < nvox; vox++)
+    backproject_voxel(data, label, depth, meta, label_3d, H, W, Cd, Cl, num_meta, G, ksize, threshold, vox,
+                      top_data + vox * Cd, top_label + vox * Cl, top_flag + vox * Cd);
+  return 0;
+}
+
+/* The same voxels, every `stride`-th one starting at `first`, written compactly (row i = voxel first + i stride):
+ * lets a test hold the kernels to the reference default grid_size = 256 (lib/fcn/config.py:106,222 — 16.7 M
+ * voxels, 4.3 GB per output tensor) without the checker producing the full tensors. */
+int oracle_backproject_sample(const float* data, const float* label, const float* depth,
+                              const float* meta, const float* label_3d, int B, int H, int W, int Cd,
+                              int Cl, int num_meta, int G, int ksize, float threshold, long first, long stride,
+                              float* top_data, float* top_label, float* top_flag)
+{
+  const long nvox = (long)B * G * G * G;
+  if (first < 0 || stride < 1) return -1;
+  const long rows = first < nvox ? (nvox - first + stride - 1) / stride : 0;
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < rows; i++)
+    backproject_voxel(data, label, depth, meta, label_3d, H, W, Cd, Cl, num_meta, G, ksize, threshold,
+                      first + i * stride, top_data + i * Cd, top_label + i * Cl, top_flag + i * Cd);
   return 0;
 }
 

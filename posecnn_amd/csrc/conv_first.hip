@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wino43_kernel(
   w += (size_t)grp * 27 * Cout;
   bias += (size_t)grp * Cout;
 
-  // input window: rows py0-1 .. py0+6, columns px0-1 .. px0+34
+  // input window: rows py0-1 .. py0+6, columns px0-1 .. px0+22 (FW_COLS + 6 = 24 columns incl. the slack of the last pixel quad)
   for (int i = tid; i < 8 * FW_INF; i += 256) {
     const int r = i / FW_INF, j = i - r * FW_INF;
     const int iy = py0 - 1 + r, ix = px0 - 1 + j / CF_CIN, ch = j % CF_CIN;
@@ -298,6 +298,8 @@ extern "C" int pcnn_conv3x3_c3_winograd43_raw_fwd(const uint8_t* color_bgr, int 
                "conv3x3_c3_winograd43_raw: NULL pointer");
   PCNN_REQUIRE(aligned16(v) && aligned16(weights) && aligned16(bias), PCNN_EINVAL,
                "conv3x3_c3_winograd43_raw: weights, bias and output must be 16-byte aligned");
+  PCNN_REQUIRE(pixel_means[0] - pixel_means[0] == 0.0 && pixel_means[1] - pixel_means[1] == 0.0 && pixel_means[2] - pixel_means[2] == 0.0,
+               PCNN_EINVAL, "conv3x3_c3_winograd43_raw: pixel_means must be finite");
   PCNN_REQUIRE((reinterpret_cast<uintptr_t>(depth) & 1u) == 0, PCNN_EINVAL, "conv3x3_c3_winograd43_raw: depth must be 2-byte aligned");
   hipStream_t stream = (hipStream_t)stream_;
   const int B = num_color + num_depth;

@@ -22,6 +22,7 @@
 //
 //   y[m, n] = act(sum_k x[m, k] wt[n, k] + bias[n])    m < min(Mcap, *num_rows_dev), else 0
 #include <algorithm>
+#include <cstdlib>
 
 #include "pcnn_device.h"
 
@@ -87,7 +88,11 @@ __device__ __forceinline__ void sk_loop(const float* const* xp, const float* con
 }
 
 // MB = 16-row blocks of x the buffer can hold (1 or 2). act: 0 none, 1 ReLU, 2 tanh (y2 = tanh(y), y = linear)
-template <int MB, int SK_U>
+// FENCED (debug, PCNN_FC_SKINNY_FENCED=1 in the environment): the textbook exchange — plain stores, an agent-scope
+// release fence before an acq_rel ticket, an acquire fence in the reducer — in place of the fence-free sc1 exchange
+// below. Twice as slow (every fence writes back / invalidates the XCD's L2); it exists so that the two can be diffed
+// (tests/test_gpu_round3.py::test_fc_skinny_fence_free_exchange_equals_the_fenced_one).
+template <int MB, int SK_U, bool FENCED>
 __global__ __launch_bounds__(64 * SK_WAVES) void fc_skinny_kernel(
     const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias, float* __restrict__ y,
     float* __restrict__ y2, int K, int N, int Mcap, int act, const int* __restrict__ num_rows_dev,
@@ -137,8 +142,9 @@ __global__ __launch_bounds__(64 * SK_WAVES) void fc_skinny_kernel(
       for (int j = 0; j < SK_NBW; j++)
 #pragma unroll
         for (int e = 0; e < 4; e++)
-          __hip_atomic_store(&part[((size_t)s * (16 * MB) + 16 * mb + 4 * q + e) * Npad + n0 + 16 * j + r], acc[mb][j][e],
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if constexpr (FENCED) part[((size_t)s * (16 * MB) + 16 * mb + 4 * q + e) * Npad + n0 + 16 * j + r] = acc[mb][j][e];
+          else __hip_atomic_store(&part[((size_t)s * (16 * MB) + 16 * mb + 4 * q + e) * Npad + n0 + 16 * j + r], acc[mb][j][e],
+                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 
@@ -149,16 +155,25 @@ __global__ __launch_bounds__(64 * SK_WAVES) void fc_skinny_kernel(
   // ~0.3 us each (119 us). The partials are therefore written with agent-scope atomic stores (sc1: written through to
   // the coherence point) and read back with agent-scope atomic loads (sc1: never served from a stale line); the
   // wait + barrier orders every wave's stores before the ticket. No fence, no invalidate.
+  // ASSUMPTIONS: (1) gfx942 / gfx950 cache policy — an agent-scope atomic store is written through to the
+  // coherence point and an agent-scope atomic load is never served from a stale L2 line (the Makefile refuses any other
+  // --offload-arch); (2) the inline-asm wait is a compiler barrier ("memory" clobber), so no store moves below it;
+  // (3) the counters are zero on entry: the last workgroup puts its counter back to zero, every launch on a stream
+  // therefore leaves them as it found them; the launcher zero-fills them if a launch is refused, and after a device fault
+  // (the only way a launch ends early) the HIP context is gone with them.
   __shared__ int s_last;
+  if constexpr (FENCED) __threadfence();
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    const int old = __hip_atomic_fetch_add(&counters[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int old = FENCED ? __hip_atomic_fetch_add(&counters[blockIdx.x], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+                           : __hip_atomic_fetch_add(&counters[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = old == S - 1;
     if (old == S - 1) __hip_atomic_store(&counters[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // leave the counter as we found it
   }
   __syncthreads();
   if (!s_last) return;
+  if constexpr (FENCED) __threadfence();
   // 256 threads over (column, row parity): thread handles column c = tid & 127, rows m = h, h + 2, ...
   const int c = tid & (SK_COLS - 1), h = tid / SK_COLS;
   const int n = blockIdx.x * SK_COLS + c;
@@ -251,10 +266,14 @@ extern "C" int pcnn_fc_skinny_fwd(const float* x, const float* wt, const float* 
   const int KS = in_features / 16;
   const int per = (KS + S - 1) / S;
   float* part = static_cast<float*>(workspace);
-#define SK_GO(MBV) PCNN_LAUNCH((fc_skinny_kernel<MBV, 2>), dim3(groups, S), dim3(64 * SK_WAVES), 0, stream, x, wt, bias, y, y_act, in_features, \
+  static const bool fenced = [] { const char* e = getenv("PCNN_FC_SKINNY_FENCED"); return e && e[0] == '1'; }();
+#define SK_GO(MBV, FV) PCNN_LAUNCH((fc_skinny_kernel<MBV, 2, FV>), dim3(groups, S), dim3(64 * SK_WAVES), 0, stream, x, wt, bias, y, y_act, in_features, \
                 out_features, rows_capacity, activation, num_rows_dev, part, counters, per)
   // (groups of 2 K steps: 66 / 80 VGPRs; groups of 4 need 114 / 140 and measured 5-10 % slower)
-  if (rows_capacity > 16) SK_GO(2); else SK_GO(1);
+  if (fenced) { if (rows_capacity > 16) SK_GO(2, true); else SK_GO(1, true); }
+  else { if (rows_capacity > 16) SK_GO(2, false); else SK_GO(1, false); }
 #undef SK_GO
-  return check_launch("fc_skinny_fwd");
+  const int rc = check_launch("fc_skinny_fwd");
+  if (rc != PCNN_OK) (void)hipMemsetAsync(counters, 0, sizeof(int32_t) * (size_t)groups, stream);   // a refused launch must not leave a ticket half-drawn
+  return rc;
 }

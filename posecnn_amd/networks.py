@@ -994,6 +994,9 @@ class vgg16_convs(Network):
                 # heads); the product itself runs on the vector ALUs, and from a few frames on the library's MFMA 1x1
                 # convolution is faster (16 frames: 237 vs 165 us, tools/bench_heads_small.py)
                 and a.shape[0] * a.shape[1] * a.shape[2] <= self.small_heads_max_pixels
+                # the kernel keeps 32 pixels x U inputs and the U x Cout weights in 60 KB of LDS (csrc/heads_small.hip);
+                # a larger head (num_classes >= 30 on the vertex head) takes the deconv + add + 1x1 path instead of EINVAL
+                and c_i % 4 == 0 and 4 * (32 * c_i + c_i * c_o) <= 60 * 1024
                 and (self.keep_prob_queue is None or float(self.keep_prob_queue) >= 1.0)
                 and (up_name + "/weights") not in self.vars
                 and not (torch.is_grad_enabled() and self.trainable)):

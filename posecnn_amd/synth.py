@@ -141,6 +141,72 @@ def init_planted_heads(net, seed=11):
         net.vars[n + "/biases"] = torch.zeros((k,), device=net.device)
 
 
+# Per-layer gains on top of He initialisation that give every layer an O(1) output on the synthetic
+# frames (uniform uint8 colour, uniform uint16 depth < 3000): LSUV-style calibration, measured ONCE on the
+# host by tools/calibrate_synth.py (two 480x640 RGB-D frames, seed 11) and frozen here so that every
+# process — CPU checker, GPU tests, bench.py — builds bit-identical weights without running a calibration
+# pass. Targets: post-ReLU std 1 for every trunk layer, score_conv4/5, fc6, fc7; 0.05 for the two vertex
+# score convs (the planted log-depth channel then reads 0.5-2 m for every class); 0.8 for fc8 (|fc8| <~ 3:
+# tanh is not saturated, as in a trained network — the reference trains from sigma = 0.001,
+# lib/networks/network.py:170, and a converged PoseCNN has O(1-10) activations behind conv1).
+CALIBRATED_GAINS = {
+    "conv1_1": 0.01671, "conv1_2": 0.9871, "conv2_1": 0.6956, "conv2_2": 0.9289, "conv3_1": 0.7484,
+    "conv3_2": 0.9021, "conv3_3": 1.031, "conv4_1": 0.7821, "conv4_2": 1.058, "conv4_3": 1.018, "conv5_1": 0.8867,
+    "conv5_2": 1.027, "conv5_3": 1, "conv1_1_p": 0.01152, "conv1_2_p": 1.024, "conv2_1_p": 0.6101,
+    "conv2_2_p": 1.04, "conv3_1_p": 0.8679, "conv3_2_p": 1.037, "conv3_3_p": 0.9219, "conv4_1_p": 0.8914,
+    "conv4_2_p": 0.952, "conv4_3_p": 1.048, "conv5_1_p": 0.9093, "conv5_2_p": 0.9724, "conv5_3_p": 1.02,
+    "score_conv5": 1.173, "score_conv4": 1.041, "score_conv5_vertex": 0.03071, "score_conv4_vertex": 0.02808,
+    "fc6": 0.5393, "fc7": 0.99, "fc8": 0.4564,
+}
+CALIBRATED_TARGET_STD = {"score_conv5_vertex": 0.05, "score_conv4_vertex": 0.05, "fc8": 0.8}
+
+
+def calibrated_layers(input_format, num_classes, num_units):
+    """(name, weight shape, fan_in, kind) of every variable-carrying layer in creation order of
+    vgg16_convs.setup() (vgg16_convs.py:36-197)."""
+    from .networks import vgg16_convs
+    out = []
+    towers = ("", "_p") if input_format == "RGBD" else ("",)
+    for sfx in towers:
+        for name, ci, co, _ in vgg16_convs.TRUNK:
+            out.append((name + sfx, (co, ci, 3, 3), 9 * ci, "conv"))
+    cin = 512 * len(towers)
+    out += [("score_conv5", (num_units, cin, 1, 1), cin, "conv"), ("score_conv4", (num_units, cin, 1, 1), cin, "conv"),
+            ("score_conv5_vertex", (128, 512, 1, 1), 512, "conv"), ("score_conv4_vertex", (128, 512, 1, 1), 512, "conv"),
+            ("fc6", (7 * 7 * 512, 4096), 7 * 7 * 512, "fc"), ("fc7", (4096, 4096), 4096, "fc"),
+            ("fc8", (4096, 4 * num_classes), 4096, "fc")]
+    return out
+
+
+def init_calibrated(net, seed=11, gains=None):
+    """Seeded weights with realistic activation scales for the whole network (VERDICT r3 "Next" #1): He
+    initialisation times the frozen per-layer gain of CALIBRATED_GAINS, zero biases, and the planted identity
+    heads of `init_planted_heads` ('score', 'vertex_pred'). Generated on the host from one torch.Generator,
+    so the CPU checker and the GPU network hold the same bits. Call before the first `run`."""
+    import math
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    gains = CALIBRATED_GAINS if gains is None else gains
+    C, U = net.num_classes, net.num_units
+    for name, shape, fan_in, kind in calibrated_layers(net.input_format, C, U):
+        w = torch.randn(shape, generator=g) * (math.sqrt(2.0 / fan_in) * float(gains.get(name, 1.0)))
+        if kind == "conv":
+            w = w.contiguous(memory_format=torch.channels_last)
+        net.vars[name + "/weights"] = w.to(net.device)
+        net.vars[name + "/biases"] = torch.zeros((shape[0] if kind == "conv" else shape[1],), device=net.device)
+    ws = torch.zeros((C, U, 1, 1))
+    for c in range(C):
+        ws[c, c, 0, 0] = 1.0
+    net.vars["score/weights"] = ws.contiguous(memory_format=torch.channels_last).to(net.device)
+    wv = torch.zeros((3 * C, 128, 1, 1))
+    for c in range(3 * C):
+        wv[c, c, 0, 0] = 1.0
+    net.vars["vertex_pred/weights"] = wv.contiguous(memory_format=torch.channels_last).to(net.device)
+    net.vars["score/biases"] = torch.zeros((C,), device=net.device)
+    net.vars["vertex_pred/biases"] = torch.zeros((3 * C,), device=net.device)
+    return net
+
+
 def make_model_points(C, P, extents=None, seed=7):
     """Stand-in for data/LOV/models/*/points.xyz: P points inside each class' extent box."""
     rng = np.random.default_rng(seed)

@@ -177,6 +177,24 @@ def backproject(data, label, depth, meta, label_3d, G, ksize, threshold):
     return top_data, top_label, top_flag
 
 
+def backproject_sample(data, label, depth, meta, label_3d, G, ksize, threshold, first, stride):
+    """Rows first, first + stride, ... of backproject's three outputs ([rows, Cd], [rows, Cl], [rows, Cd])."""
+    data, label, depth, meta, label_3d = map(_f32, (data, label, depth, meta, label_3d))
+    B, H, W, Cd = data.shape
+    Cl = label.shape[3]
+    num_meta = meta.shape[-1]
+    nvox = B * G * G * G
+    rows = (nvox - first + stride - 1) // stride
+    top_data = np.empty((rows, Cd), np.float32)
+    top_flag = np.empty((rows, Cd), np.float32)
+    top_label = np.empty((rows, Cl), np.float32)
+    rc = lib().oracle_backproject_sample(_p(data), _p(label), _p(depth), _p(meta), _p(label_3d), B, H, W, Cd, Cl, num_meta, G,
+                                         int(ksize), c_float(threshold), c_long(first), c_long(stride), _p(top_data), _p(top_label),
+                                         _p(top_flag))
+    assert rc == 0
+    return top_data, top_label, top_flag
+
+
 def backproject_bwd(top_diff, depth, meta, B, H, W, Cd, G):
     top_diff, depth, meta = map(_f32, (top_diff, depth, meta))
     num_meta = meta.shape[-1]

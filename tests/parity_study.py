@@ -14,14 +14,15 @@ max |d quaternion|, the distribution of |d translation| (absolute, and relative 
 voters of each detection that changed side of the hard inlier test (hough_voting_gpu_op.cu.cc:269-294) —
 counted by re-evaluating the canonical predicate (SURVEY.md §8a HOUGH) in torch on each run's own vertex field.
 
-Scale matters when reading the absolute numbers: the network has RANDOM He-initialised weights on raw
-pixel inputs (|x| ~ 100), so conv4_3 reaches ~800, the 1/8-resolution vertex field ~45 and fc8 ~1500 where a
-trained PoseCNN has O(1-10). Besides the 5 planted objects per frame the noise produces junk detections
-(1-2 votes, "depths" of exp(5) = hundreds of metres). Every continuous output therefore gets a relative
-figure next to the absolute one, and the planted objects are reported separately.
+Scale matters when reading the absolute numbers. Round 3 ran this on He-initialised weights fed raw pixel
+values (|x| ~ 100): conv4_3 reached ~800, the 1/8-resolution vertex field ~45 and fc8 ~1500 where a trained
+PoseCNN has O(1-10), and noise classes produced junk detections at exp(5) "metres" — north_star's absolute
+1e-4 was unassertable there (profiles/r03_parity_study.json). Round 4 runs it on the CALIBRATED synthetic
+network (synth.init_calibrated: every layer's output std ~ 1, |fc8| <~ 3, depths 0.5-2 m), the same weights
+bench.py measures, and tests/test_gpu_round3.py asserts the tolerance literally. Relative figures are kept.
 
 TEST INFRASTRUCTURE (imported by tests/test_gpu_round3.py; `python tests/parity_study.py --frames 64
---out profiles/r03_parity_study.json` writes the table DESIGN.md §4 quotes). Needs a GPU.
+--out profiles/r04_parity_study.json` writes the table DESIGN.md §4 quotes). Needs a GPU.
 """
 import argparse
 import json
@@ -91,7 +92,7 @@ def run_study(device, n_frames=32, batch=4, H=480, W=640, C=22, seed=2024, paths
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     net = vgg16_convs("RGBD", C, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True, trainable=False,
                       is_train=False, seed=3, init="he", with_losses=False, device=device)
-    synth.init_planted_heads(net)
+    synth.init_calibrated(net)
     K = config.DEMO_INTRINSICS.copy()
     K[:2] *= W / 640.0
     ext = config.LOV_EXTENTS[:C]
@@ -195,6 +196,7 @@ def run_study(device, n_frames=32, batch=4, H=480, W=640, C=22, seed=2024, paths
             "supported_detections": int(sup.sum()), "supported_trans_diff_max": float(tr[sup].max()) if sup.any() else None,
             "supported_trans_rel_diff_max": float(rt[sup].max()) if sup.any() else None,
             "supported_depth_max_m": float(dp[sup].max()) if sup.any() else None,
+            "depth_min_m": float(dp.min()) if len(dp) else None, "depth_max_m": float(dp.max()) if len(dp) else None,
             "unsupported_detections": int((~sup).sum()), "unsupported_depth_max_m": float(dp[~sup].max()) if (~sup).any() else None,
             "unsupported_max_votes": int(vt[~sup].max()) if (~sup).any() else None,
             "unsupported_trans_diff_max": float(tr[~sup].max()) if (~sup).any() else None,

@@ -1,9 +1,9 @@
 """End-to-end parity: the GPU pipeline (PyTorch-ROCm dense layers + gfx950 custom kernels) against
 the CPU restatement of the same graph (PyTorch-CPU fp32 + C oracle) on the same seeded frames and
 weights. Dense-layer numerics differ between MIOpen/hipBLASLt and the CPU (different fp32
-accumulation orders), so the bars are: label maps agree except at class boundaries flipped by
-~1e-6 logit differences (reported; >= 99.9 %), detections agree in class/box, translations and
-quaternions within 1e-4 (BASELINE.json north_star tolerance)."""
+accumulation orders); the bar is BASELINE.json's north_star as written: label maps bit-exact, detections
+identical in class / box / vote count, translations and quaternions within 1e-4 absolute — on the calibrated
+synthetic network (synth.init_calibrated: O(1) activations, the weights bench.py measures)."""
 import numpy as np
 import pytest
 
@@ -18,7 +18,7 @@ def build(gpu, input_format="COLOR", fused_heads=True):
     from posecnn_amd.networks import vgg16_convs
     net = vgg16_convs(input_format, 22, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True,
                       trainable=False, is_train=False, device=gpu, seed=3, init="he", fused_heads=fused_heads)
-    synth.init_planted_heads(net)
+    synth.init_calibrated(net)
     cpu = vgg16_convs_cpu(input_format, 22, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True,
                           trainable=False, is_train=False, init="he")
     return net, cpu
@@ -48,8 +48,9 @@ def test_batch_pipeline_matches_cpu_reference(gpu):
     ref = run_cpu_pipeline(cpu, data, K, config.LOV_EXTENTS, pts, config.LOV_SYMMETRY, planted=planted_np)
 
     lab_gpu = det.label_2d.cpu().numpy()
-    agree = (lab_gpu == ref["label_2d"]).mean()
-    assert agree >= 0.999, "label agreement %.5f" % agree
+    # north_star, literally: label maps bit-exact against the CPU restatement (calibrated network, VERDICT r3 "Next" #1)
+    flips = int((lab_gpu != ref["label_2d"]).sum())
+    assert flips == 0, "%d label pixels differ from the CPU restatement" % flips
     vp = net.get_output("vertex_pred").cpu().numpy()
     assert np.abs(vp - ref["vertex_pred"]).max() < 1e-3 * max(1.0, np.abs(ref["vertex_pred"]).max())
     # the planted scene is recovered: one detection per planted object
@@ -61,11 +62,8 @@ def test_batch_pipeline_matches_cpu_reference(gpu):
     gr, gp = g_rois[order_g], g_poses[order_g]
     cr, cp = ref["final_rois"][order_c], ref["final_poses"][order_c]
     assert np.array_equal(gr[:, :2], cr[:, :2])
-    if agree == 1.0:
-        assert np.allclose(gr[:, 2:6], cr[:, 2:6], atol=1e-3) and np.array_equal(gr[:, 6], cr[:, 6])
-    else:
-        assert np.abs(gr[:, 2:6] - cr[:, 2:6]).max() < 4.0  # a flipped boundary pixel may move a box edge
-    assert np.abs(gp[:, 4:] - cp[:, 4:]).max() < (1e-4 if agree == 1.0 else 2e-2)   # translations
+    assert np.abs(gr[:, 2:6] - cr[:, 2:6]).max() < 1e-3 and np.array_equal(gr[:, 6], cr[:, 6])   # boxes and vote counts
+    assert np.abs(gp[:, 4:] - cp[:, 4:]).max() < 1e-4                                # translations, absolute (metres)
     assert np.abs(gp[:, :4] - cp[:, :4]).max() < 1e-4                                # quaternions (tanh outputs)
     assert float(net.get_output("loss_pose")) == 0.0  # is_train = 0: no targets -> ADL skips every row
 
@@ -126,7 +124,7 @@ def test_fused_heads_equal_literal_op_order(gpu):
     for fused in (True, False):
         net = vgg16_convs("COLOR", 22, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True, trainable=False,
                           is_train=False, device=gpu, seed=3, init="he", fused_heads=fused)
-        synth.init_planted_heads(net)
+        synth.init_calibrated(net)
         if nets:
             net.vars = nets[0].vars
         nets.append(net)

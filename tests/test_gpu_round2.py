@@ -171,7 +171,7 @@ def test_winograd_mfma_trunk_at_full_size_against_direct_convolutions(gpu, capsy
     B, H, W = 4, 480, 640
     net = vgg16_convs("RGBD", 22, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True, trainable=False,
                       is_train=False, seed=3, init="he", with_losses=False, device=gpu)
-    synth.init_planted_heads(net)
+    synth.init_calibrated(net)
     K = config.DEMO_INTRINSICS.copy()
     rng = np.random.default_rng(21)
     data, data_p = _rgbd_inputs(rng, B, H, W)
@@ -193,7 +193,7 @@ def test_winograd_mfma_trunk_at_full_size_against_direct_convolutions(gpu, capsy
     report = {"label_flips": flips, "of": a[0].size, "max_prob_diff": float(np.abs(a[1] - b[1]).max()),
               "conv5_3_rel_err": float(np.abs(a[3] - b[3]).max() / np.abs(b[3]).max()),
               "conv4_3_p_rel_err": float(np.abs(a[4] - b[4]).max() / np.abs(b[4]).max()), "detections": int(a[2].shape[0])}
-    assert flips <= 2e-5 * a[0].size, report
+    assert flips == 0, report            # calibrated network: bit-identical label maps (1.2 M decisions)
     assert report["max_prob_diff"] < 1e-3 and report["conv5_3_rel_err"] < 1e-4, report
     assert a[2].shape == b[2].shape and np.array_equal(a[2][:, :2], b[2][:, :2]) and a[2].shape[0] >= 3 * B, report
     report["max_box_diff_px"] = float(np.abs(a[2][:, 2:6] - b[2][:, 2:6]).max())
@@ -203,13 +203,10 @@ def test_winograd_mfma_trunk_at_full_size_against_direct_convolutions(gpu, capsy
     report["fc8_absmax"] = float(np.abs(b[5]).max())
     report["fc8_abs_diff"] = float(np.abs(a[5] - b[5]).max())
     report["depth_max_m"] = float(b[2][:, 13].max())
-    # What the round-3 study (tests/parity_study.py) established: no voter crosses the hard inlier
-    # test; a translation is mean(exp(z)) over identical voters, so it agrees RELATIVELY to the vertex field's
-    # error (~1e-5 here, where the random-weight field reaches 45 and junk detections sit at exp(5) metres —
-    # the millimetres round 2 saw were 3e-6 of 270 m); quaternions are tanh(fc8) with fc8 ~ 1500 on these weights.
+    # calibrated network (synth.init_calibrated): north_star's tolerance holds literally between the two f32 trunks
     assert np.array_equal(a[2][:, 2:7], b[2][:, 2:7]), report                       # boxes and vote counts: identical
-    assert report["max_trans_rel_diff"] < 1e-4, report
-    assert report["fc8_abs_diff"] < 1e-5 * report["fc8_absmax"] and report["max_quat_diff"] <= 1.01 * report["fc8_abs_diff"] + 1e-7, report
+    assert report["max_trans_diff"] < 1e-4 and report["max_quat_diff"] < 1e-4 and report["depth_max_m"] < 3.0, report
+    assert report["fc8_absmax"] < 6.0 and report["fc8_abs_diff"] < 1e-5 * max(report["fc8_absmax"], 1.0), report
     with capsys.disabled():
         print("\nfull-size winograd-MFMA vs direct:", report)
 
@@ -226,7 +223,7 @@ def test_hipgraph_replay_equals_the_eager_step(gpu, B, fmt, train):
     H, W = 240, 320
     net = vgg16_convs(fmt, 22, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True, trainable=False,
                       is_train=train, seed=3, init="he", with_losses=False, device=gpu)
-    synth.init_planted_heads(net)
+    synth.init_calibrated(net)
     K = config.DEMO_INTRINSICS.copy(); K[:2] *= W / 640.0
     rng = np.random.default_rng(8)
     pts = T(gpu, synth.make_model_points(22, 256))
@@ -290,7 +287,7 @@ def test_batches_on_alternating_streams_equal_the_serial_run(gpu):
     B, H, W = 2, 240, 320
     net = vgg16_convs("RGBD", 22, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True, trainable=False,
                       is_train=True, seed=3, init="he", with_losses=False, device=gpu)
-    synth.init_planted_heads(net)
+    synth.init_calibrated(net)
     K = config.DEMO_INTRINSICS.copy(); K[:2] *= W / 640.0
     rng = np.random.default_rng(5)
     pts = T(gpu, synth.make_model_points(22, 256))
@@ -339,7 +336,7 @@ def test_batch_pipeline_rgbd_matches_cpu_reference(gpu, train):
     B, H, W = 2, 240, 320
     kw = dict(vertex_reg_2d=True, pose_reg=True, trainable=False, is_train=train, seed=3, init="he", with_losses=True)
     net = vgg16_convs("RGBD", 22, 64, (1.0,), 1.0, -1.0, device=gpu, **kw)
-    synth.init_planted_heads(net)
+    synth.init_calibrated(net)
     cpu = vgg16_convs_cpu("RGBD", 22, 64, (1.0,), 1.0, -1.0, **kw)
     K = config.DEMO_INTRINSICS.copy(); K[:2] *= W / 640.0
     rng = np.random.default_rng(2)
@@ -358,28 +355,23 @@ def test_batch_pipeline_rgbd_matches_cpu_reference(gpu, train):
     cpu.share_weights(net)
     ref = run_cpu_pipeline(cpu, data, K, config.LOV_EXTENTS, pts, config.LOV_SYMMETRY, planted=planted_np, data_p=data_p, gt_poses=gt)
 
-    agree = (det.label_2d.cpu().numpy() == ref["label_2d"]).mean()
-    assert agree >= 0.999, "label agreement %.5f" % agree
+    # north_star, literally (VERDICT r3 "Next" #1; the network carries synth.init_calibrated's realistic scales):
+    # label maps bit-exact, quaternions / translations within 1e-4 ABSOLUTE, against the CPU restatement of the same graph
+    flips = int((det.label_2d.cpu().numpy() != ref["label_2d"]).sum())
+    assert flips == 0, "%d label pixels differ from the CPU restatement" % flips
     want_cls = sorted((b, o[0]) for b, s in enumerate(scenes) for o in s["objects"] if (s["label_lowres"] == o[0]).sum() * 64 > 500)
     assert sorted((int(r[0]), int(r[1])) for r in g_rois) == want_cls
     assert g_rois.shape == ref["final_rois"].shape
     og = np.lexsort((g_rois[:, 1], g_rois[:, 0])); oc = np.lexsort((ref["final_rois"][:, 1], ref["final_rois"][:, 0]))
     gr, gp, cr, cp = g_rois[og], g_poses[og], ref["final_rois"][oc], ref["final_poses"][oc]
     assert np.array_equal(gr[:, :2], cr[:, :2])
-    # (round 3) the branch is printed and the all-labels-equal case asserts what the numerics study measured:
-    # identical boxes, translations to 1e-4 of |t|. A flipped label pixel changes the class' pixel list and with it
-    # WHICH pixels skip_pixels samples (every 10th in index order from the flip on) — a different, equally valid
-    # voter set: the bounds for that case are the Hough layer's sampling noise, not rounding.
-    rel_t = float((np.abs(gp[:, 4:] - cp[:, 4:]).max(1) / np.maximum(np.abs(cp[:, 4:]).max(1), 1e-6)).max())
+    trans_d = float(np.abs(gp[:, 4:] - cp[:, 4:]).max())
     box_d = float(np.abs(gr[:, 2:6] - cr[:, 2:6]).max())
     quat_d = float(np.abs(gp[:, :4] - cp[:, :4]).max())
-    print("\nrgbd pipeline vs cpu restatement [train=%s]: labels %s (agreement %.6f), box diff %.3g px, rel trans diff %.3g, quat diff %.3g"
-          % (train, "IDENTICAL" if agree == 1.0 else "differ", agree, box_d, rel_t, quat_d))
-    if agree == 1.0:
-        assert box_d < 1e-3 and rel_t < 1e-4
-    else:
-        assert box_d < 4.0 and rel_t < 2e-2
-    assert quat_d < 1e-3                      # tanh(fc8), |fc8| ~ 1e3 with random weights (see the study)
+    print("\nrgbd pipeline vs cpu restatement [train=%s]: 0 label flips, box diff %.3g px, trans diff %.3g m (depths %.2f-%.2f m), quat diff %.3g"
+          % (train, box_d, trans_d, float(cp[:, 6].min()), float(cp[:, 6].max()), quat_d))
+    assert box_d < 1e-3 and np.array_equal(gr[:, 6], cr[:, 6])     # boxes and vote counts
+    assert trans_d < 1e-4 and quat_d < 1e-4
     n = int(det.count.item()) * (9 if train else 1)
     w_gpu = net.get_output("poses_weight")[:n].cpu().numpy()
     loss_gpu = float(net.get_output("loss_pose"))

@@ -106,7 +106,7 @@ def test_vgg16_convs_graph_runs_on_cpu_reference():
     K = config.DEMO_INTRINSICS.copy(); K[:2] *= W / 640.0
     net = vgg16_convs_cpu("COLOR", 22, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True,
                           trainable=False, is_train=False, init="he", with_losses=True)
-    synth.init_planted_heads(net)
+    synth.init_calibrated(net)
     rng = np.random.default_rng(3)
     data = (rng.integers(0, 256, (1, H, W, 3)).astype(F) - config.PIXEL_MEANS).astype(F)
     # objects at this resolution are < 500 px: the Hough layer returns its dummy row

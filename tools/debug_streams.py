@@ -21,11 +21,11 @@ gpu = torch.device("cuda:0")
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
 B, H, W = 2, 240, 320
 net = vgg16_convs("RGBD", 22, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True, trainable=False, is_train=True, seed=3, init="he", with_losses=False, device=gpu)
-synth.init_planted_heads(net)
+synth.init_calibrated(net)
 TWO = "two_nets" in sys.argv
 if TWO:
     net2 = vgg16_convs("RGBD", 22, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True, trainable=False, is_train=True, seed=3, init="he", with_losses=False, device=gpu)
-    synth.init_planted_heads(net2)
+    synth.init_calibrated(net2)
 nets = [net, net2] if TWO else [net, net]
 SYNC_ALLOC = "fence" in sys.argv
 K = config.DEMO_INTRINSICS.copy(); K[:2] *= W / 640.0
