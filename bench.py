@@ -62,6 +62,9 @@ def parse_args(argv=None):
                     help="also run the backprojecting layer on each batch's head features (G^3 voxels per frame); "
                          "default 128 for --config linemod (configs[4] names it), 0 = off otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short configs[1] (batch-1 latency) and configs[4] (LINEMOD 1280x960 + backproject) runs whose "
+                         "summaries the default single-GPU invocation appends under `secondary`")
     ap.add_argument("--nbuf", type=int, default=2, help="distinct synthetic batches cycled through")
     ap.add_argument("--prewarm-seconds", type=float, default=8.0,
                     help="untimed sustained-load warm-up between the cold and the headline measurement")
@@ -232,6 +235,45 @@ def cpu_baseline(a, K, H, W, C, extents, symmetry, net_gpu, train, max_seconds=2
                       "fp32 (%d threads) + C oracle (OpenMP) for hough/roi_pool/softmax/hard_label/average_distance; "
                       "%d detections on the last frame" % (done, W, H, a.input, threads, out["final_rois"].shape[0]),
             "seconds": t_total}
+
+
+def secondary_configs(timeout=150):
+    """BASELINE configs[1] and configs[4] as short runs of this same script (fresh processes, after the headline
+    measurement; ~20 s each), so that the driver's one command records them too (VERDICT r3 "Next" #6). Each entry is
+    a summary of that run's own JSON line; a failed run is reported as such, never fatal for the headline."""
+    import subprocess
+    runs = {
+        "configs[1]": ["--latency", "--batch", "1", "--input", "COLOR", "--losses", "none", "--graph", "--raw-inputs",
+                       "--steps", "100", "--warmup", "5", "--prewarm-seconds", "2"],
+        "configs[4]": ["--config", "linemod", "--steps", "8", "--warmup", "3", "--prewarm-seconds", "2"],
+    }
+    out = {}
+    for name, flags in runs.items():
+        cmd = [sys.executable, os.path.abspath(__file__)] + flags + ["--no-cpu-baseline", "--no-secondary"]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            j = json.loads(line[-1]) if line else None
+        except Exception as e:
+            out[name] = {"error": repr(e), "flags": " ".join(flags)}
+            continue
+        if j is None:
+            out[name] = {"error": "rc %d: %s" % (r.returncode, r.stderr[-400:]), "flags": " ".join(flags)}
+            continue
+        e = {"flags": " ".join(flags), "wall_s": round(time.perf_counter() - t0, 1), "workload": j["config"]["workload"],
+             "frames_s": j["value"], "ms_per_step": j["ms_per_step"], "steps": j["steps"], "dtype": j["dtype"]}
+        if "latency" in j:
+            e.update({"p50_ms": j["latency"]["p50_ms"], "p99_ms": j["latency"]["p99_ms"], "min_ms": j["latency"]["min_ms"],
+                      "latency_samples": j["latency"]["samples"], "frames_s_note": "pipelined throughput of the same loop; p50 / p99 are "
+                      "synchronous per-frame times (upload -> kernels -> D2H -> host NMS)"})
+        for o in j.get("roofline_other", []):
+            if o["kernel"] == "backproject_fused_kernel":
+                e["backproject"] = {k: o[k] for k in ("bound", "achieved", "peak", "unit", "frac", "us_per_step")}
+        if j.get("roofline_dominant"):
+            e["roofline_dominant"] = {k: j["roofline_dominant"][k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "us_per_step")}
+        out[name] = e
+    return out
 
 
 def main(argv=None):
@@ -481,16 +523,25 @@ def main(argv=None):
     # HBM traffic of the kernel from PMC counters: collected offline in separate --pmc passes (they
     # cannot share a run with the timed region) at this same workload; see profiles/README.md
     traffic, traffic_src = None, None
-    for name in ("r03_hough_pmc.json", "r02_hough_pmc.json", "r01_hough_pmc.json"):
+    import hashlib
+    src_sha = hashlib.sha256(open(os.path.join(ROOT, "posecnn_amd", "csrc", "hough_voting.hip"), "rb").read()).hexdigest()[:16]
+    for name in ("r04_hough_pmc.json", "r03_hough_pmc.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
-            ent = pmc.get(vote_name) or pmc.get("hv_vote_kernel")
-            if ent and (B, H, W) == (16, 480, 640):
-                traffic = int((2.0 * ent["FETCH_SIZE_KB"] + ent["WRITE_SIZE_KB"]) * 1024)
-                traffic_src = "profiles/" + name
-                break
         except Exception:
-            pass
+            continue
+        ent = pmc.get(vote_name) or pmc.get("hv_vote_kernel")
+        if not ent or (B, H, W) != (16, 480, 640):
+            continue
+        if pmc.get("_kernel_source_sha16") != src_sha:
+            # counters of ANOTHER build of the kernel: never reported as this run's traffic
+            print("bench.py: profiles/%s was collected on hough_voting.hip %s, this build is %s -> roofline.traffic = null; "
+                  "re-collect with tools/collect_pmc_hough.sh" % (name, pmc.get("_kernel_source_sha16"), src_sha), file=sys.stderr)
+            traffic_src = "STALE: profiles/%s belongs to another build of hough_voting.hip" % name
+            break
+        traffic = int((2.0 * ent["FETCH_SIZE_KB"] + ent["WRITE_SIZE_KB"]) * 1024)
+        traffic_src = "profiles/" + name
+        break
     # brute-force-equivalent pair predicates of the reference kernel: sum_c ceil(N_c/skip)*H*W
     per_class = torch.bincount((lab.reshape(B, -1).long() + C * torch.arange(B, device=dev).unsqueeze(1)).flatten(),
                                minlength=C * B).reshape(B, C)[:, 1:]
@@ -554,8 +605,9 @@ def main(argv=None):
         "metric": "%s frames/sec (%dx%d, %d classes)" % (name_of, W, H, C - 1),
         "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (random frames; random He-init VGG16; planted 1/8-res scene "
-                                "so the heads emit 5 objects/frame with known poses — DESIGN.md §5)",
+        "dtype": "f32", "data": "synthetic (random frames; seeded VGG16 weights calibrated to O(1) activations — synth.init_calibrated, the "
+                                "weights the parity tests assert north_star's tolerance on; planted 1/8-res scene so the heads emit "
+                                "5 objects/frame with known poses — DESIGN.md §5)",
         "config": {"workload": workload, "global_batch": B * world, "per_gpu_batch": B, "height": H, "width": W,
                    "num_classes": C, "input_format": a.input, "losses": a.losses,
                    "inputs": "resident" if a.resident_inputs else ("pinned-host-raw" if a.raw_inputs else "pinned-host"),
@@ -576,6 +628,10 @@ def main(argv=None):
                                       "`frac` above is the vote kernel alone",
                      "pair_predicates_equiv_per_launch": pairs,
                      "pair_predicates_equiv_per_s": pairs / (hv["avg_us"] * 1e-6) if hv["calls"] else None},
+        # the kernel the step actually spends its time in, against ITS roof (the headline `roofline` key is the Hough vote
+        # kernel north_star names — 0.8 % of the step)
+        "roofline_dominant": (dict(max(others, key=lambda o: o["us_per_step"]), share_of_step=max(o["us_per_step"] for o in others) / 1e3 / ms_per_step)
+                              if others else None),
         "roofline_other": others,
         "dominant_library_kernel": (max(others, key=lambda o: o["us_per_step"])["kernel"] if others else None),
         "backbone": {"what": "all convolution kernels of the VGG16 trunk(s): gfx950 Winograd F(4x4,3x3) transform + fp32-MFMA kernels "
@@ -599,6 +655,9 @@ def main(argv=None):
                              "world_size": world, "collective": "all_gather_into_tensor of the packed detection block, once per step"}
                             if torch.distributed.is_initialized() else
                             {"backend": None, "ranks_seen": 1, "world_size": 1, "collective": "none (single process; --force-process-group runs it through RCCL)"})
+    if (world == 1 and not a.no_secondary and not a.latency and not a.graph and a.config == "ycb" and cfg_name == "configs[2]"
+            and "WORLD_SIZE" not in os.environ):
+        out["secondary"] = secondary_configs()
     if world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(a, K, H, W, C, extents, symmetry, net, train)

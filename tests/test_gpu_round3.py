@@ -278,7 +278,8 @@ def test_run_evaluation_executes_the_test_net_loop(gpu, tmp_path):
         # the Hough centre is the planted centroid (every voter points at it); the depth is mean(exp(log z + the random
         # network's own contribution to that channel)) — right order of magnitude, not the planted value
         u, v = t[0] / t[2] * K[0, 0] + K[0, 2], t[1] / t[2] * K[1, 1] + K[1, 2]
-        assert abs(u - cx) < 16 and abs(v - cy) < 16, (c, (u, v), (cx, cy))     # the cone test cos > 0.9 is +-25 degrees: a broad maximum
+        # the cone test cos > 0.9 is +-25 degrees and the planted directions live on 8-pixel cells: a broad maximum, within three cells
+        assert abs(u - cx) < 24 and abs(v - cy) < 24, (c, (u, v), (cx, cy))
         assert t[2] > 0      # (the depth is exp(log z + the random network's own output on that channel): any positive number)
         e = ev.pose_error(c, detected[c], fr["meta"]["poses"][:, :, [o[0] for o in objects[0]].index(c)])
         assert abs(e["translation_error"] - np.linalg.norm(t.astype(np.float64) - want_t)) < 1e-6     # the evaluator's `te` of THIS detection
