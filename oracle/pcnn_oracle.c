@@ -1212,38 +1212,135 @@ int oracle_icp_backproject(const uint16_t* depth, const int* label, int H, int W
   return 0;
 }
 
-/* icpKernel :25-136 for one pixel; returns 1 and fills J[6], r when the pixel contributes */
-static int icp_pixel(const float* live, const float* pv, const float* pn, int W, int H, const float* T /* [12] */,
+/* float -> int the way the GPU converts (`const int u = projected + 0.5` of icp.cu:78-79 is undefined in C++ for NaN /
+   out-of-range values; PTX cvt.rzi and gfx950 v_cvt_i32_f32: NaN -> 0, saturating) */
+static int icp_cvt_rz(float f)
+{
+  if (f != f) return 0;
+  if (f >= 2147483648.f) return INT32_MAX;
+  if (f <= -2147483648.f) return INT32_MIN;
+  return (int)f;
+}
+
+/* The content of the Sophus::SE3f that icpKernel receives (`updatedPose`): unit quaternion (w, x, y, z) + translation,
+   from the accumulated 3x4 transform T (row-major; f64 in the solve, rounded to f32 here). Rotation matrix -> quaternion
+   by Eigen's published algorithm (Geometry/Quaternion.h, quaternionbase_assign_impl<.,3,3>: the trace branch or the
+   largest-diagonal branch), then Sophus's normalisation (coefficients / sqrt(squaredNorm), 4-term reduction in Eigen's
+   unrolled order over (x, y, z, w)) — all in f32 with correctly rounded sqrt and division. */
+static void icp_se3f_from_matrix(const float* T /* [12] */, float* q /* wxyz */, float* t)
+{
+  const float m[3][3] = {{T[0], T[1], T[2]}, {T[4], T[5], T[6]}, {T[8], T[9], T[10]}};
+  float qq[4];   /* x, y, z, w */
+  float tr = (m[0][0] + m[1][1]) + m[2][2];
+  if (tr > 0.f) {
+    tr = sqrtf(tr + 1.0f);
+    qq[3] = 0.5f * tr;
+    tr = 0.5f / tr;
+    qq[0] = (m[2][1] - m[1][2]) * tr;
+    qq[1] = (m[0][2] - m[2][0]) * tr;
+    qq[2] = (m[1][0] - m[0][1]) * tr;
+  } else {
+    int i = 0;
+    if (m[1][1] > m[0][0]) i = 1;
+    if (m[2][2] > m[i][i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    tr = sqrtf(((m[i][i] - m[j][j]) - m[k][k]) + 1.0f);
+    qq[i] = 0.5f * tr;
+    tr = 0.5f / tr;
+    qq[3] = (m[k][j] - m[j][k]) * tr;
+    qq[j] = (m[j][i] + m[i][j]) * tr;
+    qq[k] = (m[k][i] + m[i][k]) * tr;
+  }
+  const float n = sqrtf((qq[0] * qq[0] + qq[1] * qq[1]) + (qq[2] * qq[2] + qq[3] * qq[3]));
+  q[0] = qq[3] / n; q[1] = qq[0] / n; q[2] = qq[1] / n; q[3] = qq[2] / n;
+  t[0] = T[3]; t[1] = T[7]; t[2] = T[11];
+}
+
+/* Sophus::SE3f * point = so3 * p + translation, so3 * p = Eigen's Quaternion::_transformVector:
+   uv = 2 (q.vec x p); (p + w uv) + q.vec x uv */
+static void icp_se3f_apply(const float* q /* wxyz */, const float* t, float x, float y, float z, float* o)
+{
+  const float w = q[0], a = q[1], b = q[2], c = q[3];
+  float ux = b * z - c * y, uy = c * x - a * z, uz = a * y - b * x;
+  ux = ux + ux; uy = uy + uy; uz = uz + uz;
+  const float cx = b * uz - c * uy, cy = c * ux - a * uz, cz = a * uy - b * ux;
+  o[0] = ((x + w * ux) + cx) + t[0];
+  o[1] = ((y + w * uy) + cy) + t[1];
+  o[2] = ((z + w * uz) + cz) + t[2];
+}
+
+/* icpKernel (icp.cu:25-136) for one pixel, in the body's own order of tests and — where the result of a float
+   expression depends on it — in the evaluation order Eigen publishes for fixed-size 3-vectors (3-term reductions as
+   t0 + (t1 + t2); oracle/ref_shim/eigen_sophus_on_cpu.h has the list). tests/test_oracle_vs_reference.py holds this to
+   the reference's kernel body, compiled unchanged, bit for bit (J, r and the exit reason of every pixel).
+   Returns the exit reason — 0 contributes (J[6], r filled), 1 predicted depth out of range (:60), 2 projects onto
+   the border (:81), 3 live depth out of range (:92), 4 ray / normal angle (:104), 5 |error| > maxError (:115). */
+enum { ICP_OK = 0, ICP_PRED_DEPTH = 1, ICP_BORDER = 2, ICP_LIVE_DEPTH = 3, ICP_RAY_NORMAL = 4, ICP_ERROR = 5 };
+static int icp_pixel(const float* live, const float* pv, const float* pn, int W, int H, const float* q /* wxyz */, const float* t,
                      float fx, float fy, float px, float py, float znear, float zfar, float max_error, float* J, float* r)
 {
   const float border = 2.f, ray_norm_dot_threshold = 0.1f;
   const float pdepth = pv[2];
-  if (!(pdepth >= znear) || pdepth > zfar) return 0;                 /* :60 (NaN background of the render: skipped) */
-  const float ux = ((T[0] * pv[0] + T[1] * pv[1]) + T[2] * pv[2]) + T[3];
-  const float uy = ((T[4] * pv[0] + T[5] * pv[1]) + T[6] * pv[2]) + T[7];
-  const float uz = ((T[8] * pv[0] + T[9] * pv[1]) + T[10] * pv[2]) + T[11];   /* :67 */
-  const float projx = ux / uz * fx + px, projy = uy / uz * fy + py;           /* :69, poly3.h project with k = 0 */
-  if (!(projx == projx) || !(projy == projy) || fabsf(projx) > 1e8f || fabsf(projy) > 1e8f) return 0;   /* (int conversion of NaN / huge values is UB) */
-  const int u = (int)(projx + 0.5f), v = (int)(projy + 0.5f);                  /* :78-79 */
-  if (((float)u <= border) || ((float)u >= (float)(W - 1) - border) || ((float)v <= border) || ((float)v >= (float)(H - 1) - border)) return 0;   /* :81 */
+  if ((pdepth < znear) || pdepth > zfar) return ICP_PRED_DEPTH;      /* :60 (a NaN — the render's clear colour — passes, as in the body) */
+  float u3[3];
+  icp_se3f_apply(q, t, pv[0], pv[1], pv[2], u3);                     /* :67 */
+  const float ux = u3[0], uy = u3[1], uz = u3[2];
+  /* :69 Poly3CameraModel::project with k1 = k2 = k3 = 0 (poly3.h:72-88, cameraModel.h:72-82): the distortion factor is
+     ((1 + 0 r2) + 0 r4) + 0 r6 — exactly 1 for finite r2, NaN (0 x inf) when the squared radius overflows */
+  const float dhx = ux / uz, dhy = uy / uz;
+  const float r2 = dhx * dhx + dhy * dhy, r4 = r2 * r2, r6 = r4 * r2;
+  const float factor = ((1.f + 0.f * r2) + 0.f * r4) + 0.f * r6;
+  const float projx = (factor * dhx) * fx + px, projy = (factor * dhy) * fy + py;
+  const int u = icp_cvt_rz(projx + 0.5f), v = icp_cvt_rz(projy + 0.5f);          /* :78-79 */
+  if (((float)u <= border) || ((float)u >= (float)(unsigned)(W - 1) - border) || ((float)v <= border) || ((float)v >= (float)(unsigned)(H - 1) - border))
+    return ICP_BORDER;                                                /* :81 */
   const float* lv = live + 3 * ((long)v * W + u);
   const float ldepth = lv[2];
-  if (!(ldepth >= znear) || ldepth > zfar) return 0;                 /* :92 */
-  const float nrm = sqrtf((ux * ux + uy * uy) + uz * uz);
-  const float rx = ux / nrm, ry = uy / nrm, rz = uz / nrm;          /* :100 */
-  const float dotrn = (rx * pn[0] + ry * pn[1]) + rz * pn[2];
-  if (!(-dotrn >= ray_norm_dot_threshold)) return 0;                 /* :104 */
+  if ((ldepth < znear) || (ldepth > zfar)) return ICP_LIVE_DEPTH;    /* :92 */
+  const float sq = ux * ux + (uy * uy + uz * uz);                    /* normalized(): squaredNorm, then v / sqrt(z) when z > 0 */
+  float rx = ux, ry = uy, rz = uz;
+  if (sq > 0.f) { const float nrm = sqrtf(sq); rx = ux / nrm; ry = uy / nrm; rz = uz / nrm; }   /* :100 */
+  const float dotrn = rx * pn[0] + (ry * pn[1] + rz * pn[2]);
+  if (-dotrn < ray_norm_dot_threshold) return ICP_RAY_NORMAL;        /* :104 */
   const float ex = lv[0] - ux, ey = lv[1] - uy, ez = lv[2] - uz;
-  const float error = (pn[0] * ex + pn[1] * ey) + pn[2] * ez;        /* :111 */
-  if (!(fabsf(error) <= max_error)) return 0;                        /* :115 */
+  const float error = pn[0] * ex + (pn[1] * ey + pn[2] * ez);        /* :111 */
+  if (fabsf(error) > max_error) return ICP_ERROR;                    /* :115 */
   const float w = 1.f / ldepth;                                      /* :122 */
-  const float wx = w * pn[0], wy = w * pn[1], wz = w * pn[2];        /* weightSqrt * n^T, then x [I | -[p]x] (:124-130) */
-  J[0] = wx; J[1] = wy; J[2] = wz;
-  J[3] = wy * (-uz) + wz * uy;
-  J[4] = wx * uz + wz * (-ux);
-  J[5] = wx * (-uy) + wy * ux;
+  const float wx = w * pn[0], wy = w * pn[1], wz = w * pn[2];        /* (weightSqrt n^T) first, then x [I | -[p]x] (:124-130), */
+  J[0] = wx * 1.f + (wy * 0.f + wz * 0.f);                           /* coefficient by coefficient: c0 + (c1 + c2) */
+  J[1] = wx * 0.f + (wy * 1.f + wz * 0.f);
+  J[2] = wx * 0.f + (wy * 0.f + wz * 1.f);
+  J[3] = wx * 0.f + (wy * (-uz) + wz * uy);
+  J[4] = wx * uz + (wy * 0.f + wz * (-ux));
+  J[5] = wx * (-uy) + (wy * ux + wz * 0.f);
   *r = w * error;
-  return 1;
+  return ICP_OK;
+}
+
+/* the per-pixel records of one icpKernel launch: J [P,6], r [P] (zero where the pixel does not contribute, as the body
+   leaves them), reason [P] (the enum above). pose = the content of the SE3f: q wxyz, t. */
+int oracle_icp_terms(const float* live, const float* pred_v, const float* pred_n, int H, int W, int pc, const float* q,
+                     const float* t, float fx, float fy, float px, float py, float znear, float zfar, float max_error,
+                     float* J_out, float* r_out, unsigned char* reason_out)
+{
+  const long P = (long)H * W;
+  for (long p = 0; p < P; p++) {
+    float J[6] = {0, 0, 0, 0, 0, 0}, r = 0.f;
+    const int why = icp_pixel(live, pred_v + pc * p, pred_n + pc * p, W, H, q, t, fx, fy, px, py, znear, zfar, max_error, J, &r);
+    for (int k = 0; k < 6; k++) J_out[6 * p + k] = why == ICP_OK ? J[k] : 0.f;
+    r_out[p] = why == ICP_OK ? r : 0.f;
+    reason_out[p] = (unsigned char)why;
+  }
+  return 0;
+}
+
+/* the SE3f content icp_refine hands to the per-pixel step for an accumulated transform T (f64 [12]) */
+int oracle_icp_se3f(const double* T, float* q, float* t)
+{
+  float Tf[12];
+  for (int i = 0; i < 12; i++) Tf[i] = (float)T[i];
+  icp_se3f_from_matrix(Tf, q, t);
+  return 0;
 }
 
 static void icp_exp_se3(const double* xi, double* U /* [12] */)
@@ -1355,8 +1452,9 @@ int oracle_icp_refine(const float* live, const float* pred_v, const float* pred_
     const float* pv = pred_v + (long)pc * P * n;
     const float* pn = pred_n + (long)pc * P * n;
     for (int it = 0; it < iterations; it++) {
-      float Tf[12];
+      float Tf[12], qf[4], tf[3];
       for (int i = 0; i < 12; i++) Tf[i] = (float)T[i];
+      icp_se3f_from_matrix(Tf, qf, tf);
       double S[ICP_NSUM];
       memset(rows, 0, sizeof(float) * ICP_NSUM * (size_t)nblocks);
       for (long b = 0; b < nblocks; b++) {
@@ -1366,7 +1464,7 @@ int oracle_icp_refine(const float* live, const float* pred_v, const float* pred_
           const long p = b * ICP_BLOCK + t;
           if (p >= P) break;
           float J[6], r;
-          if (!icp_pixel(lv, pv + pc * p, pn + pc * p, W, H, Tf, fx, fy, px, py, znear, zfar, max_error, J, &r)) continue;
+          if (icp_pixel(lv, pv + pc * p, pn + pc * p, W, H, qf, tf, fx, fy, px, py, znear, zfar, max_error, J, &r) != ICP_OK) continue;
           any = 1;
           int q = 0;
           for (int i = 0; i < 6; i++)
@@ -1661,57 +1759,100 @@ int oracle_icp_score(const float* live, const float* canon, const uint8_t* mask,
 /* default initial step (ub - lb) / 4) — NOT its code, and not its bits. Canonical choices:               */
 /*   - the energy: pixels of the label's bounding box in raster order dealt round-robin to 1024 partial    */
 /*     sums (f32 distance, int count), a halving tree over them, energy = sum / count in f32 (0 when       */
-/*     no pixel qualifies); the update's rotation from the un-normalised quaternion (2 / q.q form: no      */
-/*     sqrt), computed in f64 and rounded to f32 like an SE3f;                                           */
+/*     no pixel qualifies); the per-pixel term is the reference body's own arithmetic — the SE3f that     */
+/*     optEnergy builds (quaternion normalised in f32 by Sophus's constructor) applied through Eigen's    */
+/*     quaternion transform — and is held to that body bit for bit (tests/test_oracle_vs_reference.py);   */
 /*   - ties in the simplex ordering: the lower vertex index counts as better.                             */
 #define NM_N 7
 #define NM_LANES 1024
 
-static void nm_update_matrix(const double* x, float* T /* [12] */)
+/* The SE3f optEnergy builds from the optimiser's point (:2481-2484): Eigen::Quaternionf(pose[0..3]) (double -> float),
+   Sophus::SE3f(quaternion, translation) — whose constructor NORMALISES the quaternion: coefficients / sqrt(squaredNorm),
+   4-term reduction in Eigen's unrolled order over (x, y, z, w) — in f32. q out as (w, x, y, z). */
+static void nm_se3f(const double* x, float* q, float* t)
 {
-  const double w = x[0], a = x[1], b = x[2], c = x[3];
-  const double n = ((w * w + a * a) + b * b) + c * c;
-  const double s = n > 0.0 ? 2.0 / n : 0.0;
-  const double R[9] = {1.0 - s * (b * b + c * c), s * (a * b - c * w), s * (a * c + b * w),
-                       s * (a * b + c * w), 1.0 - s * (a * a + c * c), s * (b * c - a * w),
-                       s * (a * c - b * w), s * (b * c + a * w), 1.0 - s * (a * a + b * b)};
-  for (int i = 0; i < 3; i++) {
-    for (int j = 0; j < 3; j++) T[4 * i + j] = (float)R[3 * i + j];
-    T[4 * i + 3] = (float)x[4 + i];
-  }
+  const float w = (float)x[0], a = (float)x[1], b = (float)x[2], c = (float)x[3];
+  const float n = sqrtf((a * a + b * b) + (c * c + w * w));
+  q[0] = w / n; q[1] = a / n; q[2] = b / n; q[3] = c / n;
+  t[0] = (float)x[4]; t[1] = (float)x[5]; t[2] = (float)x[6];
 }
 
-/* optEnergy :2476-2526 */
+/* one pixel of optEnergy's loop (:2496-2519): 1 and the distance when the pixel counts */
+static int nm_pixel(const float* lv /* [3] */, const float* pv, const float* q, const float* t, float znear, float zfar, float* dist)
+{
+  float m[3];
+  icp_se3f_apply(q, t, pv[0], pv[1], pv[2], m);                      /* T_co * point, :2505 */
+  const float vx = lv[0], vy = lv[1], vz = lv[2];
+  if (m[0] == m[0] && m[1] == m[1] && m[2] == m[2] && vz > znear && vz < zfar && m[2] > znear && m[2] < zfar) {   /* :2515 */
+    *dist = sqrtf(((m[0] - vx) * (m[0] - vx) + (m[1] - vy) * (m[1] - vy)) + (m[2] - vz) * (m[2] - vz));             /* :2517 */
+    return 1;
+  }
+  return 0;
+}
+
+/* optEnergy :2476-2526; the SUM is the canonical parallel one (header above), the reference adds sequentially in f32 */
 static float nm_energy(const int* label, const float* live, const float* pred_v, int pc, int W, const int* box, int obj,
                        float znear, float zfar, const double* x, float* part, int* cnt)
 {
-  float T[12];
-  nm_update_matrix(x, T);
+  float q[4], t[3];
+  nm_se3f(x, q, t);
   const int bw = box[1] - box[0] + 1;
   const long nb = (long)bw * (box[3] - box[2] + 1);
-  for (int t = 0; t < NM_LANES; t++) {
+  for (int l = 0; l < NM_LANES; l++) {
     float acc = 0.f;
     int c = 0;
-    for (long j = t; j < nb; j += NM_LANES) {
+    for (long j = l; j < nb; j += NM_LANES) {
       const long p = (long)(box[2] + j / bw) * W + (box[0] + j % bw);
       if (label[p] != obj) continue;
-      const float* pv = pred_v + p * pc;
-      const float qx = ((T[0] * pv[0] + T[1] * pv[1]) + T[2] * pv[2]) + T[3];
-      const float qy = ((T[4] * pv[0] + T[5] * pv[1]) + T[6] * pv[2]) + T[7];
-      const float qz = ((T[8] * pv[0] + T[9] * pv[1]) + T[10] * pv[2]) + T[11];
-      const float vx = live[3 * p], vy = live[3 * p + 1], vz = live[3 * p + 2];
-      if (qx == qx && qy == qy && qz == qz && vz > znear && vz < zfar && qz > znear && qz < zfar) {   /* :2515 */
-        const float ex = qx - vx, ey = qy - vy, ez = qz - vz;
-        acc = acc + sqrtf((ex * ex + ey * ey) + ez * ez);
+      float d;
+      if (nm_pixel(live + 3 * p, pred_v + p * pc, q, t, znear, zfar, &d)) {
+        acc = acc + d;
         c++;
       }
     }
-    part[t] = acc;
-    cnt[t] = c;
+    part[l] = acc;
+    cnt[l] = c;
   }
   for (int s = NM_LANES / 2; s >= 1; s >>= 1)
-    for (int t = 0; t < s; t++) { part[t] = part[t] + part[t + s]; cnt[t] = cnt[t] + cnt[t + s]; }
+    for (int l = 0; l < s; l++) { part[l] = part[l] + part[l + s]; cnt[l] = cnt[l] + cnt[l + s]; }
   return cnt[0] ? part[0] / (float)cnt[0] : 0.f;
+}
+
+/* probes for tests/test_oracle_vs_reference.py: the per-pixel term of the energy for EVERY pixel of the frame
+   (dist_out [P], valid_out [P]), and the energy itself over the pixels labelled `obj` */
+int oracle_icp_energy_terms(const float* live, const float* pred_v, int pc, int H, int W, float znear, float zfar,
+                            const double* x, float* dist_out, unsigned char* valid_out)
+{
+  float q[4], t[3];
+  nm_se3f(x, q, t);
+  for (long p = 0; p < (long)H * W; p++) {
+    float d = 0.f;
+    valid_out[p] = (unsigned char)nm_pixel(live + 3 * p, pred_v + p * pc, q, t, znear, zfar, &d);
+    dist_out[p] = valid_out[p] ? d : 0.f;
+  }
+  return 0;
+}
+
+double oracle_icp_energy(const int* label, const float* live, const float* pred_v, int pc, int H, int W, int obj, float znear,
+                         float zfar, const double* x)
+{
+  int box[4] = {W, -1, H, -1};
+  for (int y = 0; y < H; y++)
+    for (int xx = 0; xx < W; xx++)
+      if (label[(long)y * W + xx] == obj) {
+        if (xx < box[0]) box[0] = xx;
+        if (xx > box[1]) box[1] = xx;
+        if (y < box[2]) box[2] = y;
+        if (y > box[3]) box[3] = y;
+      }
+  if (box[1] < box[0]) return 0.0;
+  float* part = (float*)malloc(sizeof(float) * NM_LANES);
+  int* cnt = (int*)malloc(sizeof(int) * NM_LANES);
+  if (!part || !cnt) { free(part); free(cnt); return -1.0; }
+  const double e = (double)nm_energy(label, live, pred_v, pc, W, box, obj, znear, zfar, x, part, cnt);
+  free(part);
+  free(cnt);
+  return e;
 }
 
 /* label int32 [H,W], live f32 [H,W,3], pred_v f32 [H,W,pc] (rendered at the pose the update will multiply).

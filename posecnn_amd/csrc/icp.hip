@@ -53,7 +53,61 @@ __global__ __launch_bounds__(64) void icp_init_kernel(double* __restrict__ state
   }
 }
 
-// icpKernel (icp.cu:25-136) + the per-block part of the reduction
+// The content of the Sophus::SE3f icpKernel receives (`updatedPose`): unit quaternion (w, x, y, z) + translation, from the
+// accumulated 3x4 transform (f64 in the solve, rounded to f32 here): rotation matrix -> quaternion by Eigen's published
+// algorithm (trace branch / largest-diagonal branch), then Sophus's normalisation — coefficients / sqrt(squaredNorm), the
+// 4-term reduction in Eigen's unrolled order over (x, y, z, w) — in f32 with correctly rounded sqrt and division. The
+// same statement as icp_se3f_from_matrix of the CPU checker, which is held to the reference's kernel body bit for bit.
+__device__ __forceinline__ void icp_se3f_from_matrix(const float* T, float* q /* wxyz */, float* t)
+{
+  const float m00 = T[0], m01 = T[1], m02 = T[2], m10 = T[4], m11 = T[5], m12 = T[6], m20 = T[8], m21 = T[9], m22 = T[10];
+  float qx, qy, qz, qw;
+  float tr = (m00 + m11) + m22;
+  if (tr > 0.f) {
+    tr = sqrt_rn(tr + 1.0f);
+    qw = 0.5f * tr;
+    tr = div_rn(0.5f, tr);
+    qx = (m21 - m12) * tr;
+    qy = (m02 - m20) * tr;
+    qz = (m10 - m01) * tr;
+  } else {
+    int i = 0;
+    if (m11 > m00) i = 1;
+    if (m22 > (i == 0 ? m00 : m11)) i = 2;
+    if (i == 0) {          // (i, j, k) = (0, 1, 2)
+      tr = sqrt_rn(((m00 - m11) - m22) + 1.0f);
+      qx = 0.5f * tr; tr = div_rn(0.5f, tr);
+      qw = (m21 - m12) * tr; qy = (m10 + m01) * tr; qz = (m20 + m02) * tr;
+    } else if (i == 1) {   // (1, 2, 0)
+      tr = sqrt_rn(((m11 - m22) - m00) + 1.0f);
+      qy = 0.5f * tr; tr = div_rn(0.5f, tr);
+      qw = (m02 - m20) * tr; qz = (m21 + m12) * tr; qx = (m01 + m10) * tr;
+    } else {               // (2, 0, 1)
+      tr = sqrt_rn(((m22 - m00) - m11) + 1.0f);
+      qz = 0.5f * tr; tr = div_rn(0.5f, tr);
+      qw = (m10 - m01) * tr; qx = (m02 + m20) * tr; qy = (m12 + m21) * tr;
+    }
+  }
+  const float n = sqrt_rn((qx * qx + qy * qy) + (qz * qz + qw * qw));
+  q[0] = div_rn(qw, n); q[1] = div_rn(qx, n); q[2] = div_rn(qy, n); q[3] = div_rn(qz, n);
+  t[0] = T[3]; t[1] = T[7]; t[2] = T[11];
+}
+
+// Sophus::SE3f * point = so3 * p + translation; so3 * p = Eigen's Quaternion::_transformVector: uv = 2 (q.vec x p);
+// (p + w uv) + q.vec x uv
+__device__ __forceinline__ void icp_se3f_apply(const float* q, const float* t, float x, float y, float z, float& ox, float& oy, float& oz)
+{
+  const float w = q[0], a = q[1], b = q[2], c = q[3];
+  float ux = b * z - c * y, uy = c * x - a * z, uz = a * y - b * x;
+  ux = ux + ux; uy = uy + uy; uz = uz + uz;
+  const float cx = b * uz - c * uy, cy = c * ux - a * uz, cz = a * uy - b * ux;
+  ox = ((x + w * ux) + cx) + t[0];
+  oy = ((y + w * uy) + cy) + t[1];
+  oz = ((z + w * uz) + cz) + t[2];
+}
+
+// icpKernel (icp.cu:25-136) + the per-block part of the reduction: the body's own order of tests, Eigen's published
+// evaluation order for the 3-term reductions (t0 + (t1 + t2)) — see oracle/ref_shim/eigen_sophus_on_cpu.h for the list
 __global__ __launch_bounds__(ICP_BLOCK) void icp_terms_kernel(
     const float* __restrict__ live, const float* __restrict__ pred_v, const float* __restrict__ pred_n,
     const double* __restrict__ state, long long P, int H, int W, int pc, float fx, float fy, float px, float py,
@@ -65,9 +119,10 @@ __global__ __launch_bounds__(ICP_BLOCK) void icp_terms_kernel(
   const long long p = (long long)blockIdx.x * ICP_BLOCK + t;
   if (t == 0) s_any = 0;
   __syncthreads();
-  float T[12];
+  float T[12], q[4], tt[3];
 #pragma unroll
   for (int i = 0; i < 12; i++) T[i] = (float)state[12 * n + i];
+  icp_se3f_from_matrix(T, q, tt);
   float J[6], r = 0.f;
   bool ok = false;
   if (p < P) {
@@ -76,34 +131,38 @@ __global__ __launch_bounds__(ICP_BLOCK) void icp_terms_kernel(
     const float* lv0 = live + (long long)n * P * 3;
     const float border = 2.f, ray_norm_dot_threshold = 0.1f;
     const float pvx = pv[0], pvy = pv[1], pvz = pv[2];
-    if ((pvz >= znear) && !(pvz > zfar)) {
-      const float ux = ((T[0] * pvx + T[1] * pvy) + T[2] * pvz) + T[3];
-      const float uy = ((T[4] * pvx + T[5] * pvy) + T[6] * pvz) + T[7];
-      const float uz = ((T[8] * pvx + T[9] * pvy) + T[10] * pvz) + T[11];
-      const float projx = ux / uz * fx + px, projy = uy / uz * fy + py;
-      if ((projx == projx) && (projy == projy) && !(fabsf(projx) > 1e8f) && !(fabsf(projy) > 1e8f)) {
-        const int u = (int)(projx + 0.5f), v = (int)(projy + 0.5f);
-        if (!(((float)u <= border) || ((float)u >= (float)(W - 1) - border) || ((float)v <= border) || ((float)v >= (float)(H - 1) - border))) {
-          const float* lv = lv0 + 3 * ((long long)v * W + u);
-          const float lx = lv[0], ly = lv[1], ldepth = lv[2];
-          if ((ldepth >= znear) && !(ldepth > zfar)) {
-            const float nrm = sqrt_rn((ux * ux + uy * uy) + uz * uz);
-            const float rx = ux / nrm, ry = uy / nrm, rz = uz / nrm;
-            const float nx = pn[0], ny = pn[1], nz = pn[2];
-            const float dotrn = (rx * nx + ry * ny) + rz * nz;
-            if (-dotrn >= ray_norm_dot_threshold) {
-              const float ex = lx - ux, ey = ly - uy, ez = ldepth - uz;
-              const float error = (nx * ex + ny * ey) + nz * ez;
-              if (fabsf(error) <= max_error) {
-                const float w = 1.f / ldepth;
-                const float wx = w * nx, wy = w * ny, wz = w * nz;
-                J[0] = wx; J[1] = wy; J[2] = wz;
-                J[3] = wy * (-uz) + wz * uy;
-                J[4] = wx * uz + wz * (-ux);
-                J[5] = wx * (-uy) + wy * ux;
-                r = w * error;
-                ok = true;
-              }
+    if (!((pvz < znear) || pvz > zfar)) {                                       // :60 (a NaN passes, as in the body)
+      float ux, uy, uz;
+      icp_se3f_apply(q, tt, pvx, pvy, pvz, ux, uy, uz);                         // :67
+      // :69 Poly3CameraModel::project with k = 0: the distortion factor ((1 + 0 r2) + 0 r4) + 0 r6 is exactly 1 for finite r2
+      const float dhx = div_rn(ux, uz), dhy = div_rn(uy, uz);
+      const float r2 = dhx * dhx + dhy * dhy, r4 = r2 * r2, r6 = r4 * r2;
+      const float factor = ((1.f + 0.f * r2) + 0.f * r4) + 0.f * r6;
+      const float projx = (factor * dhx) * fx + px, projy = (factor * dhy) * fy + py;
+      const int u = (int)(projx + 0.5f), v = (int)(projy + 0.5f);               // :78-79 (v_cvt_i32_f32: NaN -> 0, saturating)
+      if (!(((float)u <= border) || ((float)u >= (float)(unsigned)(W - 1) - border) || ((float)v <= border) || ((float)v >= (float)(unsigned)(H - 1) - border))) {
+        const float* lv = lv0 + 3 * ((long long)v * W + u);
+        const float lx = lv[0], ly = lv[1], ldepth = lv[2];
+        if (!((ldepth < znear) || (ldepth > zfar))) {                           // :92
+          const float sq = ux * ux + (uy * uy + uz * uz);
+          float rx = ux, ry = uy, rz = uz;
+          if (sq > 0.f) { const float nrm = sqrt_rn(sq); rx = div_rn(ux, nrm); ry = div_rn(uy, nrm); rz = div_rn(uz, nrm); }   // :100
+          const float nx = pn[0], ny = pn[1], nz = pn[2];
+          const float dotrn = rx * nx + (ry * ny + rz * nz);
+          if (!(-dotrn < ray_norm_dot_threshold)) {                             // :104
+            const float ex = lx - ux, ey = ly - uy, ez = ldepth - uz;
+            const float error = nx * ex + (ny * ey + nz * ez);                  // :111
+            if (!(fabsf(error) > max_error)) {                                  // :115
+              const float w = div_rn(1.f, ldepth);
+              const float wx = w * nx, wy = w * ny, wz = w * nz;
+              J[0] = wx * 1.f + (wy * 0.f + wz * 0.f);
+              J[1] = wx * 0.f + (wy * 1.f + wz * 0.f);
+              J[2] = wx * 0.f + (wy * 0.f + wz * 1.f);
+              J[3] = wx * 0.f + (wy * (-uz) + wz * uy);
+              J[4] = wx * uz + (wy * 0.f + wz * (-ux));
+              J[5] = wx * (-uy) + (wy * ux + wz * 0.f);
+              r = w * error;
+              ok = true;
             }
           }
         }
@@ -448,21 +507,19 @@ __device__ float nm_energy(NmShared& sh, const double* x, const int* __restrict_
   const int t = threadIdx.x;
   __syncthreads();                       // x is complete, the previous tree is consumed
   if (t == 0) {
-    const double w = x[0], a = x[1], b = x[2], c = x[3];
-    const double n = ((w * w + a * a) + b * b) + c * c;
-    const double s = n > 0.0 ? 2.0 / n : 0.0;
-    const double R[9] = {1.0 - s * (b * b + c * c), s * (a * b - c * w), s * (a * c + b * w),
-                         s * (a * b + c * w), 1.0 - s * (a * a + c * c), s * (b * c - a * w),
-                         s * (a * c - b * w), s * (b * c + a * w), 1.0 - s * (a * a + b * b)};
-    for (int i = 0; i < 3; i++) {
-      for (int j = 0; j < 3; j++) sh.T[4 * i + j] = (float)R[3 * i + j];
-      sh.T[4 * i + 3] = (float)x[4 + i];
-    }
+    // the SE3f optEnergy builds (:2481-2484): Quaternionf(pose[0..3]) in f32, normalised by Sophus's constructor
+    // (coefficients / sqrt(squaredNorm), 4-term reduction over (x, y, z, w) in Eigen's unrolled order); sh.T = (q wxyz, t)
+    const float w = (float)x[0], a = (float)x[1], b = (float)x[2], c = (float)x[3];
+    const float n = sqrt_rn((a * a + b * b) + (c * c + w * w));
+    sh.T[0] = div_rn(w, n); sh.T[1] = div_rn(a, n); sh.T[2] = div_rn(b, n); sh.T[3] = div_rn(c, n);
+    sh.T[4] = (float)x[4]; sh.T[5] = (float)x[5]; sh.T[6] = (float)x[6];
   }
   __syncthreads();
-  float T[12];
+  float q[4], tt[3];
 #pragma unroll
-  for (int i = 0; i < 12; i++) T[i] = sh.T[i];
+  for (int i = 0; i < 4; i++) q[i] = sh.T[i];
+#pragma unroll
+  for (int i = 0; i < 3; i++) tt[i] = sh.T[4 + i];
   const int bw = sh.box[1] - sh.box[0] + 1, bh = sh.box[3] - sh.box[2] + 1;
   float acc = 0.f;
   int c = 0;
@@ -491,13 +548,12 @@ __device__ float nm_energy(NmShared& sh, const double* x, const int* __restrict_
     for (int u = 0; u < NB; u++) {
       if (!live_ok[u] || lab[u] != obj) continue;
       const float p0 = pvv[u][0], p1 = pvv[u][1], p2 = pvv[u][2];
-      const float qx = ((T[0] * p0 + T[1] * p1) + T[2] * p2) + T[3];
-      const float qy = ((T[4] * p0 + T[5] * p1) + T[6] * p2) + T[7];
-      const float qz = ((T[8] * p0 + T[9] * p1) + T[10] * p2) + T[11];
+      float qx, qy, qz;
+      icp_se3f_apply(q, tt, p0, p1, p2, qx, qy, qz);                      // T_co * point, :2505
       const float vx = lv[u][0], vy = lv[u][1], vz = lv[u][2];
       if (qx == qx && qy == qy && qz == qz && vz > znear && vz < zfar && qz > znear && qz < zfar) {
         const float ex = qx - vx, ey = qy - vy, ez = qz - vz;
-        acc = acc + sqrt_rn((ex * ex + ey * ey) + ez * ez);
+        acc = acc + sqrt_rn((ex * ex + ey * ey) + ez * ez);                 // :2517
         c++;
       }
     }

@@ -289,6 +289,49 @@ def icp_refine(live, pred_v, pred_n, K, depth_range=(0.25, 6.0), max_error=0.01,
     return upd, stats
 
 
+def icp_se3f(T):
+    """The content of the SE3f (unit quaternion wxyz f32 [4], translation f32 [3]) icp_refine hands to the per-pixel step
+    for an accumulated 3x4 transform T (f64)."""
+    T = np.ascontiguousarray(np.asarray(T, dtype=np.float64).reshape(12))
+    q, t = np.empty(4, np.float32), np.empty(3, np.float32)
+    lib().oracle_icp_se3f(_p(T), _p(q), _p(t))
+    return q, t
+
+
+def icp_terms(live, pred_v, pred_n, q, t, K, depth_range=(0.25, 6.0), max_error=0.01):
+    """oracle_icp_terms: the per-pixel records of ONE icpKernel launch at the SE3f (q wxyz, t) ->
+    (J f32 [H,W,6], r f32 [H,W], reason uint8 [H,W]: 0 contributes, 1 pred depth, 2 border, 3 live depth, 4 ray/normal, 5 error)"""
+    live, pred_v, pred_n, q, t = _f32(live), _f32(pred_v), _f32(pred_n), _f32(q), _f32(t)
+    H, W, pc = pred_v.shape
+    J, r, why = np.empty((H, W, 6), np.float32), np.empty((H, W), np.float32), np.empty((H, W), np.uint8)
+    rc = lib().oracle_icp_terms(_p(live), _p(pred_v), _p(pred_n), H, W, pc, _p(q), _p(t), c_float(K[0, 0]), c_float(K[1, 1]),
+                                c_float(K[0, 2]), c_float(K[1, 2]), c_float(depth_range[0]), c_float(depth_range[1]),
+                                c_float(max_error), _p(J), _p(r), _p(why))
+    assert rc == 0
+    return J, r, why
+
+
+def icp_energy_terms(live, pred_v, x, depth_range=(0.25, 6.0)):
+    """per-pixel term of optEnergy at the optimiser's point x f64 [7] -> (dist f32 [H,W], valid uint8 [H,W])"""
+    live, pred_v = _f32(live), _f32(pred_v)
+    H, W, pc = pred_v.shape
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    d, v = np.empty((H, W), np.float32), np.empty((H, W), np.uint8)
+    lib().oracle_icp_energy_terms(_p(live), _p(pred_v), pc, H, W, c_float(depth_range[0]), c_float(depth_range[1]), _p(x), _p(d), _p(v))
+    return d, v
+
+
+def icp_energy(label, live, pred_v, obj_id, x, depth_range=(0.25, 6.0)):
+    """the polish objective (canonical parallel sum) over the pixels labelled obj_id"""
+    label, live, pred_v = _i32(label), _f32(live), _f32(pred_v)
+    H, W, pc = pred_v.shape
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    L = lib()
+    L.oracle_icp_energy.restype = ctypes.c_double
+    return float(L.oracle_icp_energy(_p(label), _p(live), _p(pred_v), pc, H, W, int(obj_id), c_float(depth_range[0]),
+                                     c_float(depth_range[1]), _p(x)))
+
+
 def render_mesh(vertices, normals, faces, poses, K, H, W, depth_range=(0.25, 6.0), model_index=0, want=("vertices", "normals", "canonical")):
     """oracle_render_mesh: poses [N,3,4] -> dict of "vertices" / "normals" f32 [N,H,W,4], "canonical" f32 [N,H,W,3] (NaN = no surface)"""
     v, f = _f32(vertices).reshape(-1, 3), _i32(faces).reshape(-1, 3)

@@ -212,3 +212,150 @@ def test_hough_voting_matches_reference_kernels_at_the_real_config(ref, vote_thr
     for name, w, g in zip(("top_box", "top_pose", "top_target", "top_weight", "top_domain", "num_rois"), want, got[:6]):
         bits_equal(w, g, name)
     bits_equal(whs, got[6], "hough_space (every cell of the 480x640 space)")
+
+
+# ---- pose refinement: df::icpKernel and optEnergy, compiled unchanged ---------------------------------
+# oracle/ref_shim/ref_icp_driver.cpp: icp.cu:20-137, poly3.h:36-88, cameraModel.h:72-82, synthesize.cpp:2476-2526 against
+# eigen_sophus_on_cpu.h (the Eigen / Sophus names in the evaluation order those libraries publish). The colour the body
+# hands to its PixelDebugger is its own exit reason, pixel by pixel.
+ICP_COLOURS = {(255, 255, 0, 255): 1, (0, 0, 255, 255): 2, (255, 0, 255, 255): 3, (255, 0, 0, 255): 4, (0, 255, 0, 255): 5}
+
+
+def ref_icp_terms(ref, live, pv, pn, q, t, K, depth_range, max_error):
+    live, pv, pn = (np.ascontiguousarray(a, F) for a in (live, pv, pn))
+    q, t = np.ascontiguousarray(q, F), np.ascontiguousarray(t, F)
+    H, W, pc = pv.shape
+    J, r, col = np.empty((H, W, 6), F), np.empty((H, W), F), np.empty((H, W, 4), np.uint8)
+    rc = ref.ref_icp_kernel(p(live), p(pv), p(pn), H, W, pc, p(q), p(t), c_float(K[0, 0]), c_float(K[1, 1]), c_float(K[0, 2]),
+                            c_float(K[1, 2]), c_float(depth_range[0]), c_float(depth_range[1]), c_float(max_error), p(J), p(r), p(col))
+    assert rc == 0
+    why = np.zeros((H, W), np.uint8)
+    grey = (col[..., 0] == col[..., 1]) & (col[..., 1] == col[..., 2]) & (col[..., 3] == 255)
+    for c, code in ICP_COLOURS.items():
+        m = (col == np.asarray(c, np.uint8)).all(-1)
+        assert not (m & grey & (code != 0)).any() or c[0] == c[1] == c[2]
+        why[m] = code
+    known = grey.copy()
+    for c in ICP_COLOURS:
+        known |= (col == np.asarray(c, np.uint8)).all(-1)
+    assert known.all(), "a pixel left the kernel body without reporting a reason"
+    return J, r, why, col
+
+
+def _icp_cases():
+    """(name, live [H,W,3], pred_v, pred_n [H,W,pc], K, list of accumulated transforms) — the box scenes of tests/test_icp.py
+    (analytic ray-cast maps, pc = 3), an ellipsoid through the rasteriser (pc = 4, NaN background), a demo depth frame."""
+    import icp_scene as sc
+    out = []
+    H, W = 96, 128
+    K = np.array([[110.0, 0, 63.5], [0, 110.0, 47.5], [0, 0, 1]])
+    T_true = sc.pose(sc.rot([0.3, 1.0, 0.2], 0.5), [0.02, -0.01, 0.8])
+    T_init = sc.compose(sc.pose(sc.rot([1, 0.2, -0.4], 0.05), [0.006, -0.004, 0.012]), T_true)
+    depth, label, pv, pn = sc.scene(T_true, T_init, (0.12, 0.09, 0.07), K, H, W, obj_id=3)
+    live = oracle.icp_backproject(depth, label, 3, K, 10000.0)
+    steps = [sc.pose(np.eye(3), [0, 0, 0]), sc.pose(sc.rot([0.2, -1, 0.1], 0.03), [-0.004, 0.003, -0.01]),
+             sc.pose(sc.rot([1, 1, 1], 2.9), [0.01, 0.0, 0.02]),          # a large rotation: the non-trace branch of matrix -> quaternion
+             sc.pose(sc.rot([0, 0, 1], 3.1), [0.0, 0.0, 0.0])]
+    out.append(("box", live, pv, pn, K, steps))
+    # ellipsoid through the triangle rasteriser: 4-channel maps with NaN background (what solveICP feeds df::icp)
+    v, n, f = sc.icosphere(1.0, 3, scale=(0.10, 0.07, 0.05))
+    T_true = sc.pose(sc.rot([0.1, 0.9, -0.3], 0.8), [-0.03, 0.02, 0.7])
+    T_init = sc.compose(sc.pose(sc.rot([0.3, -0.2, 1], 0.04), [0.004, 0.002, -0.008]), T_true)
+    maps_true = oracle.render_mesh(v, n, f, T_true[None], K, H, W, (0.25, 6.0), want=("vertices",))
+    z = maps_true["vertices"][0][..., 2]
+    hit = np.isfinite(z)
+    depth = np.clip(np.round(np.where(hit, z, 0.0).astype(np.float64) * 10000.0), 0, 65535).astype(np.uint16)
+    label = np.where(hit, 5, 0).astype(np.int32)
+    live = oracle.icp_backproject(depth, label, 5, K, 10000.0)
+    maps = oracle.render_mesh(v, n, f, T_init[None], K, H, W, (0.25, 6.0), want=("vertices", "normals"))
+    out.append(("ellipsoid", live, maps["vertices"][0], maps["normals"][0], K, steps[:2]))
+    # a real depth frame (data/demo_images, committed as tests/golden/demo_frames.npz): the scene's own geometry as the
+    # predicted maps (vertices = the frame's back-projection displaced by a small pose, normals from depth differences)
+    gold = os.path.join(ROOT, "tests", "golden", "demo_frames.npz")
+    if os.path.exists(gold):
+        z = np.load(gold)
+        dkey = [k for k in z.files if "depth" in k][0]
+        d16 = np.asarray(z[dkey])
+        d16 = d16[0] if d16.ndim == 3 else d16
+        Kd = config.DEMO_INTRINSICS.astype(np.float64)
+        sub = np.ascontiguousarray(d16[::4, ::4])
+        Ks = Kd.copy(); Ks[:2] /= 4.0
+        live = oracle.icp_backproject(sub, None, 0, Ks, 10000.0)
+        dzdx = np.gradient(live[..., 2].astype(np.float64), axis=1); dzdy = np.gradient(live[..., 2].astype(np.float64), axis=0)
+        nrm = np.stack([dzdx * Ks[0, 0], dzdy * Ks[1, 1], -np.ones_like(dzdx)], -1)
+        nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+        Rs = sc.rot([0.5, 1, 0.1], 0.01)
+        pv = (live.astype(np.float64) @ Rs.T + np.array([0.002, -0.001, 0.004])).astype(F)
+        pv[live[..., 2] == 0] = np.nan
+        out.append(("demo_depth", live, pv, nrm.astype(F), Ks, steps[:2]))
+    return out
+
+
+@pytest.mark.parametrize("max_error", [0.01, 0.004])
+def test_icp_kernel_body_matches_oracle_per_pixel(ref, max_error):
+    """Every pixel's Jacobian row, residual and exit reason of df::icpKernel (the reference's body) against
+    oracle_icp_terms, bit for bit — box / ellipsoid / real-depth scenes, 3- and 4-channel predicted maps, NaN background,
+    identity and accumulated poses (both branches of the matrix -> quaternion step)."""
+    total, contributing, seen = 0, 0, set()
+    for name, live, pv, pn, K, steps in _icp_cases():
+        for T in steps:
+            q, t = oracle.icp_se3f(T)
+            assert abs(float(np.dot(q.astype(np.float64), q.astype(np.float64))) - 1.0) < 1e-6
+            Jr, rr, wr, col = ref_icp_terms(ref, live, pv, pn, q, t, K, (0.25, 6.0), max_error)
+            Jo, ro, wo = oracle.icp_terms(live, pv, pn, q, t, K, (0.25, 6.0), max_error)
+            assert np.array_equal(wr, wo), "%s: exit reasons differ at %d pixels" % (name, (wr != wo).sum())
+            ok = wo == 0
+            bits_equal(Jr[ok], Jo[ok], name + " J")
+            bits_equal(rr[ok], ro[ok], name + " r")
+            assert not Jr[~ok].any() and not rr[~ok].any()          # the body zeroes the record before its tests
+            total += wo.size
+            contributing += int(ok.sum())
+            seen |= set(np.unique(wo).tolist())
+    assert contributing > 3000 and seen >= {0, 1, 2, 3, 4, 5}, (contributing, seen)
+
+
+def test_se3f_content_is_the_transform_it_was_built_from():
+    """oracle_icp_se3f (matrix -> unit quaternion by Eigen's published branches + Sophus's normalisation, f32): applying
+    the quaternion reproduces the matrix to f32 rounding, in the trace branch and in each largest-diagonal branch."""
+    import icp_scene as sc
+    rng = np.random.default_rng(5)
+    cases = [sc.rot(rng.standard_normal(3), a) for a in (0.0, 1e-4, 0.3, 1.5, 2.5, 3.1)]
+    cases += [sc.rot(ax, np.pi - 1e-3) for ax in ([1, 0.01, 0.02], [0.01, 1, 0.02], [0.02, 0.01, 1])]
+    for R in cases:
+        T = sc.pose(R, rng.standard_normal(3))
+        q, t = oracle.icp_se3f(T)
+        Rq = sc.quat2mat(q.astype(np.float64))
+        assert np.abs(Rq - R).max() < 5e-7 and np.array_equal(t, T[:, 3].astype(F))
+
+
+def test_opt_energy_body_matches_oracle_per_pixel(ref):
+    """optEnergy (synthesize.cpp:2476-2526, the reference's body) against the oracle's polish objective: the reference
+    is called on ONE pixel index at a time — its return value is then that pixel's distance term (or 0 when the pixel
+    does not count) — and must equal oracle_icp_energy_terms bit for bit for every pixel of the object; on the whole pixel
+    list the two energies differ only by the order of the f32 sum (the reference adds sequentially, the canonical form is
+    the parallel tree the kernel uses), i.e. by rounding."""
+    ref.ref_opt_energy.restype = ctypes.c_double
+    rng = np.random.default_rng(11)
+    checked = 0
+    for name, live, pv, pn, K, _ in _icp_cases():
+        if pv.shape[-1] == 3:
+            pv = np.concatenate([pv, np.ones(pv.shape[:2] + (1,), F)], -1)
+        pv = np.ascontiguousarray(pv, F)
+        H, W = pv.shape[:2]
+        label = (live[..., 2] > 0).astype(np.int32)
+        idx = np.flatnonzero(label.reshape(-1)).astype(np.int32)
+        for x in (np.array([1.0, 0, 0, 0, 0, 0, 0]), np.concatenate([[1.0], rng.uniform(-0.1, 0.1, 3), rng.uniform(-0.01, 0.01, 2), [rng.uniform(-0.1, 0.1)]]),
+                  np.array([0.93, 0.08, -0.1, 0.05, 0.01, -0.01, 0.09])):
+            dist, valid = oracle.icp_energy_terms(live, pv, x)
+            sample = idx if idx.size <= 4000 else idx[:: idx.size // 4000 + 1]
+            for i in sample:
+                one = np.array([i], np.int32)
+                e = ref.ref_opt_energy(p(np.ascontiguousarray(x)), p(one), 1, p(np.ascontiguousarray(live, F)), p(pv), H, W, c_float(0.25), c_float(6.0))
+                want = dist.reshape(-1)[i] if valid.reshape(-1)[i] else F(0)
+                assert np.float32(e).view(np.uint32) == np.float32(want).view(np.uint32), (name, int(i), e, want)
+                checked += 1
+            e_all = ref.ref_opt_energy(p(np.ascontiguousarray(x)), p(idx), int(idx.size), p(np.ascontiguousarray(live, F)), p(pv), H, W, c_float(0.25), c_float(6.0))
+            mine = oracle.icp_energy(label, live, pv, 1, x)
+            assert int(valid.reshape(-1)[idx].sum()) > 100
+            assert abs(e_all - mine) <= 2e-5 * max(abs(e_all), 1e-6), (name, e_all, mine)
+    assert checked > 5000
