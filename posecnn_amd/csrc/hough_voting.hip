@@ -333,6 +333,14 @@ __global__ __launch_bounds__(256) void hv_scatter_kernel(
 
   const float* md = meta + (size_t)n * num_meta;
   const float fx = md[0], px = md[2], fy = md[4], py = md[5];
+  // Pass 1: ranks. The pixels that become records (every skip-th of a class, ~1 lane in 10) are only LISTED here —
+  // (pixel | class << 24, rank) in LDS — and turned into records by pass 2 with every lane busy: the record arithmetic
+  // (bilinear taps, the f64 exp, project_box, the cone's f64 roots) is ~2000 cycles per wave pass, and run in place it
+  // was executed 32 times per block at a tenth of the lanes (hv_scatter 78 us of the sequence).
+  __shared__ int s_list[HV_CHUNK][2];
+  __shared__ int s_nlist;
+  if (tid == 0) s_nlist = 0;
+  __syncthreads();
 #pragma unroll
   for (int r = 0; r < 8; r++) {
     int l = lab[r];
@@ -347,10 +355,28 @@ __global__ __launch_bounds__(256) void hv_scatter_kernel(
       if (lane == c0) run += __popcll(m);
       mask &= ~m;
     }
-    if (l > 0) {
-      int ro = s_recoff[l];
-      if (ro >= 0 && (my_rank % skip) == 0) {
-        int i = wbase + r * 64 + lane;
+    const bool take = l > 0 && s_recoff[l] >= 0 && (my_rank % skip) == 0;
+    const unsigned long long tm = __ballot(take);
+    if (tm) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&s_nlist, __popcll(tm));
+      base = __shfl(base, 0);
+      if (take) {
+        const int slot = base + __popcll(tm & lanemask_lt());
+        s_list[slot][0] = (wbase + r * 64 + lane) | (l << 24);    // H * W < 2^24 (validate_common), classes < 64
+        s_list[slot][1] = my_rank;
+      }
+    }
+  }
+  __syncthreads();
+  // Pass 2: one record per thread (the list order is arbitrary: a record's place is its rank)
+  const int nlist = s_nlist;
+  for (int j = tid; j < nlist; j += 256) {
+    const int packed = s_list[j][0], my_rank = s_list[j][1];
+    const int i = packed & 0xffffff, l = packed >> 24;
+    const int ro = s_recoff[l];
+    {
+      {
         int x = i % W, y = i / W;
         float u, v, logd;
         if (vs.full) {
@@ -729,7 +755,7 @@ __global__ __launch_bounds__(256) void hv_select_kernel(
   // the voters are compacted IN PIXEL ORDER into LDS and summed by one lane, because the reference
   // accumulates `distance += d` sequentially and float addition does not reassociate.
   constexpr int SEL_CAP = 2048;
-  __shared__ float s_d[SEL_CAP];
+  __shared__ __attribute__((aligned(16))) float s_d[SEL_CAP];
   __shared__ int s_wc[4];
   __shared__ float s_res[4];
   __shared__ float s_bw[4], s_bh[4];
@@ -760,8 +786,20 @@ __global__ __launch_bounds__(256) void hv_select_kernel(
     fill += s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
     __syncthreads();
     if (fill > SEL_CAP - 256 || b0 + 256 >= m) {
-      if (tid == 0)
-        for (int i = 0; i < fill; i++) sumd += s_d[i];
+      if (tid == 0) {
+        // the ordered sum, 16 depths per trip: four independent 128-bit LDS reads, then the 16 additions in pixel order
+        // (one ds_read_b32 + wait per addend made this loop ~45 of the launch's 88 us)
+        int i = 0;
+        for (; i + 16 <= fill; i += 16) {
+          const float4 q0 = *reinterpret_cast<const float4*>(&s_d[i]), q1 = *reinterpret_cast<const float4*>(&s_d[i + 4]);
+          const float4 q2 = *reinterpret_cast<const float4*>(&s_d[i + 8]), q3 = *reinterpret_cast<const float4*>(&s_d[i + 12]);
+          sumd += q0.x; sumd += q0.y; sumd += q0.z; sumd += q0.w;
+          sumd += q1.x; sumd += q1.y; sumd += q1.z; sumd += q1.w;
+          sumd += q2.x; sumd += q2.y; sumd += q2.z; sumd += q2.w;
+          sumd += q3.x; sumd += q3.y; sumd += q3.z; sumd += q3.w;
+        }
+        for (; i < fill; i++) sumd += s_d[i];
+      }
       total += fill;
       fill = 0;
       __syncthreads();
@@ -1031,8 +1069,12 @@ __device__ float compute_box_overlap(int cls, const float* __restrict__ extents,
   return box_iou(box, box_gt);
 }
 
-// compute_rois_kernel (:386-576). One thread per (image, maximum), B * cap threads in all.
-__global__ __launch_bounds__(128) void hv_emit_kernel(
+// compute_rois_kernel (:386-576). One WAVE per (image, maximum) (round 4; one thread per maximum before: ~210 dependent
+// scattered stores and a serial walk over the ground-truth rows per thread, 39 us for two waves' worth of work):
+// lane j < 9 writes row j of the maximum (the box, or its j-th jitter) and that row's pose / domain entries, the lanes
+// walk the ground-truth rows 64 at a time (the FIRST matching row in ascending order wins, as in the serial loop),
+// lanes 0..35 write the 9 x 4 target / weight entries. Same expressions per value, so the same bits.
+__global__ __launch_bounds__(256) void hv_emit_kernel(
     const HvMax* __restrict__ maxima, const int* __restrict__ nmax_g,
     const float* __restrict__ extents, const float* __restrict__ meta,
     const float* __restrict__ gt, float* __restrict__ top_box, float* __restrict__ top_pose,
@@ -1040,34 +1082,37 @@ __global__ __launch_bounds__(128) void hv_emit_kernel(
     int* __restrict__ num_rois, int B, int W, int C, int cap, int capmax, int num_meta, int num_gt,
     int is_train)
 {
-  extern __shared__ int s_off[];  // [B]: rows of the images in front (every block recomputes it)
-  // (batch, class) of the first HV_GT_LDS ground-truth rows: the target search below walks all num_gt rows per thread —
-  // 80 trips of two global loads each were 40 of this launch's 52 us
-  constexpr int HV_GT_LDS = 512;
-  __shared__ int s_gtkey[HV_GT_LDS][2];
-  if (is_train)
-    for (int i = threadIdx.x; i < min(num_gt, HV_GT_LDS); i += 128) {
-      s_gtkey[i][0] = (int)gt[i * 13 + 0];
-      s_gtkey[i][1] = (int)gt[i * 13 + 1];
-    }
-  if (threadIdx.x == 0) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && wave == 0) {        // the row count (every launch, also with cap == 0)
     int acc = 0;
     if (cap > 0)
-      for (int n = 0; n < B; n++) { s_off[n] = acc; acc += nmax_g[n]; }
-    if (blockIdx.x == 0) {
+      for (int b0 = 0; b0 < B; b0 += 64) {
+        int v = b0 + lane < B ? nmax_g[b0 + lane] : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        acc += v;
+      }
+    if (lane == 0) {
       const int rows = acc * (is_train ? 9 : 1);
       num_rois[0] = rows == 0 ? 1 : rows;  // dummy row, hough_voting_gpu_op.cc:381-383
       num_rois[1] = rows;
     }
   }
-  __syncthreads();
   if (cap <= 0) return;
-  const int tid = blockIdx.x * 128 + threadIdx.x;
-  const int n = tid / cap, k = tid - n * cap;
+  const int item = blockIdx.x * 4 + wave;
+  const int n = item / cap, k = item - n * cap;
   if (n >= B || k >= nmax_g[n]) return;
+  // rows of the images in front
+  int off_n = 0;
+  for (int b0 = 0; b0 < n; b0 += 64) {
+    int v = b0 + lane < n ? nmax_g[b0 + lane] : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    off_n += v;
+  }
   const HvMax e = maxima[(size_t)n * capmax + k];
   const int rows_per = is_train ? 9 : 1;
-  const int roi_index = (s_off[n] + k) * rows_per;
+  const int roi_index = (off_n + k) * rows_per;
   const float* md = meta + (size_t)n * num_meta;
   const float fx = md[0], px = md[2], fy = md[4], py = md[5];
   const int x = e.idx % W, y = e.idx / W;
@@ -1076,59 +1121,59 @@ __global__ __launch_bounds__(128) void hv_emit_kernel(
   const float ry = div_rn((float)y - py, fy);
   const float scale = 0.05f;
   const double kk = 0.5 + (double)scale;
-  float* b = top_box + (size_t)roi_index * 7;
-  b[0] = (float)n;
-  b[1] = (float)cls;
-  b[2] = (float)((double)x - (double)e.bw2 * kk);
-  b[3] = (float)((double)y - (double)e.bh2 * kk);
-  b[4] = (float)((double)x + (double)e.bw2 * kk);
-  b[5] = (float)((double)y + (double)e.bh2 * kk);
-  b[6] = e.votes;
-  for (int i = 0; i < rows_per; i++) {
-    float* p = top_pose + (size_t)(roi_index + i) * 7;
+  float box[4];
+  box[0] = (float)((double)x - (double)e.bw2 * kk);
+  box[1] = (float)((double)y - (double)e.bh2 * kk);
+  box[2] = (float)((double)x + (double)e.bw2 * kk);
+  box[3] = (float)((double)y + (double)e.bh2 * kk);
+  if (lane < rows_per) {
+    // row `lane`: 0 = the box itself, 1..8 = its jitters (:540-574)
+    const float x1 = box[0], y1 = box[1], x2 = box[2], y2 = box[3];
+    const float ww = x2 - x1, hh = y2 - y1;
+    float r2 = x1, r3 = y1, r4 = x2, r5 = y2;
+    if (lane > 0) {
+      const int j = lane - 1;
+      const int sxj = (j == 4 || j == 6) ? 0 : ((j == 1 || j == 3 || j == 7) ? 1 : -1);     // {-1,+1,-1,+1, 0,-1, 0,+1}
+      const int syj = (j == 5 || j == 7) ? 0 : ((j == 2 || j == 3 || j == 6) ? 1 : -1);     // {-1,-1,+1,+1,-1, 0,+1, 0}
+      if (sxj < 0) r2 = (float)((double)x1 - 0.05 * (double)ww);
+      if (sxj > 0) r2 = (float)((double)x1 + 0.05 * (double)ww);
+      if (syj < 0) r3 = (float)((double)y1 - 0.05 * (double)hh);
+      if (syj > 0) r3 = (float)((double)y1 + 0.05 * (double)hh);
+      r4 = r2 + ww;
+      r5 = r3 + hh;
+    }
+    float* r = top_box + (size_t)(roi_index + lane) * 7;
+    r[0] = (float)n;
+    r[1] = (float)cls;
+    r[2] = r2;
+    r[3] = r3;
+    r[4] = r4;
+    r[5] = r5;
+    r[6] = e.votes;
+    float* p = top_pose + (size_t)(roi_index + lane) * 7;
     p[0] = 1; p[1] = 0; p[2] = 0; p[3] = 0;
     p[4] = rx * e.dist;
     p[5] = ry * e.dist;
     p[6] = e.dist;
-    if (is_train) top_domain[roi_index + i] = (num_gt == 0) ? 1 : 0;
+    if (is_train) top_domain[roi_index + lane] = (num_gt == 0) ? 1 : 0;
   }
   if (!is_train) return;
-
-  for (int i = 0; i < num_gt; i++) {
-    int gt_batch, gt_id;
-    if (i < HV_GT_LDS) { gt_batch = s_gtkey[i][0]; gt_id = s_gtkey[i][1]; }
-    else { gt_batch = (int)gt[i * 13 + 0]; gt_id = (int)gt[i * 13 + 1]; }
-    if (cls == gt_id && n == gt_batch) {
-      float overlap = compute_box_overlap(cls, extents, fx, fy, px, py, gt + i * 13, b + 2);
-      if ((double)overlap > 0.2) {
-        for (int j = 0; j < 9; j++)
-          for (int q = 0; q < 4; q++) {
-            top_target[(size_t)(roi_index + j) * 4 * C + 4 * cls + q] = gt[i * 13 + 6 + q];
-            top_weight[(size_t)(roi_index + j) * 4 * C + 4 * cls + q] = 1.f;
-          }
-        break;
-      }
+  // the first ground-truth row (ascending) of this image and class whose projected box overlaps by more than 0.2 (:440-466)
+  int found = -1;
+  for (int i0 = 0; i0 < num_gt && found < 0; i0 += 64) {
+    const int i = i0 + lane;
+    bool hit = false;
+    if (i < num_gt && cls == (int)gt[i * 13 + 1] && n == (int)gt[i * 13 + 0]) {
+      const float overlap = compute_box_overlap(cls, extents, fx, fy, px, py, gt + i * 13, box);
+      hit = (double)overlap > 0.2;
     }
+    const unsigned long long hm = __ballot(hit);
+    if (hm) found = i0 + (__ffsll((long long)hm) - 1);
   }
-  const float x1 = b[2], y1 = b[3], x2 = b[4], y2 = b[5];
-  const float ww = x2 - x1, hh = y2 - y1;
-  const int sx[8] = {-1, +1, -1, +1, 0, -1, 0, +1};
-  const int sy[8] = {-1, -1, +1, +1, -1, 0, +1, 0};
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    float* r = top_box + (size_t)(roi_index + 1 + j) * 7;
-    r[0] = (float)n;
-    r[1] = (float)cls;
-    float r2 = x1, r3 = y1;
-    if (sx[j] < 0) r2 = (float)((double)x1 - 0.05 * (double)ww);
-    if (sx[j] > 0) r2 = (float)((double)x1 + 0.05 * (double)ww);
-    if (sy[j] < 0) r3 = (float)((double)y1 - 0.05 * (double)hh);
-    if (sy[j] > 0) r3 = (float)((double)y1 + 0.05 * (double)hh);
-    r[2] = r2;
-    r[3] = r3;
-    r[4] = r2 + ww;
-    r[5] = r3 + hh;
-    r[6] = e.votes;
+  if (found >= 0 && lane < 36) {
+    const int j = lane >> 2, q = lane & 3;
+    top_target[(size_t)(roi_index + j) * 4 * C + 4 * cls + q] = gt[found * 13 + 6 + q];
+    top_weight[(size_t)(roi_index + j) * 4 * C + 4 * cls + q] = 1.f;
   }
 }
 
@@ -1264,9 +1309,9 @@ int hough_fwd_impl(const int32_t* label, const HvVertexSrc vs,
     PCNN_LAUNCH(hv_gather_kernel, dim3(B), dim3(256), 0, stream, nslots, chunkcnt,
                        chunkcand, maxima, nmax, HW, L.nlm, L.cap, L.capmax);
   }
-  const int emit_threads = B * (L.cap > 0 ? L.cap : 0);
-  PCNN_LAUNCH(hv_emit_kernel, dim3(emit_threads > 128 ? (emit_threads + 127) / 128 : 1), dim3(128),
-              sizeof(int) * (size_t)B, stream, maxima, nmax, extents, meta,
+  const int emit_items = B * (L.cap > 0 ? L.cap : 0);      // one wave per (image, maximum slot), four to a workgroup
+  PCNN_LAUNCH(hv_emit_kernel, dim3(emit_items > 4 ? (emit_items + 3) / 4 : 1), dim3(256),
+              0, stream, maxima, nmax, extents, meta,
                      gt, top_box, top_pose, top_target, top_weight, top_domain, num_rois, B, W, C,
                      L.cap, L.capmax, num_meta, num_gt, is_train);
   return check_launch("hough_voting_fwd");

@@ -42,6 +42,8 @@
 //  * `groups`: G independent filter sets over G equal slices of the tile range — the colour and the
 //    depth tower of an RGB-D network (identical shapes, different weights) run as ONE launch with
 //    twice the workgroups.
+#include <cstdlib>
+
 #include "pcnn_device.h"
 
 namespace {
@@ -89,11 +91,18 @@ __device__ __forceinline__ void at6_col(const float* m, float* t)
 // 2: 64 x 64, 8 waves, one workgroup per CU (kept for the ablation harness; see the launcher for the numbers).
 // ABL (tools/wino_ablate.hip only; the library instantiates 0): leave one ingredient of the K loop out to
 // see what it costs — 1 no barrier, 2 no DMA, 4 no LDS reads, 8 no MFMAs, 16 no column fold, 32 no epilogue.
-template <int POOL, int WR, int ABL = 0>
+// ZC (round 4): the first MFMA pair into a plane's accumulators takes C = 0 as an inline constant instead of reading
+// registers that a v_mov zeroed after every column fold (48 VALU per fold; on the Cin = 64 layers a fold comes every 6
+// stages and VALU time is paid in full next to the MFMAs). Same bits: 0 + a b either way.
+// `mode` bit 0: XCD x owns channel block x (launches with ncb == 8 whose filter bank outweighs their transformed input,
+// i.e. the deep layers of a single frame: every XCD then streams ITS eighth of U once instead of all of U);
+// bits 1-2: wave priority by the workgroup's slot on the CU (1: odd slot high, 2: even slot high) — of the two
+// workgroups sharing a CU one then runs as if alone and the other fills the matrix pipe's gaps.
+template <int POOL, int WR, int ABL = 0, int ZC = 1>
 __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
     const float* __restrict__ v, const float* __restrict__ ut, const float* __restrict__ bias,
     float* __restrict__ y, float* __restrict__ ypool, int H, int W, int Cin, int Cout, int Ht, int Wt,
-    long long T, long long tiles_per_group, int relu, int nbt, int ncb, int ksplit, long long ysplit_stride)
+    long long T, long long tiles_per_group, int relu, int nbt, int ncb, int ksplit, long long ysplit_stride, int mode)
 {
   constexpr int BT = 32 * WR, NW = 4 * WR, NT = 256 * WR;
   constexpr int RING = WM_NBUF * (BT + 64) * WM_LD, STAGE2 = 2 * BT * 4 * 64;
@@ -104,9 +113,16 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
   // XCD-aware block map: XCD x = blockIdx % 8 takes tile blocks tb == x (mod 8); on an XCD the
   // channel blocks of a tile block are consecutive
   const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
-  const int cb = q % ncb;
-  const int tb = (q / ncb) * 8 + x;
+  const bool cbmajor = (mode & 1) != 0;          // (ncb == 8, checked by the launcher)
+  const int cb = cbmajor ? x : q % ncb;
+  const int tb = cbmajor ? q : (q / ncb) * 8 + x;
   if (tb >= nbt) return;
+  if (mode & 6) {
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    const unsigned slot = (hwid >> 16) & 1u;     // TG_ID: the workgroup's slot on this CU
+    if (slot == ((mode >> 1) & 1u)) asm volatile("s_setprio 3"); else asm volatile("s_setprio 0");
+  }
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: everything derived from it (LDS bases, M0) stays on the SALU
@@ -236,6 +252,17 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
   }
 #define WM_MFMA(SA0, SA1, SB, ACC)                                                                    \
   WM_MFMA1(SA0, SA1, SB, 0, ACC) WM_MFMA1(SA0, SA1, SB, 1, ACC)
+  /* the same K group, but the first pair starts the accumulators from the constant 0 (first MFMAs of a plane) */
+#define WM_MFMA1_Z(SA0, SA1, SB, G, ACC)                                                              \
+  if constexpr (ABL & 8) { asm volatile("" :: "v"(SA0[G]), "v"(SA1[G]), "v"(SB[G])); } else {         \
+    const v4f z_ = (v4f){0.f, 0.f, 0.f, 0.f};                                                         \
+    ACC[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(SA0[G][0], SB[G][0], z_, 0, 0, 0);                  \
+    ACC[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(SA1[G][0], SB[G][0], z_, 0, 0, 0);                  \
+    _Pragma("unroll") for (int i_ = 1; i_ < 4; i_++) {                                                \
+      ACC[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(SA0[G][i_], SB[G][i_], ACC[0], 0, 0, 0);          \
+      ACC[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(SA1[G][i_], SB[G][i_], ACC[1], 0, 0, 0);          \
+    }                                                                                                 \
+  }
   // column NU of the transform domain is complete: t = A^T M[:, NU]; Y[a][e] += t[a] * A[NU][e]
   // with A[NU][:] = (1,0,0,0) (1,1,1,1) (1,-1,1,-1) (1,2,4,8) (1,-2,4,-8) (0,0,0,1); accumulators recycled
 #define WM_FOLD(NU)                                                                                   \
@@ -257,7 +284,9 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
           yo[b_][i_][4 * a_ + 3] = __builtin_fmaf(t_[a_], c3, yo[b_][i_][4 * a_ + 3]);               \
         }                                                                                             \
       }                                                                                               \
-    _Pragma("unroll") for (int x_ = 0; x_ < 6; x_++) acc[x_][0] = acc[x_][1] = (v4f){0.f, 0.f, 0.f, 0.f}; \
+    if constexpr (!ZC) {                                                                              \
+      _Pragma("unroll") for (int x_ = 0; x_ < 6; x_++) acc[x_][0] = acc[x_][1] = (v4f){0.f, 0.f, 0.f, 0.f}; \
+    }                                                                                                 \
   }
 
   // One stage on accumulator set XI (XP = the set of the stage before when that was another plane):
@@ -283,7 +312,8 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
     __builtin_amdgcn_sched_barrier(0);                                                                \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the X reads (issued 16 MFMAs ago) */        \
     __builtin_amdgcn_sched_barrier(0);                                                                \
-    WM_MFMA1(xa0, xa1, xb, 0, acc[XI]);                                                               \
+    if (ZC && kc == 0) { WM_MFMA1_Z(xa0, xa1, xb, 0, acc[XI]); }   /* a plane's first MFMAs: C = 0 */   \
+    else { WM_MFMA1(xa0, xa1, xb, 0, acc[XI]); }                                                      \
     __builtin_amdgcn_sched_barrier(0);   /* the Y reads go out between X's MFMA groups: nothing waits for them before the next barrier */ \
     WM_READ(ya0, ya1, yb, 2);                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                \
@@ -317,6 +347,7 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
 #undef WM_DSREAD
 #undef WM_MFMA
 #undef WM_MFMA1
+#undef WM_MFMA1_Z
 #undef WM_FOLD
 #undef WM_DMA
 #undef WM_PF_ADVANCE
@@ -540,8 +571,21 @@ extern "C" int pcnn_winograd43_conv_fwd(const float* v, const float* ut, const f
   int S = wino43_cin_split(nbt, ncb, Cin);
   const size_t out_elems = (size_t)B * H * W * Cout;
   if (S > 1 && !(workspace && aligned16(workspace) && workspace_bytes >= sizeof(float) * (S * out_elems + (size_t)groups * Cout))) S = 1;
-#define WM_GO(P, Y, BIAS, RELU, KS, STRIDE) PCNN_LAUNCH((wino43_mfma_kernel<P, 1>), dim3((unsigned)blocks, KS), dim3(256), 0, stream, v, ut, BIAS, Y, y_pool, \
-                             H, W, Cin, Cout, Ht, Wt, T, tpg, RELU, (int)nbt, ncb, KS, (long long)(STRIDE))
+  // block map / priority mode (see the kernel). cb-major: every XCD owns one channel block and streams its eighth of the
+  // filter bank once; pays when U outweighs V — the deep layers of a single frame (conv4_2: U 37.7 MB, V 22 MB: fabric
+  // traffic 8 U + V = 324 MB tile-block-major, U + 8 V = 215 MB channel-block-major; conv5_x 307 -> 85 MB).
+  // PCNN_WINO_MODE overrides (experiments: bit 0 map, bits 1-2 priority, bit 3 = keep the zeroing v_movs).
+  static const int env_mode = [] { const char* e = getenv("PCNN_WINO_MODE"); return e ? atoi(e) : -1; }();
+  const double u_bytes = 36.0 * Cout * (double)Cin * 4.0 * groups, v_bytes = 36.0 * (double)T * Cin * 4.0;
+  int mode = (ncb == 8 && u_bytes > v_bytes) ? 1 : 0;
+  bool zc = true;
+  if (env_mode >= 0) { mode = (env_mode & 6) | ((env_mode & 1) && ncb == 8 ? 1 : 0); zc = !(env_mode & 8); }
+  const long long blocks_cb = 8 * nbt;
+  const long long nblocks = (mode & 1) ? blocks_cb : blocks;
+#define WM_GO(P, Y, BIAS, RELU, KS, STRIDE) do { if (zc) PCNN_LAUNCH((wino43_mfma_kernel<P, 1, 0, 1>), dim3((unsigned)nblocks, KS), dim3(256), 0, stream, v, ut, BIAS, Y, y_pool, \
+                             H, W, Cin, Cout, Ht, Wt, T, tpg, RELU, (int)nbt, ncb, KS, (long long)(STRIDE), mode); \
+    else PCNN_LAUNCH((wino43_mfma_kernel<P, 1, 0, 0>), dim3((unsigned)nblocks, KS), dim3(256), 0, stream, v, ut, BIAS, Y, y_pool, \
+                             H, W, Cin, Cout, Ht, Wt, T, tpg, RELU, (int)nbt, ncb, KS, (long long)(STRIDE), mode); } while (0)
   if (S == 1) {
     if (pool == 0) WM_GO(0, y, bias, relu, 1, 0); else if (pool == 1) WM_GO(1, y, bias, relu, 1, 0); else WM_GO(2, y, bias, relu, 1, 0);
   } else {

@@ -20,10 +20,10 @@ static float run(const float* v, const float* ut, const float* bias, float* y, i
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 2; i++)
-    hipLaunchKernelGGL((wino43_mfma_kernel<0, WR, ABL>), dim3((unsigned)blocks), dim3(256 * WR), 0, 0, v, ut, bias, y, (float*)nullptr, H, W, Cin, Cout, Ht, Wt, T, T, 1, (int)nbt, ncb, 1, 0);
+    hipLaunchKernelGGL((wino43_mfma_kernel<0, WR, ABL>), dim3((unsigned)blocks), dim3(256 * WR), 0, 0, v, ut, bias, y, (float*)nullptr, H, W, Cin, Cout, Ht, Wt, T, T, 1, (int)nbt, ncb, 1, 0, 0);
   hipEventRecord(e0, 0);
   for (int i = 0; i < iters; i++)
-    hipLaunchKernelGGL((wino43_mfma_kernel<0, WR, ABL>), dim3((unsigned)blocks), dim3(256 * WR), 0, 0, v, ut, bias, y, (float*)nullptr, H, W, Cin, Cout, Ht, Wt, T, T, 1, (int)nbt, ncb, 1, 0);
+    hipLaunchKernelGGL((wino43_mfma_kernel<0, WR, ABL>), dim3((unsigned)blocks), dim3(256 * WR), 0, 0, v, ut, bias, y, (float*)nullptr, H, W, Cin, Cout, Ht, Wt, T, T, 1, (int)nbt, ncb, 1, 0, 0);
   hipEventRecord(e1, 0);
   hipEventSynchronize(e1);
   float ms = 0;
