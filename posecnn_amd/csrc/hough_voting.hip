@@ -720,7 +720,10 @@ __device__ void wave_cell_data(const HvRec* __restrict__ r0, int m, int cx, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void hv_select_kernel(
+// 1024 threads (round 4; 256 before): the two sweeps over a class' ~1500-3000 records are trips of one record per thread
+// with two barriers each — latency, not work — so four times the threads is a quarter of the trips (74 -> ~35 us).
+constexpr int HV_SEL_NT = 1024, HV_SEL_NW = HV_SEL_NT / 64;
+__global__ __launch_bounds__(HV_SEL_NT) void hv_select_kernel(
     const HvRec* __restrict__ rec, const int* __restrict__ nslots_g,
     const int* __restrict__ slots_g, const int* __restrict__ tot_g,
     const int* __restrict__ recoff_g, const int2* __restrict__ tilemax,
@@ -732,11 +735,11 @@ __global__ __launch_bounds__(256) void hv_select_kernel(
   const int ns = nslots_g[n];
   if (s == 0 && threadIdx.x == 0) nmax_g[n] = ns < cap ? ns : cap;
   if (s >= ns || s >= cap) return;
-  __shared__ int s_rv[4], s_ri[4];
+  __shared__ int s_rv[HV_SEL_NW], s_ri[HV_SEL_NW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int2* tm = tilemax + ((size_t)n * (C - 1) + s) * ntiles;
   int bv = -1, bi = 0x7fffffff;
-  for (int t = tid; t < ntiles; t += 256) {
+  for (int t = tid; t < ntiles; t += HV_SEL_NT) {
     int2 e = tm[t];
     if (e.x > bv || (e.x == bv && e.y < bi)) { bv = e.x; bi = e.y; }
   }
@@ -747,18 +750,18 @@ __global__ __launch_bounds__(256) void hv_select_kernel(
   }
   if (lane == 0) { s_rv[wave] = bv; s_ri[wave] = bi; }
   __syncthreads();
-  for (int w2 = 0; w2 < 4; w2++)
+  for (int w2 = 0; w2 < HV_SEL_NW; w2++)
     if (s_rv[w2] > bv || (s_rv[w2] == bv && s_ri[w2] < bi)) { bv = s_rv[w2]; bi = s_ri[w2]; }
 
   // hough_data of the winning cell (second half of compute_hough_kernel :296-331 and the depth sum
-  // of the first half :269-294). All 256 threads evaluate the exact vote predicate; the depths of
+  // of the first half :269-294). All threads evaluate the exact vote predicate; the depths of
   // the voters are compacted IN PIXEL ORDER into LDS and summed by one lane, because the reference
   // accumulates `distance += d` sequentially and float addition does not reassociate.
-  constexpr int SEL_CAP = 2048;
+  constexpr int SEL_CAP = 4 * HV_SEL_NT;
   __shared__ __attribute__((aligned(16))) float s_d[SEL_CAP];
-  __shared__ int s_wc[4];
+  __shared__ int s_wc[HV_SEL_NW];
   __shared__ float s_res[4];
-  __shared__ float s_bw[4], s_bh[4];
+  __shared__ float s_bw[HV_SEL_NW], s_bh[HV_SEL_NW];
   const int cls = slots_g[n * C + s];
   const int m = (tot_g[n * C + cls] + skip - 1) / skip;
   const HvRec* r0 = rec + (size_t)n * reccap + recoff_g[n * C + cls];
@@ -767,7 +770,7 @@ __global__ __launch_bounds__(256) void hv_select_kernel(
   const float cxf = (float)(bi % W), cyf = (float)(bi / W);
   float sumd = 0.f;  // meaningful in thread 0
   int total = 0, fill = 0;
-  for (int b0 = 0; b0 < m; b0 += 256) {
+  for (int b0 = 0; b0 < m; b0 += HV_SEL_NT) {
     const int ri = b0 + tid;
     bool pass = false;
     float d = 0.f;
@@ -783,9 +786,9 @@ __global__ __launch_bounds__(256) void hv_select_kernel(
     int pos = fill + __popcll(mask & lanemask_lt());
     for (int w2 = 0; w2 < wave; w2++) pos += s_wc[w2];
     if (pass) s_d[pos] = d;
-    fill += s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+    for (int w2 = 0; w2 < HV_SEL_NW; w2++) fill += s_wc[w2];
     __syncthreads();
-    if (fill > SEL_CAP - 256 || b0 + 256 >= m) {
+    if (fill > SEL_CAP - HV_SEL_NT || b0 + HV_SEL_NT >= m) {
       if (tid == 0) {
         // the ordered sum, 16 depths per trip: four independent 128-bit LDS reads, then the 16 additions in pixel order
         // (one ds_read_b32 + wait per addend made this loop ~45 of the launch's 88 us)
@@ -812,7 +815,7 @@ __global__ __launch_bounds__(256) void hv_select_kernel(
     dist = s_res[0];
     const float thr = project_box(extents, cls, fx, fy, px, py, dist);
     float bw = -1.f, bh = -1.f;
-    for (int ri = tid; ri < m; ri += 256) {
+    for (int ri = tid; ri < m; ri += HV_SEL_NT) {
       const float4 a = r0[ri].a, b = r0[ri].b;
       const float dx = cxf - a.x, dy = cyf - a.y;
       if (angle_pass_exact(b.x, b.y, b.z, dx, dy, inlier)) {
@@ -827,8 +830,8 @@ __global__ __launch_bounds__(256) void hv_select_kernel(
     }
     if (lane == 0) { s_bw[wave] = bw; s_bh[wave] = bh; }
     __syncthreads();
-    bw = fmaxf(fmaxf(s_bw[0], s_bw[1]), fmaxf(s_bw[2], s_bw[3]));
-    bh = fmaxf(fmaxf(s_bh[0], s_bh[1]), fmaxf(s_bh[2], s_bh[3]));
+    bw = s_bw[0]; bh = s_bh[0];
+    for (int w2 = 1; w2 < HV_SEL_NW; w2++) { bw = fmaxf(bw, s_bw[w2]); bh = fmaxf(bh, s_bh[w2]); }
     bh2 = 2 * bh;
     bw2 = 2 * bw;
   }
@@ -912,7 +915,7 @@ __global__ __launch_bounds__(256) void hv_localmax_kernel(
   const long long ncell = (long long)ns * HW;
   const long long cbase = (long long)chunk * LM_CHUNK;
   if (cbase >= ncell) return;
-  __shared__ int s_wc[4];
+  __shared__ int s_wc[HV_SEL_NW];
   __shared__ int s_base;
   __shared__ float s_wcd[4][WCD_CAP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1296,7 +1299,7 @@ int hough_fwd_impl(const int32_t* label, const HvVertexSrc vs,
               sizeof(int) * band_rows * (size_t)(W + 1), stream, rec, nslots, slots, tot, recoff, kmax, tilemax, hs,
               H, W, C, skip, inlier, L.reccap, need_hs ? 1 : 0, wpr);
   if (!need_hs) {
-    PCNN_LAUNCH(hv_select_kernel, dim3(C - 1, B), dim3(256), 0, stream, rec, nslots, slots,
+    PCNN_LAUNCH(hv_select_kernel, dim3(C - 1, B), dim3(HV_SEL_NT), 0, stream, rec, nslots, slots,
                        tot, recoff, tilemax, extents, meta, maxima, nmax, W, C, skip, inlier,
                        H, L.reccap, L.cap, L.capmax, num_meta);
   } else {

@@ -56,6 +56,7 @@ constexpr int WM_BC = 64;     // output channels per workgroup
 constexpr int WM_KC = 64;     // K (input channels) per pipeline stage
 constexpr int WM_LD = 64;     // LDS row (floats): unpadded, XOR-swizzled 16-byte chunks
 constexpr int WM_NBUF = 3;    // stage buffers in the LDS ring (prefetch distance 2)
+constexpr int WM_SLOTS = 512; // resident 4-wave workgroups on the chip: 2 per CU x 256 CUs (a multiple of the 8 XCDs)
 
 // 16 bytes per lane, global -> LDS, no register round trip. LDS destination = wave-uniform base +
 // 16 * lane (so the image is lane-linear); the per-lane SOURCE address carries the swizzle.
@@ -95,9 +96,10 @@ __device__ __forceinline__ void at6_col(const float* m, float* t)
 // registers that a v_mov zeroed after every column fold (48 VALU per fold; on the Cin = 64 layers a fold comes every 6
 // stages and VALU time is paid in full next to the MFMAs). Same bits: 0 + a b either way.
 // `mode` bit 0: XCD x owns channel block x (launches with ncb == 8 whose filter bank outweighs their transformed input,
-// i.e. the deep layers of a single frame: every XCD then streams ITS eighth of U once instead of all of U);
-// bits 1-2: wave priority by the workgroup's slot on the CU (1: odd slot high, 2: even slot high) — of the two
-// workgroups sharing a CU one then runs as if alone and the other fills the matrix pipe's gaps.
+// i.e. the deep layers of a single frame: every XCD then streams ITS eighth of U once instead of all of U).
+// (Measured and dropped in round 4: s_setprio 3 / 0 by the workgroup's slot on the CU (HW_ID.TG_ID), so that one of the two
+// co-resident workgroups runs as if alone and the other fills the matrix pipe's gaps — 12-layer total 14.62 -> 14.71 /
+// 14.90 ms for the two polarities: the symmetric pair is the better schedule.)
 template <int POOL, int WR, int ABL = 0, int ZC = 1>
 __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
     const float* __restrict__ v, const float* __restrict__ ut, const float* __restrict__ bias,
@@ -112,19 +114,26 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
 
   // XCD-aware block map: XCD x = blockIdx % 8 takes tile blocks tb == x (mod 8); on an XCD the
   // channel blocks of a tile block are consecutive
-  const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+  // PERSISTENT workgroups (round 4): the grid may be smaller than the number of (tile block, channel block) pairs — the
+  // launcher caps it at the 512 resident slots — and a workgroup then walks its pairs with stride gridDim.x / 8 on its XCD.
+  // On the early layers a pair is 36-72 stages (~40-80 us): a fresh workgroup per pair paid its dispatch, a cold two-stage
+  // prologue and the drain of its stores every time; a resident one starts the next pair's operand stream while the
+  // previous pair's stores are still in flight. The per-pair arithmetic is untouched.
+  const int x = blockIdx.x & 7;
+  const int qstep = (int)(gridDim.x >> 3);
   const bool cbmajor = (mode & 1) != 0;          // (ncb == 8, checked by the launcher)
-  const int cb = cbmajor ? x : q % ncb;
-  const int tb = cbmajor ? q : (q / ncb) * 8 + x;
-  if (tb >= nbt) return;
-  if (mode & 6) {
-    unsigned hwid;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    const unsigned slot = (hwid >> 16) & 1u;     // TG_ID: the workgroup's slot on this CU
-    if (slot == ((mode >> 1) & 1u)) asm volatile("s_setprio 3"); else asm volatile("s_setprio 0");
-  }
+  y += (long long)blockIdx.y * ysplit_stride;    // `ksplit` > 1: this Cin slice's partial output (see below)
+  for (int qb = (int)(blockIdx.x >> 3);; qb += qstep) {
+  const int cb = cbmajor ? x : qb % ncb;
+  const int tb = cbmajor ? qb : (qb / ncb) * 8 + x;
+  if (tb >= nbt) break;
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  int tid = threadIdx.x;
+  // (opaque per trip: everything derived from the thread index — DMA offsets, LDS read addresses, store slots — is rebuilt
+  //  for each pair instead of being hoisted out of the persistent loop and kept alive across the K loop and the epilogue,
+  //  which pushed the kernel over its 256 registers)
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: everything derived from it (LDS bases, M0) stays on the SALU
   const int wm = wave & (WR - 1), wn = wave / WR;
   const int lr = lane & 15, lk = lane >> 4;
@@ -138,7 +147,6 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
   // writes a raw partial output (the host passes no bias, no ReLU, POOL = 0); a reduction kernel finishes
   const int ks = blockIdx.y;
   const int NK = Cin / WM_KC / ksplit;
-  y += (long long)ks * ysplit_stride;
 
   // staging: a stage = BT rows x 256 B of V and 64 rows of U^T = BT/4 + 16 DMA instructions of 4 rows
   // each; wave w issues V instructions 2w, 2w + 1 and U^T instructions (16/NW) w ... Lane l of
@@ -462,6 +470,8 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
             *reinterpret_cast<const v4f*>(&sY[(tl * 4 + re) * 64 + (rc4 ^ (16 * ((tl >> 2) & 3)))]);
     }
   }
+  __syncthreads();   // the staging buffers are the ring: every reader is done before the next pair's prologue DMAs land in it
+  }                  // (persistent loop)
 }
 
 // Split-Cin reduction: y = [ReLU](sum_s part[s] + bias) [2x2 max-pooled], partials in ascending order.
@@ -571,17 +581,19 @@ extern "C" int pcnn_winograd43_conv_fwd(const float* v, const float* ut, const f
   int S = wino43_cin_split(nbt, ncb, Cin);
   const size_t out_elems = (size_t)B * H * W * Cout;
   if (S > 1 && !(workspace && aligned16(workspace) && workspace_bytes >= sizeof(float) * (S * out_elems + (size_t)groups * Cout))) S = 1;
-  // block map / priority mode (see the kernel). cb-major: every XCD owns one channel block and streams its eighth of the
-  // filter bank once; pays when U outweighs V — the deep layers of a single frame (conv4_2: U 37.7 MB, V 22 MB: fabric
-  // traffic 8 U + V = 324 MB tile-block-major, U + 8 V = 215 MB channel-block-major; conv5_x 307 -> 85 MB).
-  // PCNN_WINO_MODE overrides (experiments: bit 0 map, bits 1-2 priority, bit 3 = keep the zeroing v_movs).
+  // Block map (see the kernel). cb-major: every XCD owns one channel block and streams its eighth of the filter bank
+  // once; pays when U outweighs V — the deep layers of a single frame (conv4_2: U 37.7 MB, V 22 MB: fabric traffic
+  // 8 U + V = 324 MB tile-block-major, U + 8 V = 215 MB channel-block-major; conv5_x 307 -> 85 MB: 64 -> 42 us).
+  // PCNN_WINO_MODE overrides for experiments and the variant-equality test: bit 0 force cb-major (when ncb == 8),
+  // bit 3 keep the round-3 zeroing v_movs, bit 4 no persistent grid; -1 / unset = the library's choice.
   static const int env_mode = [] { const char* e = getenv("PCNN_WINO_MODE"); return e ? atoi(e) : -1; }();
   const double u_bytes = 36.0 * Cout * (double)Cin * 4.0 * groups, v_bytes = 36.0 * (double)T * Cin * 4.0;
   int mode = (ncb == 8 && u_bytes > v_bytes) ? 1 : 0;
-  bool zc = true;
-  if (env_mode >= 0) { mode = (env_mode & 6) | ((env_mode & 1) && ncb == 8 ? 1 : 0); zc = !(env_mode & 8); }
-  const long long blocks_cb = 8 * nbt;
-  const long long nblocks = (mode & 1) ? blocks_cb : blocks;
+  bool zc = true, persistent = true;
+  if (env_mode >= 0) { mode = ((env_mode & 1) && ncb == 8) ? 1 : 0; zc = !(env_mode & 8); persistent = !(env_mode & 16); }
+  const long long pairs = (mode & 1) ? 8 * nbt : blocks;
+  // persistent grid: the 512 resident slots (2 per CU), when there are more pairs than that and no Cin split
+  const long long nblocks = (persistent && S == 1 && pairs > WM_SLOTS) ? WM_SLOTS : pairs;
 #define WM_GO(P, Y, BIAS, RELU, KS, STRIDE) do { if (zc) PCNN_LAUNCH((wino43_mfma_kernel<P, 1, 0, 1>), dim3((unsigned)nblocks, KS), dim3(256), 0, stream, v, ut, BIAS, Y, y_pool, \
                              H, W, Cin, Cout, Ht, Wt, T, tpg, RELU, (int)nbt, ncb, KS, (long long)(STRIDE), mode); \
     else PCNN_LAUNCH((wino43_mfma_kernel<P, 1, 0, 0>), dim3((unsigned)nblocks, KS), dim3(256), 0, stream, v, ut, BIAS, Y, y_pool, \

@@ -180,7 +180,9 @@ g = torch.Generator(device="cpu").manual_seed(3)
 out = {}
 # (B, H, W, Cin, Cout, groups, pool): a Cin = 64 layer (a fold every 6 stages), a 512 -> 512 layer small enough for the
 # channel-block-major map and the Cin split, ragged tiles, both towers grouped
-for i, (B, H, W, ci, co, G, pool) in enumerate([(2, 32, 48, 64, 64, 1, 1), (1, 30, 40, 512, 512, 1, 0), (2, 14, 22, 256, 512, 2, 2), (2, 60, 80, 512, 512, 2, 0)]):
+# the last two have more (tile block, channel block) pairs than the 512 resident slots: persistent workgroups walk several
+for i, (B, H, W, ci, co, G, pool) in enumerate([(2, 32, 48, 64, 64, 1, 1), (1, 30, 40, 512, 512, 1, 0), (2, 14, 22, 256, 512, 2, 2), (2, 60, 80, 512, 512, 2, 0),
+                                                (8, 120, 160, 64, 128, 1, 1), (4, 118, 162, 64, 256, 2, 2)]):
     x = torch.relu(torch.randn((B, H, W, ci), generator=g)).to(dev)
     w = (torch.randn((G, co, ci, 3, 3), generator=g) * (2.0 / (9 * ci)) ** 0.5).to(dev)
     b = torch.randn((G, co), generator=g).to(dev)
@@ -196,12 +198,12 @@ np.savez(sys.argv[1], **out)
 
 
 def test_winograd_mfma_round4_variants_are_bit_identical(gpu, tmp_path):
-    """VERDICT r3 "Next" #3: outputs must stay bit-identical to the round-3 kernel. PCNN_WINO_MODE = 8 is that kernel (the
-    accumulators zeroed by v_movs after every fold, tile-block-major map, no priorities); 0 = C = 0 inline on a plane's
-    first MFMAs; 1 = + channel-block-major XCD map where it applies; 2 / 4 = + workgroup-slot priorities; unset = what
-    the library picks. Four layer shapes each."""
+    """VERDICT r3 "Next" #3: outputs must stay bit-identical to the round-3 kernel. PCNN_WINO_MODE = 24 is that kernel (the
+    accumulators zeroed by v_movs after every fold, tile-block-major map, one workgroup per pair); 16 = C = 0 inline on a
+    plane's first MFMAs; 0 = + persistent workgroups; 1 = + channel-block-major XCD map where it applies; 8 = persistent
+    with the v_movs; unset = what the library picks. Six layer shapes each."""
     outs = {}
-    for mode in ("8", "0", "1", "2", "4", None):
+    for mode in ("24", "16", "0", "1", "8", None):
         path = str(tmp_path / ("wino_%s.npz" % mode))
         env = dict(os.environ)
         env.pop("PCNN_WINO_MODE", None)
@@ -209,8 +211,8 @@ def test_winograd_mfma_round4_variants_are_bit_identical(gpu, tmp_path):
             env["PCNN_WINO_MODE"] = mode
         subprocess.run([sys.executable, "-c", _WINO_SCRIPT % ROOT, path], check=True, env=env, timeout=600)
         outs[mode] = np.load(path)
-    base = outs["8"]
-    assert len(base.files) == 5
+    base = outs["24"]
+    assert len(base.files) == 8
     for mode, o in outs.items():
         for k in base.files:
             same(o[k], base[k], "mode %s %s" % (mode, k))
