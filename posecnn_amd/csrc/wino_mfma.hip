@@ -56,7 +56,6 @@ constexpr int WM_BC = 64;     // output channels per workgroup
 constexpr int WM_KC = 64;     // K (input channels) per pipeline stage
 constexpr int WM_LD = 64;     // LDS row (floats): unpadded, XOR-swizzled 16-byte chunks
 constexpr int WM_NBUF = 3;    // stage buffers in the LDS ring (prefetch distance 2)
-constexpr int WM_SLOTS = 512; // resident 4-wave workgroups on the chip: 2 per CU x 256 CUs (a multiple of the 8 XCDs)
 
 // 16 bytes per lane, global -> LDS, no register round trip. LDS destination = wave-uniform base +
 // 16 * lane (so the image is lane-linear); the per-lane SOURCE address carries the swizzle.
@@ -97,9 +96,14 @@ __device__ __forceinline__ void at6_col(const float* m, float* t)
 // stages and VALU time is paid in full next to the MFMAs). Same bits: 0 + a b either way.
 // `mode` bit 0: XCD x owns channel block x (launches with ncb == 8 whose filter bank outweighs their transformed input,
 // i.e. the deep layers of a single frame: every XCD then streams ITS eighth of U once instead of all of U).
-// (Measured and dropped in round 4: s_setprio 3 / 0 by the workgroup's slot on the CU (HW_ID.TG_ID), so that one of the two
-// co-resident workgroups runs as if alone and the other fills the matrix pipe's gaps — 12-layer total 14.62 -> 14.71 /
-// 14.90 ms for the two polarities: the symmetric pair is the better schedule.)
+// Measured and dropped in round 4 (tools/r4_wino_modes.sh, 12-layer totals at 2 x 16 frames):
+//   * s_setprio 3 / 0 by the workgroup's slot on the CU (HW_ID.TG_ID), so that one of the two co-resident workgroups runs
+//     as if alone and the other fills the matrix pipe's gaps: 14.62 -> 14.71 / 14.90 ms for the two polarities — the
+//     symmetric pair is the better schedule;
+//   * persistent workgroups (a grid of the 512 resident slots, each walking its (tile block, channel block) pairs, so that
+//     the early layers' 36-72-stage pairs stop paying a dispatch, a cold prologue and a store drain each): 14.62 -> 15.07 ms
+//     (conv4_2 1.61 -> 1.73, conv2_2 1.74 -> 1.83) — the hardware's dynamic hand-out of pairs to whichever slot frees first
+//     balances better than a static walk, and the 8 extra live registers of the loop cost the kernel its last slack.
 template <int POOL, int WR, int ABL = 0, int ZC = 1>
 __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
     const float* __restrict__ v, const float* __restrict__ ut, const float* __restrict__ bias,
@@ -114,26 +118,14 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
 
   // XCD-aware block map: XCD x = blockIdx % 8 takes tile blocks tb == x (mod 8); on an XCD the
   // channel blocks of a tile block are consecutive
-  // PERSISTENT workgroups (round 4): the grid may be smaller than the number of (tile block, channel block) pairs — the
-  // launcher caps it at the 512 resident slots — and a workgroup then walks its pairs with stride gridDim.x / 8 on its XCD.
-  // On the early layers a pair is 36-72 stages (~40-80 us): a fresh workgroup per pair paid its dispatch, a cold two-stage
-  // prologue and the drain of its stores every time; a resident one starts the next pair's operand stream while the
-  // previous pair's stores are still in flight. The per-pair arithmetic is untouched.
-  const int x = blockIdx.x & 7;
-  const int qstep = (int)(gridDim.x >> 3);
+  const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
   const bool cbmajor = (mode & 1) != 0;          // (ncb == 8, checked by the launcher)
+  const int cb = cbmajor ? x : q % ncb;
+  const int tb = cbmajor ? q : (q / ncb) * 8 + x;
+  if (tb >= nbt) return;
   y += (long long)blockIdx.y * ysplit_stride;    // `ksplit` > 1: this Cin slice's partial output (see below)
-  for (int qb = (int)(blockIdx.x >> 3);; qb += qstep) {
-  const int cb = cbmajor ? x : qb % ncb;
-  const int tb = cbmajor ? qb : (qb / ncb) * 8 + x;
-  if (tb >= nbt) break;
 
-  int tid = threadIdx.x;
-  // (opaque per trip: everything derived from the thread index — DMA offsets, LDS read addresses, store slots — is rebuilt
-  //  for each pair instead of being hoisted out of the persistent loop and kept alive across the K loop and the epilogue,
-  //  which pushed the kernel over its 256 registers)
-  asm volatile("" : "+v"(tid));
-  const int lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: everything derived from it (LDS bases, M0) stays on the SALU
   const int wm = wave & (WR - 1), wn = wave / WR;
   const int lr = lane & 15, lk = lane >> 4;
@@ -470,8 +462,6 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
             *reinterpret_cast<const v4f*>(&sY[(tl * 4 + re) * 64 + (rc4 ^ (16 * ((tl >> 2) & 3)))]);
     }
   }
-  __syncthreads();   // the staging buffers are the ring: every reader is done before the next pair's prologue DMAs land in it
-  }                  // (persistent loop)
 }
 
 // Split-Cin reduction: y = [ReLU](sum_s part[s] + bias) [2x2 max-pooled], partials in ascending order.
@@ -585,15 +575,13 @@ extern "C" int pcnn_winograd43_conv_fwd(const float* v, const float* ut, const f
   // once; pays when U outweighs V — the deep layers of a single frame (conv4_2: U 37.7 MB, V 22 MB: fabric traffic
   // 8 U + V = 324 MB tile-block-major, U + 8 V = 215 MB channel-block-major; conv5_x 307 -> 85 MB: 64 -> 42 us).
   // PCNN_WINO_MODE overrides for experiments and the variant-equality test: bit 0 force cb-major (when ncb == 8),
-  // bit 3 keep the round-3 zeroing v_movs, bit 4 no persistent grid; -1 / unset = the library's choice.
+  // bit 3 keep the round-3 zeroing v_movs; -1 / unset = the library's choice.
   static const int env_mode = [] { const char* e = getenv("PCNN_WINO_MODE"); return e ? atoi(e) : -1; }();
   const double u_bytes = 36.0 * Cout * (double)Cin * 4.0 * groups, v_bytes = 36.0 * (double)T * Cin * 4.0;
   int mode = (ncb == 8 && u_bytes > v_bytes) ? 1 : 0;
-  bool zc = true, persistent = true;
-  if (env_mode >= 0) { mode = ((env_mode & 1) && ncb == 8) ? 1 : 0; zc = !(env_mode & 8); persistent = !(env_mode & 16); }
-  const long long pairs = (mode & 1) ? 8 * nbt : blocks;
-  // persistent grid: the 512 resident slots (2 per CU), when there are more pairs than that and no Cin split
-  const long long nblocks = (persistent && S == 1 && pairs > WM_SLOTS) ? WM_SLOTS : pairs;
+  bool zc = true;
+  if (env_mode >= 0) { mode = ((env_mode & 1) && ncb == 8) ? 1 : 0; zc = !(env_mode & 8); }
+  const long long nblocks = (mode & 1) ? 8 * nbt : blocks;
 #define WM_GO(P, Y, BIAS, RELU, KS, STRIDE) do { if (zc) PCNN_LAUNCH((wino43_mfma_kernel<P, 1, 0, 1>), dim3((unsigned)nblocks, KS), dim3(256), 0, stream, v, ut, BIAS, Y, y_pool, \
                              H, W, Cin, Cout, Ht, Wt, T, tpg, RELU, (int)nbt, ncb, KS, (long long)(STRIDE), mode); \
     else PCNN_LAUNCH((wino43_mfma_kernel<P, 1, 0, 0>), dim3((unsigned)nblocks, KS), dim3(256), 0, stream, v, ut, BIAS, Y, y_pool, \

@@ -85,16 +85,22 @@ def test_backproject_at_the_reference_default_grid_256(gpu, capsys):
     assert bool((tl.view(nv, Cl)[miss] == l3.view(nv, Cl)[miss]).all())
     hit_frac = float((~miss).float().mean())
     assert abs(hit_frac - float(wf[:, 0].mean())) < 0.01        # the sample is representative
-    # timing: outputs written once + label_3d and the frame read once
+    # timing: outputs written once + label_3d and the frame read once. Per-call events, best of 5 after a warm-up (the
+    # 10 GB of outputs are allocated inside the call: a trip through the caching allocator's slow path must not be timed)
     del td, tl, tf
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    ops.backproject(*args)
-    ev[0].record()
-    for _ in range(3):
-        out = ops.backproject(*args)
-    ev[1].record()
     torch.cuda.synchronize()
-    ms = ev[0].elapsed_time(ev[1]) / 3
+    out = ops.backproject(*args)
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        del out
+        e0.record()
+        out = ops.backproject(*args)
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1))
+    ms = min(times)
     byts = 4.0 * (nv * (2 * Cd + Cl) + nv * Cl + B * H * W * (Cd + Cl + 1))
     with capsys.disabled():
         print("\nbackproject G = 256 (480x640x64, C = 22, k = 3): %.2f ms, %.2f GB algorithmic -> %.2f TB/s = %.2f of the 8 TB/s HBM peak; "
@@ -180,7 +186,7 @@ g = torch.Generator(device="cpu").manual_seed(3)
 out = {}
 # (B, H, W, Cin, Cout, groups, pool): a Cin = 64 layer (a fold every 6 stages), a 512 -> 512 layer small enough for the
 # channel-block-major map and the Cin split, ragged tiles, both towers grouped
-# the last two have more (tile block, channel block) pairs than the 512 resident slots: persistent workgroups walk several
+# the last two have more (tile block, channel block) pairs than the chip has resident slots (several rounds of workgroups)
 for i, (B, H, W, ci, co, G, pool) in enumerate([(2, 32, 48, 64, 64, 1, 1), (1, 30, 40, 512, 512, 1, 0), (2, 14, 22, 256, 512, 2, 2), (2, 60, 80, 512, 512, 2, 0),
                                                 (8, 120, 160, 64, 128, 1, 1), (4, 118, 162, 64, 256, 2, 2)]):
     x = torch.relu(torch.randn((B, H, W, ci), generator=g)).to(dev)
@@ -198,12 +204,12 @@ np.savez(sys.argv[1], **out)
 
 
 def test_winograd_mfma_round4_variants_are_bit_identical(gpu, tmp_path):
-    """VERDICT r3 "Next" #3: outputs must stay bit-identical to the round-3 kernel. PCNN_WINO_MODE = 24 is that kernel (the
-    accumulators zeroed by v_movs after every fold, tile-block-major map, one workgroup per pair); 16 = C = 0 inline on a
-    plane's first MFMAs; 0 = + persistent workgroups; 1 = + channel-block-major XCD map where it applies; 8 = persistent
-    with the v_movs; unset = what the library picks. Six layer shapes each."""
+    """VERDICT r3 "Next" #3: outputs must stay bit-identical to the round-3 kernel. PCNN_WINO_MODE = 8 is that kernel (the
+    accumulators zeroed by v_movs after every fold, tile-block-major map); 0 = C = 0 inline on a plane's first MFMAs;
+    1 = + channel-block-major XCD map where it applies; 9 = that map with the v_movs; unset = what the library picks.
+    Six layer shapes each."""
     outs = {}
-    for mode in ("24", "16", "0", "1", "8", None):
+    for mode in ("8", "0", "1", "9", None):
         path = str(tmp_path / ("wino_%s.npz" % mode))
         env = dict(os.environ)
         env.pop("PCNN_WINO_MODE", None)
@@ -211,7 +217,7 @@ def test_winograd_mfma_round4_variants_are_bit_identical(gpu, tmp_path):
             env["PCNN_WINO_MODE"] = mode
         subprocess.run([sys.executable, "-c", _WINO_SCRIPT % ROOT, path], check=True, env=env, timeout=600)
         outs[mode] = np.load(path)
-    base = outs["24"]
+    base = outs["8"]
     assert len(base.files) == 8
     for mode, o in outs.items():
         for k in base.files:

@@ -1,7 +1,7 @@
-# Round-4 experiment: wino43_mfma_kernel variants (PCNN_WINO_MODE: 24 = round-3 kernel, 16 = zero-C, 8 = persistent workgroups
-# with the zeroing v_movs, 0 = zero-C + persistent, bit 0 = channel-block-major map where it applies). bash tools/r4_wino_modes.sh <outdir>
+# Round-4 experiment: wino43_mfma_kernel variants (PCNN_WINO_MODE: 8 = round-3 kernel, 0 = zero-C first MFMAs, bit 0 = channel-block-major
+# map where it applies; the priority and persistent-grid variants measured with this script are recorded in csrc/wino_mfma.hip). bash tools/r4_wino_modes.sh <outdir>
 O=${1:-gpurun_out/r4c}; mkdir -p $O
-for m in 24 16 8 0; do
+for m in 8 0; do
   PCNN_WINO_MODE=$m python tools/bench_wino_mfma.py --no-library > $O/layers_mode$m.json 2>> $O/err.log
 done
 for m in 0 1; do
