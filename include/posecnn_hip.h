@@ -176,6 +176,14 @@ int pcnn_roi_pool_add2_fwd(const float* data_a, int height_a, int width_a, float
                            const float* rois, int batch, int channels, int num_rois, int roi_cols,
                            int pooled_height, int pooled_width, const int32_t* num_rows_dev,
                            float* out, void* stream);
+/* The same with the rows at or past *num_rows_dev (required) left UNTOUCHED instead of zero-filled: for a consumer
+ * that masks those rows itself — pcnn_fc_rows_fwd / pcnn_fc_skinny_fwd take the same device-side count — three quarters
+ * of a capacity-sized buffer (235 MB of zeros per 16-frame step) need not be written at all. */
+int pcnn_roi_pool_add2_live_fwd(const float* data_a, int height_a, int width_a, float scale_a,
+                                const float* data_b, int height_b, int width_b, float scale_b,
+                                const float* rois, int batch, int channels, int num_rois, int roi_cols,
+                                int pooled_height, int pooled_width, const int32_t* num_rows_dev,
+                                float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Hard label  (REGISTER_OP("Hardlabel"), hard_label_op.cc:30-35; GPU semantics .cu.cc:17-29)

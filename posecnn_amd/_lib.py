@@ -70,6 +70,8 @@ SIGNATURES = {
                                   c_int, c_int, c_float, c_int, _P, _P]),
     "pcnn_roi_pool_add2_fwd": (c_int, [_P, c_int, c_int, c_float, _P, c_int, c_int, c_float,
                                        _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "pcnn_roi_pool_add2_live_fwd": (c_int, [_P, c_int, c_int, c_float, _P, c_int, c_int, c_float,
+                                            _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "pcnn_hard_label_fwd": (c_int, [_P, _P, c_int64, c_int, c_float, _P, _P]),
     "pcnn_hard_label_bwd": (c_int, [_P, _P, c_int64, c_int, _P]),
     "pcnn_average_distance_workspace_bytes": (c_int, [c_int, c_int, c_int, POINTER(c_size_t)]),

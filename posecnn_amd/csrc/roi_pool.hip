@@ -220,6 +220,61 @@ __global__ __launch_bounds__(128) void roi_pool_add2_perbin(
   }
 }
 
+// The same op, one workgroup per BIN ROW (roi, ph) instead of per bin (round 4). On the capacity-sized row buffer behind
+// the sync-free Hough layer (3024 rows of which ~700 exist) the per-bin grid was 148 000 workgroups of 128 threads, three
+// quarters of them writing 2 KB of zeros each: 193 us for 303 MB, 1.6 TB/s. Here a workgroup covers the PW bins of a row
+// (14 KB of output), a row past the device-side count costs one wide zero fill — or nothing at all with KEEP_DEAD, the
+// variant the network uses: fc6 (csrc/fc_mfma.hip, csrc/fc_skinny.hip) masks rows at or past the same count itself, so
+// `pool_score`'s rows past it are never read. Same per-value expressions as the per-bin kernel -> same bits.
+template <bool KEEP_DEAD>
+__global__ __launch_bounds__(256) void roi_pool_add2_rows(
+    const float* __restrict__ data_a, int Ha, int Wa, float scale_a,
+    const float* __restrict__ data_b, int Hb, int Wb, float scale_b,
+    const float* __restrict__ rois, float* __restrict__ out, int B, int C, int roi_cols, int PH,
+    int PW, const int* __restrict__ num_rows_dev)
+{
+  const int ph = blockIdx.x % PH, n = blockIdx.x / PH;
+  const bool live = num_rows_dev == nullptr || n < num_rows_dev[0];
+  if (KEEP_DEAD && !live) return;
+  const float* roi = rois + (size_t)n * roi_cols;
+  const int nq = C >> 2;
+  float* orow = out + ((size_t)n * PH + ph) * PW * C;
+  const RoiGeom ga = roi_geometry(roi, scale_a, PH, PW);
+  const bool ok = live && ga.batch >= 0 && ga.batch < B;
+  if (!ok) {
+    for (int i = threadIdx.x; i < PW * nq; i += 256) *reinterpret_cast<float4*>(orow + (size_t)i * 4) = make_float4(0, 0, 0, 0);
+    return;
+  }
+  const RoiGeom gb = roi_geometry(roi, scale_b, PH, PW);
+  int ha0, ha1, hb0, hb1;
+  bin_span(ga.bin_h, ph, ga.sh, Ha, ha0, ha1);
+  bin_span(gb.bin_h, ph, gb.sh, Hb, hb0, hb1);
+  const float* ia = data_a + (size_t)ga.batch * Ha * Wa * C;
+  const float* ib = data_b + (size_t)gb.batch * Hb * Wb * C;
+  for (int i = threadIdx.x; i < PW * nq; i += 256) {
+    const int pw = i / nq, c = (i - pw * nq) * 4;
+    int wa0, wa1, wb0, wb1;
+    bin_span(ga.bin_w, pw, ga.sw, Wa, wa0, wa1);
+    bin_span(gb.bin_w, pw, gb.sw, Wb, wb0, wb1);
+    const bool ea = ha1 <= ha0 || wa1 <= wa0, eb = hb1 <= hb0 || wb1 <= wb0;
+    const float inita = ea ? 0.f : -FLT_MAX, initb = eb ? 0.f : -FLT_MAX;
+    float4 ma = make_float4(inita, inita, inita, inita), mb = make_float4(initb, initb, initb, initb);
+    for (int h = ha0; h < ha1; ++h)
+      for (int w = wa0; w < wa1; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(ia + (h * Wa + w) * C + c);
+        ma.x = v.x > ma.x ? v.x : ma.x; ma.y = v.y > ma.y ? v.y : ma.y;
+        ma.z = v.z > ma.z ? v.z : ma.z; ma.w = v.w > ma.w ? v.w : ma.w;
+      }
+    for (int h = hb0; h < hb1; ++h)
+      for (int w = wb0; w < wb1; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(ib + (h * Wb + w) * C + c);
+        mb.x = v.x > mb.x ? v.x : mb.x; mb.y = v.y > mb.y ? v.y : mb.y;
+        mb.z = v.z > mb.z ? v.z : mb.z; mb.w = v.w > mb.w ? v.w : mb.w;
+      }
+    *reinterpret_cast<float4*>(orow + (size_t)pw * C + c) = make_float4(ma.x + mb.x, ma.y + mb.y, ma.z + mb.z, ma.w + mb.w);
+  }
+}
+
 constexpr int RB_TILE_W = 8;
 constexpr int RB_LIST = 512;
 
@@ -349,10 +404,10 @@ extern "C" int pcnn_roi_pool_fwd(const float* data, const float* rois, int B, in
   return check_launch("roi_pool_fwd");
 }
 
-extern "C" int pcnn_roi_pool_add2_fwd(const float* data_a, int Ha, int Wa, float scale_a,
-                                      const float* data_b, int Hb, int Wb, float scale_b,
-                                      const float* rois, int B, int C, int R, int roi_cols, int PH,
-                                      int PW, const int32_t* num_rows_dev, float* out, void* stream_)
+static int roi_pool_add2_impl(const float* data_a, int Ha, int Wa, float scale_a,
+                              const float* data_b, int Hb, int Wb, float scale_b,
+                              const float* rois, int B, int C, int R, int roi_cols, int PH,
+                              int PW, const int32_t* num_rows_dev, float* out, void* stream_, bool keep_dead)
 {
   int st = validate(B, Ha, Wa, C, R, roi_cols, PH, PW, scale_a, 0);
   if (st != PCNN_OK) return st;
@@ -363,13 +418,35 @@ extern "C" int pcnn_roi_pool_add2_fwd(const float* data_a, int Ha, int Wa, float
   PCNN_REQUIRE(data_a && data_b && rois && out, PCNN_ENULL, "roi_pool_add2: NULL pointer");
   PCNN_REQUIRE(aligned16(data_a) && aligned16(data_b) && aligned16(out), PCNN_EINVAL,
                "roi_pool_add2: tensors must be 16-byte aligned");
+  PCNN_REQUIRE(!keep_dead || num_rows_dev, PCNN_ENULL, "roi_pool_add2_live: needs the device-side row count");
   hipStream_t stream = (hipStream_t)stream_;
-  const long long blocks = (long long)R * PH * PW;
-  PCNN_REQUIRE(blocks < (1ll << 31), PCNN_EINVAL, "roi_pool_add2: too many bins (%lld)", blocks);
-  PCNN_LAUNCH(roi_pool_add2_perbin, dim3((unsigned)blocks), dim3(C >= 512 ? 128 : 64), 0, stream,
-              data_a, Ha, Wa, scale_a, data_b, Hb, Wb, scale_b, rois, out, B, C, roi_cols, PH, PW,
-              num_rows_dev);
+  const long long blocks = (long long)R * PH;
+  PCNN_REQUIRE(blocks < (1ll << 31), PCNN_EINVAL, "roi_pool_add2: too many bin rows (%lld)", blocks);
+  if (keep_dead)
+    PCNN_LAUNCH(roi_pool_add2_rows<true>, dim3((unsigned)blocks), dim3(256), 0, stream, data_a, Ha, Wa, scale_a, data_b, Hb,
+                Wb, scale_b, rois, out, B, C, roi_cols, PH, PW, num_rows_dev);
+  else
+    PCNN_LAUNCH(roi_pool_add2_rows<false>, dim3((unsigned)blocks), dim3(256), 0, stream, data_a, Ha, Wa, scale_a, data_b, Hb,
+                Wb, scale_b, rois, out, B, C, roi_cols, PH, PW, num_rows_dev);
   return check_launch("roi_pool_add2_fwd");
+}
+
+extern "C" int pcnn_roi_pool_add2_fwd(const float* data_a, int Ha, int Wa, float scale_a,
+                                      const float* data_b, int Hb, int Wb, float scale_b,
+                                      const float* rois, int B, int C, int R, int roi_cols, int PH,
+                                      int PW, const int32_t* num_rows_dev, float* out, void* stream_)
+{
+  return roi_pool_add2_impl(data_a, Ha, Wa, scale_a, data_b, Hb, Wb, scale_b, rois, B, C, R, roi_cols, PH, PW, num_rows_dev,
+                            out, stream_, false);
+}
+
+extern "C" int pcnn_roi_pool_add2_live_fwd(const float* data_a, int Ha, int Wa, float scale_a,
+                                           const float* data_b, int Hb, int Wb, float scale_b,
+                                           const float* rois, int B, int C, int R, int roi_cols, int PH,
+                                           int PW, const int32_t* num_rows_dev, float* out, void* stream_)
+{
+  return roi_pool_add2_impl(data_a, Ha, Wa, scale_a, data_b, Hb, Wb, scale_b, rois, B, C, R, roi_cols, PH, PW, num_rows_dev,
+                            out, stream_, true);
 }
 
 extern "C" int pcnn_roi_pool_bwd(const float* top_diff, const float* rois, const int32_t* argmax,

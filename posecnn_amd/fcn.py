@@ -195,8 +195,11 @@ def im_segment_batch(net, data, K, extents, points, symmetry, data_p=None, plant
     cap = top_box.shape[0]
     rois = top_box
     count = num_rois[1:2]
+    # rows at or past the count are not written when fc6 runs on the library's row kernels, which mask them by the same
+    # count (Network.fc); the framework fallback (a trainable graph under autograd) reads the whole buffer: zeros there
+    masked_fc = not (torch.is_grad_enabled() and net.trainable)
     pool = ops.roi_pool_add2(net.get_output("conv5_3"), 1.0 / 16.0, net.get_output("conv4_3"), 1.0 / 8.0, rois,
-                             num_rows=count)
+                             num_rows=count, dead_rows="keep" if masked_fc else "zero")
     net.layers["pool_score"] = pool
     net.rows_count = count   # fc6 / fc7 skip the rows past the device-side count
     try:

@@ -284,10 +284,11 @@ def roi_pool(data, rois, pooled_height, pooled_width, spatial_scale, pool_channe
     return _RoiPoolFn.apply(data, rois, pooled_height, pooled_width, spatial_scale, pool_channel)
 
 
-def roi_pool_add2(data_a, scale_a, data_b, scale_b, rois, pooled_height=7, pooled_width=7, num_rows=None):
+def roi_pool_add2(data_a, scale_a, data_b, scale_b, rois, pooled_height=7, pooled_width=7, num_rows=None, dead_rows="zero", out=None):
     """Fused `pool_score` = roi_pool(conv5_3, 1/16) + roi_pool(conv4_3, 1/8)
     (vgg16_convs.py:177-187), inference only (no argmax). `num_rows` (device int32[1]): true row
-    count of a capacity-sized `rois` buffer; rows past it pool to zero."""
+    count of a capacity-sized `rois` buffer; rows past it pool to zero — or, with dead_rows="keep", are not
+    written at all (for consumers that mask them by the same count: ops.fc_rows / ops.fc_skinny)."""
     data_a = _dev(data_a, "data_a", torch.float32)
     data_b = _dev(data_b, "data_b", torch.float32)
     rois = _dev(rois, "rois", torch.float32)
@@ -295,13 +296,23 @@ def roi_pool_add2(data_a, scale_a, data_b, scale_b, rois, pooled_height=7, poole
     Bb, Hb, Wb, Cb = data_b.shape
     if (B, C) != (Bb, Cb):
         raise ValueError("feature maps must share batch and channel dimensions")
+    if dead_rows not in ("zero", "keep"):
+        raise ValueError("dead_rows must be 'zero' or 'keep'")
+    if dead_rows == "keep" and num_rows is None:
+        raise ValueError("dead_rows='keep' needs num_rows")
     R, cols = rois.shape
-    out = torch.empty((R, pooled_height, pooled_width, C), dtype=torch.float32, device=data_a.device)
-    check("pcnn_roi_pool_add2_fwd",
-          lib().pcnn_roi_pool_add2_fwd(_ptr(data_a), Ha, Wa, float(scale_a), _ptr(data_b), Hb, Wb, float(scale_b),
-                                       _ptr(rois), B, C, R, cols, int(pooled_height), int(pooled_width),
-                                       _ptr(_dev(num_rows, "num_rows", torch.int32) if num_rows is not None else None),
-                                       _ptr(out), _stream(data_a)))
+    if out is None:
+        out = torch.empty((R, pooled_height, pooled_width, C), dtype=torch.float32, device=data_a.device)
+    else:
+        out = _dev(out, "out", torch.float32)
+        if tuple(out.shape) != (R, pooled_height, pooled_width, C):
+            raise ValueError("out must be [R, PH, PW, C]")
+    name = "pcnn_roi_pool_add2_live_fwd" if dead_rows == "keep" else "pcnn_roi_pool_add2_fwd"
+    check(name,
+          getattr(lib(), name)(_ptr(data_a), Ha, Wa, float(scale_a), _ptr(data_b), Hb, Wb, float(scale_b),
+                               _ptr(rois), B, C, R, cols, int(pooled_height), int(pooled_width),
+                               _ptr(_dev(num_rows, "num_rows", torch.int32) if num_rows is not None else None),
+                               _ptr(out), _stream(data_a)))
     return out
 
 

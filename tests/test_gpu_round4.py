@@ -222,3 +222,33 @@ def test_winograd_mfma_round4_variants_are_bit_identical(gpu, tmp_path):
     for mode, o in outs.items():
         for k in base.files:
             same(o[k], base[k], "mode %s %s" % (mode, k))
+
+
+# ---- roi_pool_add2: row-wise kernel, rows past the count zero-filled or left alone --------------------------------
+@pytest.mark.parametrize("R,cap,C", [(9, 24, 512), (0, 5, 512), (33, 33, 64), (5, 40, 20)])
+def test_roi_pool_add2_dead_rows_zero_or_keep(gpu, R, cap, C):
+    """pcnn_roi_pool_add2_fwd / pcnn_roi_pool_add2_live_fwd on a capacity-sized row buffer: rows below the device-side
+    count equal roi_pool(a) + roi_pool(b) of the oracle bit for bit in both; rows at or past it are zeros ("zero") or
+    keep whatever the buffer held ("keep": what the network uses — fc6 masks those rows by the same count)."""
+    import torch
+    from posecnn_amd import ops
+    from test_gpu_ops import random_rois
+    rng = np.random.default_rng(13)
+    B = 2
+    a = rng.standard_normal((B, 15, 20, C)).astype(F)
+    b = rng.standard_normal((B, 30, 40, C)).astype(F)
+    rois = random_rois(rng, cap, B, 22, 320, 240)
+    rois[cap // 2:, 0] = np.where(np.arange(cap - cap // 2) % 5 == 4, 7, rois[cap // 2:, 0])   # a few invalid batch indices
+    cnt = torch.tensor([R], dtype=torch.int32, device=gpu)
+    wa, _ = oracle.roi_pool(a, rois[:R], 7, 7, 1 / 16.0, 0)
+    wb, _ = oracle.roi_pool(b, rois[:R], 7, 7, 1 / 8.0, 0)
+    want = wa + wb
+    got0 = N(ops.roi_pool_add2(T(gpu, a), 1 / 16.0, T(gpu, b), 1 / 8.0, T(gpu, rois), num_rows=cnt))
+    same(got0[:R], want, "zero mode, live rows")
+    assert not got0[R:].any()
+    buf = torch.full((cap, 7, 7, C), 123.5, device=gpu)
+    got1 = N(ops.roi_pool_add2(T(gpu, a), 1 / 16.0, T(gpu, b), 1 / 8.0, T(gpu, rois), num_rows=cnt, dead_rows="keep", out=buf))
+    same(got1[:R], want, "keep mode, live rows")
+    assert (got1[R:] == 123.5).all()
+    with pytest.raises(ValueError):
+        ops.roi_pool_add2(T(gpu, a), 1 / 16.0, T(gpu, b), 1 / 8.0, T(gpu, rois), dead_rows="keep")
