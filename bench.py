@@ -589,7 +589,7 @@ def main(argv=None):
                        "unit": "TFLOP/s", "frac": fc_flops / (t_fc * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "us_per_step": round(t_fc, 1),
                        "note": "fc6 + fc7 on %d live rows and the 1x1 head products" % live_rows})
     # the trunk as a whole: every kernel whose name says it belongs to a convolution
-    trunk_ms = sum(v["avg_us"] * v["calls"] for k, v in kern.items() if k.startswith(("wino", "conv3x3", "bias_"))) / 1e3 / a.steps \
+    trunk_ms = sum(v["avg_us"] * v["calls"] for k, v in kern.items() if k.startswith(("wino", "conv3x3", "conv12", "bias_"))) / 1e3 / a.steps \
         + conv_ms / a.steps
     direct_flops_step = towers * 2.0 * B * (H * W) * 9 * (64 * 3 + 64 * 64 + (128 * 64 + 128 * 128) / 4 + (256 * 128 + 2 * 256 * 256) / 16
                                                          + (512 * 256 + 2 * 512 * 512) / 64 + 3 * 512 * 512 / 256)

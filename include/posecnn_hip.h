@@ -300,6 +300,21 @@ int pcnn_conv3x3_c3_winograd43_raw_fwd(const uint8_t* color_bgr, int num_color, 
                                        const double* pixel_means, const float* weights, const float* bias, int height,
                                        int width, int out_channels, int relu, float* v, void* stream);
 
+/* conv1_1 -> conv1_2 -> pool1 of a VGG16 tower (vgg16_convs.py:36-38: conv(3,3,64) -> conv(3,3,64) -> max_pool(2,2)) in ONE kernel:
+ *   y_pool [B, H/2, W/2, 64] = max_pool_2x2(act2(conv3x3(act1(conv3x3(x, w1) + b1), W2) + b2)),  H and W multiples of 16.
+ *   x f32 [B,H,W,3] blobs; w1 [groups][3,3,3,64] (ky,kx,ci,co), b1 [groups][64]; ut2 = the F(4x4,3x3) transform of conv1_2's
+ *   filter, U^T [groups][36][64 out][64 in] (what pcnn_winograd43_conv_fwd takes), b2 [groups][64]; image b uses set
+ *   b / (B / groups). Bit-identical to pcnn_conv3x3_c3_winograd43_fwd followed by pcnn_winograd43_conv_fwd(pool = 1), without
+ *   the 2.25 x 78.6 MB per frame of transformed input between them ever touching HBM. The _raw form takes the frames as
+ *   pcnn_conv3x3_c3_winograd43_raw_fwd does (colour frames use set 0, depth frames the next). */
+int pcnn_conv1_1_conv1_2_fused_fwd(const float* x, const float* w1, const float* b1, const float* ut2, const float* b2,
+                                   int batch, int height, int width, int groups, int relu1, int relu2, float* y_pool,
+                                   void* stream);
+int pcnn_conv1_1_conv1_2_fused_raw_fwd(const uint8_t* color_bgr, int num_color, const uint16_t* depth, int num_depth,
+                                       const double* pixel_means, const float* w1, const float* b1, const float* ut2,
+                                       const float* b2, int height, int width, int relu1, int relu2, float* y_pool,
+                                       void* stream);
+
 /* Data transforms of a Winograd F(2x2,3x3) evaluation of `Network.conv` for the deep 3x3 / stride 1 /
  * SAME layers of the trunk (network.py:159-187; vgg16_convs.py:42-52). All f32.
  *   pcnn_winograd_input_fwd : x f32 [B,H,W,C] (H, W even, C % 4 == 0) -> v f32 [16][T][C],

@@ -261,6 +261,247 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wino43_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// conv1_1 -> conv1_2 (-> pool1) in ONE kernel (round 4; VERDICT r3 "Next" #4). Cin = Cout = 64: the whole contraction of
+// conv1_2 is one K stage and one channel block, so nothing of it has to leave the CU: the unfused pair writes V
+// (2.25 x 78.6 MB per frame) with conv3x3_c3_wino43_kernel and reads it back with wino43_mfma_kernel — 11.3 GB of HBM
+// traffic per 2 x 16 frames and the 1.7 ms kernel that is bound by it. Here a workgroup owns a 4 x 4 block of F(4x4,3x3)
+// tiles (16 x 16 output pixels) of one image:
+//   phase 1  relu(conv1_1 + bias) on the 18 x 18 pixel patch the block's tiles need, into LDS (83 KB; zeros outside the
+//            image = conv1_2's SAME padding) — the code of conv3x3_c3_wino43_kernel's phase 1 on a taller patch;
+//   phase 2  in three groups of 12 transform planes (rows xi of B^T d B in the pairs (0,5), (1,2), (3,4), which share their
+//            first-stage terms): thread = (tile, channel quad) builds the 12 planes of its tile from the patch with the
+//            expression trees of fw_bt6 / wino43_input_kernel and parks them in LDS as the A operand (16 tiles x 64
+//            channels per plane, XOR-swizzled 16-byte chunks); then each wave contracts the 12 planes for its 16 output
+//            channels on v_mfma_f32_16x16x4_f32 — B (U^T rows, L2-resident: the filter bank is 590 KB) comes straight from
+//            global memory into registers, one plane ahead; MFMA order and K mapping are wino43_mfma_kernel's
+//            (k = 16 g + 4 (lane >> 4) + i, g then i ascending, C = 0 first), so every accumulator holds the same bits;
+//   epilogue all 36 accumulators of a (tile, channel) element are in registers (16 tiles per workgroup: 144 VGPRs), so the
+//            output transform runs once at the end with exactly the column-by-column sequence of the MFMA kernel's fold
+//            (at6_col, then Y += t (x) A[nu, :] for nu = 0..5), + bias, ReLU, 2 x 2 max — through LDS, so that the pooled
+//            8 x 8 x 64 block leaves as 2-KB contiguous rows.
+// One workgroup per CU (LDS 139 KB), 4 waves. Bit-identical to conv3x3_c3_winograd43 + winograd43_conv(pool = 1)
+// (tests/test_gpu_round4.py). H and W must be multiples of 16.
+constexpr int F12_P = 18;                       // patch rows / columns of a 4 x 4 tile block
+constexpr int F12_NQ = 5;                       // pixel quads per patch row (20 columns computed, 18 kept)
+constexpr int F12_INF = 24 * CF_CIN;            // window columns px0-1 .. px0+22 (22 used)
+
+typedef float v4f12 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void f12_at6_col(const float* m, float* t)
+{
+  const float s = m[1] + m[2], d = m[1] - m[2], S = m[3] + m[4], D = m[3] - m[4];
+  t[0] = (m[0] + s) + S;
+  t[1] = __builtin_fmaf(2.f, D, d);
+  t[2] = __builtin_fmaf(4.f, S, s);
+  t[3] = __builtin_fmaf(8.f, D, d) + m[5];
+}
+
+template <bool RAW>
+__global__ __launch_bounds__(256, 1) void conv12_wino43_fused_kernel(
+    const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ ut2, const float* __restrict__ b2, float* __restrict__ ypool, int H, int W, int nbx,
+    int nby, int imgs_per_group, int relu1, int relu2, RawFrames raw)
+{
+  __shared__ float s_in[F12_P + 2][F12_INF];
+  __shared__ __attribute__((aligned(16))) float s_y[F12_P][F12_P][64];
+  __shared__ __attribute__((aligned(16))) float s_v[12 * 16 * 64];      // 12 planes x 16 tiles x 64 channels; epilogue: 8 x 8 x 64
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bx = blockIdx.x % nbx, by = (blockIdx.x / nbx) % nby, b = blockIdx.x / (nbx * nby);
+  const int py0 = 16 * by - 1, px0 = 16 * bx - 1;   // image coordinates of patch pixel (0, 0)
+  const bool is_depth = RAW && (raw.color == nullptr || b >= raw.n_color);
+  const int grp = RAW ? ((raw.color != nullptr && is_depth) ? 1 : 0) : b / imgs_per_group;
+  w1 += (size_t)grp * 27 * 64;
+  b1 += (size_t)grp * 64;
+  ut2 += (size_t)grp * 36 * 64 * 64;
+  b2 += (size_t)grp * 64;
+
+  // input window: rows py0-1 .. py0+18, columns px0-1 .. px0+22
+  for (int i = tid; i < (F12_P + 2) * F12_INF; i += 256) {
+    const int r = i / F12_INF, j = i - r * F12_INF;
+    const int iy = py0 - 1 + r, ix = px0 - 1 + j / CF_CIN, ch = j % CF_CIN;
+    float val = 0.f;
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+      if (!RAW) {
+        val = x[(((size_t)b * H + iy) * W + ix) * CF_CIN + ch];
+      } else if (!is_depth) {
+        val = (float)((double)raw.color[(((size_t)b * H + iy) * W + ix) * CF_CIN + ch] - raw.mean[ch]);
+      } else {
+        const int bd = b - (raw.color ? raw.n_color : 0);
+        const float t = fminf(fmaxf(div_rn((float)raw.depth[((size_t)bd * H + iy) * W + ix], 2000.f), 0.f), 1.f) * 255.f;
+        val = (float)((double)t - raw.mean[ch]);
+      }
+    }
+    s_in[r][j] = val;
+  }
+  {
+    // phase 1 (see conv3x3_c3_wino43_kernel): pixel quads x channel pairs, per-pixel order (ky, kx, ci) ascending
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const int half = lane >> 5, cp = lane & 31;
+    f2 wq[27];
+#pragma unroll
+    for (int t = 0; t < 27; t++) wq[t] = *reinterpret_cast<const f2*>(w1 + (size_t)t * 64 + cp * 2);
+    const f2 bq = *reinterpret_cast<const f2*>(b1 + cp * 2);
+    __syncthreads();
+    for (int it = 0; it < (F12_P * F12_NQ + 7) / 8; it++) {
+      const int p = it * 8 + wave * 2 + half;
+      if (p < F12_P * F12_NQ) {
+        const int r = p / F12_NQ, cx = 4 * (p - r * F12_NQ);
+        const int yy = py0 + r, xx = px0 + cx;
+        f2 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = (f2){0.f, 0.f};
+        const bool rowok = yy >= 0 && yy < H;
+        if (rowok) {
+#pragma unroll
+          for (int ky = 0; ky < 3; ky++) {
+            const float* win = &s_in[r + ky][cx * CF_CIN];   // 18 floats: columns cx-1 .. cx+4
+            float wv[18];
+#pragma unroll
+            for (int j = 0; j < 18; j++) wv[j] = win[j];
+#pragma unroll
+            for (int j = 0; j < 9; j++)
+#pragma unroll
+              for (int q = 0; q < 4; q++) {
+                const f2 v = {wv[j + 3 * q], wv[j + 3 * q]};
+                acc[q] = __builtin_elementwise_fma(wq[ky * 9 + j], v, acc[q]);
+              }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          f2 a = acc[q] + bq;
+          if (relu1) {
+            a.x = a.x > 0.f ? a.x : 0.f;
+            a.y = a.y > 0.f ? a.y : 0.f;
+          }
+          if (!(rowok && xx + q >= 0 && xx + q < W)) a = (f2){0.f, 0.f};   // outside the image: conv1_2's zero padding
+          if (cx + q < F12_P) *reinterpret_cast<f2*>(&s_y[r][cx + q][cp * 2]) = a;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: 3 groups of 12 planes -------------------------------------------------------------------------------
+  const int lr = lane & 15, lk = lane >> 4;
+  const int tile = tid >> 4, cq = tid & 15;            // transform item: (tile, channel quad)
+  const int tyy = tile >> 2, txx = tile & 3;
+  v4f12 acc[36];
+  const float* ub = ut2 + (size_t)(16 * wave + lr) * 64 + 4 * lk;     // this lane's U^T row and K chunk inside a plane
+
+#define F12_GROUP(XA, XB)                                                                                       \
+  {                                                                                                             \
+    /* stage 1 along the patch rows for rows XA and XB of B^T d B, stage 2 (fw_bt6) along the columns */        \
+    f4 ta[6], tb[6];                                                                                            \
+    _Pragma("unroll") for (int s2 = 0; s2 < 6; s2++) {                                                          \
+      f4 d[6];                                                                                                  \
+      _Pragma("unroll") for (int r = ((XA) == 0 ? 0 : 1); r < ((XA) == 0 ? 6 : 5); r++)                         \
+        d[r] = *reinterpret_cast<const f4*>(&s_y[4 * tyy + r][4 * txx + s2][cq * 4]);                           \
+      if ((XA) == 0) {                                                                                          \
+        ta[s2] = (4.f * d[0] - 5.f * d[2]) + d[4];                                                              \
+        tb[s2] = (4.f * d[1] - 5.f * d[3]) + d[5];                                                              \
+      } else if ((XA) == 1) {                                                                                   \
+        const f4 a = d[4] - 4.f * d[2], b_ = d[3] - 4.f * d[1];                                                 \
+        ta[s2] = a + b_;                                                                                        \
+        tb[s2] = a - b_;                                                                                        \
+      } else {                                                                                                  \
+        const f4 c = d[4] - d[2], e = 2.f * (d[3] - d[1]);                                                      \
+        ta[s2] = c + e;                                                                                         \
+        tb[s2] = c - e;                                                                                         \
+      }                                                                                                         \
+    }                                                                                                           \
+    f4 oa[6], ob[6];                                                                                            \
+    fw_bt6(ta, oa);                                                                                             \
+    fw_bt6(tb, ob);                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < 6; j++) {                                                             \
+      *reinterpret_cast<f4*>(&s_v[((0 * 6 + j) * 16 + tile) * 64 + ((cq ^ tile) * 4)]) = oa[j];                 \
+      *reinterpret_cast<f4*>(&s_v[((1 * 6 + j) * 16 + tile) * 64 + ((cq ^ tile) * 4)]) = ob[j];                 \
+    }                                                                                                           \
+    __syncthreads();                                                                                            \
+    /* contraction: planes 6 XA + j and 6 XB + j, two at a time (independent accumulator chains) */             \
+    _Pragma("unroll") for (int j = 0; j < 6; j++) {                                                             \
+      const int ka = 6 * (XA) + j, kb = 6 * (XB) + j;                                                           \
+      f4 ua[4], ubq[4], va[4], vb[4];                                                                           \
+      _Pragma("unroll") for (int g = 0; g < 4; g++) {                                                           \
+        ua[g] = *reinterpret_cast<const f4*>(ub + (size_t)ka * 4096 + 16 * g);                                  \
+        ubq[g] = *reinterpret_cast<const f4*>(ub + (size_t)kb * 4096 + 16 * g);                                 \
+        va[g] = *reinterpret_cast<const f4*>(&s_v[((0 * 6 + j) * 16 + lr) * 64 + (((4 * g + lk) ^ lr) * 4)]);   \
+        vb[g] = *reinterpret_cast<const f4*>(&s_v[((1 * 6 + j) * 16 + lr) * 64 + (((4 * g + lk) ^ lr) * 4)]);   \
+      }                                                                                                         \
+      v4f12 ca = (v4f12){0.f, 0.f, 0.f, 0.f}, cb = ca;                                                          \
+      _Pragma("unroll") for (int g = 0; g < 4; g++)                                                             \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                         \
+          ca = __builtin_amdgcn_mfma_f32_16x16x4f32(va[g][i], ua[g][i], ca, 0, 0, 0);                           \
+          cb = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[g][i], ubq[g][i], cb, 0, 0, 0);                          \
+        }                                                                                                       \
+      acc[ka] = ca;                                                                                             \
+      acc[kb] = cb;                                                                                             \
+    }                                                                                                           \
+    __syncthreads();                                                                                            \
+  }
+  F12_GROUP(0, 5)
+  F12_GROUP(1, 2)
+  F12_GROUP(3, 4)
+#undef F12_GROUP
+
+  // ---- epilogue: output transform (the MFMA kernel's fold, column by column), bias, ReLU, 2 x 2 max -----------------
+  // lane holds tiles 4 lk + i (i = 0..3: tile row lk, tile column i) x channel 16 wave + lr
+  const int co = 16 * wave + lr;
+  const float bv = b2[co];
+  float* s_o = s_v;                                       // [8 pooled rows][8 pooled columns][64]
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    float yo[16];
+#pragma unroll
+    for (int o = 0; o < 16; o++) yo[o] = 0.f;
+#pragma unroll
+    for (int nu = 0; nu < 6; nu++) {
+      const float c0 = nu == 5 ? 0.f : 1.f;
+      const float c1 = nu == 1 ? 1.f : nu == 2 ? -1.f : nu == 3 ? 2.f : nu == 4 ? -2.f : 0.f;
+      const float c2 = (nu == 1 || nu == 2) ? 1.f : (nu == 3 || nu == 4) ? 4.f : 0.f;
+      const float c3 = nu == 1 ? 1.f : nu == 2 ? -1.f : nu == 3 ? 8.f : nu == 4 ? -8.f : nu == 5 ? 1.f : 0.f;
+      float m_[6], t_[4];
+#pragma unroll
+      for (int x_ = 0; x_ < 6; x_++) m_[x_] = acc[6 * x_ + nu][i];
+      f12_at6_col(m_, t_);
+#pragma unroll
+      for (int a_ = 0; a_ < 4; a_++) {
+        yo[4 * a_ + 0] = __builtin_fmaf(t_[a_], c0, yo[4 * a_ + 0]);
+        yo[4 * a_ + 1] = __builtin_fmaf(t_[a_], c1, yo[4 * a_ + 1]);
+        yo[4 * a_ + 2] = __builtin_fmaf(t_[a_], c2, yo[4 * a_ + 2]);
+        yo[4 * a_ + 3] = __builtin_fmaf(t_[a_], c3, yo[4 * a_ + 3]);
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < 16; o++) {
+      float val = yo[o] + bv;
+      if (relu2) val = val > 0.f ? val : 0.f;
+      yo[o] = val;
+    }
+#pragma unroll
+    for (int a2 = 0; a2 < 2; a2++)
+#pragma unroll
+      for (int e2 = 0; e2 < 2; e2++) {
+        float p = yo[4 * (2 * a2) + 2 * e2];
+        const float p1 = yo[4 * (2 * a2) + 2 * e2 + 1], p2 = yo[4 * (2 * a2 + 1) + 2 * e2], p3 = yo[4 * (2 * a2 + 1) + 2 * e2 + 1];
+        p = p1 > p ? p1 : p;
+        p = p2 > p ? p2 : p;
+        p = p3 > p ? p3 : p;
+        s_o[((2 * lk + a2) * 8 + (2 * i + e2)) * 64 + co] = p;      // tile (row lk, column i) -> pooled (2 lk + a2, 2 i + e2)
+      }
+  }
+  __syncthreads();
+  const int Hp = H >> 1, Wp = W >> 1;
+  for (int i = tid; i < 8 * 8 * 16; i += 256) {
+    const int c4 = (i & 15) * 4, pxl = (i >> 4) & 7, pyl = i >> 7;
+    *reinterpret_cast<f4*>(ypool + (((size_t)b * Hp + 8 * by + pyl) * Wp + 8 * bx + pxl) * 64 + c4) =
+        *reinterpret_cast<const f4*>(&s_o[(pyl * 8 + pxl) * 64 + c4]);
+  }
+}
+
 }  // namespace
 
 extern "C" int pcnn_conv3x3_c3_winograd43_fwd(const float* x, const float* weights, const float* bias,
@@ -332,4 +573,51 @@ extern "C" int pcnn_conv3x3_c3_fwd(const float* x, const float* weights, const f
   PCNN_LAUNCH(conv3x3_c3_bias_relu_kernel, dim3((unsigned)blocks, Cout / 64), dim3(256), 0, stream,
               x, weights, bias, y, H, W, Cout, relu, nseg, nstrip);
   return check_launch("conv3x3_c3_fwd");
+}
+
+static int conv12_check(int B, int H, int W, const void* w1, const void* b1, const void* ut2, const void* b2, const void* y)
+{
+  PCNN_REQUIRE(B >= 1 && H >= 16 && W >= 16 && H % 16 == 0 && W % 16 == 0, PCNN_EINVAL,
+               "conv1_1_conv1_2_fused: the frame must be a multiple of 16 in both directions (got %dx%d)", W, H);
+  PCNN_REQUIRE(w1 && b1 && ut2 && b2 && y, PCNN_ENULL, "conv1_1_conv1_2_fused: NULL pointer");
+  PCNN_REQUIRE(aligned16(w1) && aligned16(b1) && aligned16(ut2) && aligned16(b2) && aligned16(y), PCNN_EINVAL,
+               "conv1_1_conv1_2_fused: weights, biases and output must be 16-byte aligned");
+  PCNN_REQUIRE((long long)B * (H / 16) * (W / 16) < (1ll << 31), PCNN_EINVAL, "conv1_1_conv1_2_fused: grid too large");
+  return PCNN_OK;
+}
+
+extern "C" int pcnn_conv1_1_conv1_2_fused_fwd(const float* x, const float* w1, const float* b1, const float* ut2,
+                                              const float* b2, int B, int H, int W, int groups, int relu1, int relu2,
+                                              float* y_pool, void* stream_)
+{
+  int st = conv12_check(B, H, W, w1, b1, ut2, b2, y_pool);
+  if (st != PCNN_OK) return st;
+  PCNN_REQUIRE(x, PCNN_ENULL, "conv1_1_conv1_2_fused: NULL input");
+  PCNN_REQUIRE(groups >= 1 && B % groups == 0, PCNN_EINVAL, "conv1_1_conv1_2_fused: batch %d is not a multiple of groups %d", B, groups);
+  hipStream_t stream = (hipStream_t)stream_;
+  const RawFrames none = {nullptr, nullptr, 0, {0.0, 0.0, 0.0}};
+  PCNN_LAUNCH((conv12_wino43_fused_kernel<false>), dim3((unsigned)(B * (H / 16) * (W / 16))), dim3(256), 0, stream, x, w1, b1, ut2,
+              b2, y_pool, H, W, W / 16, H / 16, B / groups, relu1, relu2, none);
+  return check_launch("conv1_1_conv1_2_fused_fwd");
+}
+
+extern "C" int pcnn_conv1_1_conv1_2_fused_raw_fwd(const uint8_t* color_bgr, int num_color, const uint16_t* depth, int num_depth,
+                                                  const double* pixel_means, const float* w1, const float* b1, const float* ut2,
+                                                  const float* b2, int H, int W, int relu1, int relu2, float* y_pool, void* stream_)
+{
+  PCNN_REQUIRE(num_color >= 0 && num_depth >= 0 && num_color + num_depth >= 1, PCNN_EINVAL,
+               "conv1_1_conv1_2_fused_raw: bad frame counts (%d colour, %d depth)", num_color, num_depth);
+  int st = conv12_check(num_color + num_depth, H, W, w1, b1, ut2, b2, y_pool);
+  if (st != PCNN_OK) return st;
+  PCNN_REQUIRE((num_color == 0 || color_bgr) && (num_depth == 0 || depth) && pixel_means, PCNN_ENULL, "conv1_1_conv1_2_fused_raw: NULL pointer");
+  PCNN_REQUIRE(pixel_means[0] - pixel_means[0] == 0.0 && pixel_means[1] - pixel_means[1] == 0.0 && pixel_means[2] - pixel_means[2] == 0.0,
+               PCNN_EINVAL, "conv1_1_conv1_2_fused_raw: pixel_means must be finite");
+  PCNN_REQUIRE((reinterpret_cast<uintptr_t>(depth) & 1u) == 0, PCNN_EINVAL, "conv1_1_conv1_2_fused_raw: depth must be 2-byte aligned");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int B = num_color + num_depth;
+  const RawFrames raw = {num_color ? color_bgr : nullptr, num_depth ? depth : nullptr, num_color,
+                         {pixel_means[0], pixel_means[1], pixel_means[2]}};
+  PCNN_LAUNCH((conv12_wino43_fused_kernel<true>), dim3((unsigned)(B * (H / 16) * (W / 16))), dim3(256), 0, stream, (const float*)nullptr,
+              w1, b1, ut2, b2, y_pool, H, W, W / 16, H / 16, 1, relu1, relu2, raw);
+  return check_launch("conv1_1_conv1_2_fused_raw_fwd");
 }

@@ -187,6 +187,7 @@ class Network(object):
         self.winograd_mfma = True
         self.fuse_first_conv_into_winograd = True
         self.fused_first_conv = True  # 3-channel 3x3 convs go to the fused conv + bias + ReLU kernel
+        self.fused_conv12 = True      # grouped RGB-D trunk: conv1_1 -> conv1_2 -> pool1 as one LDS-resident kernel (round 4)
         self.defer_act = frozenset()  # conv layers whose bias + ReLU is left to the following max_pool
         self.dual_pool = frozenset()  # ... and those whose un-pooled output other layers read too (Winograd only)
         self.rows_count = None        # device int32[1]: true row count of capacity-sized ROI rows fed to `fc` (or None)
@@ -865,6 +866,12 @@ class vgg16_convs(Network):
             wt, bias = packed[li]
             if ci == 3:
                 continue   # conv1_1 is evaluated inside conv1_2's input transform
+            if li == 1 and self.fused_conv12 and pool == "pool1" and co == 64 and H % 16 == 0 and W % 16 == 0:
+                # conv1_1 -> conv1_2 -> pool1 in one kernel: V (2.25 x 78.6 MB per frame) never touches HBM (csrc/conv_first.hip)
+                y = (ops.conv1_1_conv1_2_fused_raw(d, dp, packed[0][0], packed[0][1], wt, bias) if raw
+                     else ops.conv1_1_conv1_2_fused(x, packed[0][0], packed[0][1], wt, bias, groups=2))
+                h, w_ = h // 2, w_ // 2
+                continue
             if li == 1:
                 v = (ops.conv3x3_c3_winograd43_raw(d, dp, packed[0][0], packed[0][1], True) if raw
                      else ops.conv3x3_c3_winograd43(x, packed[0][0], packed[0][1], True, groups=2))
@@ -892,16 +899,23 @@ class vgg16_convs(Network):
         towers = 2 if self.input_format == 'RGBD' else 1
         act = lambda div, ch: 4.0 * B * (H // div) * (W // div) * ch
         x_in = (act(2, 64) + act(2, 128) + act(4, 128) + 2 * act(4, 256) + act(8, 256) + 2 * act(8, 512) + 3 * act(16, 512))
-        return {"conv3x3_c3_wino43_kernel": towers * (act(1, 3) + 2.25 * act(1, 64)),      # reads the frame, writes V of conv1_2
-                "wino43_input_kernel": towers * 3.25 * x_in}                             # reads X, writes V = 2.25 X
+        fused = self.fused_conv12 and self.input_format == 'RGBD' and H % 16 == 0 and W % 16 == 0   # (the grouped trunk's first two layers)
+        t = {"wino43_input_kernel": towers * 3.25 * x_in}                             # reads X, writes V = 2.25 X
+        if not fused:
+            t["conv3x3_c3_wino43_kernel"] = towers * (act(1, 3) + 2.25 * act(1, 64))      # reads the frame, writes V of conv1_2
+        return t
 
     def mfma_table(self, B, H, W):
         """Executed flops per step of the library's fp32-MFMA kernels (for bench.py)."""
         towers = 2 if self.input_format == 'RGBD' else 1
         tiles = lambda div: B * ((H // div + 3) // 4) * ((W // div + 3) // 4)
         div = {"1": 1, "2": 2, "3": 4, "4": 8, "5": 16}
-        fl = sum(2.0 * 36 * tiles(div[n[4]]) * ci * co for n, ci, co, _ in self.TRUNK if ci != 3)
-        return {"wino43_mfma_kernel": towers * fl}
+        fused = self.fused_conv12 and self.input_format == 'RGBD' and H % 16 == 0 and W % 16 == 0
+        fl = sum(2.0 * 36 * tiles(div[n[4]]) * ci * co for n, ci, co, _ in self.TRUNK if ci != 3 and not (fused and n == "conv1_2"))
+        t = {"wino43_mfma_kernel": towers * fl}
+        if fused:   # conv1_1 + conv1_2 + pool1 in one kernel: its matrix work is conv1_2's Winograd-domain contraction
+            t["conv12_wino43_fused_kernel"] = towers * 2.0 * 36 * tiles(1) * 64 * 64
+        return t
 
     def _trunk_reference(self, dtype):
         """The VGG16 tower(s) (vgg16_convs.py:36-67) as plain tensor algebra in `dtype`, image by image:

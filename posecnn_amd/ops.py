@@ -18,7 +18,8 @@ from . import _lib
 from ._lib import HOUGH_ROWS_CAPACITY, MAX_ROI, POSE_CHANNELS, VERTEX_CHANNELS, check, lib
 
 __all__ = [
-    "hough_voting_gpu", "hough_voting_gpu_padded", "roi_pool", "roi_pool_add2", "hard_label",
+    "hough_voting_gpu", "hough_voting_gpu_padded", "roi_pool", "roi_pool_add2", "hard_label", "conv1_1_conv1_2_fused",
+    "conv1_1_conv1_2_fused_raw",
     "average_distance_loss", "backproject", "softmax_argmax", "deconv_bilinear", "bias_act_",
     "hough_voting_grad", "hard_label_grad", "hough_rows_capacity",
     "upscore_softmax_argmax", "Workspace",
@@ -458,6 +459,55 @@ def conv3x3_c3_winograd43_raw(color_bgr, depth, weights, bias, relu=True, pixel_
           lib().pcnn_conv3x3_c3_winograd43_raw_fwd(_ptr(c), nc, _ptr(d), nd, means, _ptr(weights), _ptr(bias), H, W, Cout,
                                                    1 if relu else 0, _ptr(v), _stream(v)))
     return v
+
+
+def conv1_1_conv1_2_fused(x, w1, b1, ut2, b2, relu1=True, relu2=True, groups=1):
+    """max_pool_2x2(relu(conv1_2(relu(conv1_1(x))))) in one kernel (csrc/conv_first.hip): x [B,H,W,3] f32 blobs, H and W multiples
+    of 16; w1 [groups,3,3,3,64], b1 [groups,64]; ut2 [groups,36,64,64] = winograd_filter(w2, 4).transpose(1, 2) per set;
+    b2 [groups,64]. Bit-identical to conv3x3_c3_winograd43 + winograd43_conv(pool=1). Returns [B,H/2,W/2,64]."""
+    x = _dev(x, "x", torch.float32)
+    w1, b1, ut2, b2 = (_dev(t, n, torch.float32) for t, n in ((w1, "w1"), (b1, "b1"), (ut2, "ut2"), (b2, "b2")))
+    if x.dim() != 4 or x.shape[3] != 3:
+        raise ValueError("x must be [B,H,W,3]")
+    B, H, W, _ = x.shape
+    if w1.numel() != groups * 27 * 64 or b1.numel() != groups * 64 or ut2.numel() != groups * 36 * 64 * 64 or b2.numel() != groups * 64:
+        raise ValueError("w1 [groups,3,3,3,64], b1 [groups,64], ut2 [groups,36,64,64], b2 [groups,64]")
+    y = torch.empty((B, H // 2, W // 2, 64), dtype=torch.float32, device=x.device)
+    check("pcnn_conv1_1_conv1_2_fused_fwd",
+          lib().pcnn_conv1_1_conv1_2_fused_fwd(_ptr(x), _ptr(w1), _ptr(b1), _ptr(ut2), _ptr(b2), B, H, W, int(groups),
+                                               1 if relu1 else 0, 1 if relu2 else 0, _ptr(y), _stream(x)))
+    return y
+
+
+def conv1_1_conv1_2_fused_raw(color_bgr, depth, w1, b1, ut2, b2, relu1=True, relu2=True, pixel_means=None):
+    """conv1_1_conv1_2_fused on the frames as the sensor delivers them (see conv3x3_c3_winograd43_raw): colour frames first
+    (filter set 0), depth frames after (next set)."""
+    from .config import PIXEL_MEANS
+    c = _dev(color_bgr, "color_bgr", torch.uint8) if color_bgr is not None else None
+    d = _dev(depth, "depth", torch.uint16) if depth is not None else None
+    if c is None and d is None:
+        raise ValueError("need colour and / or depth frames")
+    if c is not None and (c.dim() != 4 or c.shape[3] != 3):
+        raise ValueError("color_bgr must be uint8 [B,H,W,3]")
+    if d is not None and d.dim() == 4 and d.shape[3] == 1:
+        d = d.reshape(d.shape[:3])
+    if d is not None and d.dim() != 3:
+        raise ValueError("depth must be uint16 [B,H,W]")
+    H, W = (c.shape[1], c.shape[2]) if c is not None else (d.shape[1], d.shape[2])
+    if c is not None and d is not None and tuple(d.shape[1:]) != (H, W):
+        raise ValueError("colour and depth frames must have the same size")
+    nc, nd = (0 if c is None else c.shape[0]), (0 if d is None else d.shape[0])
+    sets = (nc > 0) + (nd > 0)
+    dev = (c if c is not None else d).device
+    w1, b1, ut2, b2 = (_dev(t, n, torch.float32) for t, n in ((w1, "w1"), (b1, "b1"), (ut2, "ut2"), (b2, "b2")))
+    if w1.numel() != sets * 27 * 64 or b1.numel() != sets * 64 or ut2.numel() != sets * 36 * 64 * 64 or b2.numel() != sets * 64:
+        raise ValueError("w1 [sets,3,3,3,64], b1 [sets,64], ut2 [sets,36,64,64], b2 [sets,64]")
+    means = (ctypes.c_double * 3)(*[float(v) for v in np.asarray(PIXEL_MEANS if pixel_means is None else pixel_means, dtype=np.float64).reshape(-1)[:3]])
+    y = torch.empty((nc + nd, H // 2, W // 2, 64), dtype=torch.float32, device=dev)
+    check("pcnn_conv1_1_conv1_2_fused_raw_fwd",
+          lib().pcnn_conv1_1_conv1_2_fused_raw_fwd(_ptr(c), nc, _ptr(d), nd, means, _ptr(w1), _ptr(b1), _ptr(ut2), _ptr(b2), H, W,
+                                                   1 if relu1 else 0, 1 if relu2 else 0, _ptr(y), _stream(y)))
+    return y
 
 
 _WINO_G = {

@@ -252,3 +252,44 @@ def test_roi_pool_add2_dead_rows_zero_or_keep(gpu, R, cap, C):
     assert (got1[R:] == 123.5).all()
     with pytest.raises(ValueError):
         ops.roi_pool_add2(T(gpu, a), 1 / 16.0, T(gpu, b), 1 / 8.0, T(gpu, rois), dead_rows="keep")
+
+
+# ---- conv1_1 -> conv1_2 -> pool1 in one kernel -----------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,W,groups,raw", [(2, 32, 48, 1, False), (4, 48, 32, 2, False), (2, 96, 128, 2, True), (1, 16, 16, 1, False),
+                                             (3, 32, 32, 1, True)])
+def test_conv1_1_conv1_2_fused_equals_the_unfused_pair(gpu, B, H, W, groups, raw):
+    """VERDICT r3 "Next" #4: pcnn_conv1_1_conv1_2_fused_fwd against pcnn_conv3x3_c3_winograd43_fwd + pcnn_winograd43_conv_fwd
+    (pool = 1), bit for bit — borders (the SAME padding of both layers), two filter sets, raw uint8 / uint16 frames — and
+    against a float64 convolution of the same two layers."""
+    import torch
+    from posecnn_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(100 + B * H)
+    w1 = (torch.randn((groups, 3, 3, 3, 64), generator=g) * 0.02).to(gpu)
+    b1 = (torch.randn((groups, 64), generator=g) * 0.1).to(gpu)
+    w2 = (torch.randn((groups, 64, 64, 3, 3), generator=g) * (2.0 / 576) ** 0.5).to(gpu)
+    b2 = (torch.randn((groups, 64), generator=g) * 0.1).to(gpu)
+    ut2 = torch.stack([ops.winograd_filter(w2[k], 4).transpose(1, 2) for k in range(groups)]).contiguous()
+    if raw:
+        nc = B if groups == 1 else B // 2
+        im8 = torch.randint(0, 256, (nc, H, W, 3), generator=g, dtype=torch.uint8).to(gpu)
+        d16 = torch.from_numpy(np.random.default_rng(3).integers(0, 3000, (B - nc, H, W)).astype(np.uint16)).to(gpu) if groups == 2 else None
+        v = ops.conv3x3_c3_winograd43_raw(im8, d16, w1, b1, True)
+        got = ops.conv1_1_conv1_2_fused_raw(im8, d16, w1, b1, ut2, b2)
+    else:
+        x = ((torch.randint(0, 256, (B, H, W, 3), generator=g).float() - 100.0)).to(gpu)
+        v = ops.conv3x3_c3_winograd43(x, w1, b1, True, groups=groups)
+        got = ops.conv1_1_conv1_2_fused(x, w1, b1, ut2, b2, groups=groups)
+    want = ops.winograd43_conv(v, ut2, b2, B, H, W, True, 1, groups)
+    same(N(got), N(want), "fused conv1_1 -> conv1_2 -> pool1")
+    if not raw:
+        # independent anchor: float64 convolutions of the two layers
+        xd = x.double().permute(0, 3, 1, 2)
+        outs = []
+        per = B // groups
+        for k in range(groups):
+            a = torch.relu(torch.nn.functional.conv2d(xd[k * per:(k + 1) * per], w1[k].double().permute(3, 2, 0, 1), b1[k].double(), padding=1))
+            c = torch.relu(torch.nn.functional.conv2d(a, w2[k].double(), b2[k].double(), padding=1))
+            outs.append(torch.nn.functional.max_pool2d(c, 2, 2))
+        ref = torch.cat(outs).permute(0, 2, 3, 1)
+        err = float((got.double() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-5, err
