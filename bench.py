@@ -62,6 +62,8 @@ def parse_args(argv=None):
                     help="also run the backprojecting layer on each batch's head features (G^3 voxels per frame); "
                          "default 128 for --config linemod (configs[4] names it), 0 = off otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused-conv12", action="store_true",
+                    help="A/B: conv1_1 + conv1_2's input transform and conv1_2 as the two round-3 kernels instead of the fused one")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the short configs[1] (batch-1 latency) and configs[4] (LINEMOD 1280x960 + backproject) runs whose "
                          "summaries the default single-GPU invocation appends under `secondary`")
@@ -322,6 +324,8 @@ def main(argv=None):
     # (with_losses=False: the graph itself adds no loss layers — the log-softmax `prob` feeds only loss_cls,
     # which nobody fetches here; im_segment_batch evaluates hard_label and average_distance_loss on request)
     synth.init_calibrated(net)
+    if a.no_fused_conv12:
+        net.fused_conv12 = False
     host, aux = make_host_inputs(100000 * rank, B, H, W, C, a.input, a.nbuf, extents, K, train, raw=a.raw_inputs)
     planted = [{k: torch.from_numpy(v).to(dev) for k, v in p.items()} for p, _, _ in aux]
     gts = [None if g is None else torch.from_numpy(g).to(dev) for _, g, _ in aux]

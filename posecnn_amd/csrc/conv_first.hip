@@ -270,18 +270,20 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wino43_kernel(
 // tiles (16 x 16 output pixels) of one image:
 //   phase 1  relu(conv1_1 + bias) on the 18 x 18 pixel patch the block's tiles need, into LDS (83 KB; zeros outside the
 //            image = conv1_2's SAME padding) — the code of conv3x3_c3_wino43_kernel's phase 1 on a taller patch;
-//   phase 2  in three groups of 12 transform planes (rows xi of B^T d B in the pairs (0,5), (1,2), (3,4), which share their
-//            first-stage terms): thread = (tile, channel quad) builds the 12 planes of its tile from the patch with the
-//            expression trees of fw_bt6 / wino43_input_kernel and parks them in LDS as the A operand (16 tiles x 64
-//            channels per plane, XOR-swizzled 16-byte chunks); then each wave contracts the 12 planes for its 16 output
-//            channels on v_mfma_f32_16x16x4_f32 — B (U^T rows, L2-resident: the filter bank is 590 KB) comes straight from
-//            global memory into registers, one plane ahead; MFMA order and K mapping are wino43_mfma_kernel's
-//            (k = 16 g + 4 (lane >> 4) + i, g then i ascending, C = 0 first), so every accumulator holds the same bits;
+//   phase 2  in six groups of 6 transform planes (row xi of B^T d B), producer / consumer: a PRODUCER thread = (tile, channel
+//            quad) builds the 6 planes of its tile from the patch with the expression trees of fw_bt6 / wino43_input_kernel
+//            and parks them in LDS as the A operand (16 tiles x 64 channels per plane, XOR-swizzled 16-byte chunks, two
+//            group buffers); one step later each CONSUMER wave contracts those planes for its 16 output channels on
+//            v_mfma_f32_16x16x4_f32, two planes at a time (independent accumulator chains) — B (U^T rows, L2-resident: the
+//            filter bank is 590 KB) comes straight from global memory into registers, one pair of planes ahead; MFMA
+//            order and K mapping are wino43_mfma_kernel's (k = 16 g + 4 (lane >> 4) + i, g then i ascending, C = 0
+//            first), so every accumulator holds the same bits. The producers' vector work runs under the consumers'
+//            matrix work of the previous group (other waves of the same SIMDs), one barrier per group;
 //   epilogue all 36 accumulators of a (tile, channel) element are in registers (16 tiles per workgroup: 144 VGPRs), so the
 //            output transform runs once at the end with exactly the column-by-column sequence of the MFMA kernel's fold
 //            (at6_col, then Y += t (x) A[nu, :] for nu = 0..5), + bias, ReLU, 2 x 2 max — through LDS, so that the pooled
 //            8 x 8 x 64 block leaves as 2-KB contiguous rows.
-// One workgroup per CU (LDS 139 KB), 4 waves. Bit-identical to conv3x3_c3_winograd43 + winograd43_conv(pool = 1)
+// One workgroup per CU (LDS 138 KB), 8 waves. Bit-identical to conv3x3_c3_winograd43 + winograd43_conv(pool = 1)
 // (tests/test_gpu_round4.py). H and W must be multiples of 16.
 constexpr int F12_P = 18;                       // patch rows / columns of a 4 x 4 tile block
 constexpr int F12_NQ = 5;                       // pixel quads per patch row (20 columns computed, 18 kept)
@@ -298,15 +300,17 @@ __device__ __forceinline__ void f12_at6_col(const float* m, float* t)
   t[3] = __builtin_fmaf(8.f, D, d) + m[5];
 }
 
+// 512 threads: waves 0-3 are the CONSUMERS (each owns 16 output channels: the 36 accumulators of its elements, the matrix
+// work, the output transform), waves 4-7 the PRODUCERS of the A operand (the transform planes); all eight share phase 1.
 template <bool RAW>
-__global__ __launch_bounds__(256, 1) void conv12_wino43_fused_kernel(
+__global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
     const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ ut2, const float* __restrict__ b2, float* __restrict__ ypool, int H, int W, int nbx,
     int nby, int imgs_per_group, int relu1, int relu2, RawFrames raw)
 {
   __shared__ float s_in[F12_P + 2][F12_INF];
   __shared__ __attribute__((aligned(16))) float s_y[F12_P][F12_P][64];
-  __shared__ __attribute__((aligned(16))) float s_v[12 * 16 * 64];      // 12 planes x 16 tiles x 64 channels; epilogue: 8 x 8 x 64
+  __shared__ __attribute__((aligned(16))) float s_v[2][6 * 16 * 64];   // two groups of 6 planes x 16 tiles x 64 channels; epilogue: 8 x 8 x 64
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bx = blockIdx.x % nbx, by = (blockIdx.x / nbx) % nby, b = blockIdx.x / (nbx * nby);
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(256, 1) void conv12_wino43_fused_kernel(
   b2 += (size_t)grp * 64;
 
   // input window: rows py0-1 .. py0+18, columns px0-1 .. px0+22
-  for (int i = tid; i < (F12_P + 2) * F12_INF; i += 256) {
+  for (int i = tid; i < (F12_P + 2) * F12_INF; i += 512) {
     const int r = i / F12_INF, j = i - r * F12_INF;
     const int iy = py0 - 1 + r, ix = px0 - 1 + j / CF_CIN, ch = j % CF_CIN;
     float val = 0.f;
@@ -345,8 +349,8 @@ __global__ __launch_bounds__(256, 1) void conv12_wino43_fused_kernel(
     for (int t = 0; t < 27; t++) wq[t] = *reinterpret_cast<const f2*>(w1 + (size_t)t * 64 + cp * 2);
     const f2 bq = *reinterpret_cast<const f2*>(b1 + cp * 2);
     __syncthreads();
-    for (int it = 0; it < (F12_P * F12_NQ + 7) / 8; it++) {
-      const int p = it * 8 + wave * 2 + half;
+    for (int it = 0; it < (F12_P * F12_NQ + 15) / 16; it++) {
+      const int p = it * 16 + wave * 2 + half;
       if (p < F12_P * F12_NQ) {
         const int r = p / F12_NQ, cx = 4 * (p - r * F12_NQ);
         const int yy = py0 + r, xx = px0 + cx;
@@ -385,117 +389,129 @@ __global__ __launch_bounds__(256, 1) void conv12_wino43_fused_kernel(
   }
   __syncthreads();
 
-  // ---- phase 2: 3 groups of 12 planes -------------------------------------------------------------------------------
+  // ---- phase 2: six groups of six planes (row xi of B^T d B), software pipelined by one group -------------------------
+  // step s: the producers build group s into s_v[s & 1] while the consumers contract group s - 1 out of s_v[(s - 1) & 1]
+  const bool consumer = wave < 4;
   const int lr = lane & 15, lk = lane >> 4;
-  const int tile = tid >> 4, cq = tid & 15;            // transform item: (tile, channel quad)
+  const int ptid = tid & 255;
+  const int tile = ptid >> 4, cq = ptid & 15;          // producer item: (tile, channel quad)
   const int tyy = tile >> 2, txx = tile & 3;
   v4f12 acc[36];
-  const float* ub = ut2 + (size_t)(16 * wave + lr) * 64 + 4 * lk;     // this lane's U^T row and K chunk inside a plane
-
-#define F12_GROUP(XA, XB)                                                                                       \
+  const float* ub = ut2 + (size_t)(16 * (wave & 3) + lr) * 64 + 4 * lk;     // a consumer lane's U^T row and K chunk inside a plane
+  f4 un[2][4];                                           // B operands of the NEXT pair of planes (one pair ahead)
+#define F12_LOADB(KA)                                                                                           \
+  _Pragma("unroll") for (int g = 0; g < 4; g++) {                                                               \
+    un[0][g] = *reinterpret_cast<const f4*>(ub + (size_t)(KA) * 4096 + 16 * g);                                 \
+    un[1][g] = *reinterpret_cast<const f4*>(ub + (size_t)((KA) + 1) * 4096 + 16 * g);                           \
+  }
+#define F12_PRODUCE(XI, BUF)                                                                                    \
   {                                                                                                             \
-    /* stage 1 along the patch rows for rows XA and XB of B^T d B, stage 2 (fw_bt6) along the columns */        \
-    f4 ta[6], tb[6];                                                                                            \
+    f4 ta[6];                                                                                                   \
     _Pragma("unroll") for (int s2 = 0; s2 < 6; s2++) {                                                          \
       f4 d[6];                                                                                                  \
-      _Pragma("unroll") for (int r = ((XA) == 0 ? 0 : 1); r < ((XA) == 0 ? 6 : 5); r++)                         \
-        d[r] = *reinterpret_cast<const f4*>(&s_y[4 * tyy + r][4 * txx + s2][cq * 4]);                           \
-      if ((XA) == 0) {                                                                                          \
-        ta[s2] = (4.f * d[0] - 5.f * d[2]) + d[4];                                                              \
-        tb[s2] = (4.f * d[1] - 5.f * d[3]) + d[5];                                                              \
-      } else if ((XA) == 1) {                                                                                   \
+      _Pragma("unroll") for (int r = 0; r < 6; r++)                                                             \
+        if (((XI) == 0 && (r == 0 || r == 2 || r == 4)) || ((XI) == 5 && (r == 1 || r == 3 || r == 5)) ||       \
+            ((XI) >= 1 && (XI) <= 4 && r >= 1 && r <= 4))                                                       \
+          d[r] = *reinterpret_cast<const f4*>(&s_y[4 * tyy + r][4 * txx + s2][cq * 4]);                         \
+      if ((XI) == 0) ta[s2] = (4.f * d[0] - 5.f * d[2]) + d[4];                                                 \
+      else if ((XI) == 5) ta[s2] = (4.f * d[1] - 5.f * d[3]) + d[5];                                            \
+      else if ((XI) == 1 || (XI) == 2) {                                                                        \
         const f4 a = d[4] - 4.f * d[2], b_ = d[3] - 4.f * d[1];                                                 \
-        ta[s2] = a + b_;                                                                                        \
-        tb[s2] = a - b_;                                                                                        \
+        ta[s2] = (XI) == 1 ? a + b_ : a - b_;                                                                   \
       } else {                                                                                                  \
         const f4 c = d[4] - d[2], e = 2.f * (d[3] - d[1]);                                                      \
-        ta[s2] = c + e;                                                                                         \
-        tb[s2] = c - e;                                                                                         \
+        ta[s2] = (XI) == 3 ? c + e : c - e;                                                                     \
       }                                                                                                         \
     }                                                                                                           \
-    f4 oa[6], ob[6];                                                                                            \
+    f4 oa[6];                                                                                                   \
     fw_bt6(ta, oa);                                                                                             \
-    fw_bt6(tb, ob);                                                                                             \
-    _Pragma("unroll") for (int j = 0; j < 6; j++) {                                                             \
-      *reinterpret_cast<f4*>(&s_v[((0 * 6 + j) * 16 + tile) * 64 + ((cq ^ tile) * 4)]) = oa[j];                 \
-      *reinterpret_cast<f4*>(&s_v[((1 * 6 + j) * 16 + tile) * 64 + ((cq ^ tile) * 4)]) = ob[j];                 \
-    }                                                                                                           \
-    __syncthreads();                                                                                            \
-    /* contraction: planes 6 XA + j and 6 XB + j, two at a time (independent accumulator chains) */             \
-    _Pragma("unroll") for (int j = 0; j < 6; j++) {                                                             \
-      const int ka = 6 * (XA) + j, kb = 6 * (XB) + j;                                                           \
-      f4 ua[4], ubq[4], va[4], vb[4];                                                                           \
-      _Pragma("unroll") for (int g = 0; g < 4; g++) {                                                           \
-        ua[g] = *reinterpret_cast<const f4*>(ub + (size_t)ka * 4096 + 16 * g);                                  \
-        ubq[g] = *reinterpret_cast<const f4*>(ub + (size_t)kb * 4096 + 16 * g);                                 \
-        va[g] = *reinterpret_cast<const f4*>(&s_v[((0 * 6 + j) * 16 + lr) * 64 + (((4 * g + lk) ^ lr) * 4)]);   \
-        vb[g] = *reinterpret_cast<const f4*>(&s_v[((1 * 6 + j) * 16 + lr) * 64 + (((4 * g + lk) ^ lr) * 4)]);   \
-      }                                                                                                         \
-      v4f12 ca = (v4f12){0.f, 0.f, 0.f, 0.f}, cb = ca;                                                          \
-      _Pragma("unroll") for (int g = 0; g < 4; g++)                                                             \
-        _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                         \
-          ca = __builtin_amdgcn_mfma_f32_16x16x4f32(va[g][i], ua[g][i], ca, 0, 0, 0);                           \
-          cb = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[g][i], ubq[g][i], cb, 0, 0, 0);                          \
-        }                                                                                                       \
-      acc[ka] = ca;                                                                                             \
-      acc[kb] = cb;                                                                                             \
-    }                                                                                                           \
-    __syncthreads();                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < 6; j++)                                                               \
+      *reinterpret_cast<f4*>(&s_v[BUF][(j * 16 + tile) * 64 + ((cq ^ tile) * 4)]) = oa[j];                      \
   }
-  F12_GROUP(0, 5)
-  F12_GROUP(1, 2)
-  F12_GROUP(3, 4)
-#undef F12_GROUP
+  // one pair of planes (6 XI + J, 6 XI + J + 1): B of this pair was fetched a pair ago, the next pair's B goes out first
+#define F12_PAIR(XI, J, BUF, KNEXT)                                                                             \
+  {                                                                                                             \
+    f4 ua[4], ubq[4], va[4], vb[4];                                                                             \
+    _Pragma("unroll") for (int g = 0; g < 4; g++) { ua[g] = un[0][g]; ubq[g] = un[1][g]; }                      \
+    if ((KNEXT) < 36) { F12_LOADB(KNEXT) }                                                                      \
+    _Pragma("unroll") for (int g = 0; g < 4; g++) {                                                             \
+      va[g] = *reinterpret_cast<const f4*>(&s_v[BUF][(((J) + 0) * 16 + lr) * 64 + (((4 * g + lk) ^ lr) * 4)]);  \
+      vb[g] = *reinterpret_cast<const f4*>(&s_v[BUF][(((J) + 1) * 16 + lr) * 64 + (((4 * g + lk) ^ lr) * 4)]);  \
+    }                                                                                                           \
+    v4f12 ca = (v4f12){0.f, 0.f, 0.f, 0.f}, cb = ca;                                                            \
+    _Pragma("unroll") for (int g = 0; g < 4; g++)                                                               \
+      _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                           \
+        ca = __builtin_amdgcn_mfma_f32_16x16x4f32(va[g][i], ua[g][i], ca, 0, 0, 0);                             \
+        cb = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[g][i], ubq[g][i], cb, 0, 0, 0);                            \
+      }                                                                                                         \
+    acc[6 * (XI) + (J)] = ca;                                                                                   \
+    acc[6 * (XI) + (J) + 1] = cb;                                                                               \
+  }
+#define F12_CONSUME(XI, BUF)                                                                                    \
+  F12_PAIR(XI, 0, BUF, 6 * (XI) + 2) F12_PAIR(XI, 2, BUF, 6 * (XI) + 4) F12_PAIR(XI, 4, BUF, 6 * (XI) + 6)
+#define F12_STEP(S)                                                                                             \
+  if (consumer) { if ((S) >= 1) { F12_CONSUME((S) - 1, ((S) - 1) & 1) } }                                       \
+  else { if ((S) <= 5) { F12_PRODUCE((S) <= 5 ? (S) : 5, (S) & 1) } }                                           \
+  __syncthreads();
+  if (consumer) { F12_LOADB(0) }
+  F12_STEP(0) F12_STEP(1) F12_STEP(2) F12_STEP(3) F12_STEP(4) F12_STEP(5) F12_STEP(6)
+#undef F12_STEP
+#undef F12_CONSUME
+#undef F12_PAIR
+#undef F12_PRODUCE
+#undef F12_LOADB
 
   // ---- epilogue: output transform (the MFMA kernel's fold, column by column), bias, ReLU, 2 x 2 max -----------------
-  // lane holds tiles 4 lk + i (i = 0..3: tile row lk, tile column i) x channel 16 wave + lr
-  const int co = 16 * wave + lr;
-  const float bv = b2[co];
-  float* s_o = s_v;                                       // [8 pooled rows][8 pooled columns][64]
+  // a consumer lane holds tiles 4 lk + i (i = 0..3: tile row lk, tile column i) x channel 16 wave + lr
+  float* s_o = &s_v[0][0];                                // [8 pooled rows][8 pooled columns][64]
+  if (consumer) {
+    const int co = 16 * wave + lr;
+    const float bv = b2[co];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    float yo[16];
+    for (int i = 0; i < 4; i++) {
+      float yo[16];
 #pragma unroll
-    for (int o = 0; o < 16; o++) yo[o] = 0.f;
+      for (int o = 0; o < 16; o++) yo[o] = 0.f;
 #pragma unroll
-    for (int nu = 0; nu < 6; nu++) {
-      const float c0 = nu == 5 ? 0.f : 1.f;
-      const float c1 = nu == 1 ? 1.f : nu == 2 ? -1.f : nu == 3 ? 2.f : nu == 4 ? -2.f : 0.f;
-      const float c2 = (nu == 1 || nu == 2) ? 1.f : (nu == 3 || nu == 4) ? 4.f : 0.f;
-      const float c3 = nu == 1 ? 1.f : nu == 2 ? -1.f : nu == 3 ? 8.f : nu == 4 ? -8.f : nu == 5 ? 1.f : 0.f;
-      float m_[6], t_[4];
+      for (int nu = 0; nu < 6; nu++) {
+        const float c0 = nu == 5 ? 0.f : 1.f;
+        const float c1 = nu == 1 ? 1.f : nu == 2 ? -1.f : nu == 3 ? 2.f : nu == 4 ? -2.f : 0.f;
+        const float c2 = (nu == 1 || nu == 2) ? 1.f : (nu == 3 || nu == 4) ? 4.f : 0.f;
+        const float c3 = nu == 1 ? 1.f : nu == 2 ? -1.f : nu == 3 ? 8.f : nu == 4 ? -8.f : nu == 5 ? 1.f : 0.f;
+        float m_[6], t_[4];
 #pragma unroll
-      for (int x_ = 0; x_ < 6; x_++) m_[x_] = acc[6 * x_ + nu][i];
-      f12_at6_col(m_, t_);
+        for (int x_ = 0; x_ < 6; x_++) m_[x_] = acc[6 * x_ + nu][i];
+        f12_at6_col(m_, t_);
 #pragma unroll
-      for (int a_ = 0; a_ < 4; a_++) {
-        yo[4 * a_ + 0] = __builtin_fmaf(t_[a_], c0, yo[4 * a_ + 0]);
-        yo[4 * a_ + 1] = __builtin_fmaf(t_[a_], c1, yo[4 * a_ + 1]);
-        yo[4 * a_ + 2] = __builtin_fmaf(t_[a_], c2, yo[4 * a_ + 2]);
-        yo[4 * a_ + 3] = __builtin_fmaf(t_[a_], c3, yo[4 * a_ + 3]);
+        for (int a_ = 0; a_ < 4; a_++) {
+          yo[4 * a_ + 0] = __builtin_fmaf(t_[a_], c0, yo[4 * a_ + 0]);
+          yo[4 * a_ + 1] = __builtin_fmaf(t_[a_], c1, yo[4 * a_ + 1]);
+          yo[4 * a_ + 2] = __builtin_fmaf(t_[a_], c2, yo[4 * a_ + 2]);
+          yo[4 * a_ + 3] = __builtin_fmaf(t_[a_], c3, yo[4 * a_ + 3]);
+        }
       }
-    }
 #pragma unroll
-    for (int o = 0; o < 16; o++) {
-      float val = yo[o] + bv;
-      if (relu2) val = val > 0.f ? val : 0.f;
-      yo[o] = val;
-    }
-#pragma unroll
-    for (int a2 = 0; a2 < 2; a2++)
-#pragma unroll
-      for (int e2 = 0; e2 < 2; e2++) {
-        float p = yo[4 * (2 * a2) + 2 * e2];
-        const float p1 = yo[4 * (2 * a2) + 2 * e2 + 1], p2 = yo[4 * (2 * a2 + 1) + 2 * e2], p3 = yo[4 * (2 * a2 + 1) + 2 * e2 + 1];
-        p = p1 > p ? p1 : p;
-        p = p2 > p ? p2 : p;
-        p = p3 > p ? p3 : p;
-        s_o[((2 * lk + a2) * 8 + (2 * i + e2)) * 64 + co] = p;      // tile (row lk, column i) -> pooled (2 lk + a2, 2 i + e2)
+      for (int o = 0; o < 16; o++) {
+        float val = yo[o] + bv;
+        if (relu2) val = val > 0.f ? val : 0.f;
+        yo[o] = val;
       }
+#pragma unroll
+      for (int a2 = 0; a2 < 2; a2++)
+#pragma unroll
+        for (int e2 = 0; e2 < 2; e2++) {
+          float p = yo[4 * (2 * a2) + 2 * e2];
+          const float p1 = yo[4 * (2 * a2) + 2 * e2 + 1], p2 = yo[4 * (2 * a2 + 1) + 2 * e2], p3 = yo[4 * (2 * a2 + 1) + 2 * e2 + 1];
+          p = p1 > p ? p1 : p;
+          p = p2 > p ? p2 : p;
+          p = p3 > p ? p3 : p;
+          s_o[((2 * lk + a2) * 8 + (2 * i + e2)) * 64 + co] = p;      // tile (row lk, column i) -> pooled (2 lk + a2, 2 i + e2)
+        }
+    }
   }
   __syncthreads();
   const int Hp = H >> 1, Wp = W >> 1;
-  for (int i = tid; i < 8 * 8 * 16; i += 256) {
+  for (int i = tid; i < 8 * 8 * 16; i += 512) {
     const int c4 = (i & 15) * 4, pxl = (i >> 4) & 7, pyl = i >> 7;
     *reinterpret_cast<f4*>(ypool + (((size_t)b * Hp + 8 * by + pyl) * Wp + 8 * bx + pxl) * 64 + c4) =
         *reinterpret_cast<const f4*>(&s_o[(pyl * 8 + pxl) * 64 + c4]);
@@ -596,7 +612,7 @@ extern "C" int pcnn_conv1_1_conv1_2_fused_fwd(const float* x, const float* w1, c
   PCNN_REQUIRE(groups >= 1 && B % groups == 0, PCNN_EINVAL, "conv1_1_conv1_2_fused: batch %d is not a multiple of groups %d", B, groups);
   hipStream_t stream = (hipStream_t)stream_;
   const RawFrames none = {nullptr, nullptr, 0, {0.0, 0.0, 0.0}};
-  PCNN_LAUNCH((conv12_wino43_fused_kernel<false>), dim3((unsigned)(B * (H / 16) * (W / 16))), dim3(256), 0, stream, x, w1, b1, ut2,
+  PCNN_LAUNCH((conv12_wino43_fused_kernel<false>), dim3((unsigned)(B * (H / 16) * (W / 16))), dim3(512), 0, stream, x, w1, b1, ut2,
               b2, y_pool, H, W, W / 16, H / 16, B / groups, relu1, relu2, none);
   return check_launch("conv1_1_conv1_2_fused_fwd");
 }
@@ -617,7 +633,7 @@ extern "C" int pcnn_conv1_1_conv1_2_fused_raw_fwd(const uint8_t* color_bgr, int 
   const int B = num_color + num_depth;
   const RawFrames raw = {num_color ? color_bgr : nullptr, num_depth ? depth : nullptr, num_color,
                          {pixel_means[0], pixel_means[1], pixel_means[2]}};
-  PCNN_LAUNCH((conv12_wino43_fused_kernel<true>), dim3((unsigned)(B * (H / 16) * (W / 16))), dim3(256), 0, stream, (const float*)nullptr,
+  PCNN_LAUNCH((conv12_wino43_fused_kernel<true>), dim3((unsigned)(B * (H / 16) * (W / 16))), dim3(512), 0, stream, (const float*)nullptr,
               w1, b1, ut2, b2, y_pool, H, W, W / 16, H / 16, 1, relu1, relu2, raw);
   return check_launch("conv1_1_conv1_2_fused_raw_fwd");
 }
