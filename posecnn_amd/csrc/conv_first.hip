@@ -274,8 +274,8 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wino43_kernel(
 //            quad) builds the 6 planes of its tile from the patch with the expression trees of fw_bt6 / wino43_input_kernel
 //            and parks them in LDS as the A operand (16 tiles x 64 channels per plane, XOR-swizzled 16-byte chunks, two
 //            group buffers); one step later each CONSUMER wave contracts those planes for its 16 output channels on
-//            v_mfma_f32_16x16x4_f32, two planes at a time (independent accumulator chains) — B (U^T rows, L2-resident: the
-//            filter bank is 590 KB) comes straight from global memory into registers, one pair of planes ahead; MFMA
+//            v_mfma_f32_16x16x4_f32 — B (U^T rows, L2-resident: the filter bank is 590 KB) comes straight from global
+//            memory into registers two planes ahead, A from LDS one plane ahead; MFMA
 //            order and K mapping are wino43_mfma_kernel's (k = 16 g + 4 (lane >> 4) + i, g then i ascending, C = 0
 //            first), so every accumulator holds the same bits. The producers' vector work runs under the consumers'
 //            matrix work of the previous group (other waves of the same SIMDs), one barrier per group;
@@ -398,67 +398,77 @@ __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
   const int tyy = tile >> 2, txx = tile & 3;
   v4f12 acc[36];
   const float* ub = ut2 + (size_t)(16 * (wave & 3) + lr) * 64 + 4 * lk;     // a consumer lane's U^T row and K chunk inside a plane
-  f4 un[2][4];                                           // B operands of the NEXT pair of planes (one pair ahead)
-#define F12_LOADB(KA)                                                                                           \
-  _Pragma("unroll") for (int g = 0; g < 4; g++) {                                                               \
-    un[0][g] = *reinterpret_cast<const f4*>(ub + (size_t)(KA) * 4096 + 16 * g);                                 \
-    un[1][g] = *reinterpret_cast<const f4*>(ub + (size_t)((KA) + 1) * 4096 + 16 * g);                           \
-  }
+  // Consumer schedule, one plane at a time (its 16 MFMAs are one accumulator chain; same-accumulator MFMAs issue back to
+  // back): the A operand of the NEXT plane (LDS) and the B operand of the plane AFTER THE NEXT (global / L2) are requested
+  // before the current plane's MFMAs and pinned there with sched_barrier — left to itself the compiler sinks every operand
+  // read to just in front of its first use and the matrix pipe waits out an LDS or L2 latency eight times per plane
+  // (first version: the contraction ran at half rate).
+  f4 ua[4], ubn[4], ubn2[4], va[4], van[4];
+#define F12_LOADB(DST, K)                                                                                        \
+  _Pragma("unroll") for (int g = 0; g < 4; g++) DST[g] = *reinterpret_cast<const f4*>(ub + (size_t)(K) * 4096 + 16 * g);
+#define F12_LOADA(DST, BUF, J)                                                                                   \
+  _Pragma("unroll") for (int g = 0; g < 4; g++)                                                                  \
+    DST[g] = *reinterpret_cast<const f4*>(&s_v[BUF][((J) * 16 + lr) * 64 + (((4 * g + lk) ^ lr) * 4)]);
 #define F12_PRODUCE(XI, BUF)                                                                                    \
   {                                                                                                             \
+    /* the patch values of this row of B^T d B, three columns at a time: all reads of a half first, then its arithmetic */ \
     f4 ta[6];                                                                                                   \
-    _Pragma("unroll") for (int s2 = 0; s2 < 6; s2++) {                                                          \
-      f4 d[6];                                                                                                  \
-      _Pragma("unroll") for (int r = 0; r < 6; r++)                                                             \
-        if (((XI) == 0 && (r == 0 || r == 2 || r == 4)) || ((XI) == 5 && (r == 1 || r == 3 || r == 5)) ||       \
-            ((XI) >= 1 && (XI) <= 4 && r >= 1 && r <= 4))                                                       \
-          d[r] = *reinterpret_cast<const f4*>(&s_y[4 * tyy + r][4 * txx + s2][cq * 4]);                         \
-      if ((XI) == 0) ta[s2] = (4.f * d[0] - 5.f * d[2]) + d[4];                                                 \
-      else if ((XI) == 5) ta[s2] = (4.f * d[1] - 5.f * d[3]) + d[5];                                            \
-      else if ((XI) == 1 || (XI) == 2) {                                                                        \
-        const f4 a = d[4] - 4.f * d[2], b_ = d[3] - 4.f * d[1];                                                 \
-        ta[s2] = (XI) == 1 ? a + b_ : a - b_;                                                                   \
-      } else {                                                                                                  \
-        const f4 c = d[4] - d[2], e = 2.f * (d[3] - d[1]);                                                      \
-        ta[s2] = (XI) == 3 ? c + e : c - e;                                                                     \
+    _Pragma("unroll") for (int hh = 0; hh < 2; hh++) {                                                          \
+      f4 d[3][6];                                                                                               \
+      _Pragma("unroll") for (int s3 = 0; s3 < 3; s3++)                                                          \
+        _Pragma("unroll") for (int r = 0; r < 6; r++)                                                           \
+          if (((XI) == 0 && (r == 0 || r == 2 || r == 4)) || ((XI) == 5 && (r == 1 || r == 3 || r == 5)) ||     \
+              ((XI) >= 1 && (XI) <= 4 && r >= 1 && r <= 4))                                                     \
+            d[s3][r] = *reinterpret_cast<const f4*>(&s_y[4 * tyy + r][4 * txx + 3 * hh + s3][cq * 4]);          \
+      __builtin_amdgcn_sched_barrier(0);                                                                        \
+      _Pragma("unroll") for (int s3 = 0; s3 < 3; s3++) {                                                        \
+        const int s2 = 3 * hh + s3;                                                                             \
+        if ((XI) == 0) ta[s2] = (4.f * d[s3][0] - 5.f * d[s3][2]) + d[s3][4];                                   \
+        else if ((XI) == 5) ta[s2] = (4.f * d[s3][1] - 5.f * d[s3][3]) + d[s3][5];                              \
+        else if ((XI) == 1 || (XI) == 2) {                                                                      \
+          const f4 a = d[s3][4] - 4.f * d[s3][2], b_ = d[s3][3] - 4.f * d[s3][1];                               \
+          ta[s2] = (XI) == 1 ? a + b_ : a - b_;                                                                 \
+        } else {                                                                                                \
+          const f4 c = d[s3][4] - d[s3][2], e = 2.f * (d[s3][3] - d[s3][1]);                                    \
+          ta[s2] = (XI) == 3 ? c + e : c - e;                                                                   \
+        }                                                                                                       \
       }                                                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                        \
     }                                                                                                           \
     f4 oa[6];                                                                                                   \
     fw_bt6(ta, oa);                                                                                             \
     _Pragma("unroll") for (int j = 0; j < 6; j++)                                                               \
       *reinterpret_cast<f4*>(&s_v[BUF][(j * 16 + tile) * 64 + ((cq ^ tile) * 4)]) = oa[j];                      \
   }
-  // one pair of planes (6 XI + J, 6 XI + J + 1): B of this pair was fetched a pair ago, the next pair's B goes out first
-#define F12_PAIR(XI, J, BUF, KNEXT)                                                                             \
+  // plane K = 6 XI + J out of buffer BUF. On entry: va = its A operand (J > 0: fetched a plane ago; J = 0: fetched here,
+  // right behind the group's barrier), ua = its B operand, ubn = B of plane K + 1.
+#define F12_PLANE(XI, J, BUF)                                                                                   \
   {                                                                                                             \
-    f4 ua[4], ubq[4], va[4], vb[4];                                                                             \
-    _Pragma("unroll") for (int g = 0; g < 4; g++) { ua[g] = un[0][g]; ubq[g] = un[1][g]; }                      \
-    if ((KNEXT) < 36) { F12_LOADB(KNEXT) }                                                                      \
-    _Pragma("unroll") for (int g = 0; g < 4; g++) {                                                             \
-      va[g] = *reinterpret_cast<const f4*>(&s_v[BUF][(((J) + 0) * 16 + lr) * 64 + (((4 * g + lk) ^ lr) * 4)]);  \
-      vb[g] = *reinterpret_cast<const f4*>(&s_v[BUF][(((J) + 1) * 16 + lr) * 64 + (((4 * g + lk) ^ lr) * 4)]);  \
-    }                                                                                                           \
-    v4f12 ca = (v4f12){0.f, 0.f, 0.f, 0.f}, cb = ca;                                                            \
+    if ((J) == 0) { F12_LOADA(va, BUF, 0) }                                                                     \
+    if ((J) < 5) { F12_LOADA(van, BUF, (J) + 1) }                                                               \
+    if (6 * (XI) + (J) + 2 < 36) { F12_LOADB(ubn2, 6 * (XI) + (J) + 2) }                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+    v4f12 ca = (v4f12){0.f, 0.f, 0.f, 0.f};                                                                     \
     _Pragma("unroll") for (int g = 0; g < 4; g++)                                                               \
-      _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                           \
+      _Pragma("unroll") for (int i = 0; i < 4; i++)                                                             \
         ca = __builtin_amdgcn_mfma_f32_16x16x4f32(va[g][i], ua[g][i], ca, 0, 0, 0);                             \
-        cb = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[g][i], ubq[g][i], cb, 0, 0, 0);                            \
-      }                                                                                                         \
     acc[6 * (XI) + (J)] = ca;                                                                                   \
-    acc[6 * (XI) + (J) + 1] = cb;                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+    _Pragma("unroll") for (int g = 0; g < 4; g++) { va[g] = van[g]; ua[g] = ubn[g]; ubn[g] = ubn2[g]; }         \
   }
 #define F12_CONSUME(XI, BUF)                                                                                    \
-  F12_PAIR(XI, 0, BUF, 6 * (XI) + 2) F12_PAIR(XI, 2, BUF, 6 * (XI) + 4) F12_PAIR(XI, 4, BUF, 6 * (XI) + 6)
+  F12_PLANE(XI, 0, BUF) F12_PLANE(XI, 1, BUF) F12_PLANE(XI, 2, BUF) F12_PLANE(XI, 3, BUF) F12_PLANE(XI, 4, BUF) F12_PLANE(XI, 5, BUF)
 #define F12_STEP(S)                                                                                             \
   if (consumer) { if ((S) >= 1) { F12_CONSUME((S) - 1, ((S) - 1) & 1) } }                                       \
   else { if ((S) <= 5) { F12_PRODUCE((S) <= 5 ? (S) : 5, (S) & 1) } }                                           \
   __syncthreads();
-  if (consumer) { F12_LOADB(0) }
+  if (consumer) { F12_LOADB(ua, 0) F12_LOADB(ubn, 1) }
   F12_STEP(0) F12_STEP(1) F12_STEP(2) F12_STEP(3) F12_STEP(4) F12_STEP(5) F12_STEP(6)
 #undef F12_STEP
 #undef F12_CONSUME
-#undef F12_PAIR
+#undef F12_PLANE
 #undef F12_PRODUCE
+#undef F12_LOADA
 #undef F12_LOADB
 
   // ---- epilogue: output transform (the MFMA kernel's fold, column by column), bias, ReLU, 2 x 2 max -----------------
