@@ -287,6 +287,15 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wino43_kernel(
 //            8 x 8 x 64 block leaves as 2-KB contiguous rows.
 // One workgroup per CU (LDS 138 KB), 8 waves. Bit-identical to conv3x3_c3_winograd43 + winograd43_conv(pool = 1)
 // (tests/test_gpu_round4.py). H and W must be multiples of 16.
+// tools/conv12_probe.hip defines CONV12_PROBE: wall-clock stamps of one workgroup's phases (not in the library build)
+#ifdef CONV12_PROBE
+__device__ unsigned long long g_conv12_probe[64];
+#define F12_TS(I) do { if (blockIdx.x == CONV12_PROBE && threadIdx.x == 0) g_conv12_probe[I] = wall_clock64(); } while (0)
+#define F12_TSW(I, WV) do { if (blockIdx.x == CONV12_PROBE && threadIdx.x == 64 * (WV)) g_conv12_probe[I] = wall_clock64(); } while (0)
+#else
+#define F12_TS(I)
+#define F12_TSW(I, WV)
+#endif
 constexpr int F12_P = 18;                       // patch rows / columns of a 4 x 4 tile block
 constexpr int F12_NQ = 5;                       // pixel quads per patch row (20 columns computed, 18 kept)
 constexpr int F12_INF = 24 * CF_CIN;            // window columns px0-1 .. px0+22 (22 used)
@@ -324,6 +333,7 @@ __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
   ut2 += (size_t)grp * 36 * 64 * 64;
   b2 += (size_t)grp * 64;
 
+  F12_TS(0);
   // input window: rows py0-1 .. py0+18, columns px0-1 .. px0+22
   for (int i = tid; i < (F12_P + 2) * F12_INF; i += 512) {
     const int r = i / F12_INF, j = i - r * F12_INF;
@@ -351,6 +361,7 @@ __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
     for (int t = 0; t < 27; t++) wq[t] = *reinterpret_cast<const f2*>(w1 + (size_t)t * 64 + cp * 2);
     const f2 bq = *reinterpret_cast<const f2*>(b1 + cp * 2);
     __syncthreads();
+    F12_TS(1);
     for (int it = 0; it < (F12_P * F12_NQ + 15) / 16; it++) {
       const int p = it * 16 + wave * 2 + half;
       if (p < F12_P * F12_NQ) {
@@ -391,6 +402,7 @@ __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
   }
   __syncthreads();
 
+  F12_TS(2);
   // ---- phase 2: six groups of six planes (row xi of B^T d B), software pipelined by one group -------------------------
   // step s: the producers build group s into s_v[s & 1] while the consumers contract group s - 1 out of s_v[(s - 1) & 1]
   const bool consumer = wave < 4;
@@ -400,17 +412,21 @@ __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
   const int tyy = tile >> 2, txx = tile & 3;
   v4f12 acc[36];
   const float* ub = ut2 + (size_t)(16 * (wave & 3) + lr) * 64 + 4 * lk;     // a consumer lane's U^T row and K chunk inside a plane
-  // Consumer schedule, one plane at a time (its 16 MFMAs are one accumulator chain; same-accumulator MFMAs issue back to
-  // back): the A operand of the NEXT plane (LDS) and the B operand of the plane AFTER THE NEXT (global / L2) are requested
-  // before the current plane's MFMAs and pinned there with sched_barrier — left to itself the compiler sinks every operand
-  // read to just in front of its first use and the matrix pipe waits out an LDS or L2 latency eight times per plane
-  // (first version: the contraction ran at half rate).
-  f4 ua[4], ubn[4], ubn2[4], va[4], van[4];
-#define F12_LOADB(DST, K)                                                                                        \
-  _Pragma("unroll") for (int g = 0; g < 4; g++) DST[g] = *reinterpret_cast<const f4*>(ub + (size_t)(K) * 4096 + 16 * g);
-#define F12_LOADA(DST, BUF, J)                                                                                   \
-  _Pragma("unroll") for (int g = 0; g < 4; g++)                                                                  \
-    DST[g] = *reinterpret_cast<const f4*>(&s_v[BUF][((J) * 16 + lr) * 64 + (((4 * g + lk) ^ lr) * 4)]);
+  // Consumer schedule: two planes at a time, their MFMAs interleaved — back-to-back MFMAs into ONE accumulator issue at half
+  // rate (measured with tools/conv12_probe.hip: 67 cycles per dependent v_mfma_f32_16x16x4_f32, i.e. a plane at a time ran
+  // the contraction at 47 %) — and the operands roll through one register set: behind the MFMAs of K group g the A operand
+  // (LDS) and B operand (global / L2) of the NEXT pair's K group g are requested into the registers just read, so every
+  // operand has a pair's worth of MFMAs (32 x 32 cycles) to arrive. sched_barrier pins that order: left to itself the
+  // compiler sinks each read to just in front of its first use and the matrix pipe waits out every latency.
+  f4 a0[4], a1[4], q0[4], q1[4];
+  const unsigned uoff = (unsigned)((16 * (wave & 3) + lr) * 64 + 4 * lk);
+#define F12_LOADB(D0, D1, K, G)                                                                                  \
+  { const float* pk_ = ut2 + (size_t)(K) * 4096 + 16 * (G);                                                      \
+    D0 = *reinterpret_cast<const f4*>(pk_ + uoff);                                                               \
+    D1 = *reinterpret_cast<const f4*>(pk_ + 4096 + uoff); }
+#define F12_LOADA(D0, D1, BUF, J, G)                                                                             \
+  { D0 = *reinterpret_cast<const f4*>(&s_v[BUF][((J) * 16 + lr) * 64 + (((4 * (G) + lk) ^ lr) * 4)]);            \
+    D1 = *reinterpret_cast<const f4*>(&s_v[BUF][(((J) + 1) * 16 + lr) * 64 + (((4 * (G) + lk) ^ lr) * 4)]); }
 #define F12_PRODUCE(XI, BUF)                                                                                    \
   {                                                                                                             \
     /* the patch values of this row of B^T d B, three columns at a time: all reads of a half first, then its arithmetic */ \
@@ -442,37 +458,43 @@ __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
     _Pragma("unroll") for (int j = 0; j < 6; j++)                                                               \
       *reinterpret_cast<f4*>(&s_v[BUF][(j * 16 + tile) * 64 + ((cq ^ tile) * 4)]) = oa[j];                      \
   }
-  // plane K = 6 XI + J out of buffer BUF. On entry: va = its A operand (J > 0: fetched a plane ago; J = 0: fetched here,
-  // right behind the group's barrier), ua = its B operand, ubn = B of plane K + 1.
-#define F12_PLANE(XI, J, BUF)                                                                                   \
+  // planes 6 XI + J and 6 XI + J + 1 out of buffer BUF. On entry q0 / q1 hold their B operands; a0 / a1 their A operands
+  // unless J == 0 (first pair behind the group's barrier: fetched here). NK = first plane of the next pair (its B operands
+  // are fetched behind the MFMAs) or -1.
+#define F12_PAIR(XI, J, BUF, NK)                                                                                \
   {                                                                                                             \
-    if ((J) == 0) { F12_LOADA(va, BUF, 0) }                                                                     \
-    if ((J) < 5) { F12_LOADA(van, BUF, (J) + 1) }                                                               \
-    if (6 * (XI) + (J) + 2 < 36) { F12_LOADB(ubn2, 6 * (XI) + (J) + 2) }                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                                          \
-    v4f12 ca = (v4f12){0.f, 0.f, 0.f, 0.f};                                                                     \
-    _Pragma("unroll") for (int g = 0; g < 4; g++)                                                               \
-      _Pragma("unroll") for (int i = 0; i < 4; i++)                                                             \
-        ca = __builtin_amdgcn_mfma_f32_16x16x4f32(va[g][i], ua[g][i], ca, 0, 0, 0);                             \
-    acc[6 * (XI) + (J)] = ca;                                                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                                          \
-    _Pragma("unroll") for (int g = 0; g < 4; g++) { va[g] = van[g]; ua[g] = ubn[g]; ubn[g] = ubn2[g]; }         \
+    if ((J) == 0) { _Pragma("unroll") for (int g_ = 0; g_ < 4; g_++) F12_LOADA(a0[g_], a1[g_], BUF, 0, g_) }    \
+    v4f12 ca_ = (v4f12){0.f, 0.f, 0.f, 0.f}, cb_ = ca_;                                                         \
+    _Pragma("unroll") for (int g_ = 0; g_ < 4; g_++) {                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                                        \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {                                                        \
+        ca_ = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[g_][i_], q0[g_][i_], ca_, 0, 0, 0);                       \
+        cb_ = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[g_][i_], q1[g_][i_], cb_, 0, 0, 0);                       \
+      }                                                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                        \
+      if ((J) < 4) { F12_LOADA(a0[g_], a1[g_], BUF, (J) + 2, g_) }                                              \
+      if ((NK) >= 0 && (NK) < 36) { F12_LOADB(q0[g_], q1[g_], (NK), g_) }                                       \
+    }                                                                                                           \
+    acc[6 * (XI) + (J)] = ca_;                                                                                  \
+    acc[6 * (XI) + (J) + 1] = cb_;                                                                              \
   }
 #define F12_CONSUME(XI, BUF)                                                                                    \
-  F12_PLANE(XI, 0, BUF) F12_PLANE(XI, 1, BUF) F12_PLANE(XI, 2, BUF) F12_PLANE(XI, 3, BUF) F12_PLANE(XI, 4, BUF) F12_PLANE(XI, 5, BUF)
+  F12_PAIR(XI, 0, BUF, 6 * (XI) + 2) F12_PAIR(XI, 2, BUF, 6 * (XI) + 4) F12_PAIR(XI, 4, BUF, 6 * (XI) + 6)
 #define F12_STEP(S)                                                                                             \
   if (consumer) { if ((S) >= 1) { F12_CONSUME((S) - 1, ((S) - 1) & 1) } }                                       \
   else { if ((S) <= 5) { F12_PRODUCE((S) <= 5 ? (S) : 5, (S) & 1) } }                                           \
+  F12_TS(10 + 2 * (S)); F12_TSW(11 + 2 * (S), 4);                                                                \
   __syncthreads();
-  if (consumer) { F12_LOADB(ua, 0) F12_LOADB(ubn, 1) }
+  if (consumer) { _Pragma("unroll") for (int g = 0; g < 4; g++) F12_LOADB(q0[g], q1[g], 0, g) }
   F12_STEP(0) F12_STEP(1) F12_STEP(2) F12_STEP(3) F12_STEP(4) F12_STEP(5) F12_STEP(6)
 #undef F12_STEP
 #undef F12_CONSUME
-#undef F12_PLANE
+#undef F12_PAIR
 #undef F12_PRODUCE
 #undef F12_LOADA
 #undef F12_LOADB
 
+  F12_TS(3);
   // ---- epilogue: output transform (the MFMA kernel's fold, column by column), bias, ReLU, 2 x 2 max -----------------
   // a consumer lane holds tiles 4 lk + i (i = 0..3: tile row lk, tile column i) x channel 16 wave + lr
   float* s_o = &s_v[0][0];                                // [8 pooled rows][8 pooled columns][64]
@@ -521,6 +543,7 @@ __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
         }
     }
   }
+  F12_TS(4);
   __syncthreads();
   const int Hp = H >> 1, Wp = W >> 1;
   for (int i = tid; i < 8 * 8 * 16; i += 512) {
@@ -528,6 +551,7 @@ __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
     *reinterpret_cast<f4*>(ypool + (((size_t)b * Hp + 8 * by + pyl) * Wp + 8 * bx + pxl) * 64 + c4) =
         *reinterpret_cast<const f4*>(&s_o[(pyl * 8 + pxl) * 64 + c4]);
   }
+  F12_TS(5);
 }
 
 
