@@ -976,9 +976,17 @@ static unsigned conv12_grid(long long blocks, int groups)
   if (wgs > per_group) wgs = per_group;
   return (unsigned)(wgs * groups);
 }
+// Which kernel: the per-block one (default) or the persistent half-channel pipeline (PCNN_CONV12=2). Measured at 2 x 16
+// frames of 480 x 640 (tools/conv12_probe.hip, bench.py A/B on one box): per-block kernel 4.07 ms (window 2.9 us, conv1_1
+// 5.6 us, the 36 plane contractions 16 us, output transform 2.3 us per block of 16 tiles); pipelined 4.52 ms. Both are
+// bound by the same thing: every block re-reads the whole filter bank U^T (590 KB) from L2 — 22.6 GB per launch, 16 tiles per
+// fetch where wino43_mfma_kernel has 32 — which holds the plane contractions at ~47 % of the matrix rate however the operands
+// are scheduled (one plane at a time, interleaved pairs, rolling prefetch: same 16 us), and the pipeline's static walk loses
+// the dynamic balance of 38 400 short workgroups. The per-block kernel still wins the STEP: 756.9 vs 723.7 frames/s with two
+// streams (its half-idle matrix pipe and 8 waves per CU leave room for the other batch's kernels), 716 vs 718 on one.
 static bool conv12_first_version()
 {
-  static const bool v = [] { const char* e = getenv("PCNN_CONV12"); return e && e[0] == '1'; }();
+  static const bool v = [] { const char* e = getenv("PCNN_CONV12"); return !(e && e[0] == '2'); }();
   return v;
 }
 

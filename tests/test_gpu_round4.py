@@ -293,3 +293,40 @@ def test_conv1_1_conv1_2_fused_equals_the_unfused_pair(gpu, B, H, W, groups, raw
         ref = torch.cat(outs).permute(0, 2, 3, 1)
         err = float((got.double() - ref).abs().max() / ref.abs().max())
         assert err < 2e-5, err
+
+
+_CONV12_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from posecnn_amd import ops
+dev = torch.device("cuda:0")
+g = torch.Generator(device="cpu").manual_seed(7)
+out = {}
+for i, (B, H, W, groups) in enumerate([(2, 32, 48, 1), (4, 96, 128, 2), (6, 64, 64, 2), (1, 16, 16, 1)]):
+    w1 = (torch.randn((groups, 3, 3, 3, 64), generator=g) * 0.02).to(dev); b1 = (torch.randn((groups, 64), generator=g) * 0.1).to(dev)
+    w2 = (torch.randn((groups, 64, 64, 3, 3), generator=g) * (2.0 / 576) ** 0.5).to(dev); b2 = (torch.randn((groups, 64), generator=g) * 0.1).to(dev)
+    ut2 = torch.stack([ops.winograd_filter(w2[k], 4).transpose(1, 2) for k in range(groups)]).contiguous()
+    x = (torch.randint(0, 256, (B, H, W, 3), generator=g).float() - 100.0).to(dev)
+    out["c%%d" %% i] = ops.conv1_1_conv1_2_fused(x, w1, b1, ut2, b2, groups=groups).cpu().numpy()
+    if groups == 2:
+        im8 = torch.randint(0, 256, (B // 2, H, W, 3), generator=g, dtype=torch.uint8).to(dev)
+        d16 = torch.from_numpy(np.random.default_rng(i).integers(0, 3000, (B // 2, H, W)).astype(np.uint16)).to(dev)
+        out["r%%d" %% i] = ops.conv1_1_conv1_2_fused_raw(im8, d16, w1, b1, ut2, b2).cpu().numpy()
+torch.cuda.synchronize()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_conv1_1_conv1_2_pipelined_variant_equals_the_default(gpu, tmp_path):
+    """PCNN_CONV12=2 selects the persistent half-channel pipeline (conv12_wino43_pipelined_kernel: the K = 64 contraction of a
+    plane as two halves of 32 input channels into the same accumulator, producer waves running conv1_1 of the next half
+    under the consumers' matrix work). Measured slower than the per-block kernel and therefore not the default; it must
+    stay bit-identical to it (several blocks per workgroup, two filter sets, raw frames, a single block)."""
+    outs = []
+    for mode in ("1", "2"):
+        path = str(tmp_path / ("conv12_%s.npz" % mode))
+        subprocess.run([sys.executable, "-c", _CONV12_SCRIPT % ROOT, path], check=True, env=dict(os.environ, PCNN_CONV12=mode, PCNN_CONV12_WGS="1"), timeout=600)
+        outs.append(np.load(path))
+    assert sorted(outs[0].files) == sorted(outs[1].files) and len(outs[0].files) == 6
+    for k in outs[0].files:
+        same(outs[0][k], outs[1][k], k)
