@@ -302,7 +302,8 @@ from posecnn_amd import ops
 dev = torch.device("cuda:0")
 g = torch.Generator(device="cpu").manual_seed(7)
 out = {}
-for i, (B, H, W, groups) in enumerate([(2, 32, 48, 1), (4, 96, 128, 2), (6, 64, 64, 2), (1, 16, 16, 1)]):
+# the last two give every persistent workgroup several blocks (3.1 and 3.5 on 256 CUs with one workgroup per CU), unevenly
+for i, (B, H, W, groups) in enumerate([(2, 32, 48, 1), (4, 96, 128, 2), (6, 64, 64, 2), (1, 16, 16, 1), (8, 160, 160, 2), (3, 240, 320, 1)]):
     w1 = (torch.randn((groups, 3, 3, 3, 64), generator=g) * 0.02).to(dev); b1 = (torch.randn((groups, 64), generator=g) * 0.1).to(dev)
     w2 = (torch.randn((groups, 64, 64, 3, 3), generator=g) * (2.0 / 576) ** 0.5).to(dev); b2 = (torch.randn((groups, 64), generator=g) * 0.1).to(dev)
     ut2 = torch.stack([ops.winograd_filter(w2[k], 4).transpose(1, 2) for k in range(groups)]).contiguous()
@@ -327,6 +328,6 @@ def test_conv1_1_conv1_2_pipelined_variant_equals_the_default(gpu, tmp_path):
         path = str(tmp_path / ("conv12_%s.npz" % mode))
         subprocess.run([sys.executable, "-c", _CONV12_SCRIPT % ROOT, path], check=True, env=dict(os.environ, PCNN_CONV12=mode, PCNN_CONV12_WGS="1"), timeout=600)
         outs.append(np.load(path))
-    assert sorted(outs[0].files) == sorted(outs[1].files) and len(outs[0].files) == 6
+    assert sorted(outs[0].files) == sorted(outs[1].files) and len(outs[0].files) == 9
     for k in outs[0].files:
         same(outs[0][k], outs[1][k], k)
