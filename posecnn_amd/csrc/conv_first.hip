@@ -296,6 +296,16 @@ __device__ unsigned long long g_conv12_probe[64];
 #define F12_TS(I)
 #define F12_TSW(I, WV)
 #endif
+// probe-only ablations (tools/conv12_probe.hip): drop the B operand fetches / the A operand fetches / the producers' transforms
+#ifndef F12_ABL_NO_B
+#define F12_ABL_NO_B 0
+#endif
+#ifndef F12_ABL_NO_A
+#define F12_ABL_NO_A 0
+#endif
+#ifndef F12_ABL_NO_T
+#define F12_ABL_NO_T 0
+#endif
 constexpr int F12_P = 18;                       // patch rows / columns of a 4 x 4 tile block
 constexpr int F12_NQ = 5;                       // pixel quads per patch row (20 columns computed, 18 kept)
 constexpr int F12_INF = 24 * CF_CIN;            // window columns px0-1 .. px0+22 (22 used)
@@ -472,8 +482,8 @@ __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
         cb_ = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[g_][i_], q1[g_][i_], cb_, 0, 0, 0);                       \
       }                                                                                                         \
       __builtin_amdgcn_sched_barrier(0);                                                                        \
-      if ((J) < 4) { F12_LOADA(a0[g_], a1[g_], BUF, (J) + 2, g_) }                                              \
-      if ((NK) >= 0 && (NK) < 36) { F12_LOADB(q0[g_], q1[g_], (NK), g_) }                                       \
+      if ((J) < 4 && !F12_ABL_NO_A) { F12_LOADA(a0[g_], a1[g_], BUF, (J) + 2, g_) }                             \
+      if ((NK) >= 0 && (NK) < 36 && !F12_ABL_NO_B) { F12_LOADB(q0[g_], q1[g_], (NK), g_) }                      \
     }                                                                                                           \
     acc[6 * (XI) + (J)] = ca_;                                                                                  \
     acc[6 * (XI) + (J) + 1] = cb_;                                                                              \
@@ -482,7 +492,7 @@ __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
   F12_PAIR(XI, 0, BUF, 6 * (XI) + 2) F12_PAIR(XI, 2, BUF, 6 * (XI) + 4) F12_PAIR(XI, 4, BUF, 6 * (XI) + 6)
 #define F12_STEP(S)                                                                                             \
   if (consumer) { if ((S) >= 1) { F12_CONSUME((S) - 1, ((S) - 1) & 1) } }                                       \
-  else { if ((S) <= 5) { F12_PRODUCE((S) <= 5 ? (S) : 5, (S) & 1) } }                                           \
+  else { if ((S) <= 5 && !F12_ABL_NO_T) { F12_PRODUCE((S) <= 5 ? (S) : 5, (S) & 1) } }                          \
   F12_TS(10 + 2 * (S)); F12_TSW(11 + 2 * (S), 4);                                                                \
   __syncthreads();
   if (consumer) { _Pragma("unroll") for (int g = 0; g < 4; g++) F12_LOADB(q0[g], q1[g], 0, g) }
