@@ -4,6 +4,11 @@ O=/root/repo/gpurun_out/${1:-r4p}; mkdir -p $O
 cd /root/repo
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --streams 1 --no-cpu-baseline --no-secondary > $O/bench_streams1.json 2> $O/bench_streams1.err
+python bench.py --streams 3 --no-cpu-baseline --no-secondary > $O/bench_streams3.json 2> $O/bench_streams3.err
+python bench.py --no-fused-conv12 --no-cpu-baseline --no-secondary > $O/bench_unfused_conv12.json 2> $O/bench_unfused.err
+python bench.py --no-fused-conv12 --streams 1 --no-cpu-baseline --no-secondary > $O/bench_unfused_conv12_streams1.json 2>> $O/bench_unfused.err
+tools/conv12_probe > $O/conv12_probe.txt 2>&1
+for v in NO_B1 NO_A1; do echo "== ablation $v" >> $O/conv12_probe.txt; tools/conv12_probe$v >> $O/conv12_probe.txt 2>&1; done
 python bench.py --graph --no-cpu-baseline > $O/bench_graph.json 2> $O/bench_graph.err
 python bench.py --latency --batch 1 --input COLOR --losses none --no-cpu-baseline --graph --raw-inputs --steps 200 > $O/bench_latency_b1_inference_raw.json 2> $O/bench_latency.err
 python bench.py --latency --batch 1 --input COLOR --losses test --no-cpu-baseline --graph --steps 200 > $O/bench_latency_b1.json 2>> $O/bench_latency.err
