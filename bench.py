@@ -53,8 +53,9 @@ def parse_args(argv=None):
     ap.add_argument("--latency", action="store_true", help="per-frame synchronous loop; reports p50/p99 latency")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (see posecnn_amd/pipeline.py)")
     ap.add_argument("--streams", type=int, default=None,
-                    help="HIP streams the batches alternate over (default 2; 1 with --graph): with 2, batch i+1's trunk overlaps batch "
-                         "i's heads / Hough / RoI tail (+1 %% on this workload). Round 3 found and fixed the race this mode used to "
+                    help="HIP streams the batches alternate over (default 3 since round 4; 1 with --graph): batch i+1's trunk overlaps batch "
+                         "i's heads / Hough / RoI tail, and the fused first-layers kernel (one workgroup per CU, matrix pipe half idle) "
+                         "shares the chip with the other batches' kernels: 680.6 / 757.9 / 768.0 frames/s on 1 / 2 / 3 streams. Round 3 found and fixed the race this mode used to "
                          "expose (an s_waitcnt vmcnt(0) missing in front of the barrier that recycles the MFMA kernels' LDS ring; "
                          "tools/debug_streams.py). --graph --streams 2 is legal (each graph owns its scratch) but measured slower: "
                          "689 vs 722 frames/s")
@@ -79,7 +80,7 @@ def parse_args(argv=None):
     ap.add_argument("--master-port", type=int, default=0)
     a = ap.parse_args(argv)
     if a.streams is None:
-        a.streams = 1 if a.graph else 2
+        a.streams = 1 if a.graph else 3
     return a
 
 

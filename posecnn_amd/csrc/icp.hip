@@ -115,14 +115,27 @@ __global__ __launch_bounds__(ICP_BLOCK) void icp_terms_kernel(
 {
   __shared__ float red[ICP_NSUM][ICP_BLOCK];
   __shared__ int s_any;
+  __shared__ float s_pose[7];
   const int n = blockIdx.y, t = threadIdx.x;
   const long long p = (long long)blockIdx.x * ICP_BLOCK + t;
-  if (t == 0) s_any = 0;
-  __syncthreads();
-  float T[12], q[4], tt[3];
+  if (t == 0) {
+    s_any = 0;
+    // the SE3f content once per block (2 correctly rounded square roots + 5 divisions: per thread it doubled the kernel)
+    float T[12], q0[4], t0[3];
 #pragma unroll
-  for (int i = 0; i < 12; i++) T[i] = (float)state[12 * n + i];
-  icp_se3f_from_matrix(T, q, tt);
+    for (int i = 0; i < 12; i++) T[i] = (float)state[12 * n + i];
+    icp_se3f_from_matrix(T, q0, t0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) s_pose[i] = q0[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) s_pose[4 + i] = t0[i];
+  }
+  __syncthreads();
+  float q[4], tt[3];
+#pragma unroll
+  for (int i = 0; i < 4; i++) q[i] = s_pose[i];
+#pragma unroll
+  for (int i = 0; i < 3; i++) tt[i] = s_pose[4 + i];
   float J[6], r = 0.f;
   bool ok = false;
   if (p < P) {
