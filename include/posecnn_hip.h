@@ -306,14 +306,17 @@ int pcnn_conv3x3_c3_winograd43_raw_fwd(const uint8_t* color_bgr, int num_color, 
  *   filter, U^T [groups][36][64 out][64 in] (what pcnn_winograd43_conv_fwd takes), b2 [groups][64]; image b uses set
  *   b / (B / groups). Bit-identical to pcnn_conv3x3_c3_winograd43_fwd followed by pcnn_winograd43_conv_fwd(pool = 1), without
  *   the 2.25 x 78.6 MB per frame of transformed input between them ever touching HBM. The _raw form takes the frames as
- *   pcnn_conv3x3_c3_winograd43_raw_fwd does (colour frames use set 0, depth frames the next). */
-int pcnn_conv1_1_conv1_2_fused_fwd(const float* x, const float* w1, const float* b1, const float* ut2, const float* b2,
-                                   int batch, int height, int width, int groups, int relu1, int relu2, float* y_pool,
-                                   void* stream);
+ *   pcnn_conv3x3_c3_winograd43_raw_fwd does (colour frames use set 0, depth frames the next).
+ *   ut2_layout 1: the same numbers fragment-major, [groups][36][4][4][64][4] with element (k, w, g, lane, i) =
+ *   U^T[k][16 w + (lane & 15)][16 g + 4 (lane >> 4) + i] — every B-operand load of a wave is then 1 KB of contiguous memory
+ *   (the kernel re-reads the whole bank from L2 for every 16 tiles: DESIGN.md §3.2b). */
+int pcnn_conv1_1_conv1_2_fused_fwd(const float* x, const float* w1, const float* b1, const float* ut2, int ut2_layout,
+                                   const float* b2, int batch, int height, int width, int groups, int relu1, int relu2,
+                                   float* y_pool, void* stream);
 int pcnn_conv1_1_conv1_2_fused_raw_fwd(const uint8_t* color_bgr, int num_color, const uint16_t* depth, int num_depth,
                                        const double* pixel_means, const float* w1, const float* b1, const float* ut2,
-                                       const float* b2, int height, int width, int relu1, int relu2, float* y_pool,
-                                       void* stream);
+                                       int ut2_layout, const float* b2, int height, int width, int relu1, int relu2,
+                                       float* y_pool, void* stream);
 
 /* Data transforms of a Winograd F(2x2,3x3) evaluation of `Network.conv` for the deep 3x3 / stride 1 /
  * SAME layers of the trunk (network.py:159-187; vgg16_convs.py:42-52). All f32.

@@ -61,8 +61,8 @@ SIGNATURES = {
     "pcnn_winograd43_conv_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
     "pcnn_conv3x3_c3_winograd43_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pcnn_conv3x3_c3_winograd43_raw_fwd": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
-    "pcnn_conv1_1_conv1_2_fused_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
-    "pcnn_conv1_1_conv1_2_fused_raw_fwd": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "pcnn_conv1_1_conv1_2_fused_fwd": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "pcnn_conv1_1_conv1_2_fused_raw_fwd": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "pcnn_conv3x3_c3_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pcnn_bias_relu_pool2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pcnn_hough_voting_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -327,7 +327,7 @@ template <bool RAW>
 __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
     const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ ut2, const float* __restrict__ b2, float* __restrict__ ypool, int H, int W, int nbx,
-    int nby, int imgs_per_group, int relu1, int relu2, RawFrames raw)
+    int nby, int imgs_per_group, int relu1, int relu2, RawFrames raw, int ut_frag)
 {
   __shared__ float s_in[F12_P + 2][F12_INF];
   __shared__ __attribute__((aligned(16))) float s_y[F12_P][F12_P][64];
@@ -430,10 +430,19 @@ __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
   // compiler sinks each read to just in front of its first use and the matrix pipe waits out every latency.
   f4 a0[4], a1[4], q0[4], q1[4];
   const unsigned uoff = (unsigned)((16 * (wave & 3) + lr) * 64 + 4 * lk);
+  // ut_frag: the filter bank re-laid fragment-major — [plane][consumer wave][K group][lane][4] — so that one load
+  // instruction of a wave covers 1 KB of contiguous memory (8 whole cache lines) instead of 16 half lines 256 B apart
+  const unsigned foff = (unsigned)(((wave & 3) * 4) * 256 + lane * 4);
 #define F12_LOADB(D0, D1, K, G)                                                                                  \
-  { const float* pk_ = ut2 + (size_t)(K) * 4096 + 16 * (G);                                                      \
+  if (ut_frag) {                                                                                                 \
+    const float* pk_ = ut2 + (size_t)(K) * 4096 + 256 * (G);                                                     \
+    D0 = *reinterpret_cast<const f4*>(pk_ + foff);                                                               \
+    D1 = *reinterpret_cast<const f4*>(pk_ + 4096 + foff);                                                        \
+  } else {                                                                                                       \
+    const float* pk_ = ut2 + (size_t)(K) * 4096 + 16 * (G);                                                      \
     D0 = *reinterpret_cast<const f4*>(pk_ + uoff);                                                               \
-    D1 = *reinterpret_cast<const f4*>(pk_ + 4096 + uoff); }
+    D1 = *reinterpret_cast<const f4*>(pk_ + 4096 + uoff);                                                        \
+  }
 #define F12_LOADA(D0, D1, BUF, J, G)                                                                             \
   { D0 = *reinterpret_cast<const f4*>(&s_v[BUF][((J) * 16 + lr) * 64 + (((4 * (G) + lk) ^ lr) * 4)]);            \
     D1 = *reinterpret_cast<const f4*>(&s_v[BUF][(((J) + 1) * 16 + lr) * 64 + (((4 * (G) + lk) ^ lr) * 4)]); }
@@ -1000,10 +1009,12 @@ static bool conv12_first_version()
   return v;
 }
 
-extern "C" int pcnn_conv1_1_conv1_2_fused_fwd(const float* x, const float* w1, const float* b1, const float* ut2,
+extern "C" int pcnn_conv1_1_conv1_2_fused_fwd(const float* x, const float* w1, const float* b1, const float* ut2, int ut2_layout,
                                               const float* b2, int B, int H, int W, int groups, int relu1, int relu2,
                                               float* y_pool, void* stream_)
 {
+  PCNN_REQUIRE(ut2_layout == 0 || (ut2_layout == 1 && conv12_first_version()), PCNN_EINVAL,
+               "conv1_1_conv1_2_fused: ut2_layout must be 0 (U^T [36][64][64]) or 1 (fragment-major; per-block kernel only)");
   int st = conv12_check(B, H, W, w1, b1, ut2, b2, y_pool);
   if (st != PCNN_OK) return st;
   PCNN_REQUIRE(x, PCNN_ENULL, "conv1_1_conv1_2_fused: NULL input");
@@ -1014,7 +1025,7 @@ extern "C" int pcnn_conv1_1_conv1_2_fused_fwd(const float* x, const float* w1, c
   const long long blocks = (long long)B * (H / 16) * (W / 16);
   if (conv12_first_version())
     PCNN_LAUNCH((conv12_wino43_fused_kernel<false>), dim3((unsigned)blocks), dim3(512), 0, stream, x, w1, b1, ut2,
-                b2, y_pool, H, W, W / 16, H / 16, B / groups, relu1, relu2, none);
+                b2, y_pool, H, W, W / 16, H / 16, B / groups, relu1, relu2, none, ut2_layout);
   else
     PCNN_LAUNCH((conv12_wino43_pipelined_kernel<false>), dim3(conv12_grid(blocks, groups)), dim3(512), 0, stream, x, w1, b1, ut2,
                 b2, y_pool, H, W, W / 16, H / 16, B / groups, B, groups, relu1, relu2, none);
@@ -1023,8 +1034,11 @@ extern "C" int pcnn_conv1_1_conv1_2_fused_fwd(const float* x, const float* w1, c
 
 extern "C" int pcnn_conv1_1_conv1_2_fused_raw_fwd(const uint8_t* color_bgr, int num_color, const uint16_t* depth, int num_depth,
                                                   const double* pixel_means, const float* w1, const float* b1, const float* ut2,
-                                                  const float* b2, int H, int W, int relu1, int relu2, float* y_pool, void* stream_)
+                                                  int ut2_layout, const float* b2, int H, int W, int relu1, int relu2, float* y_pool,
+                                                  void* stream_)
 {
+  PCNN_REQUIRE(ut2_layout == 0 || (ut2_layout == 1 && conv12_first_version()), PCNN_EINVAL,
+               "conv1_1_conv1_2_fused_raw: ut2_layout must be 0 (U^T [36][64][64]) or 1 (fragment-major; per-block kernel only)");
   PCNN_REQUIRE(num_color >= 0 && num_depth >= 0 && num_color + num_depth >= 1, PCNN_EINVAL,
                "conv1_1_conv1_2_fused_raw: bad frame counts (%d colour, %d depth)", num_color, num_depth);
   int st = conv12_check(num_color + num_depth, H, W, w1, b1, ut2, b2, y_pool);
@@ -1041,7 +1055,7 @@ extern "C" int pcnn_conv1_1_conv1_2_fused_raw_fwd(const uint8_t* color_bgr, int 
   const int sets = (num_color > 0) + (num_depth > 0);
   if (conv12_first_version())
     PCNN_LAUNCH((conv12_wino43_fused_kernel<true>), dim3((unsigned)blocks), dim3(512), 0, stream, (const float*)nullptr,
-                w1, b1, ut2, b2, y_pool, H, W, W / 16, H / 16, 1, relu1, relu2, raw);
+                w1, b1, ut2, b2, y_pool, H, W, W / 16, H / 16, 1, relu1, relu2, raw, ut2_layout);
   else
     PCNN_LAUNCH((conv12_wino43_pipelined_kernel<true>), dim3(conv12_grid(blocks, sets)), dim3(512), 0, stream, (const float*)nullptr,
                 w1, b1, ut2, b2, y_pool, H, W, W / 16, H / 16, sets == 2 ? num_color : B, B, sets, relu1, relu2, raw);

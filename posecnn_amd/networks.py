@@ -868,8 +868,14 @@ class vgg16_convs(Network):
                 continue   # conv1_1 is evaluated inside conv1_2's input transform
             if li == 1 and self.fused_conv12 and pool == "pool1" and co == 64 and H % 16 == 0 and W % 16 == 0:
                 # conv1_1 -> conv1_2 -> pool1 in one kernel: V (2.25 x 78.6 MB per frame) never touches HBM (csrc/conv_first.hip)
-                y = (ops.conv1_1_conv1_2_fused_raw(d, dp, packed[0][0], packed[0][1], wt, bias) if raw
-                     else ops.conv1_1_conv1_2_fused(x, packed[0][0], packed[0][1], wt, bias, groups=2))
+                frag = self._wino_u.get("conv12_frag")
+                if frag is None or frag[0] is not wt:
+                    # the filter bank fragment-major (one contiguous KB per B-operand load); the opt-in pipelined kernel takes U^T as is
+                    lay = 0 if os.environ.get("PCNN_CONV12") == "2" else 1
+                    frag = (wt, ops.conv12_fragment_major(wt) if lay else wt, lay)
+                    self._wino_u["conv12_frag"] = frag
+                y = (ops.conv1_1_conv1_2_fused_raw(d, dp, packed[0][0], packed[0][1], frag[1], bias, ut2_layout=frag[2]) if raw
+                     else ops.conv1_1_conv1_2_fused(x, packed[0][0], packed[0][1], frag[1], bias, groups=2, ut2_layout=frag[2]))
                 h, w_ = h // 2, w_ // 2
                 continue
             if li == 1:

@@ -461,7 +461,16 @@ def conv3x3_c3_winograd43_raw(color_bgr, depth, weights, bias, relu=True, pixel_
     return v
 
 
-def conv1_1_conv1_2_fused(x, w1, b1, ut2, b2, relu1=True, relu2=True, groups=1):
+def conv12_fragment_major(ut2):
+    """U^T [..., 36, 64, 64] (plane, out channel, in channel) -> the fragment-major layout of pcnn_conv1_1_conv1_2_fused_fwd's
+    ut2_layout = 1: [..., 36, 4, 4, 64, 4] with (k, w, g, lane, i) = U^T[k][16 w + (lane & 15)][16 g + 4 (lane >> 4) + i]."""
+    lead = ut2.shape[:-3]
+    t = ut2.reshape(*lead, 36, 4, 16, 4, 4, 4)          # k, w, lr, g, lk, i
+    t = t.permute(*range(len(lead)), len(lead), len(lead) + 1, len(lead) + 3, len(lead) + 4, len(lead) + 2, len(lead) + 5)   # k, w, g, lk, lr, i
+    return t.reshape(*lead, 36, 4, 4, 64, 4).contiguous()
+
+
+def conv1_1_conv1_2_fused(x, w1, b1, ut2, b2, relu1=True, relu2=True, groups=1, ut2_layout=0):
     """max_pool_2x2(relu(conv1_2(relu(conv1_1(x))))) in one kernel (csrc/conv_first.hip): x [B,H,W,3] f32 blobs, H and W multiples
     of 16; w1 [groups,3,3,3,64], b1 [groups,64]; ut2 [groups,36,64,64] = winograd_filter(w2, 4).transpose(1, 2) per set;
     b2 [groups,64]. Bit-identical to conv3x3_c3_winograd43 + winograd43_conv(pool=1). Returns [B,H/2,W/2,64]."""
@@ -474,12 +483,12 @@ def conv1_1_conv1_2_fused(x, w1, b1, ut2, b2, relu1=True, relu2=True, groups=1):
         raise ValueError("w1 [groups,3,3,3,64], b1 [groups,64], ut2 [groups,36,64,64], b2 [groups,64]")
     y = torch.empty((B, H // 2, W // 2, 64), dtype=torch.float32, device=x.device)
     check("pcnn_conv1_1_conv1_2_fused_fwd",
-          lib().pcnn_conv1_1_conv1_2_fused_fwd(_ptr(x), _ptr(w1), _ptr(b1), _ptr(ut2), _ptr(b2), B, H, W, int(groups),
+          lib().pcnn_conv1_1_conv1_2_fused_fwd(_ptr(x), _ptr(w1), _ptr(b1), _ptr(ut2), int(ut2_layout), _ptr(b2), B, H, W, int(groups),
                                                1 if relu1 else 0, 1 if relu2 else 0, _ptr(y), _stream(x)))
     return y
 
 
-def conv1_1_conv1_2_fused_raw(color_bgr, depth, w1, b1, ut2, b2, relu1=True, relu2=True, pixel_means=None):
+def conv1_1_conv1_2_fused_raw(color_bgr, depth, w1, b1, ut2, b2, relu1=True, relu2=True, pixel_means=None, ut2_layout=0):
     """conv1_1_conv1_2_fused on the frames as the sensor delivers them (see conv3x3_c3_winograd43_raw): colour frames first
     (filter set 0), depth frames after (next set)."""
     from .config import PIXEL_MEANS
@@ -505,8 +514,8 @@ def conv1_1_conv1_2_fused_raw(color_bgr, depth, w1, b1, ut2, b2, relu1=True, rel
     means = (ctypes.c_double * 3)(*[float(v) for v in np.asarray(PIXEL_MEANS if pixel_means is None else pixel_means, dtype=np.float64).reshape(-1)[:3]])
     y = torch.empty((nc + nd, H // 2, W // 2, 64), dtype=torch.float32, device=dev)
     check("pcnn_conv1_1_conv1_2_fused_raw_fwd",
-          lib().pcnn_conv1_1_conv1_2_fused_raw_fwd(_ptr(c), nc, _ptr(d), nd, means, _ptr(w1), _ptr(b1), _ptr(ut2), _ptr(b2), H, W,
-                                                   1 if relu1 else 0, 1 if relu2 else 0, _ptr(y), _stream(y)))
+          lib().pcnn_conv1_1_conv1_2_fused_raw_fwd(_ptr(c), nc, _ptr(d), nd, means, _ptr(w1), _ptr(b1), _ptr(ut2), int(ut2_layout),
+                                                   _ptr(b2), H, W, 1 if relu1 else 0, 1 if relu2 else 0, _ptr(y), _stream(y)))
     return y
 
 

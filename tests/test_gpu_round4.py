@@ -275,12 +275,15 @@ def test_conv1_1_conv1_2_fused_equals_the_unfused_pair(gpu, B, H, W, groups, raw
         d16 = torch.from_numpy(np.random.default_rng(3).integers(0, 3000, (B - nc, H, W)).astype(np.uint16)).to(gpu) if groups == 2 else None
         v = ops.conv3x3_c3_winograd43_raw(im8, d16, w1, b1, True)
         got = ops.conv1_1_conv1_2_fused_raw(im8, d16, w1, b1, ut2, b2)
+        got_f = ops.conv1_1_conv1_2_fused_raw(im8, d16, w1, b1, ops.conv12_fragment_major(ut2), b2, ut2_layout=1)
     else:
         x = ((torch.randint(0, 256, (B, H, W, 3), generator=g).float() - 100.0)).to(gpu)
         v = ops.conv3x3_c3_winograd43(x, w1, b1, True, groups=groups)
         got = ops.conv1_1_conv1_2_fused(x, w1, b1, ut2, b2, groups=groups)
+        got_f = ops.conv1_1_conv1_2_fused(x, w1, b1, ops.conv12_fragment_major(ut2), b2, groups=groups, ut2_layout=1)
     want = ops.winograd43_conv(v, ut2, b2, B, H, W, True, 1, groups)
     same(N(got), N(want), "fused conv1_1 -> conv1_2 -> pool1")
+    same(N(got_f), N(want), "fused, fragment-major filter bank")
     if not raw:
         # independent anchor: float64 convolutions of the two layers
         xd = x.double().permute(0, 3, 1, 2)
