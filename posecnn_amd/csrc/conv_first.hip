@@ -344,13 +344,6 @@ __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
   b2 += (size_t)grp * 64;
 
   F12_TS(0);
-  // phase-1 filter taps first: their L2 latency then runs under the frame window's HBM latency instead of after it
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  const int half = lane >> 5, cp = lane & 31;
-  f2 wq[27];
-#pragma unroll
-  for (int t = 0; t < 27; t++) wq[t] = *reinterpret_cast<const f2*>(w1 + (size_t)t * 64 + cp * 2);
-  const f2 bq = *reinterpret_cast<const f2*>(b1 + cp * 2);
   // input window: rows py0-1 .. py0+18, columns px0-1 .. px0+22
   for (int i = tid; i < (F12_P + 2) * F12_INF; i += 512) {
     const int r = i / F12_INF, j = i - r * F12_INF;
@@ -369,61 +362,53 @@ __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
     }
     s_in[r][j] = val;
   }
-  __syncthreads();
-  F12_TS(1);
   {
-    // phase 1 (see conv3x3_c3_wino43_kernel): pixel quads x channel pairs, per-pixel order (ky, kx, ci) ascending. The 54
-    // window floats of an item (3 filter rows x 18) are fetched an item ahead, pinned with sched_barrier: with two waves per
-    // SIMD a fetch-wait-compute sequence per filter row left the vector ALUs idle for most of this phase (5.4 us per block,
-    // 2.4 x its arithmetic).
-    constexpr int NIT = (F12_P * F12_NQ + 15) / 16;   // 6 items per thread (the last round partly idle)
-    float wvA[54], wvB[54];
-#define F12_P1_LOAD(DST, IT)                                                                                    \
-    {                                                                                                           \
-      int p_ = (IT) * 16 + wave * 2 + half;                                                                     \
-      if (p_ >= F12_P * F12_NQ) p_ = F12_P * F12_NQ - 1;      /* idle item: any valid window, never used */      \
-      const int r_ = p_ / F12_NQ, cx_ = 4 * (p_ - r_ * F12_NQ);                                                 \
-      _Pragma("unroll") for (int ky_ = 0; ky_ < 3; ky_++)                                                       \
-        _Pragma("unroll") for (int j_ = 0; j_ < 18; j_++) DST[18 * ky_ + j_] = s_in[r_ + ky_][cx_ * CF_CIN + j_]; \
+    // phase 1 (see conv3x3_c3_wino43_kernel): pixel quads x channel pairs, per-pixel order (ky, kx, ci) ascending
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const int half = lane >> 5, cp = lane & 31;
+    f2 wq[27];
+#pragma unroll
+    for (int t = 0; t < 27; t++) wq[t] = *reinterpret_cast<const f2*>(w1 + (size_t)t * 64 + cp * 2);
+    const f2 bq = *reinterpret_cast<const f2*>(b1 + cp * 2);
+    __syncthreads();
+    F12_TS(1);
+    for (int it = 0; it < (F12_P * F12_NQ + 15) / 16; it++) {
+      const int p = it * 16 + wave * 2 + half;
+      if (p < F12_P * F12_NQ) {
+        const int r = p / F12_NQ, cx = 4 * (p - r * F12_NQ);
+        const int yy = py0 + r, xx = px0 + cx;
+        f2 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = (f2){0.f, 0.f};
+        const bool rowok = yy >= 0 && yy < H;
+        if (rowok) {
+#pragma unroll
+          for (int ky = 0; ky < 3; ky++) {
+            const float* win = &s_in[r + ky][cx * CF_CIN];   // 18 floats: columns cx-1 .. cx+4
+            float wv[18];
+#pragma unroll
+            for (int j = 0; j < 18; j++) wv[j] = win[j];
+#pragma unroll
+            for (int j = 0; j < 9; j++)
+#pragma unroll
+              for (int q = 0; q < 4; q++) {
+                const f2 v = {wv[j + 3 * q], wv[j + 3 * q]};
+                acc[q] = __builtin_elementwise_fma(wq[ky * 9 + j], v, acc[q]);
+              }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          f2 a = acc[q] + bq;
+          if (relu1) {
+            a.x = a.x > 0.f ? a.x : 0.f;
+            a.y = a.y > 0.f ? a.y : 0.f;
+          }
+          if (!(rowok && xx + q >= 0 && xx + q < W)) a = (f2){0.f, 0.f};   // outside the image: conv1_2's zero padding
+          if (cx + q < F12_P) *reinterpret_cast<f2*>(&s_y[r][cx + q][cp * 2]) = a;
+        }
+      }
     }
-#define F12_P1_ITEM(SRC, IT)                                                                                    \
-    {                                                                                                           \
-      const int p_ = (IT) * 16 + wave * 2 + half;                                                               \
-      if (p_ < F12_P * F12_NQ) {                                                                                \
-        const int r_ = p_ / F12_NQ, cx_ = 4 * (p_ - r_ * F12_NQ);                                               \
-        const int yy_ = py0 + r_, xx_ = px0 + cx_;                                                              \
-        f2 acc_[4];                                                                                             \
-        _Pragma("unroll") for (int q_ = 0; q_ < 4; q_++) acc_[q_] = (f2){0.f, 0.f};                             \
-        const bool rowok_ = yy_ >= 0 && yy_ < H;                                                                \
-        if (rowok_) {                                                                                           \
-          _Pragma("unroll") for (int ky_ = 0; ky_ < 3; ky_++)                                                   \
-            _Pragma("unroll") for (int j_ = 0; j_ < 9; j_++)                                                    \
-              _Pragma("unroll") for (int q_ = 0; q_ < 4; q_++) {                                                \
-                const f2 v_ = {SRC[18 * ky_ + j_ + 3 * q_], SRC[18 * ky_ + j_ + 3 * q_]};                       \
-                acc_[q_] = __builtin_elementwise_fma(wq[ky_ * 9 + j_], v_, acc_[q_]);                           \
-              }                                                                                                 \
-        }                                                                                                       \
-        _Pragma("unroll") for (int q_ = 0; q_ < 4; q_++) {                                                      \
-          f2 a_ = acc_[q_] + bq;                                                                                \
-          if (relu1) {                                                                                          \
-            a_.x = a_.x > 0.f ? a_.x : 0.f;                                                                     \
-            a_.y = a_.y > 0.f ? a_.y : 0.f;                                                                     \
-          }                                                                                                     \
-          if (!(rowok_ && xx_ + q_ >= 0 && xx_ + q_ < W)) a_ = (f2){0.f, 0.f};   /* outside the image: conv1_2's zero padding */ \
-          if (cx_ + q_ < F12_P) *reinterpret_cast<f2*>(&s_y[r_][cx_ + q_][cp * 2]) = a_;                        \
-        }                                                                                                       \
-      }                                                                                                         \
-    }
-    static_assert(NIT == 6, "phase 1 is unrolled for six items per thread");
-    F12_P1_LOAD(wvA, 0)
-    F12_P1_LOAD(wvB, 1) __builtin_amdgcn_sched_barrier(0); F12_P1_ITEM(wvA, 0) __builtin_amdgcn_sched_barrier(0);
-    F12_P1_LOAD(wvA, 2) __builtin_amdgcn_sched_barrier(0); F12_P1_ITEM(wvB, 1) __builtin_amdgcn_sched_barrier(0);
-    F12_P1_LOAD(wvB, 3) __builtin_amdgcn_sched_barrier(0); F12_P1_ITEM(wvA, 2) __builtin_amdgcn_sched_barrier(0);
-    F12_P1_LOAD(wvA, 4) __builtin_amdgcn_sched_barrier(0); F12_P1_ITEM(wvB, 3) __builtin_amdgcn_sched_barrier(0);
-    F12_P1_LOAD(wvB, 5) __builtin_amdgcn_sched_barrier(0); F12_P1_ITEM(wvA, 4) __builtin_amdgcn_sched_barrier(0);
-    F12_P1_ITEM(wvB, 5)
-#undef F12_P1_ITEM
-#undef F12_P1_LOAD
   }
   __syncthreads();
 
