@@ -564,8 +564,12 @@ def main(argv=None):
     if G3 > 0:   # writes data + flag [G^3, 64] and label [G^3, C], reads label_3d [G^3, C]
         hbm["backproject_fused_kernel"] = 4.0 * B * G3 ** 3 * (2 * 64 + 2 * C)
 
+    # the trunk contraction has two kernels with the same arithmetic and bits: 32-tile pairs and (big launches) one wave per SIMD
+    same_work = {"wino43_mfma_kernel": ("wino43_mfma_w1_kernel",)}
+
     def us(k):  # per step, all template instances of a kernel together
-        t = sum(v["avg_us"] * v["calls"] for n, v in kern.items() if n == k or n.startswith(k + "<") or n.startswith(k + "_kernel") or n.startswith(k + "_fixed_kernel"))
+        t = sum(v["avg_us"] * v["calls"] for n, v in kern.items() if n == k or n.startswith(k + "<") or n.startswith(k + "_kernel")
+                or n.startswith(k + "_fixed_kernel") or n.lstrip("(") in same_work.get(k, ()))
         return t / a.steps if t else None
     others = []
     for k, byt in hbm.items():

@@ -206,10 +206,13 @@ np.savez(sys.argv[1], **out)
 def test_winograd_mfma_round4_variants_are_bit_identical(gpu, tmp_path):
     """VERDICT r3 "Next" #3: outputs must stay bit-identical to the round-3 kernel. PCNN_WINO_MODE = 8 is that kernel (the
     accumulators zeroed by v_movs after every fold, tile-block-major map); 0 = C = 0 inline on a plane's first MFMAs;
-    1 = + channel-block-major XCD map where it applies; 9 = that map with the v_movs; unset = what the library picks.
+    1 = + channel-block-major XCD map where it applies; 9 = that map with the v_movs; 2 / 3 = the one-wave-per-SIMD
+    v_mfma_f32_32x32x2 kernel on every shape without a Cin split (wino43_mfma_w1_kernel: 64-tile blocks, a plane's last MFMA
+    delivering to VGPRs, the rank-1 output update as 4x4x1 MFMAs — VERDICT r3 #3a; opt-in, see the launcher for the
+    measurements), without / with the channel-block-major map; unset = what the library picks.
     Six layer shapes each."""
     outs = {}
-    for mode in ("8", "0", "1", "9", None):
+    for mode in ("8", "0", "1", "9", "2", "3", None):
         path = str(tmp_path / ("wino_%s.npz" % mode))
         env = dict(os.environ)
         env.pop("PCNN_WINO_MODE", None)
