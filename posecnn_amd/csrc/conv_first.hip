@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wino43_kernel(
 // traffic per 2 x 16 frames and the 1.7 ms kernel that is bound by it. Here a workgroup owns a 4 x 4 block of F(4x4,3x3)
 // tiles (16 x 16 output pixels) of one image:
 //   phase 1  relu(conv1_1 + bias) on the 18 x 18 pixel patch the block's tiles need, into LDS (83 KB; zeros outside the
-//            image = conv1_2's SAME padding) — the code of conv3x3_c3_wino43_kernel's phase 1 on a taller patch;
+//            image = conv1_2's SAME padding) — as 16 x 16 x 28 products on the matrix cores (see the phase's comment);
 //   phase 2  in six groups of 6 transform planes (row xi of B^T d B), producer / consumer: a PRODUCER thread = (tile, channel
 //            quad) builds the 6 planes of its tile from the patch with the expression trees of fw_bt6 / wino43_input_kernel
 //            and parks them in LDS as the A operand (16 tiles x 64 channels per plane, XOR-swizzled 16-byte chunks, two
@@ -363,52 +363,89 @@ __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
     s_in[r][j] = val;
   }
   {
-    // phase 1 (see conv3x3_c3_wino43_kernel): pixel quads x channel pairs, per-pixel order (ky, kx, ci) ascending
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const int half = lane >> 5, cp = lane & 31;
-    f2 wq[27];
+    // phase 1: relu(conv1_1 + bias) on the 18 x 18 patch, ON THE MATRIX CORES. On gfx950 an fp32 MFMA and the vector ALU of
+    // a SIMD never run in the same cycle (tools/mfma_bare.hip: every VALU instruction between two MFMAs costs its 3.5
+    // cycles of matrix-pipe time), and v_mfma_f32_16x16x4_f32 retires 32 FMAs per cycle where the packed-FMA formulation of
+    // this phase (648 v_pk_fma_f32 per thread, conv3x3_c3_wino43_kernel's phase 1 on a taller patch) measured 16: the
+    // K = 27 contraction is a poor GEMM and still twice as fast there. M = 16 consecutive patch pixels (the patch as a list
+    // of 324, row-major: pixel q sits at s_y + 64 q), N = 16 channels, K = 28 = one zero slot + the 27 taps in their
+    // (ky, kx, ci) order: an f32 MFMA is a k-ordered fmaf chain, so every output is fma(x26, w26, ... fma(x0, w0,
+    // fma(0, 0, +0))) — the per-pixel chain of the vector version, bit for bit (the zero slot comes FIRST: +0 + 0 * 0
+    // is the +0 that chain starts from). Work unit = (pixel group, channel half): 42 units over 8 waves; a wave's channel
+    // half is fixed (unit = wave + 8 i), so it keeps 14 B-operand registers; the A operand is one ds_read_b32 per K step
+    // (window address = pixel base + the lane's tap offset).
+    const int n16 = lane & 15, kk = lane >> 4, chalf = wave & 1;
+    float wb[7][2], bia[2];
+    int tapoff[7];
 #pragma unroll
-    for (int t = 0; t < 27; t++) wq[t] = *reinterpret_cast<const f2*>(w1 + (size_t)t * 64 + cp * 2);
-    const f2 bq = *reinterpret_cast<const f2*>(b1 + cp * 2);
+    for (int j = 0; j < 7; j++) {
+      const int slot = 4 * j + kk, t = slot - 1;        // slot 0: the zero slot
+      const int ky = t / 9, rem = t - 9 * ky;           // rem = 3 kx + ci
+      tapoff[j] = slot == 0 ? 0 : ky * F12_INF + rem;
+#pragma unroll
+      for (int c2 = 0; c2 < 2; c2++) wb[j][c2] = slot == 0 ? 0.f : w1[(size_t)t * 64 + 32 * chalf + 16 * c2 + n16];
+    }
+#pragma unroll
+    for (int c2 = 0; c2 < 2; c2++) bia[c2] = b1[32 * chalf + 16 * c2 + n16];
+    const bool interior = py0 >= 0 && py0 + F12_P <= H && px0 >= 0 && px0 + F12_P <= W;   // (uniform) every patch pixel inside the image
+    const float* s_in_f = &s_in[0][0];
+    float* s_y_f = &s_y[0][0][0];
     __syncthreads();
     F12_TS(1);
-    for (int it = 0; it < (F12_P * F12_NQ + 15) / 16; it++) {
-      const int p = it * 16 + wave * 2 + half;
-      if (p < F12_P * F12_NQ) {
-        const int r = p / F12_NQ, cx = 4 * (p - r * F12_NQ);
-        const int yy = py0 + r, xx = px0 + cx;
-        f2 acc[4];
+    // the A operand of a unit: 7 window values per lane (pixel 16 g + n16, K slots 4 j + kk)
+#define F12_LOAD_A(DST, G)                                                                            \
+    {                                                                                                 \
+      const int q_ = 16 * (G) + n16, qc_ = q_ < F12_P * F12_P ? q_ : F12_P * F12_P - 1;   /* (the last group is ragged: 324 = 20 x 16 + 4) */ \
+      const int r_ = qc_ / F12_P, c_ = qc_ - F12_P * r_;                                              \
+      const int pixb_ = r_ * F12_INF + c_ * CF_CIN;                                                   \
+      _Pragma("unroll") for (int j = 0; j < 7; j++) DST[j] = s_in_f[pixb_ + tapoff[j]];               \
+      if (kk == 0) DST[0] = 0.f;   /* the zero slot (0 * 0, whatever the window holds) */               \
+    }
+    constexpr int NU = 2 * ((F12_P * F12_P + 15) / 16);
+    float av[7], an[7];
+    F12_LOAD_A(av, wave >> 1)
+    for (int u = wave; u < NU; u += 8) {
+      const int g = u >> 1;
+      if (u + 8 < NU) F12_LOAD_A(an, (u + 8) >> 1)   // the next unit's operand flies under this unit's MFMAs
+      v4f12 acc[2];
 #pragma unroll
-        for (int q = 0; q < 4; q++) acc[q] = (f2){0.f, 0.f};
-        const bool rowok = yy >= 0 && yy < H;
-        if (rowok) {
+      for (int c2 = 0; c2 < 2; c2++) acc[c2] = (v4f12){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int ky = 0; ky < 3; ky++) {
-            const float* win = &s_in[r + ky][cx * CF_CIN];   // 18 floats: columns cx-1 .. cx+4
-            float wv[18];
+      for (int j = 0; j < 7; j++)
 #pragma unroll
-            for (int j = 0; j < 18; j++) wv[j] = win[j];
+        for (int c2 = 0; c2 < 2; c2++) acc[c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wb[j][c2], acc[c2], 0, 0, 0);
+      // lane (channel n16, kk) holds pixels 16 g + 4 kk + i, i = 0..3
+      const int qo0 = 16 * g + 4 * kk;
+      float* dst = s_y_f + qo0 * 64 + 32 * chalf + n16;
+      if (interior && g < F12_P * F12_P / 16) {   // (uniform) nothing to mask
 #pragma unroll
-            for (int j = 0; j < 9; j++)
+        for (int i = 0; i < 4; i++)
 #pragma unroll
-              for (int q = 0; q < 4; q++) {
-                const f2 v = {wv[j + 3 * q], wv[j + 3 * q]};
-                acc[q] = __builtin_elementwise_fma(wq[ky * 9 + j], v, acc[q]);
-              }
+          for (int c2 = 0; c2 < 2; c2++) {
+            float a = acc[c2][i] + bia[c2];
+            if (relu1) a = a > 0.f ? a : 0.f;
+            dst[i * 64 + 16 * c2] = a;
           }
-        }
+      } else {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          f2 a = acc[q] + bq;
-          if (relu1) {
-            a.x = a.x > 0.f ? a.x : 0.f;
-            a.y = a.y > 0.f ? a.y : 0.f;
+        for (int i = 0; i < 4; i++) {
+          const int qo = qo0 + i;
+          const int ro = qo / F12_P, co = qo - F12_P * ro;
+          const int yy = py0 + ro, xx = px0 + co;
+          const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+#pragma unroll
+          for (int c2 = 0; c2 < 2; c2++) {
+            float a = acc[c2][i] + bia[c2];
+            if (relu1) a = a > 0.f ? a : 0.f;
+            if (!ok) a = 0.f;   // outside the image: conv1_2's zero padding
+            if (qo < F12_P * F12_P) dst[i * 64 + 16 * c2] = a;
           }
-          if (!(rowok && xx + q >= 0 && xx + q < W)) a = (f2){0.f, 0.f};   // outside the image: conv1_2's zero padding
-          if (cx + q < F12_P) *reinterpret_cast<f2*>(&s_y[r][cx + q][cp * 2]) = a;
         }
       }
+#pragma unroll
+      for (int j = 0; j < 7; j++) av[j] = an[j];
     }
+#undef F12_LOAD_A
   }
   __syncthreads();
 
