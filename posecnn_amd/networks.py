@@ -131,14 +131,18 @@ class _RawConv(object):
     """A convolution output before bias + ReLU, handed to a consumer that fuses them (max_pool).
     Fetching the layer by name materialises the activated tensor (in place) like any other."""
 
-    def __init__(self, y, bias, relu, wino=None, first=None, gemm=None):
+    def __init__(self, y, bias, relu, wino=None, first=None, gemm=None, lazy12=None):
         # y: raw NHWC conv output, or None when the conv is still pending:
         # wino  = (M [n*n,T,C], B, H, W): in the Winograd domain, waiting for its output transform
         # first = (x [B,H,W,3], w [3,3,3,C]): a 3-channel first conv not evaluated yet — a following
         #         Winograd conv computes it fused with its own input transform
         # gemm  = (V [36,T,Cin], Ut [36,Cout,Cin], B, H, W): F(4x4,3x3) input transform done, the fused
         #         GEMM + output transform kernel still to run (with or without the max-pool)
+        # lazy12 = (pending conv1_1 (_RawConv with `first`), name, w): conv1_2 on top of a pending conv1_1, nothing launched
+        #         yet — a following 2x2 max_pool runs conv1_1 -> conv1_2 -> pool1 as ONE kernel; anything else that asks for the
+        #         tensor gets the unfused pair
         self.y, self.bias, self.relu, self.out, self.wino, self.first, self.gemm = y, bias, relu, None, wino, first, gemm
+        self.lazy12 = lazy12
         self.dual = False
         self.pooled = None   # the 2x2 max-pool of `out`, when the producing kernel wrote both
 
@@ -150,6 +154,8 @@ class _RawConv(object):
             return tuple(self.first[0].shape[:3]) + (self.first[1].shape[3],)
         if self.gemm is not None:
             return (self.gemm[2], self.gemm[3], self.gemm[4], self.gemm[1].shape[-2])
+        if self.lazy12 is not None:
+            return tuple(self.lazy12[0].first[0].shape[:3]) + (self.lazy12[2].shape[0],)
         if self.y is None and self.out is not None:
             return tuple(self.out.shape)
         return tuple(self.y.shape)
@@ -187,7 +193,8 @@ class Network(object):
         self.winograd_mfma = True
         self.fuse_first_conv_into_winograd = True
         self.fused_first_conv = True  # 3-channel 3x3 convs go to the fused conv + bias + ReLU kernel
-        self.fused_conv12 = True      # grouped RGB-D trunk: conv1_1 -> conv1_2 -> pool1 as one LDS-resident kernel (round 4)
+        self.fused_conv12 = True      # conv1_1 -> conv1_2 -> pool1 as one LDS-resident kernel (round 4): the grouped RGB-D trunk, and
+                                      # (lazily, when the max_pool arrives) every single tower
         self.defer_act = frozenset()  # conv layers whose bias + ReLU is left to the following max_pool
         self.dual_pool = frozenset()  # ... and those whose un-pooled output other layers read too (Winograd only)
         self.rows_count = None        # device int32[1]: true row count of capacity-sized ROI rows fed to `fc` (or None)
@@ -229,9 +236,22 @@ class Network(object):
             elif raw.gemm is not None:
                 v, ut, B, H, W = raw.gemm
                 raw.out = ops.winograd43_conv(v, ut, raw.bias, B, H, W, raw.relu, pool=0)
+            elif raw.lazy12 is not None:   # somebody wants conv1_2 un-pooled: the unfused pair
+                pf, name12, w2 = raw.lazy12
+                B, H, W = pf.shape[:3]
+                raw.out = ops.winograd43_conv(self._first_conv_v(pf), self._winograd_filter(name12, w2, transposed=True), raw.bias,
+                                              B, H, W, raw.relu, pool=0)
             else:
                 raw.out = self._bias_act(raw.y, raw.bias, raw.relu)
         return raw.out
+
+    def _first_conv_v(self, pf):
+        """V of conv1_2 with the pending conv1_1 `pf` evaluated inside its input transform (blobs or raw frames)."""
+        x0 = pf.first[0]
+        if _is_raw(x0):
+            return ops.conv3x3_c3_winograd43_raw(x0 if x0.dtype == torch.uint8 else None, x0 if x0.dtype == torch.uint16 else None,
+                                                 pf.first[1], pf.bias, pf.relu)
+        return ops.conv3x3_c3_winograd43(x0, pf.first[1], pf.bias, pf.relu)
 
     def _winograd_filter(self, name, w, transposed=False):
         """U = G g G^T of a conv filter ([n*n, Cin, Cout]; transposed: [n*n, Cout, Cin] for the fused
@@ -408,12 +428,12 @@ class Network(object):
                 if self.conv_timing is not None:
                     timing = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), 2.0 * B_ * H_ * W_ * c_i * 27)
                     timing[0].record()
-                x0 = pending_first.first[0]
-                if _is_raw(x0):
-                    v = ops.conv3x3_c3_winograd43_raw(x0 if x0.dtype == torch.uint8 else None, x0 if x0.dtype == torch.uint16 else None,
-                                                      pending_first.first[1], pending_first.bias, pending_first.relu)
-                else:
-                    v = ops.conv3x3_c3_winograd43(x0, pending_first.first[1], pending_first.bias, pending_first.relu)
+                if (self.fused_conv12 and self.winograd_mfma and name in self.defer_act and (c_i, c_o) == (64, 64)
+                        and pending_first.first[1].shape[3] == 64 and H_ % 16 == 0 and W_ % 16 == 0):
+                    # a 2x2 max_pool follows: conv1_1 -> conv1_2 -> pool1 as one LDS-resident kernel (csrc/conv_first.hip), launched
+                    # by that max_pool; the library's own events time it
+                    return _RawConv(None, b, relu, lazy12=(pending_first, name, w))
+                v = self._first_conv_v(pending_first)
                 return self._winograd43_tail(name, v, w, b, relu, B_, H_, W_, c_i, c_o, timing)
             input = self._activate(pending_first)
         if (wino_ok and input.is_cuda
@@ -466,6 +486,18 @@ class Network(object):
                 if input.gemm is not None:
                     v, ut, B_, H_, W_ = input.gemm
                     return ops.winograd43_conv(v, ut, input.bias, B_, H_, W_, input.relu, pool=1)
+                if input.lazy12 is not None:
+                    pf, name12, w2 = input.lazy12
+                    ut = self._winograd_filter(name12, w2, transposed=True)
+                    frag = self._wino_u.get((name12, "frag"))
+                    if frag is None or frag[0] is not ut:   # the filter bank in the order the kernel's lanes consume it
+                        frag = (ut, ops.conv12_fragment_major(ut))
+                        self._wino_u[(name12, "frag")] = frag
+                    x0, w1 = pf.first
+                    if _is_raw(x0):
+                        return ops.conv1_1_conv1_2_fused_raw(x0 if x0.dtype == torch.uint8 else None, x0 if x0.dtype == torch.uint16 else None,
+                                                             w1, pf.bias, frag[1], input.bias, pf.relu, input.relu, ut2_layout=1)
+                    return ops.conv1_1_conv1_2_fused(x0, w1, pf.bias, frag[1], input.bias, pf.relu, input.relu, groups=1, ut2_layout=1)
                 if input.wino is not None and input.dual and self.winograd_tile == 4:
                     m, B_, H_, W_ = input.wino
                     input.out, pooled = ops.winograd43_output_both(m, input.bias, B_, H_, W_, input.relu)
@@ -905,7 +937,7 @@ class vgg16_convs(Network):
         towers = 2 if self.input_format == 'RGBD' else 1
         act = lambda div, ch: 4.0 * B * (H // div) * (W // div) * ch
         x_in = (act(2, 64) + act(2, 128) + act(4, 128) + 2 * act(4, 256) + act(8, 256) + 2 * act(8, 512) + 3 * act(16, 512))
-        fused = self.fused_conv12 and self.input_format == 'RGBD' and H % 16 == 0 and W % 16 == 0   # (the grouped trunk's first two layers)
+        fused = self.fused_conv12 and self.winograd_mfma and H % 16 == 0 and W % 16 == 0   # (the first two layers as one kernel)
         t = {"wino43_input_kernel": towers * 3.25 * x_in}                             # reads X, writes V = 2.25 X
         if not fused:
             t["conv3x3_c3_wino43_kernel"] = towers * (act(1, 3) + 2.25 * act(1, 64))      # reads the frame, writes V of conv1_2
@@ -916,7 +948,7 @@ class vgg16_convs(Network):
         towers = 2 if self.input_format == 'RGBD' else 1
         tiles = lambda div: B * ((H // div + 3) // 4) * ((W // div + 3) // 4)
         div = {"1": 1, "2": 2, "3": 4, "4": 8, "5": 16}
-        fused = self.fused_conv12 and self.input_format == 'RGBD' and H % 16 == 0 and W % 16 == 0
+        fused = self.fused_conv12 and self.winograd_mfma and H % 16 == 0 and W % 16 == 0
         fl = sum(2.0 * 36 * tiles(div[n[4]]) * ci * co for n, ci, co, _ in self.TRUNK if ci != 3 and not (fused and n == "conv1_2"))
         t = {"wino43_mfma_kernel": towers * fl}
         if fused:   # conv1_1 + conv1_2 + pool1 in one kernel: its matrix work is conv1_2's Winograd-domain contraction
