@@ -323,6 +323,11 @@ __device__ __forceinline__ void f12_at6_col(const float* m, float* t)
 
 // 512 threads: waves 0-3 are the CONSUMERS (each owns 16 output channels: the 36 accumulators of its elements, the matrix
 // work, the output transform), waves 4-7 the PRODUCERS of the A operand (the transform planes); all eight share phase 1.
+// Measured and dropped (round 4): workgroups of 4 consecutive blocks with the NEXT block's frame window requested by the
+// producer waves when phase 2 starts (the window load is a bare 2 us round trip in front of every block). The window
+// phase fell to 1.1 us, but the block loop cost the kernel its register slack (216 -> 256 VGPRs, scratch reloads that wait
+// — vmcnt counts in order — for the very loads they were meant to hide): 3.39 ms against 3.13 alone, and the step the same
+// within the run-to-run spread (785.0 vs 783.0 frames/s, A / B / A / B on one box).
 template <bool RAW>
 __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
     const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
