@@ -355,7 +355,11 @@ int pcnn_winograd43_output_fwd(const float* m, const float* bias, int batch, int
  *   workspace (optional, pcnn_winograd43_conv_workspace_bytes; 0 bytes for launches that fill the chip): lets a
  *        small launch (batch-1 conv4_x / conv5_x: tens of workgroups of 288 stages each) split Cin over up to 8
  *        workgroups per output block; the partial outputs are summed in a fixed order before bias / ReLU / pooling.
- *        NULL or too small: no split (same result up to f32 summation order). */
+ *        NULL or too small: no split (same result up to f32 summation order).
+ *   Environment (experiments and the variant-equality test; every variant yields the same bits): PCNN_WINO_MODE, an integer
+ *        read once per process — bit 0 the channel-block-major workgroup map, bit 1 the one-wave-per-SIMD kernel
+ *        (wino43_mfma_w1_kernel, v_mfma_f32_32x32x2_f32, launches without a Cin split), bit 3 the round-3 accumulator zeroing.
+ *        Unset: the library's choice per launch. */
 int pcnn_winograd43_conv_workspace_bytes(int batch, int height, int width, int in_channels, int out_channels,
                                          int groups, size_t* bytes);
 int pcnn_winograd43_conv_fwd(const float* v, const float* ut, const float* bias, int batch, int height,
