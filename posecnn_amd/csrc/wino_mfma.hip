@@ -90,7 +90,8 @@ __device__ __forceinline__ void at6_col(const float* m, float* t)
 // WR: wave rows — 1 (what the library launches): 32 tiles x 64 channels, 4 waves, two workgroups per CU;
 // 2: 64 x 64, 8 waves, one workgroup per CU (kept for the ablation harness; see the launcher for the numbers).
 // ABL (tools/wino_ablate.hip only; the library instantiates 0): leave one ingredient of the K loop out to
-// see what it costs — 1 no barrier, 2 no DMA, 4 no LDS reads, 8 no MFMAs, 16 no column fold, 32 no epilogue.
+// see what it costs — 1 no barrier, 2 no DMA, 4 no LDS reads, 8 no MFMAs, 16 no column fold, 32 no epilogue, 64 every
+// workgroup on the operands of block (0, 0) (L2-resident: what the fabric costs).
 // ZC (round 4): the first MFMA pair into a plane's accumulators takes C = 0 as an inline constant instead of reading
 // registers that a v_mov zeroed after every column fold (48 VALU per fold; on the Cin = 64 layers a fold comes every 6
 // stages and VALU time is paid in full next to the MFMAs). Same bits: 0 + a b either way.
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
   const int cb = cbmajor ? x : q % ncb;
   const int tb = cbmajor ? q : (q / ncb) * 8 + x;
   if (tb >= nbt) return;
+  const int tb_data = (ABL & 64) ? 0 : tb, cb_data = (ABL & 64) ? 0 : cb;   // ABL 64 (timing only): every workgroup reads block (0, 0): all operands L2-resident
   y += (long long)blockIdx.y * ysplit_stride;    // `ksplit` > 1: this Cin slice's partial output (see below)
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
   // tile blocks never straddle a group: group g owns tiles [g tpg, (g+1) tpg) in nbg blocks of 64
   const int nbg = (int)((tiles_per_group + BT - 1) / BT);
   const int grp = tb / nbg;
-  const long long t0 = (long long)grp * tiles_per_group + (long long)(tb - grp * nbg) * BT;
+  const long long t0 = (long long)grp * tiles_per_group + (long long)(tb_data - (ABL & 64 ? 0 : grp * nbg)) * BT;
   const long long tend = (long long)(grp + 1) * tiles_per_group;   // first tile that is not this block's business
   const float* utg = ut + (size_t)grp * 36 * Cout * Cin;
   // `ksplit` > 1 (small launches, see the launcher): workgroup blockIdx.y contracts only its slice of Cin and
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
   const unsigned va0 = (unsigned)((ta0 * Cin + dc0) * 4), va1 = (unsigned)((ta1 * Cin + dc1) * 4);
   unsigned ub[UB];
 #pragma unroll
-  for (int i = 0; i < UB; i++) ub[i] = (unsigned)((((size_t)(cb * WM_BC + ur0 + 4 * i)) * Cin + (lr ^ ((ur0 + 4 * i) & 15)) * 4) * 4);
+  for (int i = 0; i < UB; i++) ub[i] = (unsigned)((((size_t)(cb_data * WM_BC + ur0 + 4 * i)) * Cin + (lr ^ ((ur0 + 4 * i) & 15)) * 4) * 4);
   const char* vbase = reinterpret_cast<const char*>(v);
   const char* ubase = reinterpret_cast<const char*>(utg);
   const long long vplane = T * Cin;

@@ -52,7 +52,10 @@ int main(int argc, char** argv)
   const int it = 10;
 #define R(ABL, WHAT) { float ms = wr == 2 ? run<ABL, 2>(v, ut, bias, y, H, W, Cin, Cout, T, it) : run<ABL, 1>(v, ut, bias, y, H, W, Cin, Cout, T, it); printf("%-44s %8.3f ms  %6.1f TFLOP/s-equivalent\n", WHAT, ms, fl / ms / 1e9); }
   printf("T=%lld Cin=%d Cout=%d WR=%d\n", T, Cin, Cout, wr);
+  for (int w = 0; w < 250; w++) run<0, 1>(v, ut, bias, y, H, W, Cin, Cout, T, 5);   // clocks up (they ramp for seconds)
   R(0, "full kernel");
+  R(64, "full kernel, every operand L2-resident");
+  R(0, "full kernel (again)");
   R(32, "no epilogue");
   R(32 | 16, "no epilogue, no column fold");
   R(32 | 1, "no epilogue, no barrier");
@@ -62,5 +65,8 @@ int main(int argc, char** argv)
   R(32 | 1 | 2 | 4 | 16, "MFMAs + loop control only");
   R(32 | 8, "no epilogue, no MFMAs");
   R(32 | 8 | 4, "no epilogue, no MFMAs, no LDS reads (DMA only)");
+  R(32 | 64, "no epilogue, every operand L2-resident");
+  R(16, "no column fold (with epilogue)");
+  R(0, "full kernel (last)");
   return 0;
 }
