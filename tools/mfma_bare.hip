@@ -96,6 +96,25 @@ __global__ __launch_bounds__(256) void bare32_mem(float* out, const float* src, 
   if (r == 1234.5f) out[threadIdx.x] = r;
 }
 
+
+// the small MFMA the one-wave kernel folds with: v_mfma_f32_4x4x1_16b_f32 (64 lanes x 4 FMAs), NACC independent accumulators
+template <int NACC>
+__global__ __launch_bounds__(256) void bare4(float* out, int iters, float a0, float b0)
+{
+  v4f acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) acc[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+  float a = a0 + threadIdx.x, b = b0;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int k = 0; k < 32; k++) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc[k % NACC]) : "v"(a), "v"(b));
+  }
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < NACC; i++) r += acc[i][0] + acc[i][3];
+  if (r == 1234.5f) out[threadIdx.x] = r;
+}
+
 template <typename F>
 static double timeit(F launch)
 {
@@ -137,6 +156,10 @@ int main()
     const double fl = 2.0 * 32 * 32 * 2 * 32.0 * iters * 4 * grid; \
     printf("32x32x2  per 8 MFMAs: %d ds_read_b128 + %d LDS-DMA, one wave/SIMD : %8.3f ms  %6.1f TF\n", NR, ND, ms, fl / ms / 1e9); }
   RM(0, 0) RM(2, 0) RM(4, 0) RM(8, 0) RM(0, 1) RM(0, 2) RM(0, 4) RM(4, 2) RM(4, 4)
+#define R4(NACC) { const double ms = timeit([&] { hipLaunchKernelGGL((bare4<NACC>), dim3(grid), dim3(256), 0, 0, out, iters, 1.f, 2.f); }); \
+    const double n = 32.0 * iters * 8;   /* instructions per SIMD: 8 rounds of one wave */ \
+    printf("4x4x1    acc %d  one wave/SIMD : %8.3f ms  %5.1f cycles per instruction at 2.4 GHz\n", NACC, ms, ms * 1e-3 * 2.4e9 / n); }
+  R4(1) R4(2) R4(4) R4(8)
   R16(1, 256) R16(2, 256) R16(4, 256) R16(1, 512) R16(2, 512) R16(4, 512)
   return 0;
 }
