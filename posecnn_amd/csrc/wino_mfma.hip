@@ -354,6 +354,18 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
 #undef WM_DMA
 #undef WM_PF_ADVANCE
 
+  if constexpr (ABL & 256) {   // ablation: bias + ReLU on the registers, nothing staged or stored
+    const float bv_ = bias ? bias[(size_t)grp * Cout + cb * WM_BC + 16 * wn + lr] : 0.f;
+    float k_ = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int o = 0; o < 16; o++) { float val = yo[b][i][o] + bv_; if (relu) val = val > 0.f ? val : 0.f; k_ += val; }
+    if (k_ == 12345.678f) y[tid] = k_;
+    return;
+  }
   if constexpr (ABL & 32) {   // keep the accumulators alive, store one value per lane
     float k_ = 0.f;
 #pragma unroll
@@ -424,9 +436,12 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
         const int tl = wave + NW * r;
         const int ty = s_tyx[r] & 0xffff, tx = s_tyx[r] >> 16;
         const int oy = 4 * ty + a, ox = 4 * tx + re;
-        if (oy < H && ox < W)   // ty = 0xffff fails here
-          *reinterpret_cast<v4f*>(y + (((long long)s_img[r] * H + oy) * W + ox) * Cout + cb * WM_BC + rc4) =
-              *reinterpret_cast<const v4f*>(&sY[(tl * 4 + re) * 64 + (rc4 ^ (16 * ((tl >> 2) & 3)))]);
+        if (oy < H && ox < W) {   // ty = 0xffff fails here
+          const v4f o4 = *reinterpret_cast<const v4f*>(&sY[(tl * 4 + re) * 64 + (rc4 ^ (16 * ((tl >> 2) & 3)))]);
+          if constexpr (ABL & 128) { if (o4[0] == 12345.678f) y[tid] = o4[1]; }   // (ablation: the staged row is read, not stored)
+          else if constexpr (ABL & 512) __builtin_nontemporal_store(o4, reinterpret_cast<v4f*>(y + (((long long)s_img[r] * H + oy) * W + ox) * Cout + cb * WM_BC + rc4));
+          else *reinterpret_cast<v4f*>(y + (((long long)s_img[r] * H + oy) * W + ox) * Cout + cb * WM_BC + rc4) = o4;
+        }
       }
     }
   }

@@ -66,7 +66,12 @@ int main(int argc, char** argv)
   R(32 | 8, "no epilogue, no MFMAs");
   R(32 | 8 | 4, "no epilogue, no MFMAs, no LDS reads (DMA only)");
   R(32 | 64, "no epilogue, every operand L2-resident");
-  R(16, "no column fold (with epilogue)");
+  R(512, "full kernel, non-temporal output stores");
+  R(0, "full kernel (again 3)");
+  R(512, "full kernel, non-temporal output stores (again)");
+  R(128, "epilogue without its global stores");
+  R(256, "epilogue = bias + ReLU only (no staging, no stores)");
+  R(0, "full kernel (again 2)");
   R(0, "full kernel (last)");
   return 0;
 }
