@@ -1015,6 +1015,9 @@ int wino43_cin_split(long long nbt, int ncb, int Cin)
   // conv5_x 66 -> 82), and with one workgroup per CU ring depths 3 / 4 / 5 time the same (conv4_2, S = 1: 184 / 186 / 188 us;
   // S = 2: 111 / 114 / 113): a lone workgroup keeps its MFMA pipe ~65 % busy whatever the prefetch depth — what a small
   // launch lacks is a second workgroup per CU, not operand cover.
+  // Round 4: 16-tile workgroups for these launches (the kernel above with one A block per wave: twice the workgroups, half
+  // the matrix work each, 176 VGPRs; bit-identical) — conv3_2 at one frame 102 -> 97 us, conv4_x 103 -> 103, conv5_x 42 -> 44,
+  // the one-frame trunk 0.893 -> 0.888 ms: a half-size workgroup waits as long for its operands as a full one. Dropped.
   if (nbt * ncb >= 128) return 1;   // (152 workgroups — batch-1 conv3_x — measured slower split in two: the partials cost more than they buy)
   while (S < 8 && nbt * ncb * S * 2 <= 512 && NK % (2 * S) == 0) S *= 2;
   return S;
