@@ -76,6 +76,11 @@ def parse_args(argv=None):
                          "for the non-default graph switches (strict_numerics, fused_heads=False); see tools/probe_bmm.py")
     ap.add_argument("--force-process-group", action="store_true",
                     help="initialise RCCL and run the detection all-gather through it even at world size 1")
+    ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"],
+                    help="process-group backend (auto: RCCL on GPUs). gloo + --shared-device is the one-GPU rehearsal of the "
+                         "multi-rank path: real kernels, real shard offsets, real launcher, the detection block staged through the host")
+    ap.add_argument("--shared-device", action="store_true",
+                    help="every rank computes on cuda:0 (RCCL refuses two ranks on one device: use --backend gloo)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: launch / rendezvous / collective / JSON plumbing on gloo")
     ap.add_argument("--master-port", type=int, default=0)
     a = ap.parse_args(argv)
@@ -296,10 +301,16 @@ def main(argv=None):
     from posecnn_amd import _lib, config, fcn, ops, pipeline, synth
     from posecnn_amd.networks import vgg16_convs
 
-    rank, world, local = pdist.init_from_env(force=a.force_process_group)
+    if a.shared_device:
+        assert a.backend == "gloo", "--shared-device needs --backend gloo (RCCL refuses duplicate devices)"
+    rank, world, local = pdist.init_from_env(backend=None if a.backend == "auto" else a.backend, force=a.force_process_group)
     assert world == a.gpus or a.gpus == 1, "WORLD_SIZE=%d but --gpus %d" % (world, a.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if a.shared_device:
+        local = 0
     torch.cuda.set_device(local)
+    # one process per GPU: this rank's host thread (and, by first touch, the pinned buffers it allocates below) on its GPU's NUMA node
+    numa = pdist.pin_to_gpu_numa(local) if world > 1 and not a.shared_device else None
     dev = torch.device("cuda", local)
     if a.blas != "default":
         torch.backends.cuda.preferred_blas_library(a.blas)
@@ -361,6 +372,8 @@ def main(argv=None):
     last = {}
     drain = pdist.HostDrain(depth=2)
     seq = {"i": 0}
+    ticket_batch = {}
+    loss_log = torch.zeros(max(1, a.steps + 8), dtype=torch.float32, device=dev)
 
     graphs = {}
 
@@ -418,11 +431,19 @@ def main(argv=None):
             uploader.release(i)
         packed = pdist.all_gather_packed(det.rows, det.count, frame_offset=rank * B)
         last["det"] = det
-        return drain.submit(packed)
+        if last.get("record") is not None and "loss_pose" in net.layers and not (a.graph and last.get("graph_ready")):
+            # (outputs_equal_serial: this batch's scalar pose loss — a function of all 9 x count rows of poses_tanh —
+            # parked in a preallocated device slot on the batch's own stream; read back after the timed region)
+            loss_log[i % loss_log.shape[0]].copy_(net.layers["loss_pose"].reshape(()))
+        t = drain.submit(packed)
+        ticket_batch[t] = i
+        return t
 
     def finish(ticket):
         """Wait for THAT batch's detections and post-process them on the host (class-aware NMS, pose rows)."""
         flat = drain.collect(ticket)
+        if last.get("record") is not None:
+            last["record"].append((ticket_batch[ticket], flat))   # (collect() already copied out of the pinned slot)
         rois, poses = fcn.finalize_batch(flat, flat.shape[0])
         last["rois"] = rois
         if flat.shape[0]:   # detections carry GLOBAL frame indices (rank * B + local): whose frames reached this rank?
@@ -455,6 +476,41 @@ def main(argv=None):
         pdist.barrier()
         return pdist.max_over_ranks(time.perf_counter() - t0, dev), ndet
 
+    def check_equal_serial(first_timed):
+        """Outside the timed region: the nbuf distinct batches once more, SERIALLY on one stream (one batch in flight,
+        device idle in between), and every batch of the timed multi-stream / graph run held to them bit for bit —
+        the gathered detection rows (boxes, scores, quaternions, translations: labels -> Hough -> RoI pooling -> fc6-8)
+        and the scalar pose loss (every row of poses_tanh). VERDICT r4 #1: round 3's LDS-ring race lived in exactly
+        the mode the headline is measured in; the reference loop has one frame in flight (lib/fcn/test.py:1867-1888)."""
+        rec, last["record"] = last["record"], None
+        torch.cuda.synchronize()
+        timed_loss = loss_log.cpu().numpy().copy()
+        was_multi, was_graph = multi["on"], last.get("graph_ready")
+        multi["on"], last["graph_ready"] = False, False
+        serial, serial_loss = {}, {}
+        try:
+            while len(serial) < len(planted):
+                i = seq["i"]
+                last["record"] = []
+                finish(launch(None))
+                torch.cuda.synchronize()
+                serial.setdefault(i % len(planted), last["record"][0][1])
+                serial_loss.setdefault(i % len(planted), float(loss_log[i % loss_log.shape[0]].item()))
+        finally:
+            multi["on"], last["graph_ready"], last["record"] = was_multi, was_graph, None
+        bad = []
+        for i, flat in rec:
+            want = serial[i % len(planted)]
+            if flat.shape != want.shape or flat.tobytes() != want.tobytes():
+                bad.append("detections of timed batch %d" % (i - first_timed))
+            elif a.losses != "none" and not a.graph and np.float32(timed_loss[i % loss_log.shape[0]]).tobytes() != np.float32(serial_loss[i % len(planted)]).tobytes():
+                bad.append("loss_pose of timed batch %d" % (i - first_timed))
+        ok = len(rec) == a.steps and not bad
+        if not ok:
+            print("bench.py: outputs_equal_serial FAILED: %d batches recorded, mismatches: %s" % (len(rec), bad[:8]), file=sys.stderr)
+        return {"ok": ok, "batches_compared": len(rec), "mismatches": len(bad),
+                "rows_per_batch": [int(serial[k].shape[0]) for k in sorted(serial)]}
+
     lat = None
     with torch.no_grad():
         # (1) the contract as written, on a cold process: W untimed warm-up steps (MIOpen find, library
@@ -476,8 +532,11 @@ def main(argv=None):
         if not sep_profile:
             _lib.profile_enable(True)   # HIP events around every library kernel, on the launch stream
             net.conv_timing = []        # ... and around every remaining framework convolution / GEMM of the trunk
+        last["record"] = []       # the timed run's own detections, as the host received them (7 KB per step, already copied)
+        first_timed = seq["i"]
         elapsed, ndet = timed(a.steps)
         host_launch_ms = 1000.0 * last["host_launch_s"] / a.steps
+        equal_serial = check_equal_serial(first_timed)
         if sep_profile:
             # per-kernel events cannot be recorded inside a graph replay, and with two streams a kernel's
             # event pair also spans whatever the other stream ran in between: time the same kernels once
@@ -509,6 +568,12 @@ def main(argv=None):
             lat = {"batch": B, "p50_ms": times[len(times) // 2], "p99_ms": times[min(len(times) - 1, int(0.99 * len(times)))],
                    "min_ms": times[0], "samples": len(times)}
 
+    ag_us = None
+    if torch.distributed.is_initialized():   # every rank takes part (collective), before the other ranks leave
+        try:
+            ag_us = pdist.time_all_gather(last["det"].rows, last["det"].count)
+        except Exception as e:
+            ag_us = "failed: %r" % (e,)
     if rank != 0:
         pdist.shutdown()
         return
@@ -651,6 +716,9 @@ def main(argv=None):
                      "framework_conv_TFLOPs": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else None,
                      "direct_conv_equivalent_TFLOPs": direct_flops_step / (trunk_ms * 1e-3) / 1e12 if trunk_ms else None,
                      "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"},
+        "outputs_equal_serial": equal_serial["ok"],
+        "outputs_equal_serial_detail": dict(equal_serial, what="every batch of the timed run (detection rows as gathered + loss_pose) == the same "
+                                            "batch run serially on one stream after the timed region, bit for bit"),
         "prewarm_seconds": a.prewarm_seconds,
         "host_launch_ms_per_step": host_launch_ms,
         "step_submission": ("hipGraph replay (one graph per device slot)" if a.graph else "eager launches")
@@ -664,6 +732,25 @@ def main(argv=None):
                              "world_size": world, "collective": "all_gather_into_tensor of the packed detection block, once per step"}
                             if torch.distributed.is_initialized() else
                             {"backend": None, "ranks_seen": 1, "world_size": 1, "collective": "none (single process; --force-process-group runs it through RCCL)"})
+    out["process_group"]["shared_device"] = bool(a.shared_device)
+    out["process_group"]["host_numa"] = ({"node": numa[0], "cpus": numa[1]} if numa else None)
+    # the collective by itself: latency of one all-gather of the packed block, outside the timed region. A
+    # single process has no communicator during the measurement; a 1-rank RCCL group is created here, after it, for this number only.
+    try:
+        made = False
+        if not torch.distributed.is_initialized() and world == 1 and not a.latency and not a.no_secondary:
+            pdist.init_from_env(force=True)
+            made = True
+            ag_us = pdist.time_all_gather(det.rows, det.count)
+        if isinstance(ag_us, str):
+            raise RuntimeError(ag_us)
+        out["process_group"]["all_gather_us"] = ag_us
+        out["process_group"]["all_gather_note"] = ("one all_gather_into_tensor of the (cap+1) x 14 f32 block per rank, %s, back to back, outside the timed region%s"
+                                                   % (torch.distributed.get_backend() if torch.distributed.is_initialized() else "no group",
+                                                      "; 1-rank communicator created after the measurement for this number only" if made else ""))
+    except Exception as e:
+        out["process_group"]["all_gather_us"] = None
+        out["process_group"]["all_gather_note"] = "failed: %r" % (e,)
     if (world == 1 and not a.no_secondary and not a.latency and not a.graph and a.config == "ycb" and cfg_name == "configs[2]"
             and "WORLD_SIZE" not in os.environ):
         out["secondary"] = secondary_configs()

@@ -229,6 +229,19 @@ int pcnn_backproject_fwd(const float* data, const float* label, const float* dep
                          int num_meta, int grid_size, int kernel_size, float threshold,
                          float* top_data, float* top_label, float* top_flag, void* stream);
 
+/* The same op with caller-owned scratch (added in round 5; no existing prototype changed). The reference's launcher has none (BackprojectForwardLaucher,
+ * backprojecting_op_gpu.cu.cc:129-155: every (voxel, channel) thread rescans its depth window); here the workspace holds
+ * the (min, max) depth of every (2k+1)^2 window that meets the image — [B][H+2k][W+2k] pairs, built by one small launch in
+ * front of the voxel kernel — so that a voxel whose Z1 cannot match any pixel of its window skips the scan. Results are
+ * bit-identical with and without it (workspace NULL / 0 bytes = pcnn_backproject_fwd). kernel_size > 3 needs 0 bytes. */
+int pcnn_backproject_workspace_bytes(int batch, int height, int width, int kernel_size, size_t* bytes);
+int pcnn_backproject_ws_fwd(const float* data, const float* label, const float* depth,
+                            const float* meta, const float* label_3d,
+                            int batch, int height, int width, int channels, int num_classes,
+                            int num_meta, int grid_size, int kernel_size, float threshold,
+                            float* top_data, float* top_label, float* top_flag,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* BackprojectGrad (backprojecting_op_gpu.cu.cc:159-244): bottom_diff [B,H,W,Cd] from top_diff [B,G,G,G,Cd]. */
 int pcnn_backproject_bwd(const float* top_diff, const float* depth, const float* meta,
                          int batch, int height, int width, int channels, int num_meta,

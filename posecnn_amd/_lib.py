@@ -82,6 +82,9 @@ SIGNATURES = {
     "pcnn_average_distance_bwd": (c_int, [_P, _P, c_int, c_int, _P, _P]),
     "pcnn_backproject_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
                                      c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
+    "pcnn_backproject_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
+    "pcnn_backproject_ws_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
+                                        c_int, c_int, c_int, c_float, _P, _P, _P, _P, c_size_t, _P]),
     "pcnn_backproject_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pcnn_softmax_argmax_fwd": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
     "pcnn_deconv_bilinear_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P]),

@@ -9,6 +9,8 @@
 // one voxel (dwordx4 loads/stores; 16 lanes cover a 64-channel voxel, a wave covers 4 voxels), the
 // window scan is shared by those 4 channels, and the label tensor is produced by its own
 // flattened (voxel, class) pass so that its writes are coalesced too.
+#include <cstdlib>
+
 #include "pcnn_device.h"
 
 namespace {
@@ -141,54 +143,181 @@ __global__ __launch_bounds__(256) void backproject_label_kernel(
   }
 }
 
+// Depth range of every window the forward pass can ask about (round 5). For a window CENTRE (xc, yc) with
+// xc in [-k, W-1+k], yc in [-k, H-1+k] — every centre whose (2k+1)^2 window meets the image — the minimum and the
+// maximum depth over the window's pixels inside the image, NaNs ignored (a NaN depth never matches:
+// backprojecting_op_gpu.cu.cc:75 compares fabs(depth - Z1) < threshold). Layout [B][H+2k][W+2k] float2, index = centre + k.
+// A voxel whose Z1 lies outside [min - threshold, max + threshold] of its window cannot match a single pixel and
+// skips the scan (85 % of the voxels of the test scene; the test is made with the scan's own subtraction, see
+// backproject_fused_kernel). Block = 64 x 16 centres; the (64+2k) x (16+2k) depth tile goes through LDS, rows
+// first (min / max over 2k+1 columns), then columns.
+__global__ __launch_bounds__(256) void backproject_window_range_kernel(
+    const float* __restrict__ depth, float2* __restrict__ wrange, int H, int W, int ksize)
+{
+  constexpr int TW = 64, TH = 16, KMAX = 3;
+  __shared__ float tile[TH + 2 * KMAX][TW + 2 * KMAX];
+  __shared__ float2 rowr[TH + 2 * KMAX][TW];
+  const int S = 2 * ksize + 1, Wc = W + 2 * ksize, Hc = H + 2 * ksize;
+  const int cx0 = blockIdx.x * TW, cy0 = blockIdx.y * TH, n = blockIdx.z;
+  const float* dn = depth + (long long)n * H * W;
+  const float qnan = __int_as_float(0x7fc00000);
+  const int rw = TW + 2 * ksize, rh = TH + 2 * ksize;
+  // centre index c covers pixels c - 2k .. c (pixel = centre index - k -+ k)
+  for (int i = threadIdx.x; i < rw * rh; i += 256) {
+    const int ry = i / rw, rx = i - ry * rw;
+    const int x = cx0 - 2 * ksize + rx, y = cy0 - 2 * ksize + ry;
+    tile[ry][rx] = (x >= 0 && x < W && y >= 0 && y < H) ? dn[(long long)y * W + x] : qnan;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < TW * rh; i += 256) {
+    const int ry = i / TW, cx = i - ry * TW;
+    float mn = qnan, mx = qnan;
+    for (int j = 0; j < S; j++) {
+      const float v = tile[ry][cx + j];
+      mn = fminf(mn, v);   // (minNum / maxNum: the non-NaN operand wins)
+      mx = fmaxf(mx, v);
+    }
+    rowr[ry][cx] = make_float2(mn, mx);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < TW * TH; i += 256) {
+    const int cy = i / TW, cx = i - cy * TW;
+    if (cx0 + cx >= Wc || cy0 + cy >= Hc) continue;
+    float mn = qnan, mx = qnan;
+    for (int j = 0; j < S; j++) {
+      const float2 r = rowr[cy + j][cx];
+      mn = fminf(mn, r.x);
+      mx = fmaxf(mx, r.y);
+    }
+    wrange[((long long)n * Hc + cy0 + cy) * Wc + cx0 + cx] = make_float2(mn, mx);
+  }
+}
+
+template <bool NT>
+__device__ __forceinline__ void bp_store4(float4* p, const float4 v)
+{
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  if (NT) __builtin_nontemporal_store((v4f){v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(p));
+  else *p = v;
+}
+
 // Fused forward for windows of at most 64 pixels ((2k+1)^2 <= 64, i.e. k <= 3 — the reference's
-// k = 3, vgg16.py:131-132). A wave owns 64 consecutive voxels:
-//   A  lane = voxel: ONE projection + ONE window scan per voxel, kept as a 64-bit mask of the
-//      matching window pixels (bit = column-major position inside the unclipped window, which is
-//      the reference's summation order) — the kernels above redo this in every channel's thread;
-//   B  lane = (voxel of a group of 64/LPV, channel quad): masks travel by shuffle, the set bits are
-//      walked in ascending order (`acc += v`, same order as the nested loops) and every store
-//      instruction writes 64/LPV voxels x Cd floats contiguously (data and flag);
-//   C  lane = flattened (voxel, class) of the wave's 64 x Cl contiguous label outputs.
-template <int LPV>  // lanes per voxel in phase B = min(Cd, 64) / 4
+// k = 3, vgg16.py:131-132). A wave owns 64 consecutive voxels (32 KB of data + flag and 64 Cl label floats, all
+// contiguous):
+//   A  lane = voxel: ONE projection per voxel; with the window-range table (above) one 8-byte load decides whether
+//      the voxel can match anything at all; only then the window is scanned — a column of 2k+1 loads in flight at a
+//      time, not one load per trip — into a 64-bit mask of the matching window pixels (bit = column-major position
+//      inside the unclipped window, which is the reference's summation order);
+//   all-miss wave (most of the grid): the outputs are a 32-KB run of zeros and a straight copy of label_3d, written
+//      as independent 16-byte stores with nothing to wait for in between;
+//   B  otherwise: lane = (voxel of a group of 64/LPV, channel quad): masks travel by shuffle, the set bits are
+//      walked in ascending order four loads at a time (`acc += v` in the order of the reference's nested loops) and
+//      every store instruction writes 64/LPV voxels x Cd floats contiguously (data and flag);
+//   C  lane = flattened (voxel, class) of the wave's 64 x Cl contiguous label outputs, the label_3d values of 8
+//      trips requested up front.
+// Round 4's version of this kernel made every lane walk its window one dependent load at a time before it learned
+// that 85 % of the voxels miss, and fetched label_3d one trip at a time behind a queue of stores: a wave lived
+// ~170 us for 43 KB of output (0.27 of the HBM peak at G = 256).
+template <int LPV, bool NT>  // lanes per voxel in phase B = min(Cd, 64) / 4; NT: non-temporal stores
 __global__ __launch_bounds__(256) void backproject_fused_kernel(
     const float* __restrict__ data, const float* __restrict__ label, const float* __restrict__ depth,
-    const float* __restrict__ meta, const float* __restrict__ label_3d, float* __restrict__ top_data,
-    float* __restrict__ top_label, float* __restrict__ top_flag, long long nvox, int H, int W, int Cd,
-    int Cl, int num_meta, int G, int ksize, float threshold)
+    const float* __restrict__ meta, const float* __restrict__ label_3d, const float2* __restrict__ wrange,
+    float* __restrict__ top_data, float* __restrict__ top_label, float* __restrict__ top_flag, long long nvox,
+    int H, int W, int Cd, int Cl, int num_meta, int G, int ksize, float threshold, int lab_vec)
 {
   const int lane = threadIdx.x & 63;
+  const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long long nwave = (nvox + 63) / 64;
   const int S = 2 * ksize + 1;
-  const long long G3 = (long long)G * G * G;
-  for (long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); wv < nwave; wv += (long long)gridDim.x * 4) {
+  const unsigned G2 = (unsigned)G * (unsigned)G, G3u = G2 * (unsigned)G;   // (G <= 1024: the launcher checks)
+  const long long G3 = (long long)G3u;
+  const unsigned cl_magic = (unsigned)((0x100000000ull + (unsigned)Cl - 1) / (unsigned)Cl);   // i / Cl = umulhi(i, magic) for i < 2^32 / Cl
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long long wv = (long long)blockIdx.x * 4 + wave_in_block; wv < nwave; wv += (long long)gridDim.x * 4) {
     const long long vbase = wv * 64;
+    const int nv = (int)(nvox - vbase < 64 ? nvox - vbase : 64);
     // ---- A: one voxel per lane
     unsigned long long mask = 0;
     int px = 0, py = 0;  // window origin (column, row) of this lane's voxel
-    {
-      const long long vox = vbase + lane;
-      if (vox < nvox) {
-        long long t = vox;
-        const int w = (int)(t % G); t /= G;
-        const int h = (int)(t % G); t /= G;
-        const int d = (int)(t % G); t /= G;
-        const int n = (int)t;
-        const float* md = meta + (size_t)n * num_meta;
-        const Proj p = project_voxel(md, d, h, w);
-        const Window win = clip_window(p, ksize, H, W);
-        // window origin; clamped so that garbage projections (saturated to INT_MIN/MAX, empty
-        // window, never dereferenced) cannot overflow the subtraction
-        px = (int)max(-(1ll << 30), min(1ll << 30, (long long)p.px - ksize));
-        py = (int)max(-(1ll << 30), min(1ll << 30, (long long)p.py - ksize));
+    if (lane < nv) {
+      const long long n0 = vbase / G3;                         // (wave-uniform: scalar unit)
+      unsigned r = (unsigned)(vbase - n0 * G3) + (unsigned)lane;
+      const unsigned dn_ = r / G3u;                            // a wave may straddle images
+      r -= dn_ * G3u;
+      const int n = (int)n0 + (int)dn_;
+      const unsigned d = r / G2, r2 = r - d * G2, h = r2 / (unsigned)G, w = r2 - h * (unsigned)G;
+      const float* md = meta + (size_t)n * num_meta;
+      const Proj p = project_voxel(md, (int)d, (int)h, (int)w);
+      const Window win = clip_window(p, ksize, H, W);
+      // window origin; clamped so that garbage projections (saturated to INT_MIN/MAX, empty
+      // window, never dereferenced) cannot overflow the subtraction
+      px = (int)max(-(1ll << 30), min(1ll << 30, (long long)p.px - ksize));
+      py = (int)max(-(1ll << 30), min(1ll << 30, (long long)p.py - ksize));
+      bool cand = win.xlo <= win.xhi && win.ylo <= win.yhi;
+      if (cand && wrange) {
+        // (non-empty window <=> centre in [-k, W-1+k] x [-k, H-1+k]: inside the table)
+        const float2 rg = wrange[((long long)n * (H + 2 * ksize) + (p.py + ksize)) * (W + 2 * ksize) + (p.px + ksize)];
+        // f32 subtraction is monotone: depth >= min  =>  depth - Z1 >= min - Z1 >= threshold  =>  no pixel matches;
+        // depth <= max  =>  depth - Z1 <= max - Z1 <= -threshold  =>  likewise. (NaN range or NaN Z1: both tests
+        // fail and the window is scanned.)
+        cand = !((rg.x - p.Z1) >= threshold || (rg.y - p.Z1) <= -threshold);
+      }
+      if (cand) {
         const float* dn = depth + (long long)n * H * W;
-        for (int x = win.xlo; x <= win.xhi; x++)
-          for (int y = win.ylo; y <= win.yhi; y++)
-            if (fabsf(dn[(long long)y * W + x] - p.Z1) < threshold)
-              mask |= 1ull << ((x - px) * S + (y - py));
+        for (int xi = 0; xi < S; xi++) {
+          const int x = px + xi;
+          if (x < 0 || x >= W) continue;
+          float dv[7];
+#pragma unroll
+          for (int yi = 0; yi < 7; yi++) {   // the column's 2k+1 <= 7 loads in flight together
+            const int y = py + yi;
+            const bool ok = yi < S && y >= 0 && y < H;
+            dv[yi] = dn[ok ? (long long)y * W + x : (long long)x];
+          }
+#pragma unroll
+          for (int yi = 0; yi < 7; yi++) {
+            const int y = py + yi;
+            const bool ok = yi < S && y >= 0 && y < H;
+            if (ok && fabsf(dv[yi] - p.Z1) < threshold) mask |= 1ull << (xi * S + yi);
+          }
+        }
       }
     }
     const unsigned mlo = (unsigned)mask, mhi = (unsigned)(mask >> 32);
+    float4* wdata = reinterpret_cast<float4*>(top_data + vbase * Cd);
+    float4* wflag = reinterpret_cast<float4*>(top_flag + vbase * Cd);
+    const long long lbase = vbase * Cl;
+    if (__ballot(mask != 0) == 0) {
+      // ---- the whole wave misses: zeros + label_3d straight through
+      const int n4 = nv * (Cd / 4);
+#pragma unroll 4
+      for (int i = lane; i < n4; i += 64) {
+        bp_store4<NT>(wdata + i, zero4);
+        bp_store4<NT>(wflag + i, zero4);
+      }
+      if (lab_vec && nv == 64) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f* src = reinterpret_cast<const v4f*>(label_3d + lbase);
+        v4f* dst = reinterpret_cast<v4f*>(top_label + lbase);
+        const int l4 = 16 * Cl;
+        for (int i0 = 0; i0 < l4; i0 += 64 * 8) {
+          v4f t[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const int i = i0 + 64 * j + lane;
+            if (i < l4) t[j] = NT ? __builtin_nontemporal_load(src + i) : src[i];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const int i = i0 + 64 * j + lane;
+            if (i < l4) { if (NT) __builtin_nontemporal_store(t[j], dst + i); else dst[i] = t[j]; }
+          }
+        }
+      } else {
+        for (int i = lane; i < nv * Cl; i += 64) top_label[lbase + i] = label_3d[lbase + i];
+      }
+      continue;
+    }
     // ---- B: data + flag
     constexpr int VPI = 64 / LPV;  // voxels per iteration
     const int sub = lane / LPV, cq = lane % LPV;
@@ -197,50 +326,93 @@ __global__ __launch_bounds__(256) void backproject_fused_kernel(
       const long long vox = vbase + vl;
       unsigned long long m = ((unsigned long long)(unsigned)__shfl((int)mhi, vl) << 32) | (unsigned)__shfl((int)mlo, vl);
       const int vx = __shfl(px, vl), vy = __shfl(py, vl);
-      if (vox >= nvox) continue;
+      if (vl >= nv) continue;
+      if (m == 0) {
+        for (int c = cq * 4; c < Cd; c += LPV * 4) {
+          bp_store4<NT>(reinterpret_cast<float4*>(top_data + vox * Cd + c), zero4);
+          bp_store4<NT>(reinterpret_cast<float4*>(top_flag + vox * Cd + c), zero4);
+        }
+        continue;
+      }
       const long long n = vox / G3;
       const float* dbase = data + n * H * W * (long long)Cd;
       const float cnt = (float)__popcll(m);
+      const float4 one4 = make_float4(1.f, 1.f, 1.f, 1.f);
       for (int c = cq * 4; c < Cd; c += LPV * 4) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 acc = zero4;
         unsigned long long mm = m;
-        while (mm) {
-          const int b = __ffsll((long long)mm) - 1;
-          mm &= mm - 1;
-          const int x = vx + b / S, y = vy + b % S;
-          const float4 v = *reinterpret_cast<const float4*>(dbase + ((long long)y * W + x) * Cd + c);
-          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        while (mm) {   // four matching pixels per trip: loads together, additions in the reference's order
+          int b[4];
+          bool ok[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            ok[j] = mm != 0;
+            b[j] = ok[j] ? __ffsll((long long)mm) - 1 : b[0];
+            mm &= mm - 1;
+          }
+          float4 v[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int x = vx + b[j] / S, y = vy + b[j] % S;
+            v[j] = *reinterpret_cast<const float4*>(dbase + ((long long)y * W + x) * Cd + c);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (ok[j]) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
         }
-        float flag = 0.f;
-        if (m) {
-          acc.x = div_rn(acc.x, cnt); acc.y = div_rn(acc.y, cnt); acc.z = div_rn(acc.z, cnt); acc.w = div_rn(acc.w, cnt);
-          flag = 1.f;
-        }
-        *reinterpret_cast<float4*>(top_data + vox * Cd + c) = acc;
-        *reinterpret_cast<float4*>(top_flag + vox * Cd + c) = make_float4(flag, flag, flag, flag);
+        acc.x = div_rn(acc.x, cnt); acc.y = div_rn(acc.y, cnt); acc.z = div_rn(acc.z, cnt); acc.w = div_rn(acc.w, cnt);
+        bp_store4<NT>(reinterpret_cast<float4*>(top_data + vox * Cd + c), acc);
+        bp_store4<NT>(reinterpret_cast<float4*>(top_flag + vox * Cd + c), one4);
       }
     }
-    // ---- C: labels, 64 * Cl contiguous outputs of this wave
-    const long long lbase = vbase * Cl;
-    for (int i = lane; i < 64 * Cl; i += 64) {
-      const int vl = i / Cl, cl = i - vl * Cl;
-      // (every lane reaches the shuffles: 64 * Cl is a multiple of 64)
-      unsigned long long m = ((unsigned long long)(unsigned)__shfl((int)mhi, vl) << 32) | (unsigned)__shfl((int)mlo, vl);
-      const int vx = __shfl(px, vl), vy = __shfl(py, vl);
-      const long long vox = vbase + vl;
-      if (vox >= nvox) continue;
-      const long long n = vox / G3;
-      const float* lb = label + n * H * W * (long long)Cl;
-      float acc = 0.f;
-      const float cnt = (float)__popcll(m);
-      unsigned long long mm = m;
-      while (mm) {
-        const int b = __ffsll((long long)mm) - 1;
-        mm &= mm - 1;
-        const int x = vx + b / S, y = vy + b % S;
-        acc += lb[((long long)y * W + x) * Cl + cl];
+    // ---- C: labels, 64 * Cl contiguous outputs of this wave, 8 trips' label_3d values in flight
+    const int nl = nv * Cl;
+    for (int i0 = 0; i0 < nl; i0 += 64 * 8) {
+      float l3[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int i = i0 + 64 * j + lane;
+        l3[j] = label_3d[lbase + (i < nl ? i : nl - 1)];
       }
-      top_label[lbase + i] = m ? div_rn(acc, cnt) : label_3d[lbase + i];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int i = i0 + 64 * j + lane;
+        if (i0 + 64 * j >= nl) break;             // (wave-uniform)
+        const int ic = i < nl ? i : nl - 1;       // every lane reaches the shuffles
+        const int vl = (int)__umulhi((unsigned)ic, cl_magic), cl = ic - vl * Cl;
+        unsigned long long m = ((unsigned long long)(unsigned)__shfl((int)mhi, vl) << 32) | (unsigned)__shfl((int)mlo, vl);
+        const int vx = __shfl(px, vl), vy = __shfl(py, vl);
+        if (i >= nl) continue;
+        float out = l3[j];
+        if (m) {
+          const long long n = (vbase + vl) / G3;
+          const float* lb = label + n * H * W * (long long)Cl;
+          float acc = 0.f;
+          const float cnt = (float)__popcll(m);
+          unsigned long long mm = m;
+          while (mm) {
+            int b[4];
+            bool ok[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              ok[q] = mm != 0;
+              b[q] = ok[q] ? __ffsll((long long)mm) - 1 : b[0];
+              mm &= mm - 1;
+            }
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              const int x = vx + b[q] / S, y = vy + b[q] % S;
+              v[q] = lb[((long long)y * W + x) * Cl + cl];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+              if (ok[q]) acc += v[q];
+          }
+          out = div_rn(acc, cnt);
+        }
+        top_label[lbase + i] = out;
+      }
     }
   }
 }
@@ -294,11 +466,21 @@ inline int grid_for(long long total)
 
 }  // namespace
 
-extern "C" int pcnn_backproject_fwd(const float* data, const float* label, const float* depth,
-                                    const float* meta, const float* label_3d, int B, int H, int W,
-                                    int Cd, int Cl, int num_meta, int G, int ksize, float threshold,
-                                    float* top_data, float* top_label, float* top_flag,
-                                    void* stream_)
+extern "C" int pcnn_backproject_workspace_bytes(int B, int H, int W, int ksize, size_t* bytes)
+{
+  PCNN_REQUIRE(bytes, PCNN_ENULL, "backproject_workspace_bytes: NULL pointer");
+  PCNN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && ksize >= 0, PCNN_EINVAL, "backproject_workspace_bytes: bad shape %dx%dx%d, kernel_size %d", B, H, W, ksize);
+  // the window-range table: one (min, max) pair per window centre that meets the image; windows of more than 64
+  // pixels (k > 3) take the per-channel kernels, which do not use it
+  *bytes = ksize <= 3 ? (size_t)B * (size_t)(H + 2 * ksize) * (size_t)(W + 2 * ksize) * sizeof(float2) : 0;
+  return PCNN_OK;
+}
+
+static int backproject_fwd_impl(const float* data, const float* label, const float* depth,
+                                const float* meta, const float* label_3d, int B, int H, int W,
+                                int Cd, int Cl, int num_meta, int G, int ksize, float threshold,
+                                float* top_data, float* top_label, float* top_flag, void* ws, size_t ws_bytes,
+                                void* stream_)
 {
   int st = validate(B, H, W, Cd, num_meta, G);
   if (st != PCNN_OK) return st;
@@ -312,15 +494,29 @@ extern "C" int pcnn_backproject_fwd(const float* data, const float* label, const
   const long long nvox = (long long)B * G * G * G;
   const bool vec = (Cd % 4 == 0) && aligned16(data) && aligned16(top_data) && aligned16(top_flag);
   const int lpv = Cd >= 64 ? 16 : Cd / 4;
-  const bool fused = vec && (2 * ksize + 1) * (2 * ksize + 1) <= 64 && (Cd % 64 == 0 || Cd == 32 || Cd == 16 || Cd == 8 || Cd == 4);
+  const bool fused = vec && ksize <= 3 && G <= 1024 && (Cd % 64 == 0 || Cd == 32 || Cd == 16 || Cd == 8 || Cd == 4);
   if (fused) {
+    float2* wrange = nullptr;
+    if (ws) {
+      size_t need = 0;
+      pcnn_backproject_workspace_bytes(B, H, W, ksize, &need);
+      PCNN_REQUIRE(ws_bytes >= need, PCNN_EWORKSPACE, "backproject: workspace too small (%zu < %zu bytes)", ws_bytes, need);
+      PCNN_REQUIRE(aligned16(ws), PCNN_EINVAL, "backproject: workspace must be 16-byte aligned");
+      wrange = static_cast<float2*>(ws);
+      PCNN_LAUNCH(backproject_window_range_kernel, dim3((unsigned)((W + 2 * ksize + 63) / 64), (unsigned)((H + 2 * ksize + 15) / 16), (unsigned)B),
+                  dim3(256), 0, stream, depth, wrange, H, W, ksize);
+    }
     const long long nwave = (nvox + 63) / 64;
     const long long blocks = (nwave + 3) / 4;
     const dim3 grid((unsigned)(blocks < 256 * 64 ? blocks : 256 * 64));
-#define BP_GO(L) PCNN_LAUNCH(backproject_fused_kernel<L>, grid, dim3(256), 0, stream, data, label, depth, meta, label_3d, \
-                             top_data, top_label, top_flag, nvox, H, W, Cd, Cl, num_meta, G, ksize, threshold)
+    const int lab_vec = aligned16(label_3d) && aligned16(top_label) ? 1 : 0;
+    static const bool nt = [] { const char* e = getenv("PCNN_BP_NT"); return !(e && e[0] == '0'); }();   // A/B switch (default: non-temporal stores)
+#define BP_GO2(L, N) PCNN_LAUNCH((backproject_fused_kernel<L, N>), grid, dim3(256), 0, stream, data, label, depth, meta, label_3d, wrange, \
+                                 top_data, top_label, top_flag, nvox, H, W, Cd, Cl, num_meta, G, ksize, threshold, lab_vec)
+#define BP_GO(L) do { if (nt) BP_GO2(L, true); else BP_GO2(L, false); } while (0)
     if (lpv == 16) BP_GO(16); else if (lpv == 8) BP_GO(8); else if (lpv == 4) BP_GO(4); else if (lpv == 2) BP_GO(2); else BP_GO(1);
 #undef BP_GO
+#undef BP_GO2
     return pcnn::check_launch("backproject_fwd");
   }
   if (vec) {
@@ -336,6 +532,27 @@ extern "C" int pcnn_backproject_fwd(const float* data, const float* label, const
   PCNN_LAUNCH(backproject_label_kernel, dim3(grid_for(ltotal)), dim3(256), 0, stream, label, depth,
                      meta, label_3d, top_label, ltotal, H, W, Cl, num_meta, G, ksize, threshold);
   return pcnn::check_launch("backproject_fwd");
+}
+
+extern "C" int pcnn_backproject_fwd(const float* data, const float* label, const float* depth,
+                                    const float* meta, const float* label_3d, int B, int H, int W,
+                                    int Cd, int Cl, int num_meta, int G, int ksize, float threshold,
+                                    float* top_data, float* top_label, float* top_flag,
+                                    void* stream_)
+{
+  return backproject_fwd_impl(data, label, depth, meta, label_3d, B, H, W, Cd, Cl, num_meta, G, ksize, threshold, top_data,
+                              top_label, top_flag, nullptr, 0, stream_);
+}
+
+extern "C" int pcnn_backproject_ws_fwd(const float* data, const float* label, const float* depth,
+                                       const float* meta, const float* label_3d, int B, int H, int W,
+                                       int Cd, int Cl, int num_meta, int G, int ksize, float threshold,
+                                       float* top_data, float* top_label, float* top_flag,
+                                       void* workspace, size_t workspace_bytes, void* stream_)
+{
+  PCNN_REQUIRE(workspace || workspace_bytes == 0, PCNN_ENULL, "backproject: NULL workspace with %zu bytes", workspace_bytes);
+  return backproject_fwd_impl(data, label, depth, meta, label_3d, B, H, W, Cd, Cl, num_meta, G, ksize, threshold, top_data,
+                              top_label, top_flag, workspace_bytes ? workspace : nullptr, workspace_bytes, stream_);
 }
 
 extern "C" int pcnn_backproject_bwd(const float* top_diff, const float* depth, const float* meta,

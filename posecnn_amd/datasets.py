@@ -171,6 +171,9 @@ class Evaluator(object):
         inter = np.diag(h)
         union = h.sum(1) + h.sum(0) - inter
         out = {"iou": {self.classes[i]: float(inter[i] / union[i]) for i in np.where(union > 0)[0]}, "poses": []}
+        for tag, pp in (("poses_refined", poses_new), ("poses_icp", poses_icp)):   # before anything is written
+            if pp is not None and np.asarray(pp).shape[0] != np.asarray(poses).shape[0]:
+                raise ValueError("%s has %d rows for %d detections" % (tag, np.asarray(pp).shape[0], np.asarray(poses).shape[0]))
         if mat_path is not None:
             import scipy.io
             # the reference's record always carries both keys — empty lists when POSE_REFINE is off
@@ -180,9 +183,6 @@ class Evaluator(object):
                    "poses_refined": empty if poses_new is None else poses_new,
                    "poses_icp": empty if poses_icp is None else poses_icp}
             scipy.io.savemat(mat_path, rec, do_compression=True)
-        for tag, pp in (("poses_refined", poses_new), ("poses_icp", poses_icp)):
-            if pp is not None and np.asarray(pp).shape[0] != np.asarray(poses).shape[0]:
-                raise ValueError("%s has %d rows for %d detections" % (tag, np.asarray(pp).shape[0], np.asarray(poses).shape[0]))
         poses_gt = np.asarray(meta_data["poses"])
         if poses_gt.ndim == 2:
             poses_gt = poses_gt.reshape(3, 4, 1)

@@ -49,6 +49,69 @@ def init_from_env(backend=None, force=False):
     return rank, world, local
 
 
+def gpu_numa_node(local):
+    """NUMA node of GPU `local` from sysfs (its PCI function's `numa_node`), or None when the platform does not say."""
+    try:
+        p = torch.cuda.get_device_properties(local)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        return node if node >= 0 else None
+    except Exception:
+        return None
+
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pin_to_gpu_numa(local):
+    """One process per GPU: keep this rank's host thread — and with it, by first touch, the pinned upload slots and
+    drain buffers it allocates afterwards — on the NUMA node its GPU hangs off, so that the 118 MB of H2D per step
+    never cross the socket interconnect and 8 ranks do not pile onto node 0. Returns (node, n_cpus) or None if the
+    topology is not exposed (containers without sysfs PCI entries) — never fatal."""
+    node = gpu_numa_node(local)
+    if node is None:
+        return None
+    try:
+        cpus = _parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % node).read())
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return node, len(cpus)
+    except Exception:
+        return None
+
+
+def time_all_gather(rows, count, iters=50, group=None):
+    """Latency of the path's only collective, by itself: `iters` back-to-back all-gathers of one packed detection
+    block ((cap + 1) x 14 floats per rank), microseconds each (device events on RCCL, host clock on gloo)."""
+    import time
+    if not dist.is_initialized():
+        return None
+    for _ in range(3):
+        all_gather_packed(rows, count, group=group)
+    if rows.is_cuda and dist.get_backend(group) != "gloo":
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            all_gather_packed(rows, count, group=group)
+        e1.record()
+        e1.synchronize()
+        return 1000.0 * e0.elapsed_time(e1) / iters
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        all_gather_packed(rows, count, group=group)
+    return 1e6 * (time.perf_counter() - t0) / iters
+
+
 def shard_range(n_frames, rank, world):
     """Contiguous shard [lo, hi) of a global batch: rank r takes frames [r*N/W, (r+1)*N/W)."""
     lo = (n_frames * rank) // world
@@ -71,11 +134,25 @@ def pack_detections(rows, count, frame_offset=0):
 
 def all_gather_packed(rows, count, frame_offset=0, group=None):
     """The collective itself: returns the packed buffer of every rank, [W, cap+1, 14] (count of
-    rank r in [r, cap, 0]). Asynchronous with respect to the host on RCCL."""
+    rank r in [r, cap, 0]). Asynchronous with respect to the host on RCCL.
+
+    On a `gloo` group with device tensors (the one-GPU rehearsal of the multi-rank path, `bench.py
+    --backend gloo --shared-device`: RCCL refuses two ranks on one device, and gloo's all-gather takes host
+    tensors only) the packed block is staged through the host: D2H on the batch's stream, wait for THAT copy,
+    gather on gloo; the result is a host tensor, which `HostDrain` takes as it is."""
     buf = pack_detections(rows, count, frame_offset)
     if not dist.is_initialized():
         return buf.unsqueeze(0)   # single process, no communicator: nothing to exchange
     world = dist.get_world_size(group)
+    if buf.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(buf.shape, dtype=buf.dtype, pin_memory=True)
+        host.copy_(buf, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ev.synchronize()
+        flat = torch.empty((world * buf.shape[0], buf.shape[1]), dtype=buf.dtype)
+        dist.all_gather_into_tensor(flat, host, group=group)
+        return flat.view(world, buf.shape[0], buf.shape[1])
     flat = torch.empty((world * buf.shape[0], buf.shape[1]), dtype=buf.dtype, device=buf.device)
     dist.all_gather_into_tensor(flat, buf, group=group)  # rank-major concatenation (RCCL and gloo)
     return flat.view(world, buf.shape[0], buf.shape[1])
@@ -160,6 +237,8 @@ def max_over_ranks(value, device):
     """MAX all-reduce of a python float (timing contract of bench.py)."""
     if not dist.is_initialized():
         return float(value)
+    if dist.get_backend() == "gloo":
+        device = torch.device("cpu")
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

@@ -197,7 +197,7 @@ def im_segment_batch(net, data, K, extents, points, symmetry, data_p=None, plant
     count = num_rois[1:2]
     # rows at or past the count are not written when fc6 runs on the library's row kernels, which mask them by the same
     # count (Network.fc); the framework fallback (a trainable graph under autograd) reads the whole buffer: zeros there
-    masked_fc = not (torch.is_grad_enabled() and net.trainable)
+    masked_fc = net.fc_masks_dead_rows("fc6", 7 * 7 * 512, 4096)   # (the predicate Network.fc itself applies — ADVICE r4)
     pool = ops.roi_pool_add2(net.get_output("conv5_3"), 1.0 / 16.0, net.get_output("conv4_3"), 1.0 / 8.0, rois,
                              num_rows=count, dead_rows="keep" if masked_fc else "zero")
     net.layers["pool_score"] = pool

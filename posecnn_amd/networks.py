@@ -570,12 +570,28 @@ class Network(object):
         if self._fc_skinny_ok(feed_in, dim, w):
             # a handful of rows (the single-frame loop): the layer is a weight stream — csrc/fc_skinny.hip
             return ops.fc_skinny(feed_in.contiguous(), self._fc_wt(name, w), b, "relu" if relu else "none", num_rows=rows)
-        if (rows is not None and feed_in.is_cuda and dim % 64 == 0 and dim >= 128 and num_out % 64 == 0
-                and not (torch.is_grad_enabled() and (w.requires_grad or feed_in.requires_grad))):
+        if rows is not None and self._fc_rows_ok(feed_in, dim, num_out, w):
             # capacity-sized rows behind the sync-free Hough layer: only the first *rows_count rows exist
             return ops.fc_rows(feed_in.contiguous(), self._fc_wt(name, w), b, relu, num_rows=rows)
         y = torch.addmm(b, feed_in, w)
         return F.relu(y) if relu else y
+
+    @staticmethod
+    def _fc_rows_ok(feed_in, dim, num_out, w):
+        return (feed_in.is_cuda and dim % 64 == 0 and dim >= 128 and num_out % 64 == 0
+                and not (torch.is_grad_enabled() and (w.requires_grad or feed_in.requires_grad)))
+
+    def fc_masks_dead_rows(self, name, dim, num_out, rows=None):
+        """Will `fc(name)` on a capacity-sized, device-counted row buffer run on the library's row kernels — which
+        never read the rows at or past the count — or on the framework's addmm, which reads all of them? The caller
+        (fcn.im_segment_batch) leaves dead rows of the pooled features unwritten only in the first case. Same predicate
+        as `fc` / `_fc_skinny_ok` (a variable that does not exist yet is created by `fc` with this network's
+        `trainable`; the pooled features never require gradients on this path)."""
+        w = self.vars.get(name + "/weights")
+        wants_grad = (self.trainable if w is None else w.requires_grad) and torch.is_grad_enabled()
+        dev_ok = torch.device(self.device).type == "cuda"
+        skinny = self.fc_skinny and rows is not None and 1 <= rows <= ops.SKINNY_MAX_ROWS and dim % 16 == 0
+        return dev_ok and not wants_grad and (skinny or (dim % 64 == 0 and dim >= 128 and num_out % 64 == 0))
 
     def _fc_wt(self, name, w):
         """The TF weight variable [in, out] transposed to [out, in] (K contiguous rows for the kernels), cached."""

