@@ -383,7 +383,7 @@ def main(argv=None):
             feed_cache = fcn._feed(net, data, data_p, K, extents, pts, symmetry, C, dev)
         det = fcn.im_segment_batch(net, data, K, extents, pts, symmetry, data_p=data_p,
                                    planted=planted[k], feed_cache=feed_cache,
-                                   with_losses=a.losses != "none", gt_poses=gts[k])
+                                   with_losses=a.losses != "none", gt_poses=gts[k], frame_offset=rank * B)
         if bp is not None:
             feat = ops.deconv_bilinear(net.get_output("dropout"), int(16 * net.scale), int(8 * net.scale))   # `upscore` [B,H,W,64]
             top = ops.backproject(feat, net.get_output("prob_normalized"), bp["depth"], bp["meta"], bp["label_3d"], G3, 3, 0.02)
@@ -419,17 +419,17 @@ def main(argv=None):
             if k not in graphs:   # capture once per device slot (its tensors are the graph's static inputs)
                 def fn(data=data, data_p=data_p, k=k):
                     d = step(data, data_p, k)
-                    return d.rows, d.count, d.label_2d, net.get_output("poses_weight")
+                    return d.rows, d.count, d.label_2d, net.get_output("poses_weight"), d.packed
                 graphs[k] = pipeline.GraphedStep(fn, warmup=1, device=dev)
-            rows, count, label_2d, pw = graphs[k].replay()
-            det = fcn.Detections(rows, count, label_2d)
+            rows, count, label_2d, pw, packed_ = graphs[k].replay()
+            det = fcn.Detections(rows, count, label_2d, packed_)
             last["poses_weight"] = pw
         else:
             det = step(data, data_p, k)
             last["poses_weight"] = net.layers.get("poses_weight")
         if uploader is not None:
             uploader.release(i)
-        packed = pdist.all_gather_packed(det.rows, det.count, frame_offset=rank * B)
+        packed = pdist.all_gather_packed(det.rows, det.count, frame_offset=rank * B, packed=det.packed)
         last["det"] = det
         if last.get("record") is not None and "loss_pose" in net.layers and not (a.graph and last.get("graph_ready")):
             # (outputs_equal_serial: this batch's scalar pose loss — a function of all 9 x count rows of poses_tanh —
@@ -629,12 +629,9 @@ def main(argv=None):
     if G3 > 0:   # writes data + flag [G^3, 64] and label [G^3, C], reads label_3d [G^3, C]
         hbm["backproject_fused_kernel"] = 4.0 * B * G3 ** 3 * (2 * 64 + 2 * C)
 
-    # the trunk contraction has two kernels with the same arithmetic and bits: 32-tile pairs and (big launches) one wave per SIMD
-    same_work = {"wino43_mfma_kernel": ("wino43_mfma_w1_kernel",)}
-
     def us(k):  # per step, all template instances of a kernel together
         t = sum(v["avg_us"] * v["calls"] for n, v in kern.items() if n == k or n.startswith(k + "<") or n.startswith(k + "_kernel")
-                or n.startswith(k + "_fixed_kernel") or n.lstrip("(") in same_work.get(k, ()))
+                or n.startswith(k + "_fixed_kernel"))
         return t / a.steps if t else None
     others = []
     for k, byt in hbm.items():

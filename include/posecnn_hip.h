@@ -396,6 +396,13 @@ int pcnn_winograd43_conv_fwd(const float* v, const float* ut, const float* bias,
  *        summation order, slower when the live rows are few: fc6 at 75 rows is bound by HBM latency then)
  * fp32 MFMA (exact f32), sum over k in ascending order within a lane-fixed interleave. */
 int pcnn_fc_rows_workspace_bytes(int rows_capacity, int in_features, int out_features, size_t* bytes);
+/* The same product for a layer whose width is no multiple of 64 (round 5: fc8, 4096 -> 4 C = 88, vgg16_convs.py:192-193, at
+ * more rows than pcnn_fc_skinny_fwd takes): wt [out_padded][in_features] and bias [out_padded] are zero-padded to a multiple
+ * of 64, y / y_tanh are [rows_capacity][out_features] (out_features % 4 == 0). activation 0 none, 1 ReLU, 2 tanh: y = the
+ * linear output, y_tanh = tanh(y) (fc8 and poses_tanh in one launch). Rows at or past *num_rows_dev: zeros. */
+int pcnn_fc_rows_cols_fwd(const float* x, const float* wt, const float* bias, int rows_capacity,
+                          int in_features, int out_padded, int out_features, int activation,
+                          const int32_t* num_rows_dev, float* y, float* y_tanh, void* stream);
 int pcnn_fc_rows_fwd(const float* x, const float* wt, const float* bias, int rows_capacity,
                      int in_features, int out_features, int relu, const int32_t* num_rows_dev,
                      const float* addend, float* y, void* workspace, size_t workspace_bytes, void* stream);
@@ -429,6 +436,12 @@ int pcnn_fc_skinny_fwd(const float* x, const float* wt, const float* bias, int r
 int pcnn_head_lowres_fwd(const float* score4, const float* score5, const float* planted, const float* weights_t,
                          int batch, int height, int width, int units, int out_channels, int kernel, int stride,
                          float* add_out, float* z, void* stream);
+/* The same step with the 1x1 product on the matrix cores, for many pixels per launch (round 5): `weights_nk` is the filter
+ * N-MAJOR, [ceil(out_channels / 16) * 16][units] with K contiguous and zero rows past out_channels; units % 16 == 0,
+ * out_channels <= 96. add_out has the bits of pcnn_head_lowres_fwd; z sums K in one fixed (matrix-core) order. */
+int pcnn_head_lowres_mfma_fwd(const float* score4, const float* score5, const float* planted,
+                              const float* weights_nk, int batch, int height, int width, int units, int out_channels,
+                              int kernel, int stride, float* add_out, float* z, void* stream);
 
 /* lib/fcn/test.py:197-211 on the device, minus the NMS: detection rows for the host / the all-gather.
  *   det_rows[i] = rois[i s][0:7] | poses_tanh[i s][4 c : 4 c + 4] | top_pose[i s][4:7],  c = int(rois[i s][1]) clamped
@@ -438,6 +451,15 @@ int pcnn_head_lowres_fwd(const float* score4, const float* score5, const float* 
 int pcnn_det_assemble_fwd(const float* rois, const float* poses_tanh, const float* top_pose,
                           const int32_t* num_rows_dev, int rows, int row_stride, int num_classes, float* det_rows,
                           int32_t* det_count, void* stream);
+/* The same rows as the block one rank hands to the detection all-gather: det_block [ceil(rows / row_stride) + 1][14],
+ * column 0 of the live rows shifted by `frame_offset` (global frame index = rank * B + local), last row = (count, 0, ...). */
+int pcnn_det_assemble_packed_fwd(const float* rois, const float* poses_tanh, const float* top_pose,
+                                 const int32_t* num_rows_dev, int rows, int row_stride, int num_classes,
+                                 float frame_offset, float* det_block, int32_t* det_count, void* stream);
+/* poses_pred = l2_normalize(poses_tanh * poses_weight, dim 1) (vgg16_convs.py:195-197; network.py:573-577: x * rsqrt(max(sum
+ * x^2, 1e-12))) on [rows][cols <= 256] buffers; rows at or past *num_rows_dev (NULL: none) are zeros. Fixed summation order. */
+int pcnn_pose_l2_normalize_fwd(const float* poses_tanh, const float* poses_weight, const int32_t* num_rows_dev,
+                               int rows, int cols, float* poses_pred, void* stream);
 
 /* pcnn_winograd43_output_fwd writing BOTH the activation y f32 [B,H,W,C] and its 2x2 max-pool y_pool f32
  * [B,H/2,W/2,C] in one pass (conv4_3 -> pool4, whose un-pooled output score_conv4 and roi_pool read too). */

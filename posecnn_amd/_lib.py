@@ -52,10 +52,14 @@ SIGNATURES = {
     "pcnn_winograd43_output_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "pcnn_winograd43_output_both_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "pcnn_fc_rows_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "pcnn_fc_rows_cols_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "pcnn_fc_rows_workspace_bytes": (c_int, [c_int, c_int, c_int, POINTER(c_size_t)]),
     "pcnn_fc_skinny_workspace_bytes": (c_int, [c_int, c_int, c_int, POINTER(c_size_t), POINTER(c_int)]),
     "pcnn_fc_skinny_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t, _P, c_int, _P]),
     "pcnn_head_lowres_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "pcnn_head_lowres_mfma_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "pcnn_det_assemble_packed_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P]),
+    "pcnn_pose_l2_normalize_fwd": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
     "pcnn_det_assemble_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "pcnn_winograd43_conv_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "pcnn_winograd43_conv_workspace_bytes": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),

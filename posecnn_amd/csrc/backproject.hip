@@ -201,23 +201,26 @@ __device__ __forceinline__ void bp_store4(float4* p, const float4 v)
   else *p = v;
 }
 
-// Fused forward for windows of at most 64 pixels ((2k+1)^2 <= 64, i.e. k <= 3 — the reference's
-// k = 3, vgg16.py:131-132). A wave owns 64 consecutive voxels (32 KB of data + flag and 64 Cl label floats, all
-// contiguous):
+// Fused forward for windows of at most 49 pixels (k <= 3 — the reference's k = 3, vgg16.py:131-132). A wave owns 64
+// consecutive voxels (32 KB of data + flag and 64 Cl label floats, all contiguous):
 //   A  lane = voxel: ONE projection per voxel; with the window-range table (above) one 8-byte load decides whether
 //      the voxel can match anything at all; only then the window is scanned — a column of 2k+1 loads in flight at a
-//      time, not one load per trip — into a 64-bit mask of the matching window pixels (bit = column-major position
-//      inside the unclipped window, which is the reference's summation order);
+//      time — and the matching pixels are LISTED in LDS in the reference's summation order (x outer, y inner,
+//      backprojecting_op_gpu.cu.cc:66-92) as 16-bit offsets from the window origin: 64 x 56 entries per wave;
 //   all-miss wave (most of the grid): the outputs are a 32-KB run of zeros and a straight copy of label_3d, written
 //      as independent 16-byte stores with nothing to wait for in between;
-//   B  otherwise: lane = (voxel of a group of 64/LPV, channel quad): masks travel by shuffle, the set bits are
-//      walked in ascending order four loads at a time (`acc += v` in the order of the reference's nested loops) and
-//      every store instruction writes 64/LPV voxels x Cd floats contiguously (data and flag);
+//   B  otherwise: lane = (voxel of a group of 64/LPV, channel quad): a voxel's list is read 8 entries per LDS
+//      instruction, its 8 pixel rows are requested together and added in list order (`acc += v`, the reference's
+//      order); every store instruction writes 64/LPV voxels x Cd floats contiguously (data and flag);
 //   C  lane = flattened (voxel, class) of the wave's 64 x Cl contiguous label outputs, the label_3d values of 8
-//      trips requested up front.
-// Round 4's version of this kernel made every lane walk its window one dependent load at a time before it learned
-// that 85 % of the voxels miss, and fetched label_3d one trip at a time behind a queue of stores: a wave lived
-// ~170 us for 43 KB of output (0.27 of the HBM peak at G = 256).
+//      trips requested up front, the gathers 8 at a time from the same lists.
+// History. Round 4: every lane walked its window one dependent load at a time before it learned that 85 % of the
+// voxels miss, and fetched label_3d one trip at a time behind a queue of stores — a wave lived ~170 us for 43 KB of
+// output (0.27 of the HBM peak at G = 256). Round 5, first version: range table + batched loads + the all-miss path,
+// the matches as a 64-bit mask per voxel walked bit by bit in every lane of phases B and C (ffs, clear, a division by
+// the window side, offset arithmetic: ~50 vector instructions per matching pixel and lane): all-miss scenes at 0.70-0.86
+// of the peak, the parity scene (14 % of the voxels hit) only 0.27 -> 0.36 — its hit waves were bound by exactly that
+// instruction stream, not by the gathers' latency (4 / 8 / 16 gathers in flight per lane: 4.06 / 3.89 / 4.51 ms).
 template <int LPV, bool NT>  // lanes per voxel in phase B = min(Cd, 64) / 4; NT: non-temporal stores
 __global__ __launch_bounds__(256) void backproject_fused_kernel(
     const float* __restrict__ data, const float* __restrict__ label, const float* __restrict__ depth,
@@ -225,20 +228,24 @@ __global__ __launch_bounds__(256) void backproject_fused_kernel(
     float* __restrict__ top_data, float* __restrict__ top_label, float* __restrict__ top_flag, long long nvox,
     int H, int W, int Cd, int Cl, int num_meta, int G, int ksize, float threshold, int lab_vec)
 {
+  constexpr int LIST = 56;   // list slots per voxel: 49 rounded up to whole 16-byte LDS reads
+  typedef uint4 __attribute__((may_alias)) uint4_a;   // (the lists are written as 16-bit entries and read 8 at a time)
+  __shared__ __attribute__((aligned(16))) unsigned short s_rel[4][64][LIST];   // matched pixels: dy * W + dx from the window origin
+  __shared__ int s_cnt[4][64], s_org[4][64];                                   // matches; window origin py * W + px (may be negative)
   const int lane = threadIdx.x & 63;
-  const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long long nwave = (nvox + 63) / 64;
   const int S = 2 * ksize + 1;
   const unsigned G2 = (unsigned)G * (unsigned)G, G3u = G2 * (unsigned)G;   // (G <= 1024: the launcher checks)
   const long long G3 = (long long)G3u;
   const unsigned cl_magic = (unsigned)((0x100000000ull + (unsigned)Cl - 1) / (unsigned)Cl);   // i / Cl = umulhi(i, magic) for i < 2^32 / Cl
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (long long wv = (long long)blockIdx.x * 4 + wave_in_block; wv < nwave; wv += (long long)gridDim.x * 4) {
+  unsigned short* my_rel = &s_rel[wib][lane][0];
+  for (long long wv = (long long)blockIdx.x * 4 + wib; wv < nwave; wv += (long long)gridDim.x * 4) {
     const long long vbase = wv * 64;
     const int nv = (int)(nvox - vbase < 64 ? nvox - vbase : 64);
     // ---- A: one voxel per lane
-    unsigned long long mask = 0;
-    int px = 0, py = 0;  // window origin (column, row) of this lane's voxel
+    int cnt = 0;
     if (lane < nv) {
       const long long n0 = vbase / G3;                         // (wave-uniform: scalar unit)
       unsigned r = (unsigned)(vbase - n0 * G3) + (unsigned)lane;
@@ -249,10 +256,6 @@ __global__ __launch_bounds__(256) void backproject_fused_kernel(
       const float* md = meta + (size_t)n * num_meta;
       const Proj p = project_voxel(md, (int)d, (int)h, (int)w);
       const Window win = clip_window(p, ksize, H, W);
-      // window origin; clamped so that garbage projections (saturated to INT_MIN/MAX, empty
-      // window, never dereferenced) cannot overflow the subtraction
-      px = (int)max(-(1ll << 30), min(1ll << 30, (long long)p.px - ksize));
-      py = (int)max(-(1ll << 30), min(1ll << 30, (long long)p.py - ksize));
       bool cand = win.xlo <= win.xhi && win.ylo <= win.yhi;
       if (cand && wrange) {
         // (non-empty window <=> centre in [-k, W-1+k] x [-k, H-1+k]: inside the table)
@@ -263,6 +266,8 @@ __global__ __launch_bounds__(256) void backproject_fused_kernel(
         cand = !((rg.x - p.Z1) >= threshold || (rg.y - p.Z1) <= -threshold);
       }
       if (cand) {
+        const int px = p.px - ksize, py = p.py - ksize;        // window origin (a candidate's projection is near the image: no overflow)
+        s_org[wib][lane] = py * W + px;
         const float* dn = depth + (long long)n * H * W;
         for (int xi = 0; xi < S; xi++) {
           const int x = px + xi;
@@ -278,16 +283,17 @@ __global__ __launch_bounds__(256) void backproject_fused_kernel(
           for (int yi = 0; yi < 7; yi++) {
             const int y = py + yi;
             const bool ok = yi < S && y >= 0 && y < H;
-            if (ok && fabsf(dv[yi] - p.Z1) < threshold) mask |= 1ull << (xi * S + yi);
+            if (ok && fabsf(dv[yi] - p.Z1) < threshold) my_rel[cnt++] = (unsigned short)(yi * W + xi);   // (7 W < 65536: the launcher checks)
           }
         }
       }
     }
-    const unsigned mlo = (unsigned)mask, mhi = (unsigned)(mask >> 32);
+    s_cnt[wib][lane] = cnt;
+    __builtin_amdgcn_wave_barrier();   // (the lists are wave-private: LDS operations of one wave complete in order)
     float4* wdata = reinterpret_cast<float4*>(top_data + vbase * Cd);
     float4* wflag = reinterpret_cast<float4*>(top_flag + vbase * Cd);
     const long long lbase = vbase * Cl;
-    if (__ballot(mask != 0) == 0) {
+    if (__ballot(cnt != 0) == 0) {
       // ---- the whole wave misses: zeros + label_3d straight through
       const int n4 = nv * (Cd / 4);
 #pragma unroll 4
@@ -321,99 +327,125 @@ __global__ __launch_bounds__(256) void backproject_fused_kernel(
     // ---- B: data + flag
     constexpr int VPI = 64 / LPV;  // voxels per iteration
     const int sub = lane / LPV, cq = lane % LPV;
+    const float4 one4 = make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll 1
     for (int it = 0; it < 64 / VPI; it++) {
       const int vl = it * VPI + sub;
-      const long long vox = vbase + vl;
-      unsigned long long m = ((unsigned long long)(unsigned)__shfl((int)mhi, vl) << 32) | (unsigned)__shfl((int)mlo, vl);
-      const int vx = __shfl(px, vl), vy = __shfl(py, vl);
       if (vl >= nv) continue;
-      if (m == 0) {
-        for (int c = cq * 4; c < Cd; c += LPV * 4) {
-          bp_store4<NT>(reinterpret_cast<float4*>(top_data + vox * Cd + c), zero4);
-          bp_store4<NT>(reinterpret_cast<float4*>(top_flag + vox * Cd + c), zero4);
+      const long long vox = vbase + vl;
+      const int c = s_cnt[wib][vl];
+      if (c == 0) {
+        for (int ch = cq * 4; ch < Cd; ch += LPV * 4) {
+          bp_store4<NT>(reinterpret_cast<float4*>(top_data + vox * Cd + ch), zero4);
+          bp_store4<NT>(reinterpret_cast<float4*>(top_flag + vox * Cd + ch), zero4);
         }
         continue;
       }
-      const long long n = vox / G3;
-      const float* dbase = data + n * H * W * (long long)Cd;
-      const float cnt = (float)__popcll(m);
-      const float4 one4 = make_float4(1.f, 1.f, 1.f, 1.f);
-      for (int c = cq * 4; c < Cd; c += LPV * 4) {
+      const int org = s_org[wib][vl];
+      const float* dbase = data + (vox / G3) * H * W * (long long)Cd;
+      const float cf = (float)c;
+      for (int ch = cq * 4; ch < Cd; ch += LPV * 4) {
         float4 acc = zero4;
-        unsigned long long mm = m;
-        while (mm) {   // four matching pixels per trip: loads together, additions in the reference's order
-          int b[4];
-          bool ok[4];
+#pragma unroll 1
+        for (int k0 = 0; k0 < c; k0 += 8) {   // 8 list entries per LDS read; the pixel rows that exist are requested together
+          const uint4 r8 = *reinterpret_cast<const uint4_a*>(&s_rel[wib][vl][k0]);
+          const unsigned rr[4] = {r8.x, r8.y, r8.z, r8.w};
+          float4 v[8];
 #pragma unroll
-          for (int j = 0; j < 4; j++) {
-            ok[j] = mm != 0;
-            b[j] = ok[j] ? __ffsll((long long)mm) - 1 : b[0];
-            mm &= mm - 1;
-          }
-          float4 v[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const int x = vx + b[j] / S, y = vy + b[j] % S;
-            v[j] = *reinterpret_cast<const float4*>(dbase + ((long long)y * W + x) * Cd + c);
+          for (int j = 0; j < 8; j++) {
+            const int rel = (int)((rr[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+            v[j] = *reinterpret_cast<const float4*>(dbase + (org + (k0 + j < c ? rel : (int)(rr[0] & 0xffffu))) * Cd + ch);
           }
 #pragma unroll
-          for (int j = 0; j < 4; j++)
-            if (ok[j]) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
+          for (int j = 0; j < 8; j++)
+            if (k0 + j < c) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
         }
-        acc.x = div_rn(acc.x, cnt); acc.y = div_rn(acc.y, cnt); acc.z = div_rn(acc.z, cnt); acc.w = div_rn(acc.w, cnt);
-        bp_store4<NT>(reinterpret_cast<float4*>(top_data + vox * Cd + c), acc);
-        bp_store4<NT>(reinterpret_cast<float4*>(top_flag + vox * Cd + c), one4);
+        acc.x = div_rn(acc.x, cf); acc.y = div_rn(acc.y, cf); acc.z = div_rn(acc.z, cf); acc.w = div_rn(acc.w, cf);
+        bp_store4<NT>(reinterpret_cast<float4*>(top_data + vox * Cd + ch), acc);
+        bp_store4<NT>(reinterpret_cast<float4*>(top_flag + vox * Cd + ch), one4);
       }
     }
-    // ---- C: labels, 64 * Cl contiguous outputs of this wave, 8 trips' label_3d values in flight
+    // ---- C: labels, 64 * Cl contiguous outputs of this wave
     const int nl = nv * Cl;
-    for (int i0 = 0; i0 < nl; i0 += 64 * 8) {
-      float l3[8];
+    if (Cl >= 4) {
+      // lane = (voxel, class quad): a voxel's Cl classes are ceil(Cl / 4) dword-aligned 16-byte pieces (the last one
+      // anchored at the row's END, so that nothing is read past a pixel's classes: it overlaps the one before and
+      // delivers only the classes that one does not), 64 / nq voxels per step: 7 steps for 22 classes where the
+      // scalar form took 22, each a chain of list trips.
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      typedef v4f __attribute__((aligned(4), may_alias)) v4f_u;   // 88-byte rows: dword-aligned multi-dword accesses
+      const int nq = (Cl + 3) >> 2, vps = 64 / nq;               // voxels per step
+      const int vs = lane / nq, q = lane - vs * nq;
+      const int cb = q == nq - 1 ? Cl - 4 : 4 * q;               // first class of this lane's piece
+      const int first_new = 4 * q - cb;                          // elements below this index belong to the previous piece
+#pragma unroll 1
+      for (int v0 = 0; v0 < nv; v0 += vps) {
+        const int vl = v0 + vs;
+        const bool live = vs < vps && vl < nv;
+        const int c = live ? s_cnt[wib][vl] : -1;
+        v4f out = (v4f){0.f, 0.f, 0.f, 0.f};
+        if (c == 0) out = *reinterpret_cast<const v4f_u*>(label_3d + lbase + (long long)vl * Cl + cb);
+        if (c > 0) {
+          const int org = s_org[wib][vl];
+          const float* lb = label + ((vbase + vl) / G3) * H * W * (long long)Cl + cb;
+          v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+          for (int k0 = 0; k0 < c; k0 += 8) {
+            const uint4 r8 = *reinterpret_cast<const uint4_a*>(&s_rel[wib][vl][k0]);
+            const unsigned rr[4] = {r8.x, r8.y, r8.z, r8.w};
+            v4f v[8];
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int i = i0 + 64 * j + lane;
-        l3[j] = label_3d[lbase + (i < nl ? i : nl - 1)];
-      }
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int i = i0 + 64 * j + lane;
-        if (i0 + 64 * j >= nl) break;             // (wave-uniform)
-        const int ic = i < nl ? i : nl - 1;       // every lane reaches the shuffles
-        const int vl = (int)__umulhi((unsigned)ic, cl_magic), cl = ic - vl * Cl;
-        unsigned long long m = ((unsigned long long)(unsigned)__shfl((int)mhi, vl) << 32) | (unsigned)__shfl((int)mlo, vl);
-        const int vx = __shfl(px, vl), vy = __shfl(py, vl);
-        if (i >= nl) continue;
-        float out = l3[j];
-        if (m) {
-          const long long n = (vbase + vl) / G3;
-          const float* lb = label + n * H * W * (long long)Cl;
-          float acc = 0.f;
-          const float cnt = (float)__popcll(m);
-          unsigned long long mm = m;
-          while (mm) {
-            int b[4];
-            bool ok[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-              ok[q] = mm != 0;
-              b[q] = ok[q] ? __ffsll((long long)mm) - 1 : b[0];
-              mm &= mm - 1;
-            }
-            float v[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-              const int x = vx + b[q] / S, y = vy + b[q] % S;
-              v[q] = lb[((long long)y * W + x) * Cl + cl];
+            for (int j = 0; j < 8; j++) {
+              const int rel = (int)((rr[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+              v[j] = *reinterpret_cast<const v4f_u*>(lb + (org + (k0 + j < c ? rel : (int)(rr[0] & 0xffffu))) * Cl);
             }
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-              if (ok[q]) acc += v[q];
+            for (int j = 0; j < 8; j++)
+              if (k0 + j < c) acc += v[j];
           }
-          out = div_rn(acc, cnt);
+          const float cf = (float)c;
+#pragma unroll
+          for (int e = 0; e < 4; e++) out[e] = div_rn(acc[e], cf);
         }
-        top_label[lbase + i] = out;
+        if (c >= 0) {
+          float* dst = top_label + lbase + (long long)vl * Cl + cb;
+          if (first_new == 0) *reinterpret_cast<v4f_u*>(dst) = out;
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+              if (e >= first_new) dst[e] = out[e];
+          }
+        }
+      }
+    } else {
+      // fewer than 4 classes: one output per lane and trip, the label_3d values of 8 trips requested up front
+      for (int i0 = 0; i0 < nl; i0 += 64 * 8) {
+        float l3[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int i = i0 + 64 * j + lane;
+          l3[j] = label_3d[lbase + (i < nl ? i : nl - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int i = i0 + 64 * j + lane;
+          if (i0 + 64 * j >= nl) break;             // (wave-uniform)
+          if (i >= nl) continue;
+          const int vl = (int)__umulhi((unsigned)i, cl_magic), cl = i - vl * Cl;
+          const int c = s_cnt[wib][vl];
+          float out = l3[j];
+          if (c) {
+            const int org = s_org[wib][vl];
+            const float* lb = label + ((vbase + vl) / G3) * H * W * (long long)Cl + cl;
+            float acc = 0.f;
+            for (int k = 0; k < c; k++) acc += lb[(org + (int)s_rel[wib][vl][k]) * Cl];
+            out = div_rn(acc, (float)c);
+          }
+          top_label[lbase + i] = out;
+        }
       }
     }
+    __builtin_amdgcn_wave_barrier();   // the lists are rewritten by the next trip's phase A
   }
 }
 
@@ -494,7 +526,7 @@ static int backproject_fwd_impl(const float* data, const float* label, const flo
   const long long nvox = (long long)B * G * G * G;
   const bool vec = (Cd % 4 == 0) && aligned16(data) && aligned16(top_data) && aligned16(top_flag);
   const int lpv = Cd >= 64 ? 16 : Cd / 4;
-  const bool fused = vec && ksize <= 3 && G <= 1024 && (Cd % 64 == 0 || Cd == 32 || Cd == 16 || Cd == 8 || Cd == 4);
+  const bool fused = vec && ksize <= 3 && G <= 1024 && 7ll * W < 65536 && ((long long)H + 8) * W * (Cd > Cl ? Cd : Cl) < (1ll << 31) && (Cd % 64 == 0 || Cd == 32 || Cd == 16 || Cd == 8 || Cd == 4);
   if (fused) {
     float2* wrange = nullptr;
     if (ws) {

@@ -348,24 +348,59 @@ __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
   ut2 += (size_t)grp * 36 * 64 * 64;
   b2 += (size_t)grp * 64;
 
+  // Round 5: what a block needs from global memory besides its frame window — conv1_1's taps and bias (14 + 2 registers),
+  // conv1_2's bias — is REQUESTED here, in front of the window, and the window's (up to) three elements per thread are
+  // requested together. With one workgroup per CU nothing else covers a global round trip; in round 4 the window loop was
+  // load - wait - store three times over, and the taps followed behind it: five serial L2 / HBM latencies in front of
+  // every block. tools/conv12_probe: window phase 2.2 -> 1.0 us, block 22.1 -> 20.4 us, launch 3.22 -> 3.04 ms. (Also
+  // requesting the first plane pair's B operands up here measured 3.08 ms: not kept.) No arithmetic changes.
+  const int n16 = lane & 15, kk = lane >> 4, chalf = wave & 1;
+  float wb[7][2], bia[2];
+  int tapoff[7];
+#pragma unroll
+  for (int j = 0; j < 7; j++) {
+    const int slot = 4 * j + kk, t = slot - 1;        // slot 0: the zero slot
+    const int ky = t / 9, rem = t - 9 * ky;           // rem = 3 kx + ci
+    tapoff[j] = slot == 0 ? 0 : ky * F12_INF + rem;
+#pragma unroll
+    for (int c2 = 0; c2 < 2; c2++) wb[j][c2] = w1[(size_t)(t < 0 ? 0 : t) * 64 + 32 * chalf + 16 * c2 + n16];   // (slot 0 is zeroed behind the window loads: no use of a loaded value up here)
+  }
+#pragma unroll
+  for (int c2 = 0; c2 < 2; c2++) bia[c2] = b1[32 * chalf + 16 * c2 + n16];
+  const float bv2 = b2[16 * (wave & 3) + (lane & 15)];   // conv1_2's bias of a consumer lane's channel (epilogue)
   F12_TS(0);
-  // input window: rows py0-1 .. py0+18, columns px0-1 .. px0+22
-  for (int i = tid; i < (F12_P + 2) * F12_INF; i += 512) {
-    const int r = i / F12_INF, j = i - r * F12_INF;
-    const int iy = py0 - 1 + r, ix = px0 - 1 + j / CF_CIN, ch = j % CF_CIN;
-    float val = 0.f;
-    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+  // input window: rows py0-1 .. py0+18, columns px0-1 .. px0+22. A thread's (up to) three elements are requested
+  // together and parked in LDS afterwards: the loop this replaces (round 4) loaded, waited and stored one element per
+  // trip — three serial round trips to memory in front of every block (the 2-3 us "window" phase of the probe).
+  {
+    constexpr int NWIN = ((F12_P + 2) * F12_INF + 511) / 512;
+    float wv_[NWIN];
+#pragma unroll
+    for (int e = 0; e < NWIN; e++) {
+      const int i = tid + 512 * e;
+      const int r = i / F12_INF, j = i - r * F12_INF;
+      const int iy = py0 - 1 + r, ix = px0 - 1 + j / CF_CIN, ch = j % CF_CIN;
+      const bool ok = i < (F12_P + 2) * F12_INF && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const size_t pix = ok ? ((size_t)b * H + iy) * W + ix : (size_t)b * H * W;   // (outside: any valid address, value dropped — no branch around the load)
+      float val;
       if (!RAW) {
-        val = x[(((size_t)b * H + iy) * W + ix) * CF_CIN + ch];
+        val = x[pix * CF_CIN + (ok ? ch : 0)];
       } else if (!is_depth) {
-        val = (float)((double)raw.color[(((size_t)b * H + iy) * W + ix) * CF_CIN + ch] - raw.mean[ch]);
+        val = (float)((double)raw.color[pix * CF_CIN + (ok ? ch : 0)] - raw.mean[ch]);
       } else {
         const int bd = b - (raw.color ? raw.n_color : 0);
-        const float t = fminf(fmaxf(div_rn((float)raw.depth[((size_t)bd * H + iy) * W + ix], 2000.f), 0.f), 1.f) * 255.f;
+        const size_t pixd = ok ? ((size_t)bd * H + iy) * W + ix : (size_t)bd * H * W;
+        const float t = fminf(fmaxf(div_rn((float)raw.depth[pixd], 2000.f), 0.f), 1.f) * 255.f;
         val = (float)((double)t - raw.mean[ch]);
       }
+      if (!ok) val = 0.f;
+      wv_[e] = val;
     }
-    s_in[r][j] = val;
+#pragma unroll
+    for (int e = 0; e < NWIN; e++) {
+      const int i = tid + 512 * e;
+      if (i < (F12_P + 2) * F12_INF) (&s_in[0][0])[i] = wv_[e];
+    }
   }
   {
     // phase 1: relu(conv1_1 + bias) on the 18 x 18 patch, ON THE MATRIX CORES. On gfx950 an fp32 MFMA and the vector ALU of
@@ -379,19 +414,7 @@ __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
     // is the +0 that chain starts from). Work unit = (pixel group, channel half): 42 units over 8 waves; a wave's channel
     // half is fixed (unit = wave + 8 i), so it keeps 14 B-operand registers; the A operand is one ds_read_b32 per K step
     // (window address = pixel base + the lane's tap offset).
-    const int n16 = lane & 15, kk = lane >> 4, chalf = wave & 1;
-    float wb[7][2], bia[2];
-    int tapoff[7];
-#pragma unroll
-    for (int j = 0; j < 7; j++) {
-      const int slot = 4 * j + kk, t = slot - 1;        // slot 0: the zero slot
-      const int ky = t / 9, rem = t - 9 * ky;           // rem = 3 kx + ci
-      tapoff[j] = slot == 0 ? 0 : ky * F12_INF + rem;
-#pragma unroll
-      for (int c2 = 0; c2 < 2; c2++) wb[j][c2] = slot == 0 ? 0.f : w1[(size_t)t * 64 + 32 * chalf + 16 * c2 + n16];
-    }
-#pragma unroll
-    for (int c2 = 0; c2 < 2; c2++) bia[c2] = b1[32 * chalf + 16 * c2 + n16];
+    if (kk == 0) wb[0][0] = wb[0][1] = 0.f;           // the zero slot (K slot 0 of the lanes with kk == 0)
     const bool interior = py0 >= 0 && py0 + F12_P <= H && px0 >= 0 && px0 + F12_P <= W;   // (uniform) every patch pixel inside the image
     const float* s_in_f = &s_in[0][0];
     float* s_y_f = &s_y[0][0][0];
@@ -561,7 +584,7 @@ __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
   float* s_o = &s_v[0][0];                                // [8 pooled rows][8 pooled columns][64]
   if (consumer) {
     const int co = 16 * wave + lr;
-    const float bv = b2[co];
+    const float bv = bv2;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       float yo[16];
@@ -615,331 +638,6 @@ __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
   F12_TS(5);
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------------
-// The same layer pair as conv12_wino43_fused_kernel, software pipelined (round 4, second version). The first version
-// ran its phases one after the other — window load, conv1_1 on the patch (vector ALUs), the 36 plane contractions
-// (matrix cores), output transform — and with one workgroup per CU nothing covered anything: 4.1 ms per 2 x 16 frames
-// against 3.8 ms for the unfused pair. Here the input channels of conv1_2 are taken in two HALVES of 32: the K = 64
-// contraction of a plane is the MFMAs of K groups 0, 1 (first half) followed by those of groups 2, 3 (second half) into
-// the same accumulator — the same instruction sequence per accumulator, so the same bits — and a half needs only half a
-// patch (18 x 18 x 32 floats), which makes room for TWO of them: while the consumer waves contract half h of block n,
-// the producer waves run conv1_1 for the NEXT half (3 patch rows per step) and transform the next plane group.
-// Workgroups are persistent (one per CU, all blocks of one filter set each), so the next block's frame window, first
-// half-patch and first plane group are ready when the current block's output transform runs.
-//   step (n, h, xi), one barrier each:   consumers  C(n, h, xi): planes 6 xi .. 6 xi + 5, K groups 2h, 2h + 1
-//                                        producers  T(n, h, xi + 1) and slice xi of P1(next half)
-//   between halves: producers T(next half, 0); consumers idle (h = 0) or output transform + pooling of block n (h = 1)
-constexpr int F12_YS = 36;                      // floats per patch pixel (32 channels + 4 of padding: conflict-free 128-bit reads)
-constexpr int F12_VS = 36;                      // floats per (plane, tile) row of the A operand
-
-template <bool RAW>
-__global__ __launch_bounds__(512, 1) void conv12_wino43_pipelined_kernel(
-    const float* __restrict__ x, const float* __restrict__ w1g, const float* __restrict__ b1g,
-    const float* __restrict__ ut2g, const float* __restrict__ b2g, float* __restrict__ ypool, int H, int W, int nbx,
-    int nby, int nimg0, int nimg, int groups, int relu1, int relu2, RawFrames raw)
-{
-  __shared__ float s_in[2][F12_P + 2][F12_INF];
-  __shared__ __attribute__((aligned(16))) float s_y[2][F12_P * F12_P * F12_YS];
-  __shared__ __attribute__((aligned(16))) float s_v[2][6 * 16 * F12_VS];
-  __shared__ __attribute__((aligned(16))) float s_o[8 * 8 * 64];
-  __shared__ __attribute__((aligned(16))) float s_w1[27 * 64];
-  __shared__ float s_b1[64];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // this workgroup's filter set and its share of that set's blocks
-  const int grp = (int)(blockIdx.x % (unsigned)groups);
-  const int wg = (int)(blockIdx.x / (unsigned)groups), nwg = (int)(gridDim.x / (unsigned)groups);
-  const int img_base = grp == 0 ? 0 : nimg0;
-  const int img_cnt = groups == 1 ? nimg : (grp == 0 ? nimg0 : nimg - nimg0);
-  const int per_img = nbx * nby;
-  const int nblk = img_cnt * per_img;
-  if (wg >= nblk) return;
-  const bool is_depth = RAW && (raw.color == nullptr || grp == 1);
-  const float* w1 = w1g + (size_t)grp * 27 * 64;
-  const float* ut2 = ut2g + (size_t)grp * 36 * 64 * 64;
-  const float* b2 = b2g + (size_t)grp * 64;
-
-  for (int i = tid; i < 27 * 64; i += 512) s_w1[i] = w1[i];
-  if (tid < 64) s_b1[tid] = b1g[(size_t)grp * 64 + tid];
-
-  const bool consumer = wave < 4;
-  const int lr = lane & 15, lk = lane >> 4;
-  const int ptid = tid & 255;
-
-  // ---- pieces ---------------------------------------------------------------------------------------------------------
-  // frame window of block m into s_in[WB] (threads T0 .. T0 + NT - 1 of the caller)
-#define F12_WINDOW(M, WB, T0, NT)                                                                               \
-  {                                                                                                             \
-    const int bi_ = img_base + (M) / per_img, rem_ = (M) % per_img;                                             \
-    const int py0_ = 16 * (rem_ / nbx) - 1, px0_ = 16 * (rem_ % nbx) - 1;                                        \
-    for (int i_ = (T0); i_ < (F12_P + 2) * F12_INF; i_ += (NT)) {                                                \
-      const int r_ = i_ / F12_INF, j_ = i_ - r_ * F12_INF;                                                       \
-      const int iy_ = py0_ - 1 + r_, ix_ = px0_ - 1 + j_ / CF_CIN, ch_ = j_ % CF_CIN;                            \
-      float val_ = 0.f;                                                                                         \
-      if (iy_ >= 0 && iy_ < H && ix_ >= 0 && ix_ < W) {                                                         \
-        if (!RAW) {                                                                                             \
-          val_ = x[(((size_t)bi_ * H + iy_) * W + ix_) * CF_CIN + ch_];                                         \
-        } else if (!is_depth) {                                                                                 \
-          val_ = (float)((double)raw.color[(((size_t)bi_ * H + iy_) * W + ix_) * CF_CIN + ch_] - raw.mean[ch_]); \
-        } else {                                                                                                \
-          const int bd_ = bi_ - (raw.color ? raw.n_color : 0);                                                  \
-          const float t_ = fminf(fmaxf(div_rn((float)raw.depth[((size_t)bd_ * H + iy_) * W + ix_], 2000.f), 0.f), 1.f) * 255.f; \
-          val_ = (float)((double)t_ - raw.mean[ch_]);                                                           \
-        }                                                                                                       \
-      }                                                                                                         \
-      s_in[WB][r_][j_] = val_;                                                                                  \
-    }                                                                                                           \
-  }
-  // conv1_1 + bias + ReLU for channels 32 HH .. 32 HH + 31 on patch rows [R0, R0 + NR) of block m: item = (pixel quad,
-  // channel pair), 16 lanes per quad; per-pixel order (ky, kx, ci) ascending, as conv3x3_c3_wino43_kernel
-#define F12_P1(M, WB, PB, HH, R0, NR, ITEM)                                                                     \
-  {                                                                                                             \
-    typedef float f2_ __attribute__((ext_vector_type(2)));                                                      \
-    const int qi_ = (ITEM) >> 4, cp_ = (ITEM) & 15;                                                             \
-    if (qi_ < (NR) * F12_NQ) {                                                                                  \
-      const int rem_ = (M) % per_img;                                                                           \
-      const int py0_ = 16 * (rem_ / nbx) - 1, px0_ = 16 * (rem_ % nbx) - 1;                                      \
-      const int r_ = (R0) + qi_ / F12_NQ, cx_ = 4 * (qi_ % F12_NQ);                                             \
-      const int yy_ = py0_ + r_, xx_ = px0_ + cx_;                                                              \
-      const int c_ = 32 * (HH) + 2 * cp_;                                                                       \
-      f2_ acc_[4];                                                                                              \
-      _Pragma("unroll") for (int q_ = 0; q_ < 4; q_++) acc_[q_] = (f2_){0.f, 0.f};                              \
-      const bool rowok_ = yy_ >= 0 && yy_ < H;                                                                  \
-      if (rowok_) {                                                                                             \
-        _Pragma("unroll") for (int ky_ = 0; ky_ < 3; ky_++) {                                                   \
-          const float* win_ = &s_in[WB][r_ + ky_][cx_ * CF_CIN];                                                \
-          float wv_[18];                                                                                        \
-          _Pragma("unroll") for (int j_ = 0; j_ < 18; j_++) wv_[j_] = win_[j_];                                 \
-          _Pragma("unroll") for (int j_ = 0; j_ < 9; j_++) {                                                    \
-            const f2_ wq_ = *reinterpret_cast<const f2_*>(&s_w1[(ky_ * 9 + j_) * 64 + c_]);                     \
-            _Pragma("unroll") for (int q_ = 0; q_ < 4; q_++) {                                                  \
-              const f2_ v_ = {wv_[j_ + 3 * q_], wv_[j_ + 3 * q_]};                                              \
-              acc_[q_] = __builtin_elementwise_fma(wq_, v_, acc_[q_]);                                          \
-            }                                                                                                   \
-          }                                                                                                     \
-        }                                                                                                       \
-      }                                                                                                         \
-      const f2_ bq_ = *reinterpret_cast<const f2_*>(&s_b1[c_]);                                                 \
-      _Pragma("unroll") for (int q_ = 0; q_ < 4; q_++) {                                                        \
-        f2_ a_ = acc_[q_] + bq_;                                                                                \
-        if (relu1) {                                                                                            \
-          a_.x = a_.x > 0.f ? a_.x : 0.f;                                                                       \
-          a_.y = a_.y > 0.f ? a_.y : 0.f;                                                                       \
-        }                                                                                                       \
-        if (!(rowok_ && xx_ + q_ >= 0 && xx_ + q_ < W)) a_ = (f2_){0.f, 0.f};                                   \
-        if (cx_ + q_ < F12_P) *reinterpret_cast<f2_*>(&s_y[PB][(r_ * F12_P + cx_ + q_) * F12_YS + 2 * cp_]) = a_; \
-      }                                                                                                         \
-    }                                                                                                           \
-  }
-  // row XI of B^T d B for the 16 tiles x 32 channels of half-patch PB -> 6 planes of the A operand in s_v[VB]:
-  // item = (tile, channel quad), 128 items
-#define F12_T(XI, PB, VB, ITEM)                                                                                 \
-  if ((ITEM) < 128) {                                                                                           \
-    const int tile_ = (ITEM) >> 3, cq_ = (ITEM) & 7;                                                            \
-    const int tyy_ = tile_ >> 2, txx_ = tile_ & 3;                                                              \
-    f4 ta_[6];                                                                                                  \
-    _Pragma("unroll") for (int hh_ = 0; hh_ < 2; hh_++) {                                                       \
-      f4 d_[3][6];                                                                                              \
-      _Pragma("unroll") for (int s3_ = 0; s3_ < 3; s3_++)                                                       \
-        _Pragma("unroll") for (int r_ = 0; r_ < 6; r_++)                                                        \
-          if (((XI) == 0 && (r_ == 0 || r_ == 2 || r_ == 4)) || ((XI) == 5 && (r_ == 1 || r_ == 3 || r_ == 5)) || \
-              ((XI) >= 1 && (XI) <= 4 && r_ >= 1 && r_ <= 4))                                                   \
-            d_[s3_][r_] = *reinterpret_cast<const f4*>(&s_y[PB][((4 * tyy_ + r_) * F12_P + 4 * txx_ + 3 * hh_ + s3_) * F12_YS + cq_ * 4]); \
-      __builtin_amdgcn_sched_barrier(0);                                                                        \
-      _Pragma("unroll") for (int s3_ = 0; s3_ < 3; s3_++) {                                                     \
-        const int s2_ = 3 * hh_ + s3_;                                                                          \
-        if ((XI) == 0) ta_[s2_] = (4.f * d_[s3_][0] - 5.f * d_[s3_][2]) + d_[s3_][4];                           \
-        else if ((XI) == 5) ta_[s2_] = (4.f * d_[s3_][1] - 5.f * d_[s3_][3]) + d_[s3_][5];                      \
-        else if ((XI) == 1 || (XI) == 2) {                                                                      \
-          const f4 a_ = d_[s3_][4] - 4.f * d_[s3_][2], b_ = d_[s3_][3] - 4.f * d_[s3_][1];                      \
-          ta_[s2_] = (XI) == 1 ? a_ + b_ : a_ - b_;                                                             \
-        } else {                                                                                                \
-          const f4 c_ = d_[s3_][4] - d_[s3_][2], e_ = 2.f * (d_[s3_][3] - d_[s3_][1]);                          \
-          ta_[s2_] = (XI) == 3 ? c_ + e_ : c_ - e_;                                                             \
-        }                                                                                                       \
-      }                                                                                                         \
-      __builtin_amdgcn_sched_barrier(0);                                                                        \
-    }                                                                                                           \
-    f4 oa_[6];                                                                                                  \
-    fw_bt6(ta_, oa_);                                                                                           \
-    _Pragma("unroll") for (int j_ = 0; j_ < 6; j_++)                                                            \
-      *reinterpret_cast<f4*>(&s_v[VB][(j_ * 16 + tile_) * F12_VS + cq_ * 4]) = oa_[j_];                         \
-  }
-
-  // consumer state: the 36 accumulators of this lane's 4 (tile, channel) elements; B operands of 6 planes (2 K groups
-  // each), refilled plane by plane right behind their last use with those of the same planes one step on
-  v4f12 acc[36];
-  f4 ubq[6][2];
-  // (scalar plane base + one 32-bit lane offset: as per-lane 64-bit pointers the 72 plane / K-group addresses were hoisted
-  //  out of the block loop into 144 VGPRs and the consumer path spilled)
-  const unsigned uoff = (unsigned)((16 * (wave & 3) + lr) * 64 + 4 * lk);
-#define F12_LOADB(J, K, HH)                                                                                     \
-  { const float* pk_ = ut2 + (size_t)(K) * 4096 + 16 * (2 * (HH));                                              \
-    asm volatile("" : "+s"(pk_));   /* stays a scalar base of its own: not folded into 72 hoisted vector addresses */ \
-    ubq[J][0] = *reinterpret_cast<const f4*>(pk_ + uoff);                                                       \
-    ubq[J][1] = *reinterpret_cast<const f4*>(pk_ + 16 + uoff); }
-#define F12_LOADA(DST, VB, J)                                                                                   \
-  { DST[0] = *reinterpret_cast<const f4*>(&s_v[VB][((J) * 16 + lr) * F12_VS + lk * 4]);                         \
-    DST[1] = *reinterpret_cast<const f4*>(&s_v[VB][((J) * 16 + lr) * F12_VS + (4 + lk) * 4]); }
-  // planes 6 XI + j (j = 0..5), K groups 2 HH, 2 HH + 1; afterwards ubq[j] holds plane j's B of the NEXT step (NXI, NHH);
-  // NXI < 0: nothing to fetch
-#define F12_C(XI, HH, VB, NXI, NHH)                                                                             \
-  {                                                                                                             \
-    f4 va_[3][2];                                                                                               \
-    F12_LOADA(va_[0], VB, 0)                                                                                    \
-    F12_LOADA(va_[1], VB, 1)                                                                                    \
-    _Pragma("unroll") for (int j_ = 0; j_ < 6; j_++) {                                                          \
-      if (j_ + 2 < 6) { F12_LOADA(va_[(j_ + 2) % 3], VB, j_ + 2) }                                              \
-      __builtin_amdgcn_sched_barrier(0);                                                                        \
-      v4f12 c_ = (HH) == 0 ? (v4f12){0.f, 0.f, 0.f, 0.f} : acc[6 * (XI) + j_];                                  \
-      _Pragma("unroll") for (int g_ = 0; g_ < 2; g_++)                                                          \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++)                                                        \
-          c_ = __builtin_amdgcn_mfma_f32_16x16x4f32(va_[j_ % 3][g_][i_], ubq[j_][g_][i_], c_, 0, 0, 0);         \
-      acc[6 * (XI) + j_] = c_;                                                                                  \
-      __builtin_amdgcn_sched_barrier(0);                                                                        \
-      if ((NXI) >= 0) { F12_LOADB(j_, 6 * ((NXI) >= 0 ? (NXI) : 0) + j_, NHH) }                                 \
-    }                                                                                                           \
-  }
-  // output transform of block m's elements (the MFMA kernel's fold, column by column), bias, ReLU, 2 x 2 max -> s_o
-#define F12_E()                                                                                                 \
-  {                                                                                                             \
-    const int co_ = 16 * wave + lr;                                                                             \
-    const float bv_ = b2[co_];                                                                                  \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {                                                          \
-      float yo_[16];                                                                                            \
-      _Pragma("unroll") for (int o_ = 0; o_ < 16; o_++) yo_[o_] = 0.f;                                          \
-      _Pragma("unroll") for (int nu_ = 0; nu_ < 6; nu_++) {                                                     \
-        const float c0_ = nu_ == 5 ? 0.f : 1.f;                                                                 \
-        const float c1_ = nu_ == 1 ? 1.f : nu_ == 2 ? -1.f : nu_ == 3 ? 2.f : nu_ == 4 ? -2.f : 0.f;            \
-        const float c2_ = (nu_ == 1 || nu_ == 2) ? 1.f : (nu_ == 3 || nu_ == 4) ? 4.f : 0.f;                    \
-        const float c3_ = nu_ == 1 ? 1.f : nu_ == 2 ? -1.f : nu_ == 3 ? 8.f : nu_ == 4 ? -8.f : nu_ == 5 ? 1.f : 0.f; \
-        float m_[6], t_[4];                                                                                     \
-        _Pragma("unroll") for (int x_ = 0; x_ < 6; x_++) m_[x_] = acc[6 * x_ + nu_][i_];                        \
-        f12_at6_col(m_, t_);                                                                                    \
-        _Pragma("unroll") for (int a_ = 0; a_ < 4; a_++) {                                                      \
-          yo_[4 * a_ + 0] = __builtin_fmaf(t_[a_], c0_, yo_[4 * a_ + 0]);                                       \
-          yo_[4 * a_ + 1] = __builtin_fmaf(t_[a_], c1_, yo_[4 * a_ + 1]);                                       \
-          yo_[4 * a_ + 2] = __builtin_fmaf(t_[a_], c2_, yo_[4 * a_ + 2]);                                       \
-          yo_[4 * a_ + 3] = __builtin_fmaf(t_[a_], c3_, yo_[4 * a_ + 3]);                                       \
-        }                                                                                                       \
-      }                                                                                                         \
-      _Pragma("unroll") for (int o_ = 0; o_ < 16; o_++) {                                                       \
-        float val_ = yo_[o_] + bv_;                                                                             \
-        if (relu2) val_ = val_ > 0.f ? val_ : 0.f;                                                              \
-        yo_[o_] = val_;                                                                                         \
-      }                                                                                                         \
-      _Pragma("unroll") for (int a2_ = 0; a2_ < 2; a2_++)                                                       \
-        _Pragma("unroll") for (int e2_ = 0; e2_ < 2; e2_++) {                                                   \
-          float p_ = yo_[4 * (2 * a2_) + 2 * e2_];                                                              \
-          const float p1_ = yo_[4 * (2 * a2_) + 2 * e2_ + 1], p2_ = yo_[4 * (2 * a2_ + 1) + 2 * e2_],            \
-                      p3_ = yo_[4 * (2 * a2_ + 1) + 2 * e2_ + 1];                                               \
-          p_ = p1_ > p_ ? p1_ : p_;                                                                             \
-          p_ = p2_ > p_ ? p2_ : p_;                                                                             \
-          p_ = p3_ > p_ ? p3_ : p_;                                                                             \
-          s_o[((2 * lk + a2_) * 8 + (2 * i_ + e2_)) * 64 + co_] = p_;                                           \
-        }                                                                                                       \
-    }                                                                                                           \
-  }
-  // the pooled 8 x 8 x 64 block of block m: s_o -> global, 256 threads
-#define F12_STORE(M)                                                                                            \
-  {                                                                                                             \
-    const int bi_ = img_base + (M) / per_img, rem_ = (M) % per_img;                                             \
-    const int by_ = rem_ / nbx, bx_ = rem_ % nbx;                                                               \
-    const int Hp_ = H >> 1, Wp_ = W >> 1;                                                                       \
-    for (int i_ = ptid; i_ < 8 * 8 * 16; i_ += 256) {                                                           \
-      const int c4_ = (i_ & 15) * 4, pxl_ = (i_ >> 4) & 7, pyl_ = i_ >> 7;                                      \
-      *reinterpret_cast<f4*>(ypool + (((size_t)bi_ * Hp_ + 8 * by_ + pyl_) * Wp_ + 8 * bx_ + pxl_) * 64 + c4_) = \
-          *reinterpret_cast<const f4*>(&s_o[(pyl_ * 8 + pxl_) * 64 + c4_]);                                     \
-    }                                                                                                           \
-  }
-
-  // ---- prologue: everything the first block needs before its first step ---------------------------------------------
-  int m = wg;
-  F12_WINDOW(m, 0, tid, 512)
-  __syncthreads();
-  for (int it = 0; it < 3; it++) {            // P1(m, 0): 18 rows as 3 x 6 rows, 512 threads = 32 quad items of 16 lanes
-    F12_P1(m, 0, 0, 0, 6 * it, 6, tid)
-  }
-  if (m + nwg < nblk) { F12_WINDOW(m + nwg, 1, tid, 512) }
-  __syncthreads();
-  if (!consumer) { F12_T(0, 0, 0, ptid) }
-  else { _Pragma("unroll") for (int j = 0; j < 6; j++) F12_LOADB(j, j, 0) }
-  __syncthreads();
-
-  // ---- the pipeline: two role-specialised loops with the same barrier sequence (14 per block) -----------------------------
-  // (separate code paths so that each role's registers are allocated for that role alone: in one shared loop body the
-  //  consumers' 192 registers of accumulators and B operands stay live across the producers' code and the kernel spilled)
-  if (consumer) {
-    int wb = 0;                                  // s_in buffer holding block m's window
-    bool pending_store = false;
-    int m_prev = 0;
-    for (; m < nblk; m += nwg) {
-      const int mn = m + nwg;
-      const bool has_next = mn < nblk;
-      if (pending_store) { F12_STORE(m_prev) }
-      // half 0: planes of group xi, K groups 0, 1
-      F12_C(0, 0, 0, 1, 0) __syncthreads();
-      F12_C(1, 0, 1, 2, 0) __syncthreads();
-      F12_C(2, 0, 0, 3, 0) __syncthreads();
-      F12_C(3, 0, 1, 4, 0) __syncthreads();
-      F12_C(4, 0, 0, 5, 0) __syncthreads();
-      F12_C(5, 0, 1, 0, 1) __syncthreads();
-      // between the halves the producers transform group 0 of half 1; the consumers fetch the next block's frame window
-      // (the first block's successor was fetched in the prologue)
-      if (has_next && m != wg) { F12_WINDOW(mn, wb ^ 1, ptid, 256) }
-      __syncthreads();
-      // half 1: K groups 2, 3
-      F12_C(0, 1, 0, 1, 1) __syncthreads();
-      F12_C(1, 1, 1, 2, 1) __syncthreads();
-      F12_C(2, 1, 0, 3, 1) __syncthreads();
-      F12_C(3, 1, 1, 4, 1) __syncthreads();
-      F12_C(4, 1, 0, 5, 1) __syncthreads();
-      F12_C(5, 1, 1, (has_next ? 0 : -1), 0) __syncthreads();
-      // block m is contracted: output transform, pooling -> s_o (stored at the top of the next trip / after the loop)
-      F12_E()
-      __syncthreads();
-      pending_store = true;
-      m_prev = m;
-      wb ^= 1;
-    }
-    if (pending_store) { F12_STORE(m_prev) }
-  } else {
-    int wb = 0;
-    for (; m < nblk; m += nwg) {
-      const int mn = m + nwg;
-      const bool has_next = mn < nblk;
-      // half 0: T(m, 0, xi + 1) and slice xi of P1(m, half 1) (patch buffer 1, window wb)
-      F12_T(1, 0, 1, ptid) F12_P1(m, wb, 1, 1, 0, 3, ptid) __syncthreads();
-      F12_T(2, 0, 0, ptid) F12_P1(m, wb, 1, 1, 3, 3, ptid) __syncthreads();
-      F12_T(3, 0, 1, ptid) F12_P1(m, wb, 1, 1, 6, 3, ptid) __syncthreads();
-      F12_T(4, 0, 0, ptid) F12_P1(m, wb, 1, 1, 9, 3, ptid) __syncthreads();
-      F12_T(5, 0, 1, ptid) F12_P1(m, wb, 1, 1, 12, 3, ptid) __syncthreads();
-      F12_P1(m, wb, 1, 1, 15, 3, ptid) __syncthreads();
-      F12_T(0, 1, 0, ptid)
-      __syncthreads();
-      // half 1: T(m, 1, xi + 1) and slice xi of P1(next block, half 0) (patch buffer 0, window wb ^ 1)
-      F12_T(1, 1, 1, ptid) if (has_next) { F12_P1(mn, wb ^ 1, 0, 0, 0, 3, ptid) } __syncthreads();
-      F12_T(2, 1, 0, ptid) if (has_next) { F12_P1(mn, wb ^ 1, 0, 0, 3, 3, ptid) } __syncthreads();
-      F12_T(3, 1, 1, ptid) if (has_next) { F12_P1(mn, wb ^ 1, 0, 0, 6, 3, ptid) } __syncthreads();
-      F12_T(4, 1, 0, ptid) if (has_next) { F12_P1(mn, wb ^ 1, 0, 0, 9, 3, ptid) } __syncthreads();
-      F12_T(5, 1, 1, ptid) if (has_next) { F12_P1(mn, wb ^ 1, 0, 0, 12, 3, ptid) } __syncthreads();
-      if (has_next) { F12_P1(mn, wb ^ 1, 0, 0, 15, 3, ptid) } __syncthreads();
-      // the consumers' output transform step: group 0 of the next block's first half
-      if (has_next) { F12_T(0, 0, 0, ptid) }
-      __syncthreads();
-      wb ^= 1;
-    }
-  }
-#undef F12_STORE
-#undef F12_E
-#undef F12_C
-#undef F12_LOADA
-#undef F12_LOADB
-#undef F12_T
-#undef F12_P1
-#undef F12_WINDOW
-}
 
 }  // namespace
 
@@ -1025,38 +723,15 @@ static int conv12_check(int B, int H, int W, const void* w1, const void* b1, con
   return PCNN_OK;
 }
 
-// grid of the pipelined kernel: PCNN_CONV12_WGS workgroups per CU (default 2: two rounds of one resident workgroup per CU —
-// a late CU costs half as much as with one long-lived workgroup each), a multiple of the filter sets
-static unsigned conv12_grid(long long blocks, int groups)
-{
-  static const int per_cu = [] { const char* e = getenv("PCNN_CONV12_WGS"); const int v = e ? atoi(e) : 2; return v >= 1 ? v : 1; }();
-  static const int cus = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; return n; }();
-  long long per_group = (blocks + groups - 1) / groups;
-  long long wgs = (long long)cus * per_cu / groups;
-  if (wgs < 1) wgs = 1;
-  if (wgs > per_group) wgs = per_group;
-  return (unsigned)(wgs * groups);
-}
-// Which kernel: the per-block one (default) or the persistent half-channel pipeline (PCNN_CONV12=2). Measured at 2 x 16
-// frames of 480 x 640 (tools/conv12_probe.hip, bench.py A/B on one box): per-block kernel 4.07 ms (window 2.9 us, conv1_1
-// 5.6 us, the 36 plane contractions 16 us, output transform 2.3 us per block of 16 tiles); pipelined 4.52 ms. Both are
-// bound by the same thing: every block re-reads the whole filter bank U^T (590 KB) from L2 — 22.6 GB per launch, 16 tiles per
-// fetch where wino43_mfma_kernel has 32 — which holds the plane contractions at ~47 % of the matrix rate however the operands
-// are scheduled (one plane at a time, interleaved pairs, rolling prefetch: same 16 us), and the pipeline's static walk loses
-// the dynamic balance of 38 400 short workgroups. The per-block kernel still wins the STEP: 756.9 vs 723.7 frames/s with two
-// streams (its half-idle matrix pipe and 8 waves per CU leave room for the other batch's kernels), 716 vs 718 on one.
-static bool conv12_first_version()
-{
-  static const bool v = [] { const char* e = getenv("PCNN_CONV12"); return !(e && e[0] == '2'); }();
-  return v;
-}
-
+// (Round 4 also built a persistent half-channel pipeline of this layer pair — 4.52 vs 3.15 ms, bound by the same filter-bank
+// re-reads, its static walk losing the dynamic balance of 38 400 short workgroups; it left the library in round 5:
+// tools/variants/conv12_wino43_pipelined_kernel.inc)
 extern "C" int pcnn_conv1_1_conv1_2_fused_fwd(const float* x, const float* w1, const float* b1, const float* ut2, int ut2_layout,
                                               const float* b2, int B, int H, int W, int groups, int relu1, int relu2,
                                               float* y_pool, void* stream_)
 {
-  PCNN_REQUIRE(ut2_layout == 0 || (ut2_layout == 1 && conv12_first_version()), PCNN_EINVAL,
-               "conv1_1_conv1_2_fused: ut2_layout must be 0 (U^T [36][64][64]) or 1 (fragment-major; per-block kernel only)");
+  PCNN_REQUIRE(ut2_layout == 0 || ut2_layout == 1, PCNN_EINVAL,
+               "conv1_1_conv1_2_fused: ut2_layout must be 0 (U^T [36][64][64]) or 1 (fragment-major)");
   int st = conv12_check(B, H, W, w1, b1, ut2, b2, y_pool);
   if (st != PCNN_OK) return st;
   PCNN_REQUIRE(x, PCNN_ENULL, "conv1_1_conv1_2_fused: NULL input");
@@ -1065,12 +740,8 @@ extern "C" int pcnn_conv1_1_conv1_2_fused_fwd(const float* x, const float* w1, c
   const RawFrames none = {nullptr, nullptr, 0, {0.0, 0.0, 0.0}};
   PCNN_REQUIRE(groups <= 2, PCNN_EINVAL, "conv1_1_conv1_2_fused: at most two filter sets (got %d)", groups);
   const long long blocks = (long long)B * (H / 16) * (W / 16);
-  if (conv12_first_version())
-    PCNN_LAUNCH((conv12_wino43_fused_kernel<false>), dim3((unsigned)blocks), dim3(512), 0, stream, x, w1, b1, ut2,
-                b2, y_pool, H, W, W / 16, H / 16, B / groups, relu1, relu2, none, ut2_layout);
-  else
-    PCNN_LAUNCH((conv12_wino43_pipelined_kernel<false>), dim3(conv12_grid(blocks, groups)), dim3(512), 0, stream, x, w1, b1, ut2,
-                b2, y_pool, H, W, W / 16, H / 16, B / groups, B, groups, relu1, relu2, none);
+  PCNN_LAUNCH((conv12_wino43_fused_kernel<false>), dim3((unsigned)blocks), dim3(512), 0, stream, x, w1, b1, ut2,
+              b2, y_pool, H, W, W / 16, H / 16, B / groups, relu1, relu2, none, ut2_layout);
   return check_launch("conv1_1_conv1_2_fused_fwd");
 }
 
@@ -1079,8 +750,8 @@ extern "C" int pcnn_conv1_1_conv1_2_fused_raw_fwd(const uint8_t* color_bgr, int 
                                                   int ut2_layout, const float* b2, int H, int W, int relu1, int relu2, float* y_pool,
                                                   void* stream_)
 {
-  PCNN_REQUIRE(ut2_layout == 0 || (ut2_layout == 1 && conv12_first_version()), PCNN_EINVAL,
-               "conv1_1_conv1_2_fused_raw: ut2_layout must be 0 (U^T [36][64][64]) or 1 (fragment-major; per-block kernel only)");
+  PCNN_REQUIRE(ut2_layout == 0 || ut2_layout == 1, PCNN_EINVAL,
+               "conv1_1_conv1_2_fused_raw: ut2_layout must be 0 (U^T [36][64][64]) or 1 (fragment-major)");
   PCNN_REQUIRE(num_color >= 0 && num_depth >= 0 && num_color + num_depth >= 1, PCNN_EINVAL,
                "conv1_1_conv1_2_fused_raw: bad frame counts (%d colour, %d depth)", num_color, num_depth);
   int st = conv12_check(num_color + num_depth, H, W, w1, b1, ut2, b2, y_pool);
@@ -1094,12 +765,7 @@ extern "C" int pcnn_conv1_1_conv1_2_fused_raw_fwd(const uint8_t* color_bgr, int 
   const RawFrames raw = {num_color ? color_bgr : nullptr, num_depth ? depth : nullptr, num_color,
                          {pixel_means[0], pixel_means[1], pixel_means[2]}};
   const long long blocks = (long long)B * (H / 16) * (W / 16);
-  const int sets = (num_color > 0) + (num_depth > 0);
-  if (conv12_first_version())
-    PCNN_LAUNCH((conv12_wino43_fused_kernel<true>), dim3((unsigned)blocks), dim3(512), 0, stream, (const float*)nullptr,
-                w1, b1, ut2, b2, y_pool, H, W, W / 16, H / 16, 1, relu1, relu2, raw, ut2_layout);
-  else
-    PCNN_LAUNCH((conv12_wino43_pipelined_kernel<true>), dim3(conv12_grid(blocks, sets)), dim3(512), 0, stream, (const float*)nullptr,
-                w1, b1, ut2, b2, y_pool, H, W, W / 16, H / 16, sets == 2 ? num_color : B, B, sets, relu1, relu2, raw);
+  PCNN_LAUNCH((conv12_wino43_fused_kernel<true>), dim3((unsigned)blocks), dim3(512), 0, stream, (const float*)nullptr,
+              w1, b1, ut2, b2, y_pool, H, W, W / 16, H / 16, 1, relu1, relu2, raw, ut2_layout);
   return check_launch("conv1_1_conv1_2_fused_raw_fwd");
 }

@@ -57,8 +57,11 @@ __global__ __launch_bounds__(512, 4) void fc_rows_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ addend, float* __restrict__ y, int K, int N, int Mcap, int relu,
     const int* __restrict__ num_rows_dev, int nbm, int ncb, int tall, float* __restrict__ part,
-    int smax, int ws_rows)
+    int smax, int ws_rows, int ldy, int nvalid, float* __restrict__ y2)
 {
+  // ldy / nvalid (pcnn_fc_rows_cols_fwd): y has `ldy` floats per row and only output columns < nvalid exist (the weight rows
+  // past them are zero padding up to the kernel's 64-column blocks); y2, if given, receives tanh(y). Plain fc_rows: ldy =
+  // nvalid = N, y2 = NULL.
   __shared__ __attribute__((aligned(16))) float smem[FC_NBUF * 128 * FC_LD];   // sA[3][64][64] | sB[3][64][64]
   float* sAp = smem;
   float* sBp = smem + FC_NBUF * 64 * FC_LD;
@@ -86,7 +89,11 @@ __global__ __launch_bounds__(512, 4) void fc_rows_mfma_kernel(
     if (ks > 0) return;
     for (int i = tid; i < 64 * 16; i += 512) {
       const int r = m0 + (i >> 4);
-      if (r < Mcap) *reinterpret_cast<v4f*>(y + (size_t)r * N + cb * 64 + (i & 15) * 4) = (v4f){0.f, 0.f, 0.f, 0.f};
+      const int c4_ = cb * 64 + (i & 15) * 4;
+      if (r < Mcap && c4_ < nvalid) {
+        *reinterpret_cast<v4f*>(y + (size_t)r * ldy + c4_) = (v4f){0.f, 0.f, 0.f, 0.f};
+        if (y2) *reinterpret_cast<v4f*>(y2 + (size_t)r * ldy + c4_) = (v4f){0.f, 0.f, 0.f, 0.f};   // tanh(0)
+      }
     }
     return;
   }
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(512, 4) void fc_rows_mfma_kernel(
         *reinterpret_cast<v4f*>(part + ((size_t)ks * ws_rows + m) * N + cb * 64 + c4) = *reinterpret_cast<const v4f*>(&sY[row * 64 + c4]);
       continue;
     }
-    if (m < Mcap) {
+    if (m < Mcap && cb * 64 + c4 < nvalid) {
       v4f val = (v4f){0.f, 0.f, 0.f, 0.f};
       if (m < count) {
         val = *reinterpret_cast<const v4f*>(&sY[row * 64 + c4]);
@@ -223,7 +230,13 @@ __global__ __launch_bounds__(512, 4) void fc_rows_mfma_kernel(
           for (int e = 0; e < 4; e++) val[e] = val[e] > 0.f ? val[e] : 0.f;
         }
       }
-      *reinterpret_cast<v4f*>(y + (size_t)m * N + cb * 64 + c4) = val;
+      *reinterpret_cast<v4f*>(y + (size_t)m * ldy + cb * 64 + c4) = val;
+      if (y2) {
+        v4f t;
+#pragma unroll
+        for (int e = 0; e < 4; e++) t[e] = tanhf(val[e]);
+        *reinterpret_cast<v4f*>(y2 + (size_t)m * ldy + cb * 64 + c4) = t;
+      }
     }
   }
 }
@@ -304,11 +317,43 @@ extern "C" int pcnn_fc_rows_fwd(const float* x, const float* wt, const float* bi
   const int smax = (workspace && workspace_bytes >= need && fc_can_split(rows_capacity, in_features, out_features) && aligned16(workspace)) ? smax_cap : 1;
   float* part = smax > 1 ? static_cast<float*>(workspace) : nullptr;
   PCNN_LAUNCH(fc_rows_mfma_kernel, dim3((unsigned)blocks, smax), dim3(512), 0, stream, x, wt, bias, addend, y, in_features,
-              out_features, rows_capacity, relu, num_rows_dev, nbm, ncb, tall, part, smax, ws_rows);
+              out_features, rows_capacity, relu, num_rows_dev, nbm, ncb, tall, part, smax, ws_rows, out_features, out_features, (float*)nullptr);
   if (smax > 1) {
     const long long items = (long long)ws_rows * (out_features / 4);
     PCNN_LAUNCH(fc_rows_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, part, bias, addend, y,
                 in_features, out_features, rows_capacity, relu, num_rows_dev, ncb, smax, ws_rows);
   }
   return check_launch("fc_rows_fwd");
+}
+
+// The same product for a layer whose width is no multiple of the kernel's 64-column blocks (fc8: 4 C = 88 outputs of 4096
+// inputs, lib/networks/vgg16_convs.py:192-193, at more rows than csrc/fc_skinny.hip takes): `wt` / `bias` are PADDED with
+// zero rows / entries to `out_padded` (a multiple of 64), y and y_tanh are [rows_capacity][out_features] with out_features
+// % 4 == 0; activation 0 none, 1 ReLU, 2 tanh — then y holds the linear output and y_tanh its tanh (fc8 and poses_tanh
+// from one launch). No split-K (the layer's K is 4096: 64 stages per workgroup). Replaces the library GEMM + tanh.
+extern "C" int pcnn_fc_rows_cols_fwd(const float* x, const float* wt, const float* bias, int rows_capacity,
+                                     int in_features, int out_padded, int out_features, int activation,
+                                     const int32_t* num_rows_dev, float* y, float* y_tanh, void* stream_)
+{
+  PCNN_REQUIRE(rows_capacity >= 0, PCNN_EINVAL, "fc_rows_cols: negative row capacity");
+  PCNN_REQUIRE(in_features >= 128 && in_features % 64 == 0, PCNN_EINVAL,
+               "fc_rows_cols: in_features must be a multiple of 64, >= 128 (got %d)", in_features);
+  PCNN_REQUIRE(out_padded >= 64 && out_padded % 64 == 0, PCNN_EINVAL, "fc_rows_cols: out_padded must be a multiple of 64 (got %d)", out_padded);
+  PCNN_REQUIRE(out_features >= 4 && out_features % 4 == 0 && out_features <= out_padded && out_features > out_padded - 64, PCNN_EINVAL,
+               "fc_rows_cols: out_features must be a multiple of 4 inside the last 64-column block of out_padded (got %d of %d)", out_features, out_padded);
+  PCNN_REQUIRE(activation >= 0 && activation <= 2, PCNN_EINVAL, "fc_rows_cols: activation 0 (none), 1 (ReLU) or 2 (tanh)");
+  if (rows_capacity == 0) return PCNN_OK;
+  PCNN_REQUIRE(x && wt && bias && y && (activation != 2 || y_tanh), PCNN_ENULL, "fc_rows_cols: NULL pointer");
+  PCNN_REQUIRE(aligned16(x) && aligned16(wt) && aligned16(y) && aligned16(y_tanh) && aligned16(bias), PCNN_EINVAL,
+               "fc_rows_cols: pointers (x, wt, bias, y, y_tanh) must be 16-byte aligned");
+  PCNN_REQUIRE((long long)rows_capacity * in_features < (1ll << 30) && (long long)out_padded * in_features < (1ll << 30),
+               PCNN_EINVAL, "fc_rows_cols: operand larger than the 32-bit byte offsets of the kernel");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int nbm = (rows_capacity + 63) / 64, ncb = out_padded / 64;
+  const int tall = (long long)rows_capacity > (long long)out_padded;
+  const long long blocks = tall ? (long long)((nbm + 7) / 8) * 8 * ncb : (long long)((ncb + 7) / 8) * 8 * nbm;
+  PCNN_LAUNCH(fc_rows_mfma_kernel, dim3((unsigned)blocks, 1), dim3(512), 0, stream, x, wt, bias, (const float*)nullptr, y, in_features,
+              out_padded, rows_capacity, activation == 1 ? 1 : 0, num_rows_dev, nbm, ncb, tall, (float*)nullptr, 1, 0, out_features, out_features,
+              activation == 2 ? y_tanh : (float*)nullptr);
+  return check_launch("fc_rows_cols_fwd");
 }

@@ -79,20 +79,133 @@ __global__ __launch_bounds__(256) void head_lowres_kernel(
   }
 }
 
+// The same head step for MANY pixels (round 5: 16 frames = 76 800 low-resolution pixels per launch): the t-phase of
+// head_lowres_kernel unchanged (so `add_score` keeps its bits), the 1x1 product on the matrix cores. A workgroup owns 64
+// pixels (4 waves x 16 rows); t sits in LDS with a 4-float row pad (conflict-free 128-bit operand reads); the filter —
+// `wN` [Npad][U], N-major with K contiguous, zero rows up to a multiple of 16 — comes straight from L2 (it is 6-34 KB and
+// every wave reads all of it). v_mfma_f32_16x16x4_f32, K ascending in steps of 16 (g), the four K quarters of a step in
+// the lanes' lk: one fixed order per output, whatever the batch. Replaces, at 16 frames, deconv_bilinear + two
+// at::native adds + a library (CK) 1x1 convolution per head: the last framework kernels of the heads.
+constexpr int HM_PX = 64;
+
+template <int NT>   // 16-column output tiles: Npad / 16
+__global__ __launch_bounds__(256) void head_lowres_mfma_kernel(
+    const float* __restrict__ a, const float* __restrict__ b5, const float* __restrict__ planted,
+    const float* __restrict__ wN, float* __restrict__ add_out, float* __restrict__ z, int B, int h, int w, int U,
+    int Cout, int k, int s)
+{
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int LD = U + 4;
+  float* tL = smem;                  // [HM_PX][U + 4]
+  __shared__ Taps s_ty[HM_PX], s_tx[HM_PX];
+  __shared__ int s_img[HM_PX];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long total = (long long)B * h * w;
+  const long long gp0 = (long long)blockIdx.x * HM_PX;
+  const int h5 = h / s, w5 = w / s, pad = (k - s) / 2;
+  if (tid < HM_PX) {
+    const long long gp = gp0 + tid < total ? gp0 + tid : total - 1;
+    s_tx[tid] = make_taps((int)(gp % w), k, s, pad, w5);
+    s_ty[tid] = make_taps((int)((gp / w) % h), k, s, pad, h5);
+    s_img[tid] = (int)(gp / ((long long)w * h));
+  }
+  __syncthreads();
+  for (int idx = tid; idx < HM_PX * U; idx += 256) {
+    const int p = idx / U, c = idx - p * U;
+    const long long gp = gp0 + p;
+    float t = 0.f;
+    if (gp < total) {
+      const float up = bilinear_at(b5 + (size_t)s_img[p] * h5 * w5 * U, s_ty[p], s_tx[p], w5, U, c);
+      t = a[gp * U + c] + up;                       // add_score = score_conv4 + upscore_conv5   (tf.add_n order)
+      if (planted) t = t + planted[gp * U + c];     // bench aid: the planted scene
+      add_out[gp * U + c] = t;
+    }
+    tL[p * LD + c] = t;
+  }
+  __syncthreads();
+  const int lr = lane & 15, lk = lane >> 4;
+  v4f acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) acc[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+  const float* arow = tL + (16 * wave + lr) * LD + 4 * lk;
+  const float* brow = wN + (size_t)lr * U + 4 * lk;
+  for (int g = 0; g < U / 16; g++) {
+    const v4f av = *reinterpret_cast<const v4f*>(arow + 16 * g);
+    v4f bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) bv[nt] = *reinterpret_cast<const v4f*>(brow + (size_t)(16 * nt) * U + 16 * g);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[nt][i], acc[nt], 0, 0, 0);
+  }
+  // lane (column lr of tile nt, lk) holds pixels 16 wave + 4 lk + i
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) {
+    const int co = 16 * nt + lr;
+    if (co < Cout) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const long long gp = gp0 + 16 * wave + 4 * lk + i;
+        if (gp < total) z[gp * Cout + co] = acc[nt][i];
+      }
+    }
+  }
+}
+
+// `poses_mul = poses_tanh * poses_weight; poses_pred = l2_normalize(poses_mul, dim = 1)` (vgg16_convs.py:195-197,
+// network.py:573-577: x * rsqrt(max(sum(x^2), 1e-12))) on the capacity-sized row buffer: one wave per row, the row's squares
+// summed in a fixed order (lane partials over the columns lane, lane + 64, ... ascending, then a 6-step butterfly), 1 / sqrt
+// correctly rounded. Rows at or past the device-side count: zeros. Replaces six framework element-wise / reduce launches.
+__global__ __launch_bounds__(256) void pose_l2_normalize_kernel(
+    const float* __restrict__ x, const float* __restrict__ wgt, const int* __restrict__ count_dev, int rows, int cols,
+    float* __restrict__ out)
+{
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int count = count_dev ? min(max(count_dev[0], 0), rows) : rows;
+  const size_t base = (size_t)row * cols;
+  if (row >= count) {
+    for (int c = lane; c < cols; c += 64) out[base + c] = 0.f;
+    return;
+  }
+  float m[4], ss = 0.f;   // cols <= 256 (the launcher checks)
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int c = lane + 64 * j;
+    m[j] = c < cols ? x[base + c] * wgt[base + c] : 0.f;
+    ss = ss + m[j] * m[j];
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) ss = ss + __shfl_xor(ss, o);
+  const float inv = div_rn(1.f, sqrt_rn(fmaxf(ss, 1e-12f)));
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int c = lane + 64 * j;
+    if (c < cols) out[base + c] = m[j] * inv;
+  }
+}
+
 __global__ __launch_bounds__(256) void det_assemble_kernel(
     const float* __restrict__ rois, const float* __restrict__ poses_tanh, const float* __restrict__ top_pose,
     const int* __restrict__ count_dev, int rows_in, int stride, int C, float* __restrict__ rows_out,
-    int* __restrict__ count_out, int rows_out_n)
+    int* __restrict__ count_out, int rows_out_n, float frame_offset, int packed_tail)
 {
   const int count = min(max(count_dev[0], 0), rows_in);
   if (blockIdx.x == 0 && threadIdx.x == 0) count_out[0] = count / stride;
+  // packed_tail: rows_out has one more row, (count, 0, ..., 0) — the block one rank hands to the all-gather
+  // (posecnn_amd/dist.py pack_detections), written here instead of by four framework launches
+  if (packed_tail && blockIdx.x == 0 && threadIdx.x < 14) rows_out[(size_t)rows_out_n * 14 + threadIdx.x] = threadIdx.x == 0 ? (float)(count / stride) : 0.f;
   const int total = rows_out_n * 14;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     const int ro = i / 14, col = i - ro * 14;
     const int ri = ro * stride;
     float v = 0.f;
     if (ri < count) {
-      if (col < 7) v = rois[(size_t)ri * 7 + col];
+      if (col < 7) { v = rois[(size_t)ri * 7 + col]; if (col == 0) v = v + frame_offset; }   // global frame index: rank * B + local
       else if (col < 11) {
         int cls = (int)rois[(size_t)ri * 7 + 1];
         cls = cls < 0 ? 0 : (cls > C - 1 ? C - 1 : cls);
@@ -125,9 +238,34 @@ extern "C" int pcnn_head_lowres_fwd(const float* score4, const float* score5, co
   return check_launch("head_lowres_fwd");
 }
 
-extern "C" int pcnn_det_assemble_fwd(const float* rois, const float* poses_tanh, const float* top_pose,
-                                     const int32_t* num_rows_dev, int rows, int row_stride, int num_classes,
-                                     float* det_rows, int32_t* det_count, void* stream_)
+extern "C" int pcnn_head_lowres_mfma_fwd(const float* score4, const float* score5, const float* planted,
+                                         const float* weights_nk, int B, int h, int w, int units, int out_channels,
+                                         int kernel, int stride, float* add_out, float* z, void* stream_)
+{
+  PCNN_REQUIRE(B >= 1 && h >= 1 && w >= 1 && units >= 16 && units % 16 == 0 && out_channels >= 1, PCNN_EINVAL,
+               "head_lowres_mfma: bad shape (units must be a multiple of 16, got %d)", units);
+  PCNN_REQUIRE(out_channels <= 96, PCNN_EINVAL, "head_lowres_mfma: at most 96 output channels (got %d)", out_channels);
+  PCNN_REQUIRE(stride >= 1 && kernel >= stride && (kernel - stride) % 2 == 0 && kernel <= 2 * stride && h % stride == 0 && w % stride == 0,
+               PCNN_EINVAL, "head_lowres_mfma: need stride <= kernel <= 2 stride, (kernel - stride) even, %dx%d divisible by the stride %d", h, w, stride);
+  PCNN_REQUIRE(score4 && score5 && weights_nk && add_out && z, PCNN_ENULL, "head_lowres_mfma: NULL pointer");
+  PCNN_REQUIRE(aligned16(weights_nk), PCNN_EINVAL, "head_lowres_mfma: the filter must be 16-byte aligned");
+  const size_t lds = sizeof(float) * (size_t)HM_PX * (units + 4);
+  PCNN_REQUIRE(lds <= 60 * 1024, PCNN_EINVAL, "head_lowres_mfma: %d units exceed the kernel's LDS", units);
+  hipStream_t stream = (hipStream_t)stream_;
+  const long long total = (long long)B * h * w;
+  const long long blocks = (total + HM_PX - 1) / HM_PX;
+  PCNN_REQUIRE(blocks < (1ll << 31), PCNN_EINVAL, "head_lowres_mfma: grid too large");
+  const int nt = (out_channels + 15) / 16;
+#define HM_GO(N) PCNN_LAUNCH((head_lowres_mfma_kernel<N>), dim3((unsigned)blocks), dim3(256), lds, stream, score4, score5, planted, weights_nk, \
+                             add_out, z, B, h, w, units, out_channels, kernel, stride)
+  switch (nt) { case 1: HM_GO(1); break; case 2: HM_GO(2); break; case 3: HM_GO(3); break; case 4: HM_GO(4); break; case 5: HM_GO(5); break; default: HM_GO(6); }
+#undef HM_GO
+  return check_launch("head_lowres_mfma_fwd");
+}
+
+static int det_assemble_impl(const float* rois, const float* poses_tanh, const float* top_pose,
+                             const int32_t* num_rows_dev, int rows, int row_stride, int num_classes,
+                             float* det_rows, int32_t* det_count, float frame_offset, int packed_tail, void* stream_)
 {
   PCNN_REQUIRE(rows >= 0 && row_stride >= 1 && num_classes >= 1, PCNN_EINVAL, "det_assemble: bad shape");
   PCNN_REQUIRE(num_rows_dev && det_count, PCNN_ENULL, "det_assemble: NULL count pointer");
@@ -136,6 +274,33 @@ extern "C" int pcnn_det_assemble_fwd(const float* rois, const float* poses_tanh,
   hipStream_t stream = (hipStream_t)stream_;
   const int blocks = std::max(1, std::min(64, (n_out * 14 + 255) / 256));
   PCNN_LAUNCH(det_assemble_kernel, dim3(blocks), dim3(256), 0, stream, rois, poses_tanh, top_pose, num_rows_dev, rows, row_stride,
-              num_classes, det_rows, det_count, n_out);
+              num_classes, det_rows, det_count, n_out, frame_offset, packed_tail);
   return check_launch("det_assemble_fwd");
+}
+
+extern "C" int pcnn_det_assemble_fwd(const float* rois, const float* poses_tanh, const float* top_pose,
+                                     const int32_t* num_rows_dev, int rows, int row_stride, int num_classes,
+                                     float* det_rows, int32_t* det_count, void* stream_)
+{
+  return det_assemble_impl(rois, poses_tanh, top_pose, num_rows_dev, rows, row_stride, num_classes, det_rows, det_count, 0.f, 0, stream_);
+}
+
+extern "C" int pcnn_det_assemble_packed_fwd(const float* rois, const float* poses_tanh, const float* top_pose,
+                                            const int32_t* num_rows_dev, int rows, int row_stride, int num_classes,
+                                            float frame_offset, float* det_block, int32_t* det_count, void* stream_)
+{
+  PCNN_REQUIRE(det_block, PCNN_ENULL, "det_assemble_packed: NULL block");
+  return det_assemble_impl(rois, poses_tanh, top_pose, num_rows_dev, rows, row_stride, num_classes, det_block, det_count, frame_offset, 1, stream_);
+}
+
+extern "C" int pcnn_pose_l2_normalize_fwd(const float* poses_tanh, const float* poses_weight, const int32_t* num_rows_dev,
+                                          int rows, int cols, float* poses_pred, void* stream_)
+{
+  PCNN_REQUIRE(rows >= 0 && cols >= 1 && cols <= 256, PCNN_EINVAL, "pose_l2_normalize: bad shape %d x %d (at most 256 columns)", rows, cols);
+  if (rows == 0) return PCNN_OK;
+  PCNN_REQUIRE(poses_tanh && poses_weight && poses_pred, PCNN_ENULL, "pose_l2_normalize: NULL pointer");
+  hipStream_t stream = (hipStream_t)stream_;
+  PCNN_LAUNCH(pose_l2_normalize_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, poses_tanh, poses_weight, num_rows_dev,
+              rows, cols, poses_pred);
+  return check_launch("pose_l2_normalize_fwd");
 }

@@ -169,6 +169,9 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
   const unsigned lds_a0 = lds_base_ + (unsigned)ldsw * 4u;
   const unsigned lds_b0 = lds_base_ + (unsigned)(WM_NBUF * BT * WM_LD + ldsu) * 4u;
 
+  // the lane's bias value, requested HERE: issued where it is first used (the epilogue, round 4) it was a bare global
+  // round trip between the last MFMA and the first staged row of every workgroup (~1 us of a 15-us conv2_1 workgroup)
+  const float bv = bias ? bias[(size_t)grp * Cout + cb * WM_BC + 16 * wn + lr] : 0.f;   // (no bias: the raw partial output of a Cin split)
   v4f acc[6][2];
 #pragma unroll
   for (int i = 0; i < 6; i++) acc[i][0] = acc[i][1] = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
 #undef WM_PF_ADVANCE
 
   if constexpr (ABL & 256) {   // ablation: bias + ReLU on the registers, nothing staged or stored
-    const float bv_ = bias ? bias[(size_t)grp * Cout + cb * WM_BC + 16 * wn + lr] : 0.f;
+    const float bv_ = bv;
     float k_ = 0.f;
 #pragma unroll
     for (int b = 0; b < 2; b++)
@@ -382,8 +385,6 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
   // ---- epilogue -------------------------------------------------------------------------------
   // lane holds, per block b, tiles 32 wm + 16 b + 4 lk + i (i = 0..3) x channel 16 wn + lr
   const int col = 16 * wn + lr;
-  const int co = cb * WM_BC + col;
-  const float bv = bias ? bias[(size_t)grp * Cout + co] : 0.f;   // (no bias: the raw partial output of a Cin split)
 #pragma unroll
   for (int b = 0; b < 2; b++)
 #pragma unroll
@@ -477,485 +478,6 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
       if (py < Hp && px < Wp)
         *reinterpret_cast<v4f*>(yp + (((long long)s_img[r] * Hp + py) * Wp + px) * Cout + cb * WM_BC + rc4) =
             *reinterpret_cast<const v4f*>(&sY[(tl * 4 + re) * 64 + (rc4 ^ (16 * ((tl >> 2) & 3)))]);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// The same contraction as ONE wave per SIMD on v_mfma_f32_32x32x2_f32 (round 4; VERDICT r3 #3a, the structural candidate
-// of DESIGN §3.2c). Workgroup = 64 tiles x 64 output channels, 4 waves in a 2 x 2 arrangement, wave (wm, wn) owns tiles
-// [32 wm, +32) x channels [32 wn, +32) as one 32x32 accumulator block (16 registers), i.e. 16 (tile, channel) elements per
-// lane; a lone wave on a SIMD may use 512 registers. Against the 2 x (32 x 64) pair above, per CU and per flop:
-//   * operand bytes L2 -> LDS: (64 + 64) rows per 64 x 64 elements instead of 2 x (32 + 64) per 2 x 32 x 64: -33 %;
-//   * LDS -> register reads: one A and one B register per 4096-flop MFMA instead of 3 per 2 x 2048: -33 %;
-//   * half the MFMA instructions, each with a 64-cycle shadow; there is no second wave on the SIMD to hide anything, so the
-//     stream is placed by hand: the MFMAs, LDS reads and DMAs are inline asm in program order, one filler (two reads, one
-//     DMA, a piece of the prefetch-pointer arithmetic, a few VALU of the column transform) behind each MFMA.
-// Where the state lives (what three measured versions of this kernel taught, tools/wino_w1_probe.hip):
-//   * v_accvgpr_read / _write are MAI instructions: they go through the matrix pipe. The first versions kept six plane
-//     accumulators and most outputs in AGPRs and folded a finished column with VALU FMAs — ~500 accvgpr moves per fold,
-//     13 000 cycles each, 13-19 % of conv4_2, whether the fold ran in place or spread behind the next column's MFMAs.
-//   * So nothing here moves between the register classes inside the loop nest. ONE accumulator tuple (in VGPRs): the LAST
-//     MFMA of a plane writes its result to another VGPR tuple (vDst != srcC), where the column transform t = A^T M[:, nu] is
-//     built up plane by plane with plain VALU (s, d after plane 2; S, D, t0, t1, t2, 8 D + d after plane 4; + m5 after
-//     plane 5 — at6_col's expression trees exactly), in the shadows of the next plane's MFMAs.
-//   * The outputs of 15 of the 16 elements live in AGPRs (240 of the 256), one element's in VGPRs, and the rank-1 update Y[a][:] += t[a] A[nu][:] is ONE v_mfma_f32_4x4x1_16B_f32 per (element,
-//     output row) accumulating in place: A operand = A[nu][lane & 3] (a per-column lane constant), B operand = the lane's
-//     t[a]: D[i] = fma(A[nu][i], t, C[i]) — the same single-rounding FMA as the VALU fold, 8 cycles of matrix pipe per
-//     item, 64 items per column, no register moves.
-// Same bits as wino43_mfma_kernel: an f32 MFMA is a k-ordered fmaf chain, and the chain order is kept — the 16x16x4
-// instruction (G, i) of the kernel above contracts k = 16 G + 4 lk + i for lk = 0..3 in that order; here lane (row, h)
-// reads the chunks 4 G + 2 m + h (m = 0, 1) and instruction (G, i, m) contracts lk = 2 m + h for h = 0, 1: the same
-// sequence of (k) per accumulator, the same fold expression trees, the same epilogue arithmetic
-// (tests/test_gpu_round4.py::test_winograd_mfma_one_wave_variant_is_bit_identical).
-typedef float v16f __attribute__((ext_vector_type(16)));
-
-// NB: stage buffers in the LDS ring: 3, or 4 — the 128 KB the epilogue stages through anyway. SB = 0: one s_barrier per
-// stage, prefetch distance NB - 1. SB = 1 (needs NB = 4): no rendezvous at all — a lone wave per SIMD has nobody to run
-// under its barrier waits, and with four waves coupled every stage the slowest one's LDS / DMA arbitration luck sets the
-// pace (ablation: 15-17 % of conv4_2). Instead two LDS counters per buffer, arrive and wait apart:
-//   landed[b] += 1 by each wave once ITS DMAs of the stage in buffer b are in (mid-way through the stage before);
-//                a wave starts the stage when landed[b] says all four did;
-//   freed[b]  += 1 by each wave once its reads of buffer b are back (start of its next stage); the DMAs that refill b —
-//                prefetch distance 2, i.e. two stages later — wait for all four.
-// A wave may run up to a stage ahead of the slowest; the counter reads are requested a stage early and cost two lane
-// reads per stage when (as almost always) they are already satisfied.
-template <int POOL, int ABL = 0, int NB = 3, int SB = 0>
-__global__ __launch_bounds__(256, 1) void wino43_mfma_w1_kernel(
-    const float* __restrict__ v, const float* __restrict__ ut, const float* __restrict__ bias,
-    float* __restrict__ y, float* __restrict__ ypool, int H, int W, int Cin, int Cout, int Ht, int Wt,
-    long long T, long long tiles_per_group, int relu, int nbt, int ncb, int mode)
-{
-  constexpr int BT = 64, NW = 4;
-  constexpr int W1_NA = 15;   // elements (of a lane's 16) whose 16 outputs live in AGPRs; the last one's live in VGPRs
-  static_assert(!SB || NB == 4, "the counter protocol is written for a ring of four");
-  constexpr int PD = SB ? 2 : NB - 1;   // prefetch distance (stages)
-  constexpr int RING = NB * (BT + 64) * WM_LD, STAGE2 = 2 * BT * 4 * 64;
-  __shared__ __attribute__((aligned(16))) float smem[(RING > STAGE2 ? RING : STAGE2) + 16];   // sA[NB][64][64] | sB[NB][64][64]; epilogue: 2 x [64][4][64]; 8 counters
-
-  const int x = blockIdx.x & 7, q0 = blockIdx.x >> 3;
-  const bool cbmajor = (mode & 1) != 0;
-  const int cb = cbmajor ? x : q0 % ncb;
-  const int tb = cbmajor ? q0 : (q0 / ncb) * 8 + x;
-  if (tb >= nbt) return;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 1, wn = wave >> 1;
-  const int lr = lane & 15, lk = lane >> 4;        // DMA geometry (4 rows x 16 chunks per instruction)
-  const int lc = lane & 31, lh = lane >> 5;        // MFMA geometry (row / column of the 32 x 32 block, k half)
-  const int nbg = (int)((tiles_per_group + BT - 1) / BT);
-  const int grp = tb / nbg;
-  const long long t0 = (long long)grp * tiles_per_group + (long long)(tb - grp * nbg) * BT;
-  const long long tend = (long long)(grp + 1) * tiles_per_group;
-  const float* utg = ut + (size_t)grp * 36 * Cout * Cin;
-  const int NK = Cin / WM_KC;
-  const unsigned lds_flags = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)(smem + (RING > STAGE2 ? RING : STAGE2));
-  if constexpr (SB) {   // landed[4] | freed[4]
-    if (tid < 8) reinterpret_cast<unsigned*>(smem + (RING > STAGE2 ? RING : STAGE2))[tid] = 0u;
-    __syncthreads();
-  }
-
-  // staging: a stage = 64 rows of V and 64 rows of U^T = 16 + 16 DMA instructions of 4 rows; wave w issues V instructions
-  // 4 w .. 4 w + 3 and the same U^T instructions. Lane l of instruction ii lands at row 4 ii + (l >> 4), physical chunk
-  // l & 15, and fetches logical chunk (l & 15) ^ (row & 15).
-  const long long tlast = tend - 1;
-  unsigned va[4], ub[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int dr = 16 * wave + 4 * i + lk;
-    const long long ta = t0 + dr < tend ? t0 + dr : tlast;   // rows past the end: any finite data, never stored
-    va[i] = (unsigned)((ta * Cin + (lr ^ (dr & 15)) * 4) * 4);
-    ub[i] = (unsigned)((((size_t)(cb * WM_BC + dr)) * Cin + (lr ^ (dr & 15)) * 4) * 4);
-  }
-  const char* vbase = reinterpret_cast<const char*>(v);
-  const char* ubase = reinterpret_cast<const char*>(utg);
-  const long long vplane = T * Cin;
-  const long long uplane = (long long)Cout * Cin;
-  const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)smem;
-  const unsigned lds_a0 = lds0 + (unsigned)(16 * wave * WM_LD) * 4u;
-  const unsigned lds_b0 = lds0 + (unsigned)(NB * BT * WM_LD + 16 * wave * WM_LD) * 4u;
-
-  v16f acc;          // the plane in flight (VGPR: an MFMA's vDst and srcC share one register class, and the finished plane
-                     // must land in VGPRs); written by the plane's first MFMA (C = 0) before anything reads it
-  v16f pA, pB, pC, pD, pE;   // finished planes of the column / the transform built from them (VGPR), see the header
-  v4f yo[16][4];     // [accumulator register r = 4 q + p: tile 8 q + 4 lh + p of the wave's 32][output row a][e]
-#pragma unroll
-  for (int r = 0; r < 16; r++)
-#pragma unroll
-    for (int a = 0; a < 4; a++) yo[r][a] = (v4f){0.f, 0.f, 0.f, 0.f};
-#define W1_PIN_YOA(R, A)                                                                              \
-  if ((R) < W1_NA) { asm volatile("" : "+a"(yo[R][A])); } else { asm volatile("" : "+v"(yo[R][A])); }
-#pragma unroll
-  for (int r = 0; r < 16; r++)
-#pragma unroll
-    for (int a = 0; a < 4; a++) { W1_PIN_YOA(r, a) }
-
-  // one DMA instruction of the prefetch stage: V rows / U^T rows, index I = 0..3 (pvp / pup: the stage's byte pointers)
-#define W1_DMAV(BUF, I)                                                                               \
-  if constexpr (!(ABL & 2)) glds16_s(pvp, va[I], lds_a0 + (unsigned)(BUF) * (BT * WM_LD * 4) + (I) * 4 * WM_LD * 4);
-#define W1_DMAU(BUF, I)                                                                               \
-  if constexpr (!(ABL & 2)) glds16_s(pup, ub[I], lds_b0 + (unsigned)(BUF) * (64 * WM_LD * 4) + (I) * 4 * WM_LD * 4);
-#define W1_DMA(BUF, I) { W1_DMAV(BUF, I) W1_DMAU(BUF, I) }
-  // Prefetch pointer, two stages ahead of the compute pointer; stage order nu outer, xi, then kc fastest. Advanced
-  // without branches, in four pieces that each fit an MFMA's shadow (the if-chain of the kernel above compiled to ~40
-  // scalar instructions and five branches in ONE shadow here):
-  // next K slice +256 bytes; next plane of the column k += 6; next column k: 30 + nu -> nu + 1; past the last stage the
-  // pointer parks (the two extra prefetches re-load the last stage into a free buffer).
-  int pnu = 0, pxi = 0, pkc = 0;
-  const char* pvp = vbase;
-  const char* pup = ubase;
-  const long long kback = (long long)(NK - 1) * WM_KC;
-  const long long dvx = 4 * (6 * vplane - kback), dux = 4 * (6 * uplane - kback);
-  const long long dvn = 4 * (-29 * vplane - kback), dun = 4 * (-29 * uplane - kback);
-  long long pdv = 0, pdu = 0;
-  int pwk = 0, pwx = 0, plast = 0;
-#define W1_PF_FLAGS() do { pwk = pkc + 1 == NK ? 1 : 0; pwx = pwk & (pxi == 5 ? 1 : 0); plast = pwx & (pnu == 5 ? 1 : 0); } while (0)
-#define W1_PF_SELV() do { pdv = plast ? 0ll : pwx ? dvn : pwk ? dvx : (long long)(4 * WM_KC); } while (0)
-#define W1_PF_SELU() do { pdu = plast ? 0ll : pwx ? dun : pwk ? dux : (long long)(4 * WM_KC); } while (0)
-#define W1_PF_ADD()                                                                                   \
-  do {                                                                                                \
-    pvp += pdv; pup += pdu;                                                                           \
-    pkc = plast ? pkc : pwk ? 0 : pkc + 1;                                                            \
-    pxi = plast ? pxi : pwx ? 0 : pxi + pwk;                                                          \
-    pnu += pwx & (plast ^ 1);                                                                         \
-  } while (0)
-#define W1_PF_ADVANCE() do { W1_PF_FLAGS(); W1_PF_SELV(); W1_PF_SELU(); W1_PF_ADD(); } while (0)
-#pragma unroll
-  for (int bq = 0; bq < PD; bq++) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) W1_DMA(bq, i);
-    W1_PF_ADVANCE();
-  }
-  int cur = 0;
-  // counter protocol state (SB): stage index, the two counter values requested a stage ahead
-  unsigned sidx = 0, fl_landed = 0, fl_freed = 0;
-  const unsigned v1 = 1u;   // lane 0 adds 1 (64 lanes adding to one address serialise in the LDS atomic unit: 2 x 4 waves x 64 per
-                            // stage made the first version of this protocol 16 % SLOWER than the barrier)
-#define W1_FLAG_ADD(ADDR) do { if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"(ADDR), "v"(v1) : "memory"); } while (0)
-#define W1_FLAG_READ(DST, ADDR) asm volatile("ds_read_b32 %0, %1" : "=v"(DST) : "v"(ADDR))
-#define W1_FLAG_WAIT(VAL, ADDR, NEED)                                                                 \
-  while ((unsigned)__builtin_amdgcn_readfirstlane((int)(VAL)) < (NEED)) {                             \
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(VAL) : "v"(ADDR) : "memory");    \
-  }
-  if constexpr (SB) {   // this wave's DMAs of stage 0 are in; stage 1's are confirmed mid-way through stage 0
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    const unsigned a0_ = lds_flags;
-    W1_FLAG_ADD(a0_);
-    W1_FLAG_READ(fl_landed, a0_);
-  }
-
-  // ds_read side: A row 32 wm + lc, B row 32 wn + lc; K group G, half m: logical chunk 4 G + 2 m + lh -> physical ^ (lc & 15)
-  unsigned adA[4][2], adB[4][2];
-#pragma unroll
-  for (int g = 0; g < 4; g++)
-#pragma unroll
-    for (int m = 0; m < 2; m++) {
-      const unsigned chb = (unsigned)(((4 * g + 2 * m + lh) ^ (lc & 15)) * 16);
-      adA[g][m] = lds0 + (unsigned)((32 * wm + lc) * WM_LD) * 4u + chb;
-      adB[g][m] = lds0 + (unsigned)((NB * BT + 32 * wn + lc) * WM_LD) * 4u + chb;
-    }
-  // two operand register sets, one K group each: P (groups 0, 2), Q (groups 1, 3)
-  v4f pa[2], pb[2], qa[2], qb[2];
-#pragma unroll
-  for (int m = 0; m < 2; m++) pa[m] = pb[m] = qa[m] = qb[m] = (v4f){0.f, 0.f, 0.f, 0.f};
-#define W1_DSREAD(DST, ADDR)                                                                          \
-  if constexpr (!(ABL & 4)) asm volatile("ds_read_b128 %0, %1" : "=v"(DST) : "v"(ADDR));              \
-  else asm volatile("" : "+v"(DST) : "v"(ADDR))
-#define W1_READ_A(SA, G) { W1_DSREAD(SA[0], adA[G][0] + curA); W1_DSREAD(SA[1], adA[G][1] + curA); }
-#define W1_READ_B(SB, G) { W1_DSREAD(SB[0], adB[G][0] + curB); W1_DSREAD(SB[1], adB[G][1] + curB); }
-#define W1_READ(SA, SB, G) { W1_READ_A(SA, G) W1_READ_B(SB, G) }
-  // one MFMA: element I of K group chunk M (M = 0, 1: the two k pairs of a 16x16x4 step) into the accumulator.
-  // (Inline asm: program order is the schedule. The accumulator is srcC and vDst of consecutive MFMAs of one shape, which
-  // needs no wait states.)
-#define W1_M1(SA, SB, I, M)                                                                           \
-  if constexpr (ABL & 8) { asm volatile("" :: "v"(SA[M]), "v"(SB[M])); }                              \
-  else { asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(SA[M][I]), "v"(SB[M][I])); }
-  // a plane's first MFMA starts the accumulator from the constant 0
-#define W1_M1_Z(SA, SB)                                                                               \
-  if constexpr (ABL & 8) { asm volatile("" : "=v"(acc) : "v"(SA[0]), "v"(SB[0])); }                   \
-  else { asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(acc) : "v"(SA[0][0]), "v"(SB[0][0])); }
-  // a plane's LAST MFMA delivers the finished plane to a VGPR tuple (vDst != srcC; srcC is exactly the vDst of the MFMA
-  // in front of it; a few wait states for the hazard classes the assembler cannot see through the asm statements)
-#define W1_M1_FIN(SA, SB, DST)                                                                        \
-  if constexpr (ABL & 8) { asm volatile("" : "=v"(DST) : "v"(SA[1]), "v"(SB[1]), "v"(acc)); }         \
-  else { asm volatile("s_nop 7\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %3" : "=&v"(DST) : "v"(SA[1][3]), "v"(SB[1][3]), "v"(acc)); }   /* (&: srcC may not partially overlap vDst) */
-  // A K group's 8 MFMAs with one filler behind EACH of them: a lone wave issues in order, so what sits between two MFMAs
-  // runs in the shadow of ONE of them (64 cycles, 16 issue slots). ZERO: the plane's first group (C = 0). FIN: not void
-  // -> the plane's last group, whose last MFMA writes the VGPR tuple FIN.
-#define W1_GROUP_(SA, SB, ZERO, LAST, F0, F1, F2, F3, F4, F5, F6, F7)                                 \
-  do {                                                                                                \
-    if constexpr (ZERO) { W1_M1_Z(SA, SB); } else { W1_M1(SA, SB, 0, 0); }                            \
-    __builtin_amdgcn_sched_barrier(0); F0; __builtin_amdgcn_sched_barrier(0);                         \
-    W1_M1(SA, SB, 0, 1);                                                                              \
-    __builtin_amdgcn_sched_barrier(0); F1; __builtin_amdgcn_sched_barrier(0);                         \
-    W1_M1(SA, SB, 1, 0);                                                                              \
-    __builtin_amdgcn_sched_barrier(0); F2; __builtin_amdgcn_sched_barrier(0);                         \
-    W1_M1(SA, SB, 1, 1);                                                                              \
-    __builtin_amdgcn_sched_barrier(0); F3; __builtin_amdgcn_sched_barrier(0);                         \
-    W1_M1(SA, SB, 2, 0);                                                                              \
-    __builtin_amdgcn_sched_barrier(0); F4; __builtin_amdgcn_sched_barrier(0);                         \
-    W1_M1(SA, SB, 2, 1);                                                                              \
-    __builtin_amdgcn_sched_barrier(0); F5; __builtin_amdgcn_sched_barrier(0);                         \
-    W1_M1(SA, SB, 3, 0);                                                                              \
-    __builtin_amdgcn_sched_barrier(0); F6; __builtin_amdgcn_sched_barrier(0);                         \
-    LAST;                                                                                             \
-    __builtin_amdgcn_sched_barrier(0); F7; __builtin_amdgcn_sched_barrier(0);                         \
-  } while (0)
-#define W1_GROUP(SA, SB, ZERO, F0, F1, F2, F3, F4, F5, F6, F7) W1_GROUP_(SA, SB, ZERO, W1_M1(SA, SB, 3, 1), F0, F1, F2, F3, F4, F5, F6, F7)
-#define W1_GROUP_FIN(SA, SB, DST, F0, F1, F2, F3, F4, F5, F6, F7) W1_GROUP_(SA, SB, false, W1_M1_FIN(SA, SB, DST), F0, F1, F2, F3, F4, F5, F6, F7)
-
-  // ---- the column transform, plane by plane (VGPR tuples, elements R0 .. R0 + 3 per call; at6_col's trees) -------------
-  // after plane 2:  pA = m0, pB = m1, pC = m2  ->  pB = s = m1 + m2, pC = d = m1 - m2, pA = m0 + s
-#define W1_T2(R0)                                                                                     \
-  if constexpr (!(ABL & 16)) {                                                                        \
-    asm volatile("" : "+v"(pA), "+v"(pB), "+v"(pC));                                                  \
-    _Pragma("unroll") for (int r_ = (R0); r_ < (R0) + 4; r_++) {                                      \
-      const float s_ = pB[r_] + pC[r_]; const float d_ = pB[r_] - pC[r_];   /* (no top-level commas: macro argument) */ \
-      pA[r_] = pA[r_] + s_; pB[r_] = s_; pC[r_] = d_;                                                 \
-    }                                                                                                 \
-    asm volatile("" : "+v"(pA), "+v"(pB), "+v"(pC));                                                  \
-  }
-  // after plane 4:  pD = m3, pE = m4  ->  S, D;  pA = t0 = (m0 + s) + S, pB = t2 = 4 S + s, pC = t1 = 2 D + d, pD = 8 D + d
-#define W1_T4(R0)                                                                                     \
-  if constexpr (!(ABL & 16)) {                                                                        \
-    asm volatile("" : "+v"(pA), "+v"(pB), "+v"(pC), "+v"(pD), "+v"(pE));                              \
-    _Pragma("unroll") for (int r_ = (R0); r_ < (R0) + 4; r_++) {                                      \
-      const float S_ = pD[r_] + pE[r_]; const float D_ = pD[r_] - pE[r_];                             \
-      pA[r_] = pA[r_] + S_;                                                                           \
-      pD[r_] = __builtin_fmaf(8.f, D_, pC[r_]);                                                       \
-      pC[r_] = __builtin_fmaf(2.f, D_, pC[r_]);                                                       \
-      pB[r_] = __builtin_fmaf(4.f, S_, pB[r_]);                                                       \
-    }                                                                                                 \
-    asm volatile("" : "+v"(pA), "+v"(pB), "+v"(pC), "+v"(pD), "+v"(pE));                              \
-  }
-  // the rank-1 update of output row AI of elements R0 .. R0 + 3: yo[r][a][i] = fma(A[nu][i], t_a[r], yo[r][a][i]) as one
-  // 4x4x1 MFMA per (element, row), accumulating in place; TT = the tuple holding t_a (pA: a = 0, pC: 1, pB: 2, pD: 3)
-#define W1_ITEMS(TT, AI, R0)                                                                          \
-  if constexpr (!(ABL & 16)) {                                                                        \
-    _Pragma("unroll") for (int r_ = (R0); r_ < (R0) + 4; r_++) {                                      \
-      if (r_ < W1_NA) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+a"(yo[r_][AI]) : "v"(cvec), "v"(TT[r_])); \
-      else asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(yo[r_][AI]) : "v"(cvec), "v"(TT[r_])); \
-    }                                                                                                 \
-  }
-  float cvec = 0.f;   // A[nu][lane & 3] of the column being folded
-
-  // One stage (64 input channels of one plane); the K group 3 of the stage before (operands in Q since before the barrier)
-  // comes first, right behind the barrier, and covers the latency of this stage's first reads. FIRST (a column's first
-  // stage): nothing is pending. PSTART: the plane's first stage — the pending group is the LAST of the plane before and
-  // delivers it to the VGPR tuple FIN; G1 / G2: the fillers of this stage's last two groups (column transform pieces).
-#define W1_STAGE(FIRST, PSTART, FIN, G1A, G1B, G1C, G1D, G2A, G2B, G2C, G2D, G2E, G2F)                \
-  do {                                                                                                \
-    const unsigned curA = (unsigned)cur * (BT * WM_LD * 4), curB = (unsigned)cur * (64 * WM_LD * 4);  \
-    const int nb = SB ? (cur + 2) & 3 : (cur >= 1 ? cur - 1 : NB - 1);   /* the buffer the prefetch stage goes to */ \
-    if constexpr (SB) {                                                                               \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the Q reads of the stage before; the two counter reads */ \
-      __builtin_amdgcn_sched_barrier(0);                                                              \
-      const unsigned prevb_ = lds_flags + 16u + 4u * (unsigned)((cur + 3) & 3);                        \
-      if (sidx > 0) W1_FLAG_ADD(prevb_);   /* this wave is done reading the buffer of the stage before */ \
-      const unsigned la_ = lds_flags + 4u * (unsigned)cur;                                             \
-      W1_FLAG_WAIT(fl_landed, la_, (sidx & ~3u) + 4u);   /* all four waves' DMAs of this stage are in */ \
-      __builtin_amdgcn_sched_barrier(0);                                                              \
-    } else if constexpr (ABL & 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(8 * (NB - 2)) : "memory"); \
-    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(8 * (NB - 2)) : "memory");   \
-    W1_READ(pa, pb, 0);                                                                               \
-    __builtin_amdgcn_sched_barrier(0);                                                                \
-    if constexpr (SB) {   /* the refill target held stage sidx - 2: every wave must be done reading it */ \
-      const unsigned fa_ = lds_flags + 16u + 4u * (unsigned)nb;                                        \
-      if (sidx >= 2) { W1_FLAG_WAIT(fl_freed, fa_, ((sidx - 2u) & ~3u) + 4u); }                \
-      __builtin_amdgcn_sched_barrier(0);                                                              \
-    }                                                                                                 \
-    if constexpr (FIRST) { W1_DMA(nb, 0) W1_DMA(nb, 1) }                                              \
-    else if constexpr (PSTART) { W1_GROUP_FIN(qa, qb, FIN, W1_DMAV(nb, 0), W1_DMAU(nb, 0), W1_DMAV(nb, 1), W1_DMAU(nb, 1), (void)0, (void)0, (void)0, (void)0); } \
-    else { W1_GROUP(qa, qb, false, W1_DMAV(nb, 0), W1_DMAU(nb, 0), W1_DMAV(nb, 1), W1_DMAU(nb, 1), (void)0, (void)0, (void)0, (void)0); } \
-    __builtin_amdgcn_sched_barrier(0);                                                                \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                                \
-    W1_GROUP(pa, pb, PSTART, W1_READ_A(qa, 1), W1_READ_B(qb, 1), W1_DMAV(nb, 2), W1_DMAU(nb, 2),      \
-             W1_DMAV(nb, 3), W1_DMAU(nb, 3), W1_PF_FLAGS(), W1_PF_SELV());                            \
-    if constexpr (SB) {   /* this wave's DMAs of the NEXT stage (issued a stage ago) are in: say so */    \
-      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                     \
-      const unsigned na_ = lds_flags + 4u * (unsigned)((cur + 1) & 3);                                 \
-      W1_FLAG_ADD(na_);                                                                               \
-    } else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                                \
-    W1_GROUP(qa, qb, false, W1_READ_A(pa, 2), W1_READ_B(pb, 2), W1_PF_SELU(), W1_PF_ADD(), G1A, G1B, G1C, G1D); \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                                \
-    W1_GROUP(pa, pb, false, W1_READ_A(qa, 3), W1_READ_B(qb, 3), G2A, G2B, G2C, G2D, G2E, G2F);        \
-    if constexpr (SB) {   /* next stage's counters: landed[cur + 1], freed[its refill target = cur + 3] */ \
-      const unsigned nl_ = lds_flags + 4u * (unsigned)((cur + 1) & 3), nf_ = lds_flags + 16u + 4u * (unsigned)((cur + 3) & 3); \
-      W1_FLAG_READ(fl_landed, nl_);                                                                   \
-      W1_FLAG_READ(fl_freed, nf_);                                                                    \
-      sidx++;                                                                                         \
-    }                                                                                                 \
-    cur = cur == NB - 1 ? 0 : cur + 1;                                                                \
-  } while (0)
-#define W1_NOFILL (void)0, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0
-#define W1_STAGE_X(...) W1_STAGE(__VA_ARGS__)
-#define W1_BODY() W1_STAGE_X(false, false, pE, W1_NOFILL)
-
-  for (int nu = 0; nu < 6; nu++) {
-    W1_STAGE_X(true, true, pE, W1_NOFILL);
-    for (int kc = 1; kc < NK; kc++) W1_BODY();
-    W1_STAGE_X(false, true, pA, W1_NOFILL);                                   // plane 0 -> pA
-    for (int kc = 1; kc < NK; kc++) W1_BODY();
-    W1_STAGE_X(false, true, pB, W1_NOFILL);                                   // plane 1 -> pB
-    for (int kc = 1; kc < NK; kc++) W1_BODY();
-    W1_STAGE(false, true, pC, (void)0, (void)0, W1_T2(0), W1_T2(4), W1_T2(8), W1_T2(12), (void)0, (void)0, (void)0, (void)0);   // plane 2 -> pC, then s, d, m0 + s
-    for (int kc = 1; kc < NK; kc++) W1_BODY();
-    W1_STAGE_X(false, true, pD, W1_NOFILL);                                   // plane 3 -> pD
-    for (int kc = 1; kc < NK; kc++) W1_BODY();
-    W1_STAGE(false, true, pE, (void)0, (void)0, W1_T4(0), W1_T4(4), W1_T4(8), W1_T4(12), (void)0, (void)0, (void)0, (void)0);   // plane 4 -> pE, then t0, t1, t2, 8 D + d
-    for (int kc = 1; kc < NK; kc++) W1_BODY();
-    // the column's last K group (operands in Q) delivers plane 5 to pE; the output rows 0..2 of the finished column are
-    // folded while it drains, then t3 = (8 D + d) + m5 and row 3. The next column's first stage starts cold.
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    W1_GROUP_FIN(qa, qb, pE, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0);
-    if constexpr (!(ABL & 16)) {
-      // A[nu][:] = (1,0,0,0) (1,1,1,1) (1,-1,1,-1) (1,2,4,8) (1,-2,4,-8) (0,0,0,1); lane l carries entry l & 3
-      const float c0 = nu == 5 ? 0.f : 1.f;
-      const float c1 = nu == 1 ? 1.f : nu == 2 ? -1.f : nu == 3 ? 2.f : nu == 4 ? -2.f : 0.f;
-      const float c2 = (nu == 1 || nu == 2) ? 1.f : (nu == 3 || nu == 4) ? 4.f : 0.f;
-      const float c3 = nu == 1 ? 1.f : nu == 2 ? -1.f : nu == 3 ? 8.f : nu == 4 ? -8.f : nu == 5 ? 1.f : 0.f;
-      cvec = (lane & 3) == 0 ? c0 : (lane & 3) == 1 ? c1 : (lane & 3) == 2 ? c2 : c3;
-      asm volatile("s_nop 4" : "+v"(cvec), "+v"(pA), "+v"(pB), "+v"(pC));   // VALU-written operands -> MFMA
-      __builtin_amdgcn_sched_barrier(0);
-      W1_ITEMS(pA, 0, 0) W1_ITEMS(pA, 0, 4) W1_ITEMS(pA, 0, 8) W1_ITEMS(pA, 0, 12)
-      W1_ITEMS(pC, 1, 0) W1_ITEMS(pC, 1, 4) W1_ITEMS(pC, 1, 8) W1_ITEMS(pC, 1, 12)
-      W1_ITEMS(pB, 2, 0) W1_ITEMS(pB, 2, 4) W1_ITEMS(pB, 2, 8) W1_ITEMS(pB, 2, 12)
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_nop 15\n\ts_nop 3" : "+v"(pD), "+v"(pE));   // plane 5's MFMA result -> VALU (48 small MFMAs later, but the assembler cannot know)
-#pragma unroll
-      for (int r = 0; r < 16; r++) pD[r] = pD[r] + pE[r];
-      asm volatile("s_nop 4" : "+v"(pD));
-      __builtin_amdgcn_sched_barrier(0);
-      W1_ITEMS(pD, 3, 0) W1_ITEMS(pD, 3, 4) W1_ITEMS(pD, 3, 8) W1_ITEMS(pD, 3, 12)
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's parked prefetches have landed before the ring is recycled
-  __syncthreads();
-#undef W1_BODY
-#undef W1_STAGE_X
-#undef W1_NOFILL
-#undef W1_STAGE
-#undef W1_ITEMS
-#undef W1_T4
-#undef W1_T2
-#undef W1_GROUP_FIN
-#undef W1_GROUP
-#undef W1_GROUP_
-#undef W1_M1_FIN
-#undef W1_M1_Z
-#undef W1_M1
-#undef W1_READ
-#undef W1_READ_A
-#undef W1_READ_B
-#undef W1_DSREAD
-#undef W1_PF_ADVANCE
-#undef W1_PF_ADD
-#undef W1_PF_SELU
-#undef W1_PF_SELV
-#undef W1_PF_FLAGS
-#undef W1_DMA
-#undef W1_DMAV
-#undef W1_DMAU
-#undef W1_PIN_YOA
-#undef W1_FLAG_WAIT
-#undef W1_FLAG_READ
-#undef W1_FLAG_ADD
-
-  if constexpr (ABL & 32) {
-    float k_ = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; r++)
-#pragma unroll
-      for (int o = 0; o < 16; o++) k_ += yo[r][o >> 2][o & 3];
-    k_ += pA[0] + pB[1] + pC[2] + pD[3] + pE[4];
-    if (k_ == 12345.678f) y[tid] = k_;
-    return;
-  }
-  // ---- epilogue (the arithmetic and the staging scheme of the kernel above on this kernel's element map) ----------
-  // lane holds tiles 32 wm + 8 q + 4 lh + p (r = 4 q + p) x channel 32 wn + lc
-  const int col = 32 * wn + lc;
-  const int co = cb * WM_BC + col;
-  const float bv = bias ? bias[(size_t)grp * Cout + co] : 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; r++)
-#pragma unroll
-    for (int o = 0; o < 16; o++) {
-      float val = yo[r][o >> 2][o & 3] + bv;
-      if (relu) val = val > 0.f ? val : 0.f;
-      yo[r][o >> 2][o & 3] = val;
-    }
-  constexpr int SYF = BT * 4 * 64;
-  const int wcol = col ^ (32 * lh);   // the two k halves write rows 4 tiles apart = the same banks: swap their channel halves
-  const int HtWt = Ht * Wt;
-  const int bimg0 = (int)(t0 / HtWt);
-  const int rem0 = (int)(t0 - (long long)bimg0 * HtWt);
-  const int ty0 = rem0 / Wt, tx0 = rem0 - ty0 * Wt;
-  const int re = (tid >> 4) & 3, rc4 = (tid & 15) * 4;
-  int s_img[16], s_tyx[16];
-#pragma unroll
-  for (int r = 0; r < 16; r++) {
-    const int tl = wave + NW * r;
-    const unsigned n = (unsigned)(tx0 + tl), qq = n / (unsigned)Wt, tx = n - qq * (unsigned)Wt;
-    const unsigned m = (unsigned)ty0 + qq, q2 = m / (unsigned)Ht, ty = m - q2 * (unsigned)Ht;
-    s_img[r] = bimg0 + (int)q2;
-    s_tyx[r] = t0 + tl < tend ? (int)(ty | (tx << 16)) : 0xffff;
-  }
-  if (POOL != 1) {
-#pragma unroll
-    for (int a = 0; a < 4; a++) {
-      float* sY = smem + (a & 1) * SYF;
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int tl = 32 * wm + 8 * (r >> 2) + 4 * lh + (r & 3);
-#pragma unroll
-        for (int e = 0; e < 4; e++) sY[(tl * 4 + e) * 64 + wcol] = yo[r][a][e];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int tl = wave + NW * r;
-        const int ty = s_tyx[r] & 0xffff, tx = s_tyx[r] >> 16;
-        const int oy = 4 * ty + a, ox = 4 * tx + re;
-        if (oy < H && ox < W)
-          *reinterpret_cast<v4f*>(y + (((long long)s_img[r] * H + oy) * W + ox) * Cout + cb * WM_BC + rc4) =
-              *reinterpret_cast<const v4f*>(&sY[(tl * 4 + re) * 64 + (rc4 ^ (32 * ((tl >> 2) & 1)))]);
-      }
-    }
-  }
-  if (POOL != 0) {
-    float* yp = POOL == 1 ? y : ypool;
-    float* sY = smem;
-    const int Hp = H / 2, Wp = W / 2;
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int tl = 32 * wm + 8 * (r >> 2) + 4 * lh + (r & 3);
-#pragma unroll
-      for (int a2 = 0; a2 < 2; a2++)
-#pragma unroll
-        for (int e2 = 0; e2 < 2; e2++) {
-          float p = yo[r][2 * a2][2 * e2];
-          const float p1 = yo[r][2 * a2][2 * e2 + 1], p2 = yo[r][2 * a2 + 1][2 * e2], p3 = yo[r][2 * a2 + 1][2 * e2 + 1];
-          p = p1 > p ? p1 : p;
-          p = p2 > p ? p2 : p;
-          p = p3 > p ? p3 : p;
-          sY[(tl * 4 + 2 * a2 + e2) * 64 + wcol] = p;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int tl = wave + NW * r;
-      const int ty = s_tyx[r] & 0xffff, tx = s_tyx[r] >> 16;
-      const int py = 2 * ty + (re >> 1), px = 2 * tx + (re & 1);
-      if (py < Hp && px < Wp)
-        *reinterpret_cast<v4f*>(yp + (((long long)s_img[r] * Hp + py) * Wp + px) * Cout + cb * WM_BC + rc4) =
-            *reinterpret_cast<const v4f*>(&sY[(tl * 4 + re) * 64 + (rc4 ^ (32 * ((tl >> 2) & 1)))]);
     }
   }
 }
@@ -1073,36 +595,16 @@ extern "C" int pcnn_winograd43_conv_fwd(const float* v, const float* ut, const f
   // Block map (see the kernel). cb-major: every XCD owns one channel block and streams its eighth of the filter bank
   // once; pays when U outweighs V — the deep layers of a single frame (conv4_2: U 37.7 MB, V 22 MB: fabric traffic
   // 8 U + V = 324 MB tile-block-major, U + 8 V = 215 MB channel-block-major; conv5_x 307 -> 85 MB: 64 -> 42 us).
-  // PCNN_WINO_MODE overrides for experiments and the variant-equality test: bit 0 force cb-major (when ncb == 8),
-  // bit 1 the one-wave-per-SIMD kernel, bit 3 keep the round-3 zeroing v_movs; -1 / unset = the library's choice.
+  // PCNN_WINO_MODE overrides the map for experiments and the variant-equality test: 1 = cb-major wherever ncb == 8,
+  // 0 = never; unset = the library's choice. (The round-4 kernel variants this switch also selected — the one-wave-per-
+  // SIMD 32x32x2 kernel, the round-3 zeroing v_movs — left the library in round 5: tools/variants/)
   static const int env_mode = [] { const char* e = getenv("PCNN_WINO_MODE"); return e ? atoi(e) : -1; }();
   const double u_bytes = 36.0 * Cout * (double)Cin * 4.0 * groups, v_bytes = 36.0 * (double)T * Cin * 4.0;
   int mode = (ncb == 8 && u_bytes > v_bytes) ? 1 : 0;
-  bool zc = true;
-  if (env_mode >= 0) { mode = ((env_mode & 1) && ncb == 8) ? 1 : 0; zc = !(env_mode & 8); }
+  if (env_mode >= 0) mode = ((env_mode & 1) && ncb == 8) ? 1 : 0;
   const long long nblocks = (mode & 1) ? 8 * nbt : blocks;
-  // One wave per SIMD on the 32x32x2 MFMA (wino43_mfma_w1_kernel, 64-tile blocks, same bits): opt-in, PCNN_WINO_MODE bit 1
-  // (wherever there is no Cin split). Measured at 2 x 16 frames on warmed-up clocks (tools/wino_w1_probe.hip, best of 4
-  // alternating runs; profiles/r04_wino_w1_probe.txt): alone it loses to the 32-tile pairs on every layer — conv4_2 1.60 vs
-  // 1.54 ms, conv3_2 1.70 vs 1.56, conv2_2 1.83 vs 1.75, conv2_1 1.11 vs 1.03, conv5_x (320 blocks on 256 CUs) 0.64 vs
-  // 0.49 — and the step on ONE stream loses 3.3 % (709 vs 733 frames/s); on two or three streams the step GAINS 0.8 %
-  // (777.6 vs 771.6, 779.5 vs 773.5; LINEMOD 186.7 vs 185.3; profiles/r04_w1_pipeline_ab.txt): a third less operand
-  // traffic leaves more of the fabric to the other batches' streaming kernels. Under one percent either way, against a
-  // trunk kernel that is 6 % slower whenever it runs alone: the pairs stay the default.
-  const long long nbt64 = (long long)groups * ((tpg + 63) / 64);
-  const bool w1 = env_mode >= 0 && (env_mode & 2) && S == 1;   // (a Cin split sums in another order: its launches keep their kernel)
-  if (w1) {
-    const long long nb64 = (mode & 1) ? 8 * nbt64 : ((nbt64 + 7) / 8) * 8 * ncb;
-#define WM_GO1(P) PCNN_LAUNCH((wino43_mfma_w1_kernel<P, 0, 3, 0>), dim3((unsigned)nb64), dim3(256), 0, stream, v, ut, bias, y, y_pool, \
-                              H, W, Cin, Cout, Ht, Wt, T, tpg, relu, (int)nbt64, ncb, mode)
-    if (pool == 0) WM_GO1(0); else if (pool == 1) WM_GO1(1); else WM_GO1(2);
-#undef WM_GO1
-    return check_launch("winograd43_conv_fwd");
-  }
-#define WM_GO(P, Y, BIAS, RELU, KS, STRIDE) do { if (zc) PCNN_LAUNCH((wino43_mfma_kernel<P, 1, 0, 1>), dim3((unsigned)nblocks, KS), dim3(256), 0, stream, v, ut, BIAS, Y, y_pool, \
-                             H, W, Cin, Cout, Ht, Wt, T, tpg, RELU, (int)nbt, ncb, KS, (long long)(STRIDE), mode); \
-    else PCNN_LAUNCH((wino43_mfma_kernel<P, 1, 0, 0>), dim3((unsigned)nblocks, KS), dim3(256), 0, stream, v, ut, BIAS, Y, y_pool, \
-                             H, W, Cin, Cout, Ht, Wt, T, tpg, RELU, (int)nbt, ncb, KS, (long long)(STRIDE), mode); } while (0)
+#define WM_GO(P, Y, BIAS, RELU, KS, STRIDE) PCNN_LAUNCH((wino43_mfma_kernel<P, 1, 0, 1>), dim3((unsigned)nblocks, KS), dim3(256), 0, stream, v, ut, BIAS, Y, y_pool, \
+                             H, W, Cin, Cout, Ht, Wt, T, tpg, RELU, (int)nbt, ncb, KS, (long long)(STRIDE), mode)
   if (S == 1) {
     if (pool == 0) WM_GO(0, y, bias, relu, 1, 0); else if (pool == 1) WM_GO(1, y, bias, relu, 1, 0); else WM_GO(2, y, bias, relu, 1, 0);
   } else {

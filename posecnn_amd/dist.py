@@ -132,7 +132,7 @@ def pack_detections(rows, count, frame_offset=0):
     return buf
 
 
-def all_gather_packed(rows, count, frame_offset=0, group=None):
+def all_gather_packed(rows, count, frame_offset=0, group=None, packed=None):
     """The collective itself: returns the packed buffer of every rank, [W, cap+1, 14] (count of
     rank r in [r, cap, 0]). Asynchronous with respect to the host on RCCL.
 
@@ -140,7 +140,9 @@ def all_gather_packed(rows, count, frame_offset=0, group=None):
     --backend gloo --shared-device`: RCCL refuses two ranks on one device, and gloo's all-gather takes host
     tensors only) the packed block is staged through the host: D2H on the batch's stream, wait for THAT copy,
     gather on gloo; the result is a host tensor, which `HostDrain` takes as it is."""
-    buf = pack_detections(rows, count, frame_offset)
+    # `packed`: the block already assembled on the device by ops.det_assemble(..., frame_offset=...) — same content as
+    # pack_detections(rows, count, frame_offset), without its four framework launches
+    buf = packed if packed is not None else pack_detections(rows, count, frame_offset)
     if not dist.is_initialized():
         return buf.unsqueeze(0)   # single process, no communicator: nothing to exchange
     world = dist.get_world_size(group)

@@ -139,10 +139,11 @@ class Detections(object):
     """Fixed-capacity per-batch detections kept on the device (what ranks exchange, §8e):
     rows[cap,14] = box7 | pose7 (quaternion already taken from poses_tanh), count[1]."""
 
-    def __init__(self, rows, count, label_2d=None):
+    def __init__(self, rows, count, label_2d=None, packed=None):
         self.rows = rows
         self.count = count
         self.label_2d = label_2d
+        self.packed = packed      # [cap + 1, 14]: the rows in global frame numbering + (count, 0, ...): what dist.all_gather_packed sends
 
     def to_host(self):
         n = int(self.count.item())
@@ -151,7 +152,7 @@ class Detections(object):
 
 
 def im_segment_batch(net, data, K, extents, points, symmetry, data_p=None, planted=None, feed_cache=None,
-                     with_losses=False, gt_poses=None, strict_reference=False):
+                     with_losses=False, gt_poses=None, strict_reference=False, frame_offset=None):
     """B frames, one pass, no host synchronisation. `data` is the mean-subtracted BGR blob
     [B,H,W,3] already on the device. Returns `Detections` (device tensors; rows past count are 0).
 
@@ -213,7 +214,12 @@ def im_segment_batch(net, data, K, extents, points, symmetry, data_p=None, plant
     # poses[i,:4] = poses_tanh[i, 4c:4c+4] (lib/fcn/test.py:206-211) and the detection rows box7 | quat4 | trans3, on
     # the device; training mode emits 9 rows per maximum (the box + 8 jitters, .cu.cc:440-466) — the detection
     # product is the un-jittered first row of each group
-    det_rows, det_count = ops.det_assemble(rois, poses_tanh, top_pose, count, row_stride=9 if is_train else 1)
+    packed = None
+    if frame_offset is None:
+        det_rows, det_count = ops.det_assemble(rois, poses_tanh, top_pose, count, row_stride=9 if is_train else 1)
+    else:   # (a rank's first global frame index: the all-gather block comes out of the same launch)
+        det_rows, det_count, packed = ops.det_assemble(rois, poses_tanh, top_pose, count, row_stride=9 if is_train else 1,
+                                                       frame_offset=frame_offset)
     net.layers.update({"rois": rois, "poses_init": top_pose, "poses_tanh": poses_tanh,
                        "poses_target": top_target, "poses_weight": top_weight})
     if with_losses:
@@ -223,12 +229,15 @@ def im_segment_batch(net, data, K, extents, points, symmetry, data_p=None, plant
         if "gt_label_weight" not in net.layers:   # (a with_losses graph has evaluated it in setup())
             net.layers["gt_label_weight"] = ops.hard_label(net.get_output("prob_normalized"), feed["gt_label_2d"],
                                                            net.threshold_label)
-        mul = poses_tanh * top_weight
-        pred = mul * torch.rsqrt(torch.clamp((mul * mul).sum(dim=1, keepdim=True), min=1e-12))
+        if poses_tanh.is_cuda and poses_tanh.shape[1] <= 256 and not (torch.is_grad_enabled() and poses_tanh.requires_grad):
+            pred = ops.pose_l2_normalize(poses_tanh, top_weight, num_rows=count)   # (one launch instead of six framework ops)
+        else:
+            mul = poses_tanh * top_weight
+            pred = mul * torch.rsqrt(torch.clamp((mul * mul).sum(dim=1, keepdim=True), min=1e-12))
         net.layers["poses_pred"] = pred
         net.layers["loss_pose"] = ops.average_distance_loss(pred, top_target, top_weight, feed["points"],
                                                             feed["symmetry"], 0.01, num_rows=count)[0]
-    return Detections(det_rows, det_count, label_2d)
+    return Detections(det_rows, det_count, label_2d, packed)
 
 
 def finalize_batch(det_rows, count):

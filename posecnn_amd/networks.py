@@ -620,6 +620,22 @@ class Network(object):
             y, t = ops.fc_skinny(x.contiguous(), self._fc_wt(name, w), b, "tanh", num_rows=self.rows_count)
             self.layers[name], self.layers[tanh_name] = y, t
             return self.feed(t)
+        if (x.dim() == 2 and getattr(self, "rows_count", None) is not None and x.is_cuda and dim % 64 == 0 and dim >= 128
+                and num_out % 4 == 0 and not (torch.is_grad_enabled() and (w.requires_grad or x.requires_grad))):
+            # more rows than the skinny kernel takes (a batch): the row kernel on a zero-padded filter, tanh in its epilogue
+            key = (w.data_ptr(), w._version, b.data_ptr(), b._version)
+            hit = self._wino_u.get(("fc_pad", name))
+            if hit is None or hit[0] != key:
+                npad = (num_out + 63) // 64 * 64
+                wp = torch.zeros((npad, dim), dtype=torch.float32, device=w.device)
+                wp[:num_out] = w.detach().t()
+                bp = torch.zeros((npad,), dtype=torch.float32, device=w.device)
+                bp[:num_out] = b.detach()
+                hit = (key, wp, bp)
+                self._wino_u[("fc_pad", name)] = hit
+            y, t = ops.fc_rows_cols(x.contiguous(), hit[1], hit[2], num_out, "tanh", num_rows=self.rows_count)
+            self.layers[name], self.layers[tanh_name] = y, t
+            return self.feed(t)
         return self.fc(num_out, relu=False, name=name, num_in=num_in).tanh(name=tanh_name)
 
     # ---- element-wise -----------------------------------------------------------------------------
@@ -777,6 +793,7 @@ class vgg16_convs(Network):
         self.with_losses = bool(is_train) if with_losses is None else bool(with_losses)
         self.planted = None
         self.grouped_towers = True    # RGB-D inference: both towers as one grouped launch sequence
+        self.mfma_heads = True        # big batches: add_score / add_score_vertex + the 1/8-resolution `score` / `vertex_pred` products in one launch per head
         self.head_gemm = True         # 1x1 head convs (incl. the RGB-D concat) on the library's own fp32-MFMA row kernel
         self._head_wt = {}
 
@@ -918,9 +935,8 @@ class vgg16_convs(Network):
                 # conv1_1 -> conv1_2 -> pool1 in one kernel: V (2.25 x 78.6 MB per frame) never touches HBM (csrc/conv_first.hip)
                 frag = self._wino_u.get("conv12_frag")
                 if frag is None or frag[0] is not wt:
-                    # the filter bank fragment-major (one contiguous KB per B-operand load); the opt-in pipelined kernel takes U^T as is
-                    lay = 0 if os.environ.get("PCNN_CONV12") == "2" else 1
-                    frag = (wt, ops.conv12_fragment_major(wt) if lay else wt, lay)
+                    # the filter bank fragment-major (one contiguous KB per B-operand load)
+                    frag = (wt, ops.conv12_fragment_major(wt), 1)
                     self._wino_u["conv12_frag"] = frag
                 y = (ops.conv1_1_conv1_2_fused_raw(d, dp, packed[0][0], packed[0][1], frag[1], bias, ut2_layout=frag[2]) if raw
                      else ops.conv1_1_conv1_2_fused(x, packed[0][0], packed[0][1], frag[1], bias, groups=2, ut2_layout=frag[2]))
@@ -1058,13 +1074,14 @@ class vgg16_convs(Network):
         a, b5 = self.layers.get(s4), self.layers.get(s5)
         if not (self.small_heads and self.fused_heads and isinstance(a, torch.Tensor) and isinstance(b5, torch.Tensor)
                 and a.is_cuda and a.dim() == 4 and a.shape[1] % 2 == 0 and a.shape[2] % 2 == 0
-                # a latency tool: one launch instead of five wins while the launch is what costs (1 frame: 54 vs 88 us for both
-                # heads); the product itself runs on the vector ALUs, and from a few frames on the library's MFMA 1x1
-                # convolution is faster (16 frames: 237 vs 165 us, tools/bench_heads_small.py)
-                and a.shape[0] * a.shape[1] * a.shape[2] <= self.small_heads_max_pixels
-                # the kernel keeps 32 pixels x U inputs and the U x Cout weights in 60 KB of LDS (csrc/heads_small.hip);
-                # a larger head (num_classes >= 30 on the vertex head) takes the deconv + add + 1x1 path instead of EINVAL
-                and c_i % 4 == 0 and 4 * (32 * c_i + c_i * c_o) <= 60 * 1024
+                # one launch instead of five. Up to a frame or two (`small_heads_max_pixels`) the product runs on the vector
+                # ALUs out of LDS (csrc/heads_small.hip head_lowres_kernel: 54 vs 88 us for both heads of one frame; its LDS
+                # holds 32 pixels x U inputs and the U x Cout filter: 60 KB); beyond that on the matrix cores
+                # (head_lowres_mfma_kernel, round 5: at 16 frames the vector version lost to the library's 1x1 convolution,
+                # 237 vs 165 us — the last framework kernels of the heads). Heads that fit neither take deconv + add + 1x1.
+                and c_i % 4 == 0
+                and ((a.shape[0] * a.shape[1] * a.shape[2] <= self.small_heads_max_pixels and 4 * (32 * c_i + c_i * c_o) <= 60 * 1024)
+                     or (self.mfma_heads and c_i % 16 == 0 and c_o <= 96 and 4 * 64 * (c_i + 4) <= 60 * 1024))
                 and (self.keep_prob_queue is None or float(self.keep_prob_queue) >= 1.0)
                 and (up_name + "/weights") not in self.vars
                 and not (torch.is_grad_enabled() and self.trainable)):
@@ -1078,7 +1095,14 @@ class vgg16_convs(Network):
             hit = (key, w.detach().reshape(c_o, c_i).t().contiguous())     # [units, out]: the TF variable [1,1,in,out] as it is
             self._head_wt[("lowres", conv_name)] = hit
         planted = self.planted.get(plant_key) if self.planted is not None else None
-        add, z = ops.head_lowres(a, b5, hit[1], planted=planted, kernel=4, stride=2)
+        if a.shape[0] * a.shape[1] * a.shape[2] <= self.small_heads_max_pixels and 4 * (32 * c_i + c_i * c_o) <= 60 * 1024:
+            add, z = ops.head_lowres(a, b5, hit[1], planted=planted, kernel=4, stride=2)
+        else:
+            hitm = self._head_wt.get(("lowres_mfma", conv_name))
+            if hitm is None or hitm[0] != key:
+                hitm = (key, ops.head_lowres_mfma_filter(hit[1]))
+                self._head_wt[("lowres_mfma", conv_name)] = hitm
+            add, z = ops.head_lowres_mfma(a, b5, hitm[1], c_o, planted=planted, kernel=4, stride=2)
         self.layers[up_name] = _Lazy(lambda: self._deconv_bilinear(b5, 4, 2))
         self.layers[add_name] = add
         self.layers[drop_name] = add

@@ -635,6 +635,24 @@ def fc_rows(x, wt, bias, relu=True, num_rows=None, addend=None):
     return y
 
 
+def fc_rows_cols(x, wt_padded, bias_padded, out_features, activation="none", num_rows=None):
+    """`fc_rows` for a width that is no multiple of 64 (fc8: 88): wt_padded [Npad, K] / bias_padded [Npad] zero-padded to a
+    multiple of 64, y [M, out_features]. activation "none" | "relu" | "tanh"; "tanh" returns (linear, tanh(linear))."""
+    x = _dev(x, "x", torch.float32)
+    wt_padded = _dev(wt_padded, "wt_padded", torch.float32)
+    bias_padded = _aligned16(_dev(bias_padded, "bias_padded", torch.float32))
+    if x.dim() != 2 or wt_padded.dim() != 2 or wt_padded.shape[1] != x.shape[1] or bias_padded.numel() != wt_padded.shape[0]:
+        raise ValueError("x must be [M, K], wt_padded [Npad, K], bias_padded [Npad]")
+    M, K = x.shape
+    act = {"none": 0, "relu": 1, "tanh": 2}[activation]
+    y = torch.empty((M, int(out_features)), dtype=torch.float32, device=x.device)
+    y2 = torch.empty_like(y) if act == 2 else None
+    nr = _dev(num_rows, "num_rows", torch.int32) if num_rows is not None else None
+    check("pcnn_fc_rows_cols_fwd", lib().pcnn_fc_rows_cols_fwd(_ptr(x), _ptr(wt_padded), _ptr(bias_padded), M, K, wt_padded.shape[0],
+                                                              int(out_features), act, _ptr(nr), _ptr(y), _ptr(y2), _stream(x)))
+    return (y, y2) if act == 2 else y
+
+
 _tickets = {}
 
 
@@ -695,9 +713,54 @@ def head_lowres(score4, score5, weights_t, planted=None, kernel=4, stride=2):
     return add, z
 
 
-def det_assemble(rois, poses_tanh, top_pose, num_rows, row_stride=1):
+def head_lowres_mfma_filter(weights_t):
+    """The filter of `head_lowres_mfma`: weights_t [U, Cout] (the TF variable [1,1,U,Cout] as it is) -> [ceil(Cout/16)*16, U],
+    N-major with K contiguous, zero rows past Cout (cache it per weight version)."""
+    U, Cout = weights_t.shape
+    npad = (Cout + 15) // 16 * 16
+    w = torch.zeros((npad, U), dtype=torch.float32, device=weights_t.device)
+    w[:Cout] = weights_t.t()
+    return w
+
+
+def head_lowres_mfma(score4, score5, weights_nk, out_channels, planted=None, kernel=4, stride=2):
+    """`head_lowres` for many pixels per launch: the same add (bit-identical `add`), the 1x1 product on the matrix cores.
+    weights_nk from `head_lowres_mfma_filter`. U % 16 == 0, out_channels <= 96."""
+    score4 = _dev(score4, "score4", torch.float32)
+    score5 = _dev(score5, "score5", torch.float32)
+    weights_nk = _dev(weights_nk, "weights_nk", torch.float32)
+    pl = _dev(planted, "planted", torch.float32) if planted is not None else None
+    B, h, w, U = score4.shape
+    Cout = int(out_channels)
+    if (tuple(score5.shape) != (B, h // stride, w // stride, U) or weights_nk.dim() != 2 or weights_nk.shape[1] != U
+            or weights_nk.shape[0] != (Cout + 15) // 16 * 16 or (pl is not None and tuple(pl.shape) != tuple(score4.shape))):
+        raise ValueError("score4 [B,h,w,U], score5 [B,h/s,w/s,U], weights_nk [ceil(Cout/16)*16, U], planted like score4")
+    add = torch.empty_like(score4)
+    z = torch.empty((B, h, w, Cout), dtype=torch.float32, device=score4.device)
+    check("pcnn_head_lowres_mfma_fwd", lib().pcnn_head_lowres_mfma_fwd(_ptr(score4), _ptr(score5), _ptr(pl), _ptr(weights_nk), B, h, w, U, Cout,
+                                                                      int(kernel), int(stride), _ptr(add), _ptr(z), _stream(score4)))
+    return add, z
+
+
+def pose_l2_normalize(poses_tanh, poses_weight, num_rows=None):
+    """poses_pred = l2_normalize(poses_tanh * poses_weight, dim=1) (vgg16_convs.py:195-197) in one launch; rows at or past
+    the device-side count are zeros."""
+    x = _dev(poses_tanh, "poses_tanh", torch.float32)
+    w = _dev(poses_weight, "poses_weight", torch.float32)
+    if x.dim() != 2 or tuple(w.shape) != tuple(x.shape):
+        raise ValueError("poses_tanh and poses_weight must be [R, 4C]")
+    nr = _dev(num_rows, "num_rows", torch.int32) if num_rows is not None else None
+    out = torch.empty_like(x)
+    check("pcnn_pose_l2_normalize_fwd", lib().pcnn_pose_l2_normalize_fwd(_ptr(x), _ptr(w), _ptr(nr), x.shape[0], x.shape[1], _ptr(out), _stream(x)))
+    return out
+
+
+def det_assemble(rois, poses_tanh, top_pose, num_rows, row_stride=1, frame_offset=None):
     """lib/fcn/test.py:206-211 on the device: rows [ceil(R / stride), 14] = box7 | quaternion of the row's class |
-    translation, zeros past the device-side count; count [1] int32 = *num_rows // stride."""
+    translation, zeros past the device-side count; count [1] int32 = *num_rows // stride.
+    With `frame_offset` (a rank's first global frame index) the same launch writes the block that rank hands to the
+    detection all-gather — rows with column 0 shifted to global frame numbering + a last row (count, 0, ...) — and
+    returns (rows, count, block) with `rows` a view of the block's first rows."""
     rois = _dev(rois, "rois", torch.float32)
     poses_tanh = _dev(poses_tanh, "poses_tanh", torch.float32)
     top_pose = _dev(top_pose, "top_pose", torch.float32)
@@ -706,8 +769,14 @@ def det_assemble(rois, poses_tanh, top_pose, num_rows, row_stride=1):
     if rois.dim() != 2 or rois.shape[1] != 7 or tuple(top_pose.shape) != (R, 7) or poses_tanh.shape[0] != R or poses_tanh.shape[1] % 4:
         raise ValueError("rois [R,7], top_pose [R,7], poses_tanh [R,4C]")
     n_out = (R + row_stride - 1) // row_stride
-    rows = torch.empty((n_out, 14), dtype=torch.float32, device=rois.device)
     count = torch.empty((1,), dtype=torch.int32, device=rois.device)
+    if frame_offset is not None:
+        block = torch.empty((n_out + 1, 14), dtype=torch.float32, device=rois.device)
+        check("pcnn_det_assemble_packed_fwd",
+              lib().pcnn_det_assemble_packed_fwd(_ptr(rois), _ptr(poses_tanh), _ptr(top_pose), _ptr(nr), R, int(row_stride),
+                                                 poses_tanh.shape[1] // 4, float(frame_offset), _ptr(block), _ptr(count), _stream(rois)))
+        return block[:n_out], count, block
+    rows = torch.empty((n_out, 14), dtype=torch.float32, device=rois.device)
     check("pcnn_det_assemble_fwd", lib().pcnn_det_assemble_fwd(_ptr(rois), _ptr(poses_tanh), _ptr(top_pose), _ptr(nr), R, int(row_stride),
                                                               poses_tanh.shape[1] // 4, _ptr(rows), _ptr(count), _stream(rois)))
     return rows, count

@@ -134,3 +134,98 @@ def test_two_ranks_on_one_gpu_through_the_real_launcher(gpu):
     assert out["outputs_equal_serial"] is True, out["outputs_equal_serial_detail"]
     assert out["config"]["detections_per_step"] >= 2 * 3 * 16    # both ranks' frames carry their planted objects
     assert pg["all_gather_us"] is not None and pg["all_gather_us"] > 0
+
+
+def test_head_lowres_mfma_equals_the_op_sequence_it_replaces(gpu):
+    """csrc/heads_small.hip head_lowres_mfma_kernel (what `vgg16_convs` launches per head from a few frames on: vgg16_convs.py:128-142,
+    :151-163 in the fused-heads form): add_score = score_conv4 + deconv(4,2)(score_conv5) [+ planted] must carry the bits of
+    pcnn_deconv_bilinear_fwd + two framework adds (and of the few-frame kernel head_lowres); the 1x1 product, now on the
+    matrix cores, is checked against float64. Shapes: the two heads at 16 frames' scale, a pixel count that is no multiple
+    of the 64-pixel workgroup, 93 outputs (6 column tiles, the last one ragged), 5 outputs (one ragged tile)."""
+    import torch
+    from posecnn_amd import ops
+    F = np.float32
+    rng = np.random.default_rng(21)
+    for (B, h, w, U, Cout, plant) in ((4, 60, 80, 64, 22, True), (2, 60, 80, 128, 66, False), (3, 6, 10, 64, 5, True), (1, 2, 2, 16, 3, False),
+                                      (1, 12, 16, 128, 93, True)):
+        a = T(gpu, rng.standard_normal((B, h, w, U)).astype(F))
+        b5 = T(gpu, rng.standard_normal((B, h // 2, w // 2, U)).astype(F))
+        pl = T(gpu, rng.standard_normal((B, h, w, U)).astype(F)) if plant else None
+        wt = T(gpu, (rng.standard_normal((U, Cout)) / U ** 0.5).astype(F))
+        add, z = ops.head_lowres_mfma(a, b5, ops.head_lowres_mfma_filter(wt), Cout, planted=pl)
+        want = a + ops.deconv_bilinear(b5, 4, 2)
+        if plant:
+            want = want + pl
+        same(N(add), N(want), "add_score %s" % ((B, h, w, U),))
+        if 4 * (32 * U + U * Cout) <= 60 * 1024:
+            add_v, z_v = ops.head_lowres(a, b5, wt, planted=pl)
+            same(N(add), N(add_v), "add_score vs the few-frame kernel")
+            assert float((z - z_v).abs().max()) < 1e-5 * max(1.0, float(z_v.abs().max()))
+        zr = want.double().reshape(-1, U) @ wt.double()
+        assert float((z.double().reshape(-1, Cout) - zr).abs().max()) < 1e-5 * max(1.0, float(zr.abs().max()))
+    with pytest.raises(Exception):
+        ops.head_lowres_mfma(a, b5, ops.head_lowres_mfma_filter(wt)[:16], Cout)          # filter rows != ceil(Cout / 16) * 16
+
+
+def test_fc_rows_cols_is_fc8_and_tanh_in_one_launch(gpu):
+    """pcnn_fc_rows_cols_fwd (`Network.fc_tanh` at more rows than the skinny kernel takes: fc8 4096 -> 4 C = 88 and
+    poses_tanh, lib/networks/vgg16_convs.py:192-193): the row kernel on a zero-padded filter, only the 88 real columns
+    stored, tanh in the epilogue, rows at or past the device-side count zero. Against float64."""
+    import torch
+    from posecnn_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for (M, K, N_, cnt) in ((300, 4096, 88, 131), (64, 256, 56, 64), (130, 128, 4, 1), (70, 512, 128, 0)):
+        x = torch.randn((M, K), generator=g).to(gpu)
+        w = (torch.randn((N_, K), generator=g) / K ** 0.5).to(gpu)
+        b = torch.randn((N_,), generator=g).to(gpu)
+        npad = (N_ + 63) // 64 * 64
+        wp = torch.zeros((npad, K), device=gpu); wp[:N_] = w
+        bp = torch.zeros((npad,), device=gpu); bp[:N_] = b
+        count = torch.tensor([cnt], dtype=torch.int32, device=gpu)
+        y, t = ops.fc_rows_cols(x, wp, bp, N_, "tanh", num_rows=count)
+        ref = x.double() @ w.double().t() + b.double()
+        assert tuple(y.shape) == (M, N_) and tuple(t.shape) == (M, N_)
+        assert float((y[:cnt].double() - ref[:cnt]).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())) if cnt else True
+        assert float((t[:cnt].double() - torch.tanh(ref[:cnt])).abs().max()) < 2e-6 if cnt else True
+        assert not bool(y[cnt:].any()) and not bool(t[cnt:].any())
+        yr = ops.fc_rows_cols(x, wp, bp, N_, "relu", num_rows=count)
+        assert float((yr[:cnt].double() - torch.relu(ref[:cnt])).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())) if cnt else True
+    with pytest.raises(Exception):
+        ops.fc_rows_cols(x, wp, bp, 30, "none")        # 30 is no multiple of 4
+
+
+def test_pose_l2_normalize_and_the_packed_detection_block(gpu):
+    """Two launches that replace ten framework ones per step: poses_pred = l2_normalize(poses_tanh * poses_weight, dim 1)
+    (vgg16_convs.py:195-197) and the all-gather block of posecnn_amd/dist.py::pack_detections written by det_assemble."""
+    import torch
+    from posecnn_amd import dist as pdist, ops
+    rng = np.random.default_rng(8)
+    F = np.float32
+    for (R, C, cnt) in ((45, 22, 30), (9, 14, 9), (200, 64, 0)):
+        x = T(gpu, np.tanh(rng.standard_normal((R, 4 * C))).astype(F))
+        w = np.zeros((R, 4 * C), F)
+        for r in range(R):
+            if r % 3:
+                c = int(rng.integers(1, C)); w[r, 4 * c:4 * c + 4] = 1
+        w = T(gpu, w)
+        count = torch.tensor([cnt], dtype=torch.int32, device=gpu)
+        got = ops.pose_l2_normalize(x, w, num_rows=count)
+        mul = (x * w).double()
+        want = mul * torch.rsqrt(torch.clamp((mul * mul).sum(dim=1, keepdim=True), min=1e-12))
+        assert float((got[:cnt].double() - want[:cnt]).abs().max()) < 3e-7 if cnt else True
+        assert not bool(got[cnt:].any())
+    # the packed block
+    C, R, n = 22, 27, 18
+    rois = rng.standard_normal((R, 7)).astype(F)
+    rois[:, 0] = rng.integers(0, 16, R)
+    rois[:, 1] = rng.integers(0, C, R)
+    pt = np.tanh(rng.standard_normal((R, 4 * C))).astype(F)
+    tp = rng.standard_normal((R, 7)).astype(F)
+    count = torch.tensor([n], dtype=torch.int32, device=gpu)
+    for stride in (1, 9):
+        rows0, c0 = ops.det_assemble(T(gpu, rois), T(gpu, pt), T(gpu, tp), count, row_stride=stride)
+        for off in (0, 48):
+            rows, c1, block = ops.det_assemble(T(gpu, rois), T(gpu, pt), T(gpu, tp), count, row_stride=stride, frame_offset=off)
+            want = pdist.pack_detections(rows0, c0, off)
+            same(N(block), N(want), "packed block, stride %d offset %d" % (stride, off))
+            assert int(c1) == int(c0) and rows.data_ptr() == block.data_ptr()

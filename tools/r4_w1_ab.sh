@@ -1,3 +1,4 @@
+# HISTORICAL (round 4): the kernel variants these switches selected (PCNN_WINO_MODE bits 1 / 3, PCNN_CONV12=2) left the library in round 5 -> tools/variants/
 # Round-4 experiment: the one-wave-per-SIMD trunk kernel (wino43_mfma_w1_kernel, PCNN_WINO_MODE=2) against the 32-tile pairs
 # (the library's choice) — alone (tools/wino_w1_probe, tools/mfma_bare) and in the whole step on 1 / 2 / 3 streams and at the
 # LINEMOD configuration. bash tools/r4_w1_ab.sh <outdir>; what it printed for round 4 is profiles/r04_w1_pipeline_ab.txt,

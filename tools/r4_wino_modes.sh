@@ -1,3 +1,4 @@
+# HISTORICAL (round 4): the kernel variants these switches selected (PCNN_WINO_MODE bits 1 / 3, PCNN_CONV12=2) left the library in round 5 -> tools/variants/
 # Round-4 experiment: wino43_mfma_kernel variants (PCNN_WINO_MODE: 8 = round-3 kernel, 0 = zero-C first MFMAs, bit 0 = channel-block-major
 # map where it applies; the priority and persistent-grid variants measured with this script are recorded in csrc/wino_mfma.hip). bash tools/r4_wino_modes.sh <outdir>
 O=${1:-gpurun_out/r4c}; mkdir -p $O

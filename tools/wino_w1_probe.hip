@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../posecnn_amd/csrc/wino_mfma.hip"
+#include "variants/wino43_mfma_w1_kernel.inc"   // (round 5: the kernel under test lives here, no longer in the library)
 
 struct Shape { const char* name; int B, H, W, Cin, Cout, groups; };
 
