@@ -590,32 +590,56 @@ def main(argv=None):
     hv = kern.get(vote_name, {"avg_us": float("nan"), "calls": 0})
     achieved = alg_bytes / (hv["avg_us"] * 1e-6) / 1e9 if hv["calls"] else float("nan")
     hough_us = sum(v["avg_us"] for k, v in kern.items() if k.startswith("hv_"))
-    # HBM traffic of the kernel from PMC counters: collected offline in separate --pmc passes (they
-    # cannot share a run with the timed region) at this same workload; see profiles/README.md
-    traffic, traffic_src = None, None
+    # PMC counters: collected offline in separate rocprofv3 --pmc passes (they cannot share a run with the timed region) at this
+    # same workload (tools/collect_pmc_step.sh -> profiles/r05_step_pmc.json); every kernel's entry is reported only while
+    # the source file the kernel lives in still hashes to what the counters were collected on
     import hashlib
-    src_sha = hashlib.sha256(open(os.path.join(ROOT, "posecnn_amd", "csrc", "hough_voting.hip"), "rb").read()).hexdigest()[:16]
-    for name in ("r04_hough_pmc.json", "r03_hough_pmc.json"):
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
-        except Exception:
-            continue
-        ent = pmc.get(vote_name) or pmc.get("hv_vote_kernel")
-        if not ent or (B, H, W) != (16, 480, 640):
-            continue
-        if pmc.get("_kernel_source_sha16") != src_sha:
-            # counters of ANOTHER build of the kernel: never reported as this run's traffic
-            print("bench.py: profiles/%s was collected on hough_voting.hip %s, this build is %s -> roofline.traffic = null; "
-                  "re-collect with tools/collect_pmc_hough.sh" % (name, pmc.get("_kernel_source_sha16"), src_sha), file=sys.stderr)
-            traffic_src = "STALE: profiles/%s belongs to another build of hough_voting.hip" % name
-            break
-        traffic = int((2.0 * ent["FETCH_SIZE_KB"] + ent["WRITE_SIZE_KB"]) * 1024)
-        traffic_src = "profiles/" + name
-        break
-    # brute-force-equivalent pair predicates of the reference kernel: sum_c ceil(N_c/skip)*H*W
-    per_class = torch.bincount((lab.reshape(B, -1).long() + C * torch.arange(B, device=dev).unsqueeze(1)).flatten(),
-                               minlength=C * B).reshape(B, C)[:, 1:]
-    pairs = float(((per_class + net.skip_pixels - 1) // net.skip_pixels * (per_class > 500)).sum().item()) * H * W
+    pmc, pmc_src = {}, None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_step_pmc.json")))
+        pmc_src = "profiles/r05_step_pmc.json"
+    except Exception:
+        pass
+    sha_now = {}
+
+    def pmc_of(kernel):
+        """The counters of `kernel` if they belong to this build and this workload, else (None, why)."""
+        ent = pmc.get(kernel)
+        if not ent or (B, H, W, a.input) != (16, 480, 640, "RGBD"):
+            return None, "no counters for this kernel / workload"
+        f = ent.get("_src")
+        if f not in sha_now:
+            sha_now[f] = hashlib.sha256(open(os.path.join(ROOT, "posecnn_amd", "csrc", f), "rb").read()).hexdigest()[:16]
+        if pmc.get("_source_sha16", {}).get(f) != sha_now[f]:
+            print("bench.py: %s was collected on %s %s, this build is %s -> its counters are not reported; re-collect with "
+                  "tools/collect_pmc_step.sh" % (pmc_src, f, pmc.get("_source_sha16", {}).get(f), sha_now[f]), file=sys.stderr)
+            return None, "STALE: %s belongs to another build of %s" % (pmc_src, f)
+        return ent, pmc_src
+
+    clock_hz = 1e3 * torch.cuda.get_device_properties(dev).clock_rate if hasattr(torch.cuda.get_device_properties(dev), "clock_rate") else 2.4e9
+    simds = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+    ent, traffic_src = pmc_of(vote_name)
+    traffic = int((2.0 * ent["FETCH_SIZE_KB"] + ent["WRITE_SIZE_KB"]) * 1024) if ent and "FETCH_SIZE_KB" in ent else None
+
+    def issue_fracs(ent, avg_us):
+        """What the kernel's REAL bound looks like: share of the chip's vector-ALU issue slots it used — a wave64
+        VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md) —, and the instruction mix."""
+        if not ent or not avg_us or "SQ_INSTS_VALU" not in ent:
+            return {}
+        cyc = simds * clock_hz * avg_us * 1e-6
+        tot = float(ent["SQ_INSTS_VALU"] + ent.get("SQ_INSTS_SALU", 0) + ent.get("SQ_INSTS_LDS", 0) + ent.get("SQ_INSTS_MFMA", 0))
+        o = {"valu_frac": 2.0 * ent["SQ_INSTS_VALU"] / cyc, "valu_insts_per_launch": ent["SQ_INSTS_VALU"],
+             "lds_inst_share": ent.get("SQ_INSTS_LDS", 0) / tot if tot else None,
+             "salu_inst_share": ent.get("SQ_INSTS_SALU", 0) / tot if tot else None,
+             "valu_frac_note": "SQ_INSTS_VALU x 2 issue cycles / (%d SIMDs x %.2f GHz x the live launch duration)" % (simds, clock_hz / 1e9)}
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in ent and ent.get("SQ_INSTS_MFMA"):
+            o["mfma_busy_share"] = ent["SQ_VALU_MFMA_BUSY_CYCLES"] / cyc
+            o["valu_per_mfma"] = ent["SQ_INSTS_VALU"] / float(ent["SQ_INSTS_MFMA"])
+            o["mfma_busy_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x clock x duration): the matrix pipe's busy share; every other vector "
+                                   "instruction of either wave on the SIMD is paid in matrix time (SQ_VALU_MFMA_COEXEC_CYCLES = 0 on gfx950, DESIGN §3.2c)")
+        if "SQ_WAIT_ANY" in ent and ent.get("SQ_WAVE_CYCLES"):
+            o["wave_cycles_waiting"] = ent["SQ_WAIT_ANY"] / float(ent["SQ_WAVE_CYCLES"])
+        return o
     adl_rows = int((last["poses_weight"].sum(dim=1) > 0).sum().item()) if a.losses != "none" and last.get("poses_weight") is not None else 0
 
     # HBM-bound kernels of the library: algorithmic bytes per step / live event time per step
@@ -691,17 +715,20 @@ def main(argv=None):
         "roofline": {"kernel": vote_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) from separate rocprofv3 --pmc passes (%s)" % traffic_src,
+                     "real_bound": "vector-ALU issue + latency (valu_frac, lds_inst_share below): the HBM fraction is what north_star asks for, not what limits the kernel",
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": hv["avg_us"], "launches": hv["calls"],
                      "note": "Hough voting is VALU/LDS bound, not HBM bound (SURVEY.md §8d): compulsory traffic is ~2 MB/frame",
                      "hough_sequence_us": hough_us, "hough_GBps_whole_sequence": alg_bytes / (hough_us * 1e-6) / 1e9 if hough_us else None,
                      "frac_whole_sequence": alg_bytes / (hough_us * 1e-6) / 1e9 / HBM_PEAK_GBPS if hough_us else None,
                      "sequence_note": "SURVEY.md §8d defines the Hough-vote rate over the whole launch sequence (hist + scatter + vote + select + emit); "
                                       "`frac` above is the vote kernel alone",
-                     "pair_predicates_equiv_per_launch": pairs,
-                     "pair_predicates_equiv_per_s": pairs / (hv["avg_us"] * 1e-6) if hv["calls"] else None},
+                     **issue_fracs(ent, hv["avg_us"] if hv["calls"] else None)},
         # the kernel the step actually spends its time in, against ITS roof (the headline `roofline` key is the Hough vote
         # kernel north_star names — 0.8 % of the step)
-        "roofline_dominant": (dict(max(others, key=lambda o: o["us_per_step"]), share_of_step=max(o["us_per_step"] for o in others) / 1e3 / ms_per_step)
+        "roofline_dominant": (dict(max(others, key=lambda o: o["us_per_step"]), share_of_step=max(o["us_per_step"] for o in others) / 1e3 / ms_per_step,
+                                   **issue_fracs(pmc_of(max(others, key=lambda o: o["us_per_step"])["kernel"])[0],
+                                                 (lambda k_: (us(k_) or 0) * a.steps / max(1, sum(v["calls"] for n, v in kern.items() if n == k_ or n.startswith(k_ + "<"))))
+                                                 (max(others, key=lambda o: o["us_per_step"])["kernel"])))
                               if others else None),
         "roofline_other": others,
         "dominant_library_kernel": (max(others, key=lambda o: o["us_per_step"])["kernel"] if others else None),

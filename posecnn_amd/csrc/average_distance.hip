@@ -60,7 +60,9 @@ __global__ __launch_bounds__(ADL_THREADS) void adl_terms_kernel(
     const float* __restrict__ symmetry, float* __restrict__ terms, int R_cap, int C, int P,
     float margin, const int* __restrict__ num_rows_dev)
 {
-  __shared__ float s_q[ADL_QTILE * 3];
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) float s_qx[ADL_QTILE], s_qy[ADL_QTILE], s_qz[ADL_QTILE];   // gt-rotated model points, coordinate-major
   const int n = blockIdx.y;
   const int p = blockIdx.x * ADL_THREADS + threadIdx.x;
   // R = the op's row count: the buffers' row capacity, or (capacity-sized buffers of the sync-free
@@ -92,19 +94,35 @@ __global__ __launch_bounds__(ADL_THREADS) void adl_terms_kernel(
       __syncthreads();
       for (int j = threadIdx.x; j < ADL_QTILE; j += ADL_THREADS) {
         int q = q0 + j;
+        // past the last point: +inf coordinates -> distance +inf (or NaN), never '<' anything: the scan below runs over
+        // whole groups of four without a tail
+        float qx = __builtin_inff(), qy = qx, qz = qx;
         if (q < P) {
           float a = pts[q * 3], b = pts[q * 3 + 1], c = pts[q * 3 + 2];
-          s_q[j * 3 + 0] = rg[0] * a + rg[1] * b + rg[2] * c;
-          s_q[j * 3 + 1] = rg[3] * a + rg[4] * b + rg[5] * c;
-          s_q[j * 3 + 2] = rg[6] * a + rg[7] * b + rg[8] * c;
+          qx = rg[0] * a + rg[1] * b + rg[2] * c;
+          qy = rg[3] * a + rg[4] * b + rg[5] * c;
+          qz = rg[6] * a + rg[7] * b + rg[8] * c;
         }
+        s_qx[j] = qx; s_qy[j] = qy; s_qz[j] = qz;
       }
       __syncthreads();
       const int lim = min(ADL_QTILE, P - q0);
-      for (int j = 0; j < lim; j++) {
-        float ex = x1 - s_q[j * 3], ey = y1 - s_q[j * 3 + 1], ez = z1 - s_q[j * 3 + 2];
-        float distance = ex * ex + ey * ey + ez * ez;
-        if (distance < dmin) { dmin = distance; qmin = q0 + j; }
+      // Four candidates per trip: one 128-bit LDS read per coordinate (every lane reads the same address: a broadcast)
+      // and the squared distance of two candidates per packed-f32 instruction — v_pk_add / v_pk_mul round each half
+      // like the scalar form, so every distance is ((ex ex) + (ey ey)) + (ez ez) bit for bit (:160-163); the strict '<'
+      // walks the four in ascending q. Round 4's loop took 3 LDS reads + 14 vector instructions per candidate, this one
+      // 0.75 + ~7: the kernel is bound by exactly this instruction stream (P^2 = 6.9 M candidates per symmetric RoI).
+      const v2f x1v = (v2f){x1, x1}, y1v = (v2f){y1, y1}, z1v = (v2f){z1, z1};
+      for (int j = 0; j < lim; j += 4) {
+        const v4f qx = *reinterpret_cast<const v4f*>(&s_qx[j]), qy = *reinterpret_cast<const v4f*>(&s_qy[j]), qz = *reinterpret_cast<const v4f*>(&s_qz[j]);
+        const v2f ex0 = x1v - qx.xy, ey0 = y1v - qy.xy, ez0 = z1v - qz.xy;
+        const v2f ex1 = x1v - qx.zw, ey1 = y1v - qy.zw, ez1 = z1v - qz.zw;
+        const v2f d0 = (ex0 * ex0 + ey0 * ey0) + ez0 * ez0;
+        const v2f d1 = (ex1 * ex1 + ey1 * ey1) + ez1 * ez1;
+        if (d0.x < dmin) { dmin = d0.x; qmin = q0 + j; }
+        if (d0.y < dmin) { dmin = d0.y; qmin = q0 + j + 1; }
+        if (d1.x < dmin) { dmin = d1.x; qmin = q0 + j + 2; }
+        if (d1.y < dmin) { dmin = d1.y; qmin = q0 + j + 3; }
       }
     }
   }

@@ -231,6 +231,7 @@ __global__ __launch_bounds__(256) void backproject_fused_kernel(
   constexpr int LIST = 56;   // list slots per voxel: 49 rounded up to whole 16-byte LDS reads
   typedef uint4 __attribute__((may_alias)) uint4_a;   // (the lists are written as 16-bit entries and read 8 at a time)
   __shared__ __attribute__((aligned(16))) unsigned short s_rel[4][64][LIST];   // matched pixels: dy * W + dx from the window origin
+  __shared__ unsigned char s_hit[4][64];                                       // the wave's hit voxels, ascending
   __shared__ int s_cnt[4][64], s_org[4][64];                                   // matches; window origin py * W + px (may be negative)
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -324,37 +325,47 @@ __global__ __launch_bounds__(256) void backproject_fused_kernel(
       }
       continue;
     }
-    // ---- B: data + flag
+    // ---- B: data + flag. The voxels that hit are listed (ascending) so that every gather instruction works for
+    // 64/LPV voxels that have something to gather — about half of a hit wave's voxels miss, and walked in voxel
+    // order their lane groups would idle through the other half's trips; the misses get their zeros first.
     constexpr int VPI = 64 / LPV;  // voxels per iteration
     const int sub = lane / LPV, cq = lane % LPV;
     const float4 one4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    const unsigned long long hitmask = __ballot(cnt != 0);
+    const int nhit = __popcll(hitmask);
+    if (cnt != 0) s_hit[wib][__popcll(hitmask & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
     for (int it = 0; it < 64 / VPI; it++) {
       const int vl = it * VPI + sub;
-      if (vl >= nv) continue;
-      const long long vox = vbase + vl;
-      const int c = s_cnt[wib][vl];
-      if (c == 0) {
+      if (vl < nv && !((hitmask >> vl) & 1ull)) {
+        const long long vox = vbase + vl;
         for (int ch = cq * 4; ch < Cd; ch += LPV * 4) {
           bp_store4<NT>(reinterpret_cast<float4*>(top_data + vox * Cd + ch), zero4);
           bp_store4<NT>(reinterpret_cast<float4*>(top_flag + vox * Cd + ch), zero4);
         }
-        continue;
       }
+    }
+#pragma unroll 1
+    for (int h0 = 0; h0 < nhit; h0 += VPI) {
+      if (h0 + sub >= nhit) continue;
+      const int vl = s_hit[wib][h0 + sub];
+      const long long vox = vbase + vl;
+      const int c = s_cnt[wib][vl];
       const int org = s_org[wib][vl];
       const float* dbase = data + (vox / G3) * H * W * (long long)Cd;
       const float cf = (float)c;
       for (int ch = cq * 4; ch < Cd; ch += LPV * 4) {
         float4 acc = zero4;
 #pragma unroll 1
-        for (int k0 = 0; k0 < c; k0 += 8) {   // 8 list entries per LDS read; the pixel rows that exist are requested together
+        for (int k0 = 0; k0 < c; k0 += 8) {   // 8 list entries per LDS read, their pixel rows requested together
           const uint4 r8 = *reinterpret_cast<const uint4_a*>(&s_rel[wib][vl][k0]);
           const unsigned rr[4] = {r8.x, r8.y, r8.z, r8.w};
           float4 v[8];
 #pragma unroll
           for (int j = 0; j < 8; j++) {
             const int rel = (int)((rr[j >> 1] >> (16 * (j & 1))) & 0xffffu);
-            v[j] = *reinterpret_cast<const float4*>(dbase + (org + (k0 + j < c ? rel : (int)(rr[0] & 0xffffu))) * Cd + ch);
+            v[j] = *reinterpret_cast<const float4*>(dbase + (org + (k0 + j < c ? rel : (int)(rr[0] & 0xffffu))) * Cd + ch);   // (H W Cd < 2^31: the launcher checks)
           }
 #pragma unroll
           for (int j = 0; j < 8; j++)

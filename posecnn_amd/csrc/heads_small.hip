@@ -112,17 +112,37 @@ __global__ __launch_bounds__(256) void head_lowres_mfma_kernel(
     s_img[tid] = (int)(gp / ((long long)w * h));
   }
   __syncthreads();
-  for (int idx = tid; idx < HM_PX * U; idx += 256) {
-    const int p = idx / U, c = idx - p * U;
+  // four channels per thread and trip (128-bit loads / stores; U % 16 == 0): per channel the same taps in the same order as
+  // bilinear_at — rows ascending, columns ascending, acc = acc + (wy wx) in — so add_score keeps the bits of
+  // deconv_bilinear_kernel + the two adds. (The scalar form of this phase made the kernel 196 us for the vertex head at 16
+  // frames: 32 trips of 4 dependent scalar loads per thread.)
+  const int U4 = U >> 2;
+  for (int idx = tid; idx < HM_PX * U4; idx += 256) {
+    const int p = idx / U4, c = (idx - p * U4) * 4;
     const long long gp = gp0 + p;
-    float t = 0.f;
+    v4f t = (v4f){0.f, 0.f, 0.f, 0.f};
     if (gp < total) {
-      const float up = bilinear_at(b5 + (size_t)s_img[p] * h5 * w5 * U, s_ty[p], s_tx[p], w5, U, c);
-      t = a[gp * U + c] + up;                       // add_score = score_conv4 + upscore_conv5   (tf.add_n order)
-      if (planted) t = t + planted[gp * U + c];     // bench aid: the planted scene
-      add_out[gp * U + c] = t;
+      const Taps ty = s_ty[p], tx = s_tx[p];
+      const float* inb = b5 + (size_t)s_img[p] * h5 * w5 * U + c;
+      v4f up = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int jy = 0; jy < 4; jy++) {
+        if (jy < ty.n) {
+          const float* row = inb + (size_t)(ty.i0 + jy) * w5 * U;
+#pragma unroll
+          for (int jx = 0; jx < 4; jx++) {
+            if (jx < tx.n) {
+              const float wgt = ty.w[jy] * tx.w[jx];
+              up = up + wgt * *reinterpret_cast<const v4f*>(row + (size_t)(tx.i0 + jx) * U);
+            }
+          }
+        }
+      }
+      t = *reinterpret_cast<const v4f*>(a + gp * U + c) + up;                       // add_score = score_conv4 + upscore_conv5   (tf.add_n order)
+      if (planted) t = t + *reinterpret_cast<const v4f*>(planted + gp * U + c);     // bench aid: the planted scene
+      *reinterpret_cast<v4f*>(add_out + gp * U + c) = t;
     }
-    tL[p * LD + c] = t;
+    *reinterpret_cast<v4f*>(tL + p * LD + c) = t;
   }
   __syncthreads();
   const int lr = lane & 15, lk = lane >> 4;
@@ -248,7 +268,8 @@ extern "C" int pcnn_head_lowres_mfma_fwd(const float* score4, const float* score
   PCNN_REQUIRE(stride >= 1 && kernel >= stride && (kernel - stride) % 2 == 0 && kernel <= 2 * stride && h % stride == 0 && w % stride == 0,
                PCNN_EINVAL, "head_lowres_mfma: need stride <= kernel <= 2 stride, (kernel - stride) even, %dx%d divisible by the stride %d", h, w, stride);
   PCNN_REQUIRE(score4 && score5 && weights_nk && add_out && z, PCNN_ENULL, "head_lowres_mfma: NULL pointer");
-  PCNN_REQUIRE(aligned16(weights_nk), PCNN_EINVAL, "head_lowres_mfma: the filter must be 16-byte aligned");
+  PCNN_REQUIRE(aligned16(weights_nk) && aligned16(score4) && aligned16(score5) && aligned16(planted) && aligned16(add_out), PCNN_EINVAL,
+               "head_lowres_mfma: score4, score5, planted, the filter and add_out must be 16-byte aligned");
   const size_t lds = sizeof(float) * (size_t)HM_PX * (units + 4);
   PCNN_REQUIRE(lds <= 60 * 1024, PCNN_EINVAL, "head_lowres_mfma: %d units exceed the kernel's LDS", units);
   hipStream_t stream = (hipStream_t)stream_;

@@ -1066,6 +1066,9 @@ class vgg16_convs(Network):
                  .conv(3, 3, 512, 1, 1, name='conv5_3_p', c_i=512, trainable=t))
         return self._setup_heads()
 
+    def _mfma_head_ok(self, c_i, c_o):
+        return bool(self.mfma_heads) and c_i % 16 == 0 and c_o <= 96 and 4 * 64 * (c_i + 4) <= 60 * 1024
+
     def _small_head(self, s5, s4, up_name, add_name, drop_name, plant_key, conv_name, c_o, c_i):
         """`deconv(4,4,·,2,2)(s5) -> add(s4, ·) [-> plant] -> dropout(1.0)` and the bias-free 1x1 product `conv_name` of
         the fused-heads form, as ONE launch (ops.head_lowres). Registers the same layer names; the up-sampled
@@ -1074,14 +1077,14 @@ class vgg16_convs(Network):
         a, b5 = self.layers.get(s4), self.layers.get(s5)
         if not (self.small_heads and self.fused_heads and isinstance(a, torch.Tensor) and isinstance(b5, torch.Tensor)
                 and a.is_cuda and a.dim() == 4 and a.shape[1] % 2 == 0 and a.shape[2] % 2 == 0
-                # one launch instead of five. Up to a frame or two (`small_heads_max_pixels`) the product runs on the vector
-                # ALUs out of LDS (csrc/heads_small.hip head_lowres_kernel: 54 vs 88 us for both heads of one frame; its LDS
-                # holds 32 pixels x U inputs and the U x Cout filter: 60 KB); beyond that on the matrix cores
-                # (head_lowres_mfma_kernel, round 5: at 16 frames the vector version lost to the library's 1x1 convolution,
-                # 237 vs 165 us — the last framework kernels of the heads). Heads that fit neither take deconv + add + 1x1.
+                # one launch instead of five (csrc/heads_small.hip). The 1x1 product runs on the matrix cores
+                # (head_lowres_mfma_kernel, round 5: any batch) when the head fits it — units a multiple of 16, at most 96
+                # outputs —, else, up to a frame or two (`small_heads_max_pixels`), on the vector ALUs out of LDS
+                # (head_lowres_kernel, round 3: 32 pixels x U inputs and the U x Cout filter in 60 KB; at 16 frames it lost to
+                # the library's 1x1 convolution, 237 vs 165 us). Heads that fit neither take deconv + add + 1x1.
                 and c_i % 4 == 0
-                and ((a.shape[0] * a.shape[1] * a.shape[2] <= self.small_heads_max_pixels and 4 * (32 * c_i + c_i * c_o) <= 60 * 1024)
-                     or (self.mfma_heads and c_i % 16 == 0 and c_o <= 96 and 4 * 64 * (c_i + 4) <= 60 * 1024))
+                and (self._mfma_head_ok(c_i, c_o)
+                     or (a.shape[0] * a.shape[1] * a.shape[2] <= self.small_heads_max_pixels and 4 * (32 * c_i + c_i * c_o) <= 60 * 1024))
                 and (self.keep_prob_queue is None or float(self.keep_prob_queue) >= 1.0)
                 and (up_name + "/weights") not in self.vars
                 and not (torch.is_grad_enabled() and self.trainable)):
@@ -1095,7 +1098,7 @@ class vgg16_convs(Network):
             hit = (key, w.detach().reshape(c_o, c_i).t().contiguous())     # [units, out]: the TF variable [1,1,in,out] as it is
             self._head_wt[("lowres", conv_name)] = hit
         planted = self.planted.get(plant_key) if self.planted is not None else None
-        if a.shape[0] * a.shape[1] * a.shape[2] <= self.small_heads_max_pixels and 4 * (32 * c_i + c_i * c_o) <= 60 * 1024:
+        if not self._mfma_head_ok(c_i, c_o):
             add, z = ops.head_lowres(a, b5, hit[1], planted=planted, kernel=4, stride=2)
         else:
             hitm = self._head_wt.get(("lowres_mfma", conv_name))

@@ -74,16 +74,19 @@ def test_world1_force_process_group_runs_the_collective():
     assert out["n_gpus"] == 1 and out["process_group"] is True and out["detections_gathered_per_step"] == 3
 
 
-def test_hough_pmc_file_belongs_to_this_build_of_the_kernel():
-    """bench.py's `roofline.traffic` comes from PMC counters collected in separate rocprofv3 passes
-    (profiles/r0N_hough_pmc.json). The file records the hash of the kernel source it was collected on; bench.py reports
-    traffic = null when that differs from the build it runs — and this test fails, so a change to hough_voting.hip
-    cannot silently keep quoting another build's counters (re-collect with tools/collect_pmc_hough.sh)."""
+def test_step_pmc_file_belongs_to_this_build_of_the_kernels():
+    """bench.py's `roofline.traffic`, `valu_frac` and `roofline_dominant.mfma_busy_share` come from
+    PMC counters collected in separate rocprofv3 passes (profiles/r05_step_pmc.json, tools/collect_pmc_step.sh). The file
+    records the hash of every kernel source it was collected on; bench.py drops a kernel's counters when its source
+    differs from the build it runs — and this test fails, so a change to the Hough or trunk kernels cannot silently keep
+    quoting another build's counters."""
     import hashlib
     import json
-    sha = hashlib.sha256(open(os.path.join(ROOT, "posecnn_amd", "csrc", "hough_voting.hip"), "rb").read()).hexdigest()[:16]
-    newest = next(n for n in ("r04_hough_pmc.json", "r03_hough_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
-    pmc = json.load(open(os.path.join(ROOT, "profiles", newest)))
-    assert pmc.get("_kernel_source_sha16") == sha, "profiles/%s was collected on another build of hough_voting.hip" % newest
-    ent = pmc["hv_vote_kernel"]
-    assert ent["FETCH_SIZE_KB"] > 0 and ent["WRITE_SIZE_KB"] > 0
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_step_pmc.json")))
+    for kernel in ("hv_vote_kernel", "wino43_mfma_kernel"):
+        ent = pmc[kernel]
+        src = ent["_src"]
+        sha = hashlib.sha256(open(os.path.join(ROOT, "posecnn_amd", "csrc", src), "rb").read()).hexdigest()[:16]
+        assert pmc["_source_sha16"][src] == sha, "profiles/r05_step_pmc.json was collected on another build of %s" % src
+        assert ent["SQ_INSTS_VALU"] > 0 and ent["FETCH_SIZE_KB"] > 0 and ent["WRITE_SIZE_KB"] > 0
+    assert pmc["wino43_mfma_kernel"]["SQ_VALU_MFMA_BUSY_CYCLES"] > 0 and pmc["wino43_mfma_kernel"]["SQ_INSTS_MFMA"] > 0

@@ -50,10 +50,13 @@ def main():
     ap.add_argument("--once", action="store_true")
     ap.add_argument("--grids", default="256,128")
     ap.add_argument("--iters", type=int, default=8)
+    ap.add_argument("--kinds", default="smooth,random")
     a = ap.parse_args()
     out = {}
     for G in [int(x) for x in a.grids.split(",")]:
         for kind, (H, W, Cl, B) in (("smooth", (480, 640, 22, 1)), ("random", (960, 1280, 14, 4 if G <= 128 else 1))):
+            if kind not in a.kinds.split(","):
+                continue
             args = scene(G, H, W, 64, Cl, B, kind)
             nv = B * G ** 3
             byts = 4.0 * (nv * (2 * 64 + Cl) + nv * Cl + B * H * W * (64 + Cl + 1))
