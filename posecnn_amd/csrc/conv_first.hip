@@ -638,7 +638,6 @@ __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
   F12_TS(5);
 }
 
-
 }  // namespace
 
 extern "C" int pcnn_conv3x3_c3_winograd43_fwd(const float* x, const float* weights, const float* bias,
@@ -726,6 +725,8 @@ static int conv12_check(int B, int H, int W, const void* w1, const void* b1, con
 // (Round 4 also built a persistent half-channel pipeline of this layer pair — 4.52 vs 3.15 ms, bound by the same filter-bank
 // re-reads, its static walk losing the dynamic balance of 38 400 short workgroups; it left the library in round 5:
 // tools/variants/conv12_wino43_pipelined_kernel.inc)
+// (Round 5 built the two-workgroups-per-CU form of this kernel — four waves, two channel halves of 32, 78 KB of LDS: bit-
+// identical, 3 % faster alone, 2 % slower in the three-stream step and at one frame; tools/variants/conv12_wino43_pair_kernel.inc.)
 extern "C" int pcnn_conv1_1_conv1_2_fused_fwd(const float* x, const float* w1, const float* b1, const float* ut2, int ut2_layout,
                                               const float* b2, int B, int H, int W, int groups, int relu1, int relu2,
                                               float* y_pool, void* stream_)
