@@ -511,10 +511,13 @@ __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
 #define F12_LOADA(D0, D1, BUF, J, G)                                                                             \
   { D0 = *reinterpret_cast<const f4*>(&s_v[BUF][((J) * 16 + lr) * 64 + (((4 * (G) + lk) ^ lr) * 4)]);            \
     D1 = *reinterpret_cast<const f4*>(&s_v[BUF][(((J) + 1) * 16 + lr) * 64 + (((4 * (G) + lk) ^ lr) * 4)]); }
+  // (round 5: the arithmetic runs on the two 64-bit halves of every 128-bit patch value — v_pk_add / v_pk_mul with negate
+  //  modifiers; written on 4-wide vectors the compiler split every subtraction into four scalar ones: 480 v_sub_f32 — same
+  //  expression trees per element, as fw_bt6 / wino43_input_kernel)
 #define F12_PRODUCE(XI, BUF)                                                                                    \
   {                                                                                                             \
-    /* the patch values of this row of B^T d B, three columns at a time: all reads of a half first, then its arithmetic */ \
-    f4 ta[6];                                                                                                   \
+    typedef float f2p __attribute__((ext_vector_type(2)));                                                      \
+    f2p ta[2][6];                                                                                               \
     _Pragma("unroll") for (int hh = 0; hh < 2; hh++) {                                                          \
       f4 d[3][6];                                                                                               \
       _Pragma("unroll") for (int s3 = 0; s3 < 3; s3++)                                                          \
@@ -525,22 +528,33 @@ __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
       __builtin_amdgcn_sched_barrier(0);                                                                        \
       _Pragma("unroll") for (int s3 = 0; s3 < 3; s3++) {                                                        \
         const int s2 = 3 * hh + s3;                                                                             \
-        if ((XI) == 0) ta[s2] = (4.f * d[s3][0] - 5.f * d[s3][2]) + d[s3][4];                                   \
-        else if ((XI) == 5) ta[s2] = (4.f * d[s3][1] - 5.f * d[s3][3]) + d[s3][5];                              \
-        else if ((XI) == 1 || (XI) == 2) {                                                                      \
-          const f4 a = d[s3][4] - 4.f * d[s3][2], b_ = d[s3][3] - 4.f * d[s3][1];                               \
-          ta[s2] = (XI) == 1 ? a + b_ : a - b_;                                                                 \
-        } else {                                                                                                \
-          const f4 c = d[s3][4] - d[s3][2], e = 2.f * (d[s3][3] - d[s3][1]);                                    \
-          ta[s2] = (XI) == 3 ? c + e : c - e;                                                                   \
+        _Pragma("unroll") for (int hf = 0; hf < 2; hf++) {                                                      \
+          f2p e_[6];                                                                                            \
+          _Pragma("unroll") for (int r = 0; r < 6; r++) e_[r] = hf ? d[s3][r].zw : d[s3][r].xy;                 \
+          if ((XI) == 0) ta[hf][s2] = (4.f * e_[0] - 5.f * e_[2]) + e_[4];                                      \
+          else if ((XI) == 5) ta[hf][s2] = (4.f * e_[1] - 5.f * e_[3]) + e_[5];                                 \
+          else if ((XI) == 1 || (XI) == 2) {                                                                    \
+            const f2p a = e_[4] - 4.f * e_[2], b_ = e_[3] - 4.f * e_[1];                                        \
+            ta[hf][s2] = (XI) == 1 ? a + b_ : a - b_;                                                           \
+          } else {                                                                                              \
+            const f2p c = e_[4] - e_[2], e = 2.f * (e_[3] - e_[1]);                                             \
+            ta[hf][s2] = (XI) == 3 ? c + e : c - e;                                                             \
+          }                                                                                                     \
         }                                                                                                       \
       }                                                                                                         \
       __builtin_amdgcn_sched_barrier(0);                                                                        \
     }                                                                                                           \
-    f4 oa[6];                                                                                                   \
-    fw_bt6(ta, oa);                                                                                             \
+    f2p oa[2][6];                                                                                               \
+    _Pragma("unroll") for (int hf = 0; hf < 2; hf++) {                                                          \
+      const f2p* t_ = ta[hf];                                                                                   \
+      oa[hf][0] = (4.f * t_[0] - 5.f * t_[2]) + t_[4];                                                          \
+      { const f2p a = t_[4] - 4.f * t_[2], b_ = t_[3] - 4.f * t_[1]; oa[hf][1] = a + b_; oa[hf][2] = a - b_; }  \
+      { const f2p c = t_[4] - t_[2], e = 2.f * (t_[3] - t_[1]); oa[hf][3] = c + e; oa[hf][4] = c - e; }         \
+      oa[hf][5] = (4.f * t_[1] - 5.f * t_[3]) + t_[5];                                                          \
+    }                                                                                                           \
     _Pragma("unroll") for (int j = 0; j < 6; j++)                                                               \
-      *reinterpret_cast<f4*>(&s_v[BUF][(j * 16 + tile) * 64 + ((cq ^ tile) * 4)]) = oa[j];                      \
+      *reinterpret_cast<f4*>(&s_v[BUF][(j * 16 + tile) * 64 + ((cq ^ tile) * 4)]) =                             \
+          (f4){oa[0][j].x, oa[0][j].y, oa[1][j].x, oa[1][j].y};                                                 \
   }
   // planes 6 XI + J and 6 XI + J + 1 out of buffer BUF. On entry q0 / q1 hold their B operands; a0 / a1 their A operands
   // unless J == 0 (first pair behind the group's barrier: fetched here). NK = first plane of the next pair (its B operands
@@ -583,47 +597,59 @@ __global__ __launch_bounds__(512, 1) void conv12_wino43_fused_kernel(
   // a consumer lane holds tiles 4 lk + i (i = 0..3: tile row lk, tile column i) x channel 16 wave + lr
   float* s_o = &s_v[0][0];                                // [8 pooled rows][8 pooled columns][64]
   if (consumer) {
+    // Two of a lane's four tiles per pass, on packed f32 (round 5): the accumulators of tiles i, i + 1 are adjacent registers, so
+    // the column transforms and the 96 rank-1 FMAs of a pass are v_pk_add / v_pk_mul / v_pk_fma on register pairs as they lie —
+    // element for element the scalar sequence of wino43_mfma_kernel's fold (one rounding per operation, explicit FMAs), half
+    // the instructions (the output transform was 770 vector instructions per thread, paid in matrix time: 2.4 of a block's 20 us).
+    typedef float f2e __attribute__((ext_vector_type(2)));
     const int co = 16 * wave + lr;
     const float bv = bv2;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      float yo[16];
+    for (int ih = 0; ih < 2; ih++) {
+      f2e yo[16];
 #pragma unroll
-      for (int o = 0; o < 16; o++) yo[o] = 0.f;
+      for (int o = 0; o < 16; o++) yo[o] = (f2e){0.f, 0.f};
 #pragma unroll
       for (int nu = 0; nu < 6; nu++) {
         const float c0 = nu == 5 ? 0.f : 1.f;
         const float c1 = nu == 1 ? 1.f : nu == 2 ? -1.f : nu == 3 ? 2.f : nu == 4 ? -2.f : 0.f;
         const float c2 = (nu == 1 || nu == 2) ? 1.f : (nu == 3 || nu == 4) ? 4.f : 0.f;
         const float c3 = nu == 1 ? 1.f : nu == 2 ? -1.f : nu == 3 ? 8.f : nu == 4 ? -8.f : nu == 5 ? 1.f : 0.f;
-        float m_[6], t_[4];
+        f2e m_[6], t_[4];
 #pragma unroll
-        for (int x_ = 0; x_ < 6; x_++) m_[x_] = acc[6 * x_ + nu][i];
-        f12_at6_col(m_, t_);
+        for (int x_ = 0; x_ < 6; x_++) m_[x_] = (f2e){acc[6 * x_ + nu][2 * ih], acc[6 * x_ + nu][2 * ih + 1]};
+        {   // f12_at6_col, two elements at a time
+          const f2e s = m_[1] + m_[2], d = m_[1] - m_[2], S = m_[3] + m_[4], D = m_[3] - m_[4];
+          t_[0] = (m_[0] + s) + S;
+          t_[1] = __builtin_elementwise_fma((f2e){2.f, 2.f}, D, d);
+          t_[2] = __builtin_elementwise_fma((f2e){4.f, 4.f}, S, s);
+          t_[3] = __builtin_elementwise_fma((f2e){8.f, 8.f}, D, d) + m_[5];
+        }
 #pragma unroll
         for (int a_ = 0; a_ < 4; a_++) {
-          yo[4 * a_ + 0] = __builtin_fmaf(t_[a_], c0, yo[4 * a_ + 0]);
-          yo[4 * a_ + 1] = __builtin_fmaf(t_[a_], c1, yo[4 * a_ + 1]);
-          yo[4 * a_ + 2] = __builtin_fmaf(t_[a_], c2, yo[4 * a_ + 2]);
-          yo[4 * a_ + 3] = __builtin_fmaf(t_[a_], c3, yo[4 * a_ + 3]);
+          yo[4 * a_ + 0] = __builtin_elementwise_fma(t_[a_], (f2e){c0, c0}, yo[4 * a_ + 0]);
+          yo[4 * a_ + 1] = __builtin_elementwise_fma(t_[a_], (f2e){c1, c1}, yo[4 * a_ + 1]);
+          yo[4 * a_ + 2] = __builtin_elementwise_fma(t_[a_], (f2e){c2, c2}, yo[4 * a_ + 2]);
+          yo[4 * a_ + 3] = __builtin_elementwise_fma(t_[a_], (f2e){c3, c3}, yo[4 * a_ + 3]);
         }
       }
 #pragma unroll
       for (int o = 0; o < 16; o++) {
-        float val = yo[o] + bv;
-        if (relu2) val = val > 0.f ? val : 0.f;
+        f2e val = yo[o] + (f2e){bv, bv};
+        if (relu2) { val.x = val.x > 0.f ? val.x : 0.f; val.y = val.y > 0.f ? val.y : 0.f; }
         yo[o] = val;
       }
 #pragma unroll
       for (int a2 = 0; a2 < 2; a2++)
 #pragma unroll
         for (int e2 = 0; e2 < 2; e2++) {
-          float p = yo[4 * (2 * a2) + 2 * e2];
-          const float p1 = yo[4 * (2 * a2) + 2 * e2 + 1], p2 = yo[4 * (2 * a2 + 1) + 2 * e2], p3 = yo[4 * (2 * a2 + 1) + 2 * e2 + 1];
-          p = p1 > p ? p1 : p;
-          p = p2 > p ? p2 : p;
-          p = p3 > p ? p3 : p;
-          s_o[((2 * lk + a2) * 8 + (2 * i + e2)) * 64 + co] = p;      // tile (row lk, column i) -> pooled (2 lk + a2, 2 i + e2)
+          f2e p = yo[4 * (2 * a2) + 2 * e2];
+          const f2e p1 = yo[4 * (2 * a2) + 2 * e2 + 1], p2 = yo[4 * (2 * a2 + 1) + 2 * e2], p3 = yo[4 * (2 * a2 + 1) + 2 * e2 + 1];
+          p.x = p1.x > p.x ? p1.x : p.x; p.y = p1.y > p.y ? p1.y : p.y;
+          p.x = p2.x > p.x ? p2.x : p.x; p.y = p2.y > p.y ? p2.y : p.y;
+          p.x = p3.x > p.x ? p3.x : p.x; p.y = p3.y > p.y ? p3.y : p.y;
+          s_o[((2 * lk + a2) * 8 + (2 * (2 * ih) + e2)) * 64 + co] = p.x;          // tile (row lk, column i) -> pooled (2 lk + a2, 2 i + e2)
+          s_o[((2 * lk + a2) * 8 + (2 * (2 * ih + 1) + e2)) * 64 + co] = p.y;
         }
     }
   }

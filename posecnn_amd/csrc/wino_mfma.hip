@@ -105,7 +105,15 @@ __device__ __forceinline__ void at6_col(const float* m, float* t)
 //     the early layers' 36-72-stage pairs stop paying a dispatch, a cold prologue and a store drain each): 14.62 -> 15.07 ms
 //     (conv4_2 1.61 -> 1.73, conv2_2 1.74 -> 1.83) — the hardware's dynamic hand-out of pairs to whichever slot frees first
 //     balances better than a static walk, and the 8 extra live registers of the loop cost the kernel its last slack.
-template <int POOL, int WR, int ABL = 0, int ZC = 1>
+// EPI (round 5; not instantiated by the library — tools/wino_ablate.hip can): 1 = the MFMA operand roles swapped (A = U^T rows,
+// B = V rows: the same products in the same K order, so the same bits — verified against EPI = 0 on seven layer shapes, all pool
+// modes, both block maps) — a lane then holds FOUR CONSECUTIVE CHANNELS of one tile instead of one channel of four tiles, and the
+// epilogue stores its outputs straight from registers as 16-byte pieces (16 lanes x 4 quads = a tile's 64 channels per 256
+// bytes): no LDS staging, no barriers. The warm ablation had priced the staging at 7 / 5 / 4 % of conv2_1 / conv2_2 / conv3_2;
+// measured, the direct form gives it back in 64-byte partial-line stores: 12 layers 14.136 vs 14.169 ms alone (conv2_1 1.052
+// vs 1.022, conv2_2 1.656 vs 1.676, conv3_1 0.868 vs 0.885, conv4_2 1.569 vs 1.589), the kernel inside the step 1107 / 1118 vs
+// 1098 / 1098 us per launch, the step 796 / 794 vs 764 / 808 frames/s: no gain — the staged epilogue (0) stays.
+template <int POOL, int WR, int ABL = 0, int ZC = 1, int EPI = 0>
 __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
     const float* __restrict__ v, const float* __restrict__ ut, const float* __restrict__ bias,
     float* __restrict__ y, float* __restrict__ ypool, int H, int W, int Cin, int Cout, int Ht, int Wt,
@@ -171,7 +179,8 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
 
   // the lane's bias value, requested HERE: issued where it is first used (the epilogue, round 4) it was a bare global
   // round trip between the last MFMA and the first staged row of every workgroup (~1 us of a 15-us conv2_1 workgroup)
-  const float bv = bias ? bias[(size_t)grp * Cout + cb * WM_BC + 16 * wn + lr] : 0.f;   // (no bias: the raw partial output of a Cin split)
+  const float bv = (bias && !EPI) ? bias[(size_t)grp * Cout + cb * WM_BC + 16 * wn + lr] : 0.f;   // (no bias: the raw partial output of a Cin split)
+  const v4f bv4 = (bias && EPI) ? *reinterpret_cast<const v4f*>(bias + (size_t)grp * Cout + cb * WM_BC + 16 * wn + 4 * lk) : (v4f){0.f, 0.f, 0.f, 0.f};
   v4f acc[6][2];
 #pragma unroll
   for (int i = 0; i < 6; i++) acc[i][0] = acc[i][1] = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -252,8 +261,10 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
 #define WM_MFMA1(SA0, SA1, SB, G, ACC)                                                                \
   if constexpr (ABL & 8) { asm volatile("" :: "v"(SA0[G]), "v"(SA1[G]), "v"(SB[G])); } else           \
   _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) {                                                  \
-    ACC[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(SA0[G][i_], SB[G][i_], ACC[0], 0, 0, 0);            \
-    ACC[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(SA1[G][i_], SB[G][i_], ACC[1], 0, 0, 0);            \
+    ACC[0] = EPI ? __builtin_amdgcn_mfma_f32_16x16x4f32(SB[G][i_], SA0[G][i_], ACC[0], 0, 0, 0)       \
+                 : __builtin_amdgcn_mfma_f32_16x16x4f32(SA0[G][i_], SB[G][i_], ACC[0], 0, 0, 0);      \
+    ACC[1] = EPI ? __builtin_amdgcn_mfma_f32_16x16x4f32(SB[G][i_], SA1[G][i_], ACC[1], 0, 0, 0)       \
+                 : __builtin_amdgcn_mfma_f32_16x16x4f32(SA1[G][i_], SB[G][i_], ACC[1], 0, 0, 0);      \
   }
 #define WM_MFMA(SA0, SA1, SB, ACC)                                                                    \
   WM_MFMA1(SA0, SA1, SB, 0, ACC) WM_MFMA1(SA0, SA1, SB, 1, ACC)
@@ -261,11 +272,15 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
 #define WM_MFMA1_Z(SA0, SA1, SB, G, ACC)                                                              \
   if constexpr (ABL & 8) { asm volatile("" :: "v"(SA0[G]), "v"(SA1[G]), "v"(SB[G])); } else {         \
     const v4f z_ = (v4f){0.f, 0.f, 0.f, 0.f};                                                         \
-    ACC[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(SA0[G][0], SB[G][0], z_, 0, 0, 0);                  \
-    ACC[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(SA1[G][0], SB[G][0], z_, 0, 0, 0);                  \
+    ACC[0] = EPI ? __builtin_amdgcn_mfma_f32_16x16x4f32(SB[G][0], SA0[G][0], z_, 0, 0, 0)             \
+                 : __builtin_amdgcn_mfma_f32_16x16x4f32(SA0[G][0], SB[G][0], z_, 0, 0, 0);            \
+    ACC[1] = EPI ? __builtin_amdgcn_mfma_f32_16x16x4f32(SB[G][0], SA1[G][0], z_, 0, 0, 0)             \
+                 : __builtin_amdgcn_mfma_f32_16x16x4f32(SA1[G][0], SB[G][0], z_, 0, 0, 0);            \
     _Pragma("unroll") for (int i_ = 1; i_ < 4; i_++) {                                                \
-      ACC[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(SA0[G][i_], SB[G][i_], ACC[0], 0, 0, 0);          \
-      ACC[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(SA1[G][i_], SB[G][i_], ACC[1], 0, 0, 0);          \
+      ACC[0] = EPI ? __builtin_amdgcn_mfma_f32_16x16x4f32(SB[G][i_], SA0[G][i_], ACC[0], 0, 0, 0)     \
+                   : __builtin_amdgcn_mfma_f32_16x16x4f32(SA0[G][i_], SB[G][i_], ACC[0], 0, 0, 0);    \
+      ACC[1] = EPI ? __builtin_amdgcn_mfma_f32_16x16x4f32(SB[G][i_], SA1[G][i_], ACC[1], 0, 0, 0)     \
+                   : __builtin_amdgcn_mfma_f32_16x16x4f32(SA1[G][i_], SB[G][i_], ACC[1], 0, 0, 0);    \
     }                                                                                                 \
   }
   // column NU of the transform domain is complete: t = A^T M[:, NU]; Y[a][e] += t[a] * A[NU][e]
@@ -380,6 +395,63 @@ __global__ __launch_bounds__(256 * WR, 2) void wino43_mfma_kernel(
 #pragma unroll
     for (int x_ = 0; x_ < 6; x_++) k_ += acc[x_][0][0] + acc[x_][1][1];
     if (k_ == 12345.678f) y[tid] = k_;
+    return;
+  }
+  if constexpr (EPI == 1) {
+    // ---- epilogue, straight from registers (operand roles swapped: see EPI) ------------------------------------------------
+    // lane holds, per block b, tile 32 wm + 16 b + lr x channels 16 wn + 4 lk + i (i = 0..3): yo[b][i][4 a + e]
+    static_assert(WR == 1 || !EPI, "the direct epilogue is written for 32-tile blocks");
+    const int HtWt = Ht * Wt;
+    const int bimg0 = (int)(t0 / HtWt);
+    const int rem0 = (int)(t0 - (long long)bimg0 * HtWt);
+    const int ty0 = rem0 / Wt, tx0 = rem0 - ty0 * Wt;
+    const int co4 = cb * WM_BC + 16 * wn + 4 * lk;
+    const int Hp = H / 2, Wp = W / 2;
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      const int tl = 16 * b + lr;
+      const unsigned n = (unsigned)(tx0 + tl), q = n / (unsigned)Wt, tx = n - q * (unsigned)Wt;
+      const unsigned m = (unsigned)ty0 + q, q2 = m / (unsigned)Ht, ty = m - q2 * (unsigned)Ht;
+      const int img = bimg0 + (int)q2;
+      const bool mine = t0 + tl < tend;                      // (rows past the end of the group: computed on clamped operands, never stored)
+      v4f o[16];
+#pragma unroll
+      for (int px = 0; px < 16; px++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          float val = yo[b][i][px] + bv4[i];
+          if (relu) val = val > 0.f ? val : 0.f;
+          o[px][i] = val;
+        }
+      }
+      if (POOL != 1) {
+        float* yb = y + (((long long)img * H + 4 * (int)ty) * W + 4 * (int)tx) * Cout + co4;
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            if (mine && 4 * (int)ty + a < H && 4 * (int)tx + e < W)
+              *reinterpret_cast<v4f*>(yb + ((long long)a * W + e) * Cout) = o[4 * a + e];
+      }
+      if (POOL != 0) {
+        float* yp = (POOL == 1 ? y : ypool) + (((long long)img * Hp + 2 * (int)ty) * Wp + 2 * (int)tx) * Cout + co4;
+#pragma unroll
+        for (int a2 = 0; a2 < 2; a2++)
+#pragma unroll
+          for (int e2 = 0; e2 < 2; e2++) {
+            v4f p = o[4 * (2 * a2) + 2 * e2];
+            const v4f p1 = o[4 * (2 * a2) + 2 * e2 + 1], p2 = o[4 * (2 * a2 + 1) + 2 * e2], p3 = o[4 * (2 * a2 + 1) + 2 * e2 + 1];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              p[i] = p1[i] > p[i] ? p1[i] : p[i];
+              p[i] = p2[i] > p[i] ? p2[i] : p[i];
+              p[i] = p3[i] > p[i] ? p3[i] : p[i];
+            }
+            if (mine && 2 * (int)ty + a2 < Hp && 2 * (int)tx + e2 < Wp)
+              *reinterpret_cast<v4f*>(yp + ((long long)a2 * Wp + e2) * Cout) = p;
+          }
+      }
+    }
     return;
   }
   // ---- epilogue -------------------------------------------------------------------------------

@@ -133,11 +133,14 @@ def test_fused_heads_equal_literal_op_order(gpu):
             net.run(feed, planted=planted)
         outs.append({k: net.get_output(k).cpu().numpy() for k in ("label_2d", "prob_normalized", "vertex_pred", "rois", "poses_tanh")})
     a, b = outs
-    assert (a["label_2d"] == b["label_2d"]).mean() >= 0.9995
+    # literal since round 5: north_star's "label maps bit-exact" between the two op orders on the calibrated
+    # network — 0 flips in 76 800 pixels, and with identical labels the Hough boxes agree to the vertex field's rounding
+    flips = int((a["label_2d"] != b["label_2d"]).sum())
+    assert flips == 0, "%d label flips between fused and literal head order" % flips
     assert np.abs(a["prob_normalized"] - b["prob_normalized"]).max() < 1e-4
     assert np.abs(a["vertex_pred"] - b["vertex_pred"]).max() < 1e-4 * max(1.0, np.abs(b["vertex_pred"]).max())
     assert a["rois"].shape == b["rois"].shape and np.array_equal(a["rois"][:, :2], b["rois"][:, :2])
-    assert np.abs(a["rois"][:, 2:6] - b["rois"][:, 2:6]).max() < 2.0
+    assert np.abs(a["rois"][:, 2:6] - b["rois"][:, 2:6]).max() < 1e-3
     assert "upscore" not in nets[0].layers and "upscore" in nets[1].layers
 
 
@@ -172,11 +175,10 @@ def test_winograd_trunk_end_to_end_against_direct_convolutions(gpu, capsys):
         flips = int((lab != ref[0]).sum())
         report[mode] = {"label_flips": flips, "of": lab.size, "max_prob_diff": float(np.abs(prob - ref[1]).max()),
                         "conv5_3_rel_err": float(np.abs(c5 - ref[3]).max() / np.abs(ref[3]).max())}
-        assert flips <= 1e-4 * lab.size, report
-        assert report[mode]["max_prob_diff"] < 1e-3, report
+        assert flips == 0, report          # literal (round 5): label maps bit-exact between the f32 trunks on the calibrated network
+        assert report[mode]["max_prob_diff"] < 1e-4, report
         assert rows.shape == ref[2].shape and np.array_equal(rows[:, :2], ref[2][:, :2]), report
-        if flips == 0:
-            assert np.abs(rows[:, 2:6] - ref[2][:, 2:6]).max() < 1e-3
+        assert np.abs(rows[:, 2:6] - ref[2][:, 2:6]).max() < 1e-3
         report[mode]["max_quat_diff"] = float(np.abs(rows[:, 7:11] - ref[2][:, 7:11]).max())
         report[mode]["max_trans_diff"] = float(np.abs(rows[:, 11:] - ref[2][:, 11:]).max())
         assert report[mode]["max_quat_diff"] < 1e-4, report

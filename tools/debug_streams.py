@@ -53,7 +53,10 @@ with torch.no_grad():
 bad = 0
 for j, g in enumerate(got):
     w = serial[j % 4]
+    live = 9 * int(w[1])   # rows at or past the device-side count of the capacity-sized buffers are not defined
     for nm, a, b in zip(("rows", "count") + names, g, w):
+        if nm in ("poses_tanh", "poses_pred", "fc7", "fc6", "pool_score"):
+            a, b = a[:live], b[:live]
         if not torch.equal(a, b):
             d = (a.float() - b.float()).abs()
             print("batch", j, nm, "differs: max", float(d.max()), "n", int((d > 0).sum()), "rows touched", sorted(set(torch.nonzero(d.reshape(d.shape[0], -1).sum(1) > 0).flatten().tolist()))[:12] if d.dim() > 1 else "")
