@@ -370,7 +370,7 @@ def main(argv=None):
         assert len(host) == 2 and not a.resident_inputs, "--graph uses --nbuf 2 and pinned-host inputs"
     feed_cache = None
     last = {}
-    drain = pdist.HostDrain(depth=2)
+    drain = pdist.HostDrain(depth=2, spin=a.latency)
     seq = {"i": 0}
     ticket_batch = {}
     loss_log = torch.zeros(max(1, a.steps + 8), dtype=torch.float32, device=dev)
@@ -627,14 +627,15 @@ def main(argv=None):
         if not ent or not avg_us or "SQ_INSTS_VALU" not in ent:
             return {}
         cyc = simds * clock_hz * avg_us * 1e-6
-        tot = float(ent["SQ_INSTS_VALU"] + ent.get("SQ_INSTS_SALU", 0) + ent.get("SQ_INSTS_LDS", 0) + ent.get("SQ_INSTS_MFMA", 0))
-        o = {"valu_frac": 2.0 * ent["SQ_INSTS_VALU"] / cyc, "valu_insts_per_launch": ent["SQ_INSTS_VALU"],
+        valu = ent["SQ_INSTS_VALU"] - ent.get("SQ_INSTS_MFMA", 0)     # (SQ_INSTS_VALU counts the MFMAs too)
+        tot = float(ent["SQ_INSTS_VALU"] + ent.get("SQ_INSTS_SALU", 0) + ent.get("SQ_INSTS_LDS", 0))
+        o = {"valu_frac": 2.0 * valu / cyc, "valu_insts_per_launch": valu,
              "lds_inst_share": ent.get("SQ_INSTS_LDS", 0) / tot if tot else None,
              "salu_inst_share": ent.get("SQ_INSTS_SALU", 0) / tot if tot else None,
-             "valu_frac_note": "SQ_INSTS_VALU x 2 issue cycles / (%d SIMDs x %.2f GHz x the live launch duration)" % (simds, clock_hz / 1e9)}
+             "valu_frac_note": "(SQ_INSTS_VALU - SQ_INSTS_MFMA) x 2 issue cycles / (%d SIMDs x %.2f GHz x the live launch duration)" % (simds, clock_hz / 1e9)}
         if "SQ_VALU_MFMA_BUSY_CYCLES" in ent and ent.get("SQ_INSTS_MFMA"):
             o["mfma_busy_share"] = ent["SQ_VALU_MFMA_BUSY_CYCLES"] / cyc
-            o["valu_per_mfma"] = ent["SQ_INSTS_VALU"] / float(ent["SQ_INSTS_MFMA"])
+            o["valu_per_mfma"] = valu / float(ent["SQ_INSTS_MFMA"])
             o["mfma_busy_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x clock x duration): the matrix pipe's busy share; every other vector "
                                    "instruction of either wave on the SIMD is paid in matrix time (SQ_VALU_MFMA_COEXEC_CYCLES = 0 on gfx950, DESIGN §3.2c)")
         if "SQ_WAIT_ANY" in ent and ent.get("SQ_WAVE_CYCLES"):
