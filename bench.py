@@ -52,6 +52,11 @@ def parse_args(argv=None):
                          "2 x 3.7 MB of f32 blobs); the first trunk kernel forms the blobs of lib/fcn/test.py:56-74 itself, bit for bit")
     ap.add_argument("--latency", action="store_true", help="per-frame synchronous loop; reports p50/p99 latency")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (see posecnn_amd/pipeline.py)")
+    ap.add_argument("--graph-upload", action="store_true", default=None,
+                    help="with --graph: the H2D copy of the frame(s) is a node of the captured graph (pinned host buffer -> the graph's "
+                         "device slot) instead of a side-stream copy fenced by events: one launch per frame, nothing to hand over "
+                         "between streams. Default in --latency mode (a synchronous single-frame loop has nothing to overlap the "
+                         "upload with); throughput runs keep the side-stream uploader, which copies batch i+1 under batch i's kernels")
     ap.add_argument("--streams", type=int, default=None,
                     help="HIP streams the batches alternate over (default 3 since round 4; 1 with --graph): batch i+1's trunk overlaps batch "
                          "i's heads / Hough / RoI tail, and the fused first-layers kernel (one workgroup per CU, matrix pipe half idle) "
@@ -86,6 +91,9 @@ def parse_args(argv=None):
     a = ap.parse_args(argv)
     if a.streams is None:
         a.streams = 1 if a.graph else 3
+    if a.graph_upload is None:
+        a.graph_upload = bool(a.graph and a.latency)
+    a.graph_upload = bool(a.graph_upload and a.graph and not a.resident_inputs)
     return a
 
 
@@ -365,7 +373,10 @@ def main(argv=None):
         uploader = None
     else:
         # (--graph: one captured step per device slot, so slot k always holds host batch k: nbuf = slots = 2)
-        uploader = pipeline.FrameUploader(host, dev, depth=1 if a.graph else 2)
+        uploader = None if a.graph_upload else pipeline.FrameUploader(host, dev, depth=1 if a.graph else 2)
+    # --graph-upload: one device slot per distinct host batch; the copy into it is part of the captured step
+    gslots = [pipeline.alloc_adjacent(hb, dev) for hb in host] if a.graph_upload else None
+    h2d_bytes = sum(t.numel() * t.element_size() for t in host[0] if t is not None)
     if a.graph:
         assert len(host) == 2 and not a.resident_inputs, "--graph uses --nbuf 2 and pinned-host inputs"
     feed_cache = None
@@ -413,11 +424,21 @@ def main(argv=None):
     def _launch():
         i = seq["i"]
         seq["i"] += 1
-        data, data_p = uploader.get(i) if uploader is not None else resident[i % len(resident)]
         k = i % len(planted)
+        if gslots is not None:
+            data, data_p = gslots[k]
+        else:
+            data, data_p = uploader.get(i) if uploader is not None else resident[i % len(resident)]
+
+        def upload(k=k):
+            for d_, h_ in zip(gslots[k], host[k]):
+                if d_ is not None:
+                    d_.copy_(h_, non_blocking=True)
         if a.graph and last.get("graph_ready"):
             if k not in graphs:   # capture once per device slot (its tensors are the graph's static inputs)
                 def fn(data=data, data_p=data_p, k=k):
+                    if gslots is not None:
+                        upload(k)     # a memcpy node: pinned host buffer k -> device slot k
                     d = step(data, data_p, k)
                     return d.rows, d.count, d.label_2d, net.get_output("poses_weight"), d.packed
                 graphs[k] = pipeline.GraphedStep(fn, warmup=1, device=dev)
@@ -425,6 +446,8 @@ def main(argv=None):
             det = fcn.Detections(rows, count, label_2d, packed_)
             last["poses_weight"] = pw
         else:
+            if gslots is not None:
+                upload(k)
             det = step(data, data_p, k)
             last["poses_weight"] = net.layers.get("poses_weight")
         if uploader is not None:
@@ -707,7 +730,7 @@ def main(argv=None):
         "config": {"workload": workload, "global_batch": B * world, "per_gpu_batch": B, "height": H, "width": W,
                    "num_classes": C, "input_format": a.input, "losses": a.losses,
                    "inputs": "resident" if a.resident_inputs else ("pinned-host-raw" if a.raw_inputs else "pinned-host"),
-                   "h2d_MB_per_step": None if a.resident_inputs else round(uploader.bytes_per_batch / 1e6, 1),
+                   "h2d_MB_per_step": None if a.resident_inputs else round(h2d_bytes / 1e6, 1),
                    "parallelism": "dp%d (frames sharded, 1 all-gather of detections)" % world,
                    "detections_per_step": ndet / a.steps, "adl_rows_with_targets": adl_rows},
         "value_cold": frames / elapsed_cold,
@@ -746,7 +769,7 @@ def main(argv=None):
                                             "batch run serially on one stream after the timed region, bit for bit"),
         "prewarm_seconds": a.prewarm_seconds,
         "host_launch_ms_per_step": host_launch_ms,
-        "step_submission": ("hipGraph replay (one graph per device slot)" if a.graph else "eager launches")
+        "step_submission": ("hipGraph replay (one graph per device slot" + (", the frame's H2D copy a node of it)" if a.graph_upload else ")") if a.graph else "eager launches")
                            + ("; batches alternate over %d HIP streams (per-kernel times from a separate single-stream pass)" % len(streams) if len(streams) > 1 else ""),
         "kernels_us": {k: round(v["avg_us"], 2) for k, v in sorted(kern.items())},
         "kernel_calls_per_step": {k: round(v["calls"] / a.steps, 2) for k, v in sorted(kern.items())},

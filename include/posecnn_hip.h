@@ -403,6 +403,12 @@ int pcnn_fc_rows_workspace_bytes(int rows_capacity, int in_features, int out_fea
 int pcnn_fc_rows_cols_fwd(const float* x, const float* wt, const float* bias, int rows_capacity,
                           int in_features, int out_padded, int out_features, int activation,
                           const int32_t* num_rows_dev, float* y, float* y_tanh, void* stream);
+/* Two layers that read the same rows as one product (round 5: score_conv4 + score_conv4_vertex on conv4_3, vgg16_convs.py:128-133,
+ * 151-157): wt [out_a + out_b][in_features] (the two filters one after the other), bias likewise, y_a [rows][out_a] and y_b
+ * [rows][out_b] with a ReLU flag each; out_a, out_b multiples of 64. Bit-identical to two pcnn_fc_rows_fwd calls. */
+int pcnn_fc_rows_split_fwd(const float* x, const float* wt, const float* bias, int rows_capacity, int in_features,
+                           int out_a, int out_b, int relu_a, int relu_b, const int32_t* num_rows_dev,
+                           float* y_a, float* y_b, void* stream);
 int pcnn_fc_rows_fwd(const float* x, const float* wt, const float* bias, int rows_capacity,
                      int in_features, int out_features, int relu, const int32_t* num_rows_dev,
                      const float* addend, float* y, void* workspace, size_t workspace_bytes, void* stream);

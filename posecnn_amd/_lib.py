@@ -53,6 +53,7 @@ SIGNATURES = {
     "pcnn_winograd43_output_both_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "pcnn_fc_rows_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
     "pcnn_fc_rows_cols_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "pcnn_fc_rows_split_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "pcnn_fc_rows_workspace_bytes": (c_int, [c_int, c_int, c_int, POINTER(c_size_t)]),
     "pcnn_fc_skinny_workspace_bytes": (c_int, [c_int, c_int, c_int, POINTER(c_size_t), POINTER(c_int)]),
     "pcnn_fc_skinny_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t, _P, c_int, _P]),

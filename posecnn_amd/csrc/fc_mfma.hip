@@ -57,8 +57,10 @@ __global__ __launch_bounds__(512, 4) void fc_rows_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ addend, float* __restrict__ y, int K, int N, int Mcap, int relu,
     const int* __restrict__ num_rows_dev, int nbm, int ncb, int tall, float* __restrict__ part,
-    int smax, int ws_rows, int ldy, int nvalid, float* __restrict__ y2)
+    int smax, int ws_rows, int ldy, int nvalid, float* __restrict__ y2, int split_col, float* __restrict__ y_b, int relu_b)
 {
+  // split_col / y_b (pcnn_fc_rows_split_fwd): output columns [split_col, N) go to a SECOND tensor y_b [Mcap][N - split_col] with
+  // their own ReLU flag — two layers that read the same rows (score_conv4 and score_conv4_vertex on conv4_3) as one product.
   // ldy / nvalid (pcnn_fc_rows_cols_fwd): y has `ldy` floats per row and only output columns < nvalid exist (the weight rows
   // past them are zero padding up to the kernel's 64-column blocks); y2, if given, receives tanh(y). Plain fc_rows: ldy =
   // nvalid = N, y2 = NULL.
@@ -91,6 +93,7 @@ __global__ __launch_bounds__(512, 4) void fc_rows_mfma_kernel(
       const int r = m0 + (i >> 4);
       const int c4_ = cb * 64 + (i & 15) * 4;
       if (r < Mcap && c4_ < nvalid) {
+        if (y_b != nullptr && c4_ >= split_col) { *reinterpret_cast<v4f*>(y_b + (size_t)r * (N - split_col) + (c4_ - split_col)) = (v4f){0.f, 0.f, 0.f, 0.f}; continue; }
         *reinterpret_cast<v4f*>(y + (size_t)r * ldy + c4_) = (v4f){0.f, 0.f, 0.f, 0.f};
         if (y2) *reinterpret_cast<v4f*>(y2 + (size_t)r * ldy + c4_) = (v4f){0.f, 0.f, 0.f, 0.f};   // tanh(0)
       }
@@ -221,16 +224,19 @@ __global__ __launch_bounds__(512, 4) void fc_rows_mfma_kernel(
       continue;
     }
     if (m < Mcap && cb * 64 + c4 < nvalid) {
+      const int col0 = cb * 64 + c4;
+      const bool second = y_b != nullptr && col0 >= split_col;
       v4f val = (v4f){0.f, 0.f, 0.f, 0.f};
       if (m < count) {
         val = *reinterpret_cast<const v4f*>(&sY[row * 64 + c4]);
-        if (addend) val += *reinterpret_cast<const v4f*>(addend + (size_t)m * N + cb * 64 + c4);
-        if (relu) {
+        if (addend) val += *reinterpret_cast<const v4f*>(addend + (size_t)m * N + col0);
+        if (second ? relu_b : relu) {
 #pragma unroll
           for (int e = 0; e < 4; e++) val[e] = val[e] > 0.f ? val[e] : 0.f;
         }
       }
-      *reinterpret_cast<v4f*>(y + (size_t)m * ldy + cb * 64 + c4) = val;
+      if (second) { *reinterpret_cast<v4f*>(y_b + (size_t)m * (N - split_col) + (col0 - split_col)) = val; continue; }
+      *reinterpret_cast<v4f*>(y + (size_t)m * ldy + col0) = val;
       if (y2) {
         v4f t;
 #pragma unroll
@@ -317,7 +323,7 @@ extern "C" int pcnn_fc_rows_fwd(const float* x, const float* wt, const float* bi
   const int smax = (workspace && workspace_bytes >= need && fc_can_split(rows_capacity, in_features, out_features) && aligned16(workspace)) ? smax_cap : 1;
   float* part = smax > 1 ? static_cast<float*>(workspace) : nullptr;
   PCNN_LAUNCH(fc_rows_mfma_kernel, dim3((unsigned)blocks, smax), dim3(512), 0, stream, x, wt, bias, addend, y, in_features,
-              out_features, rows_capacity, relu, num_rows_dev, nbm, ncb, tall, part, smax, ws_rows, out_features, out_features, (float*)nullptr);
+              out_features, rows_capacity, relu, num_rows_dev, nbm, ncb, tall, part, smax, ws_rows, out_features, out_features, (float*)nullptr, 0, (float*)nullptr, 0);
   if (smax > 1) {
     const long long items = (long long)ws_rows * (out_features / 4);
     PCNN_LAUNCH(fc_rows_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, part, bias, addend, y,
@@ -354,6 +360,36 @@ extern "C" int pcnn_fc_rows_cols_fwd(const float* x, const float* wt, const floa
   const long long blocks = tall ? (long long)((nbm + 7) / 8) * 8 * ncb : (long long)((ncb + 7) / 8) * 8 * nbm;
   PCNN_LAUNCH(fc_rows_mfma_kernel, dim3((unsigned)blocks, 1), dim3(512), 0, stream, x, wt, bias, (const float*)nullptr, y, in_features,
               out_padded, rows_capacity, activation == 1 ? 1 : 0, num_rows_dev, nbm, ncb, tall, (float*)nullptr, 1, 0, out_features, out_features,
-              activation == 2 ? y_tanh : (float*)nullptr);
+              activation == 2 ? y_tanh : (float*)nullptr, 0, (float*)nullptr, 0);
   return check_launch("fc_rows_cols_fwd");
+}
+
+// Two layers on the same rows as ONE product (round 5: score_conv4 [ReLU] and score_conv4_vertex [none] both read conv4_3,
+// likewise on conv5_3 — vgg16_convs.py:128-133,151-157): wt [out_a + out_b][in_features] = the two filters one after the other,
+// y_a [rows][out_a], y_b [rows][out_b], a ReLU flag each. out_a, out_b multiples of 64. Same per-output arithmetic as two
+// pcnn_fc_rows_fwd calls (the K loop does not know which layer a column belongs to): same bits, one launch less.
+extern "C" int pcnn_fc_rows_split_fwd(const float* x, const float* wt, const float* bias, int rows_capacity, int in_features,
+                                      int out_a, int out_b, int relu_a, int relu_b, const int32_t* num_rows_dev,
+                                      float* y_a, float* y_b, void* stream_)
+{
+  PCNN_REQUIRE(rows_capacity >= 0, PCNN_EINVAL, "fc_rows_split: negative row capacity");
+  PCNN_REQUIRE(in_features >= 128 && in_features % 64 == 0, PCNN_EINVAL,
+               "fc_rows_split: in_features must be a multiple of 64, >= 128 (got %d)", in_features);
+  PCNN_REQUIRE(out_a >= 64 && out_a % 64 == 0 && out_b >= 64 && out_b % 64 == 0, PCNN_EINVAL,
+               "fc_rows_split: both widths must be multiples of 64 (got %d, %d)", out_a, out_b);
+  if (rows_capacity == 0) return PCNN_OK;
+  PCNN_REQUIRE(x && wt && bias && y_a && y_b, PCNN_ENULL, "fc_rows_split: NULL pointer");
+  PCNN_REQUIRE(aligned16(x) && aligned16(wt) && aligned16(y_a) && aligned16(y_b) && aligned16(bias), PCNN_EINVAL,
+               "fc_rows_split: pointers (x, wt, bias, y_a, y_b) must be 16-byte aligned");
+  const int N = out_a + out_b;
+  PCNN_REQUIRE((long long)rows_capacity * in_features < (1ll << 30) && (long long)N * in_features < (1ll << 30),
+               PCNN_EINVAL, "fc_rows_split: operand larger than the 32-bit byte offsets of the kernel");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int nbm = (rows_capacity + 63) / 64, ncb = N / 64;
+  const int tall = (long long)rows_capacity > (long long)N;
+  const long long blocks = tall ? (long long)((nbm + 7) / 8) * 8 * ncb : (long long)((ncb + 7) / 8) * 8 * nbm;
+  PCNN_LAUNCH(fc_rows_mfma_kernel, dim3((unsigned)blocks, 1), dim3(512), 0, stream, x, wt, bias, (const float*)nullptr, y_a, in_features,
+              N, rows_capacity, relu_a ? 1 : 0, num_rows_dev, nbm, ncb, tall, (float*)nullptr, 1, 0, out_a, N, (float*)nullptr, out_a, y_b,
+              relu_b ? 1 : 0);
+  return check_launch("fc_rows_split_fwd");
 }

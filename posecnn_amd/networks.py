@@ -793,6 +793,7 @@ class vgg16_convs(Network):
         self.with_losses = bool(is_train) if with_losses is None else bool(with_losses)
         self.planted = None
         self.grouped_towers = True    # RGB-D inference: both towers as one grouped launch sequence
+        self.merge_head_convs = True  # COLOR: the label and vertex 1x1 convolutions of a source as one product (fc_rows_split)
         self.mfma_heads = True        # big batches: add_score / add_score_vertex + the 1/8-resolution `score` / `vertex_pred` products in one launch per head
         self.head_gemm = True         # 1x1 head convs (incl. the RGB-D concat) on the library's own fp32-MFMA row kernel
         self._head_wt = {}
@@ -1112,10 +1113,44 @@ class vgg16_convs(Network):
         self.feed(add)
         return z, b
 
+    def _merged_head_convs(self):
+        """COLOR networks (round 5, the single-frame loop's launch count): `score_conv5` [ReLU] and `score_conv5_vertex` [none] both
+        read conv5_3, `score_conv4` / `score_conv4_vertex` both read conv4_3 (vgg16_convs.py:128-133,151-157) — one product per
+        source instead of two (ops.fc_rows_split: the same kernel, the same bits per column). Only when every variable already
+        exists (loaded / calibrated / a previous run): a lazily initialised network creates them in the reference's order first."""
+        names = ('score_conv5', 'score_conv4', 'score_conv5_vertex', 'score_conv4_vertex')
+        if not (self.input_format != 'RGBD' and self.vertex_reg and self.head_gemm and self.merge_head_convs
+                and all((n + sfx) in self.vars for n in names for sfx in ('/weights', '/biases'))
+                and not (torch.is_grad_enabled() and self.trainable)):
+            return False
+        srcs = {'conv5_3': ('score_conv5', 'score_conv5_vertex'), 'conv4_3': ('score_conv4', 'score_conv4_vertex')}
+        xs = {k: self.get_output(k) for k in srcs}
+        if not all(isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and x.shape[-1] % 64 == 0 and x.shape[-1] >= 128 for x in xs.values()):
+            return False
+        for src, (na, nb) in srcs.items():
+            wa, wb = self.vars[na + '/weights'], self.vars[nb + '/weights']
+            ba, bb = self.vars[na + '/biases'], self.vars[nb + '/biases']
+            c_i = int(xs[src].shape[-1])
+            if tuple(wa.shape[1:]) != (c_i, 1, 1) or tuple(wb.shape[1:]) != (c_i, 1, 1) or wa.shape[0] % 64 or wb.shape[0] % 64:
+                return False
+            key = tuple((t.data_ptr(), t._version) for t in (wa, wb, ba, bb))
+            hit = self._head_wt.get(('merged', src))
+            if hit is None or hit[0] != key:
+                hit = (key, torch.cat([wa.detach().reshape(wa.shape[0], c_i), wb.detach().reshape(wb.shape[0], c_i)]).contiguous(),
+                       torch.cat([ba.detach(), bb.detach()]).contiguous())
+                self._head_wt[('merged', src)] = hit
+            B_, h, w_ = xs[src].shape[:3]
+            ya, yb = ops.fc_rows_split(xs[src].reshape(-1, c_i), hit[1], hit[2], wa.shape[0], relu_a=True, relu_b=False)
+            self.layers[na] = ya.view(B_, h, w_, wa.shape[0])
+            self.layers[nb] = yb.view(B_, h, w_, wb.shape[0])
+        return True
+
     def _setup_heads(self):
         towers = ('', '_p') if self.input_format == 'RGBD' else ('',)
-        self._head_conv1x1(['conv5_3' + t for t in towers], self.num_units, 'score_conv5')
-        self._head_conv1x1(['conv4_3' + t for t in towers], self.num_units, 'score_conv4')
+        merged = self._merged_head_convs()
+        if not merged:
+            self._head_conv1x1(['conv5_3' + t for t in towers], self.num_units, 'score_conv5')
+            self._head_conv1x1(['conv4_3' + t for t in towers], self.num_units, 'score_conv4')
         small = self._small_head('score_conv5', 'score_conv4', 'upscore_conv5', 'add_score', 'dropout', 'add_score',
                                  'score', self.num_classes, self.num_units)
         if small is None:
@@ -1163,8 +1198,9 @@ class vgg16_convs(Network):
                  .hard_label(threshold=self.threshold_label, name='gt_label_weight'))
 
         if self.vertex_reg:
-            self._head_conv1x1(['conv5_3'], 128, 'score_conv5_vertex', relu=False)
-            self._head_conv1x1(['conv4_3'], 128, 'score_conv4_vertex', relu=False)
+            if not merged:
+                self._head_conv1x1(['conv5_3'], 128, 'score_conv5_vertex', relu=False)
+                self._head_conv1x1(['conv4_3'], 128, 'score_conv4_vertex', relu=False)
             small_v = self._small_head('score_conv5_vertex', 'score_conv4_vertex', 'upscore_conv5_vertex', 'add_score_vertex',
                                        'dropout_vertex', 'add_score_vertex', 'vertex_pred', 3 * self.num_classes, 128)
             if small_v is None:

@@ -635,6 +635,24 @@ def fc_rows(x, wt, bias, relu=True, num_rows=None, addend=None):
     return y
 
 
+def fc_rows_split(x, wt, bias, out_a, relu_a=True, relu_b=False, num_rows=None):
+    """Two layers on the same rows as one product: wt [out_a + out_b, K] and bias [out_a + out_b] hold the two filters one
+    after the other; returns (y_a [M, out_a], y_b [M, out_b]) with a ReLU flag each. Bit-identical to two `fc_rows` calls."""
+    x = _dev(x, "x", torch.float32)
+    wt = _dev(wt, "wt", torch.float32)
+    bias = _aligned16(_dev(bias, "bias", torch.float32))
+    if x.dim() != 2 or wt.dim() != 2 or wt.shape[1] != x.shape[1] or bias.numel() != wt.shape[0] or not 0 < out_a < wt.shape[0]:
+        raise ValueError("x must be [M, K], wt [out_a + out_b, K], bias [out_a + out_b]")
+    M, K = x.shape
+    out_b = wt.shape[0] - int(out_a)
+    ya = torch.empty((M, int(out_a)), dtype=torch.float32, device=x.device)
+    yb = torch.empty((M, out_b), dtype=torch.float32, device=x.device)
+    nr = _dev(num_rows, "num_rows", torch.int32) if num_rows is not None else None
+    check("pcnn_fc_rows_split_fwd", lib().pcnn_fc_rows_split_fwd(_ptr(x), _ptr(wt), _ptr(bias), M, K, int(out_a), out_b, 1 if relu_a else 0,
+                                                                1 if relu_b else 0, _ptr(nr), _ptr(ya), _ptr(yb), _stream(x)))
+    return ya, yb
+
+
 def fc_rows_cols(x, wt_padded, bias_padded, out_features, activation="none", num_rows=None):
     """`fc_rows` for a width that is no multiple of 64 (fc8: 88): wt_padded [Npad, K] / bias_padded [Npad] zero-padded to a
     multiple of 64, y [M, out_features]. activation "none" | "relu" | "tanh"; "tanh" returns (linear, tanh(linear))."""

@@ -229,3 +229,31 @@ def test_pose_l2_normalize_and_the_packed_detection_block(gpu):
             want = pdist.pack_detections(rows0, c0, off)
             same(N(block), N(want), "packed block, stride %d offset %d" % (stride, off))
             assert int(c1) == int(c0) and rows.data_ptr() == block.data_ptr()
+
+
+def test_merged_head_convs_equal_the_separate_products(gpu):
+    """COLOR networks run `score_conv5` + `score_conv5_vertex` (both on conv5_3) and `score_conv4` + `score_conv4_vertex` (both on
+    conv4_3; vgg16_convs.py:128-133,151-157) as one product per source (pcnn_fc_rows_split_fwd): every layer downstream must carry
+    the bits of the four separate launches."""
+    import torch
+    from posecnn_amd import fcn
+    from posecnn_amd.networks import vgg16_convs
+    C, H, W = 22, 96, 128
+    rng = np.random.default_rng(4)
+    K = config.DEMO_INTRINSICS.copy(); K[:2] *= W / 640.0
+    pts = synth.make_model_points(C, 32)
+    outs = []
+    for merge in (True, False):
+        net = vgg16_convs("COLOR", C, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True, trainable=False, is_train=False,
+                          seed=3, init="he", with_losses=False, device=gpu)
+        synth.init_calibrated(net)
+        net.merge_head_convs = merge
+        data = T(gpu, (np.random.default_rng(9).integers(0, 256, (2, H, W, 3)).astype(np.float32) - config.PIXEL_MEANS).astype(np.float32))
+        feed = fcn._feed(net, data, None, K, config.LOV_EXTENTS, pts, config.LOV_SYMMETRY, C, gpu)
+        planted_np, _ = synth.make_planted_batch(3, 2, H=H, W=W, K=K, C=C, n_obj=2)
+        with torch.no_grad():
+            net.run(feed, planted={k: T(gpu, v) for k, v in planted_np.items()})
+        outs.append({n: N(net.get_output(n)) for n in ("score_conv5", "score_conv4", "score_conv5_vertex", "score_conv4_vertex", "add_score",
+                                                      "add_score_vertex", "label_2d", "vertex_pred_lowres", "rois", "poses_tanh")})
+    for n in outs[0]:
+        same(outs[0][n], outs[1][n], n)
