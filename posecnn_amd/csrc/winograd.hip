@@ -17,6 +17,8 @@
 //
 //   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]      A^T = [1 1 1 0; 0 1 -1 -1]
 // Canonical order: rows first, then columns; sums left to right; + bias last.
+#include <cstdlib>
+
 #include "pcnn_device.h"
 
 namespace {
@@ -193,6 +195,10 @@ __device__ __forceinline__ void at6(const VT* m, VT* y)
   y[3] = (d + 8.f * D) + m[5];
 }
 
+// (Round 5 measured non-temporal stores for V — written once here, read back by wino43_mfma_kernel: the 12 transforms 4.57 ->
+//  4.45 ms alone (conv4_1 0.113 -> 0.085, conv5_x 0.051 -> 0.044, conv2_2 0.819 -> 0.797) and the MFMA kernels behind them no
+//  slower (14.37 -> 14.29 ms) — but inside the three-stream step the transform came out 3 % SLOWER (258 -> 265 us per launch),
+//  the MFMA kernel 0.7 % faster, the step 805 vs 808 frames/s: nothing; plain stores stay.)
 template <typename VT>
 __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restrict__ x,
                                                            float* __restrict__ v, int H, int W, int C,
