@@ -2,7 +2,7 @@
 set -x
 O=/root/repo/gpurun_out/${1:-r5q}; mkdir -p $O
 cd /root/repo
-python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --streams 1 --no-cpu-baseline --no-secondary > $O/bench_streams1.json 2> $O/bench_streams.err
 python bench.py --graph --no-cpu-baseline --no-secondary > $O/bench_graph.json 2> $O/bench_graph.err
 python bench.py --latency --batch 1 --input COLOR --losses none --no-cpu-baseline --graph --raw-inputs --steps 200 --no-secondary > $O/bench_latency_b1_inference_raw.json 2> $O/bench_latency.err
