@@ -149,8 +149,9 @@ def test_fc_skinny_fence_free_exchange_equals_the_fenced_one(gpu, tmp_path):
 # ---- _small_head eligibility --------------------------------------------------------------------
 def test_small_head_falls_back_when_the_head_does_not_fit_the_one_launch_kernel(gpu):
     """With num_classes >= 30 the vertex head (128 units -> 3 C outputs) needs more than the 60 KB of LDS the
-    one-launch head kernel has: `_small_head` must decline (deconv + add + 1x1 path) instead of raising EINVAL, and
-    the label head (64 -> C), which still fits, keeps using it. Both must equal the network with small_heads off."""
+    vector-ALU one-launch head kernel has: `_small_head` must pick a path that fits instead of raising EINVAL — since
+    round 5 the matrix-core head kernel (up to 96 outputs: 93 here), before that deconv + add + 1x1 — and the label head
+    (64 -> C) keeps its one launch. Both must equal the network with small_heads off (deconv + add + 1x1 for both heads)."""
     import torch
     from posecnn_amd import fcn
     from posecnn_amd.networks import vgg16_convs

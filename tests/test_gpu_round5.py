@@ -59,7 +59,7 @@ def test_three_streams_full_size_batches_equal_the_serial_run(gpu):
     def one(b):
         det = fcn.im_segment_batch(net, b[0], K, config.LOV_EXTENTS, pts, config.LOV_SYMMETRY, data_p=b[1], planted=b[2],
                                    with_losses=True, gt_poses=b[3])
-        n = det.count   # device-side; rows past 9 x count of fc7 / poses_tanh are not defined (dead_rows="keep")
+        # (rows past 9 x count of fc7 / poses_tanh are not defined — dead_rows="keep" — and are not compared below)
         return (det.rows.clone(), det.count.clone(), net.get_output("loss_pose").clone(), net.get_output("fc7").clone(),
                 net.get_output("poses_tanh").clone(), net.get_output("label_2d").clone())
 
