@@ -113,16 +113,30 @@ __global__ __launch_bounds__(ADL_THREADS) void adl_terms_kernel(
       // walks the four in ascending q. Round 4's loop took 3 LDS reads + 14 vector instructions per candidate, this one
       // 0.75 + ~7: the kernel is bound by exactly this instruction stream (P^2 = 6.9 M candidates per symmetric RoI).
       const v2f x1v = (v2f){x1, x1}, y1v = (v2f){y1, y1}, z1v = (v2f){z1, z1};
-      for (int j = 0; j < lim; j += 4) {
-        const v4f qx = *reinterpret_cast<const v4f*>(&s_qx[j]), qy = *reinterpret_cast<const v4f*>(&s_qy[j]), qz = *reinterpret_cast<const v4f*>(&s_qz[j]);
-        const v2f ex0 = x1v - qx.xy, ey0 = y1v - qy.xy, ez0 = z1v - qz.xy;
-        const v2f ex1 = x1v - qx.zw, ey1 = y1v - qy.zw, ez1 = z1v - qz.zw;
-        const v2f d0 = (ex0 * ex0 + ey0 * ey0) + ez0 * ez0;
-        const v2f d1 = (ex1 * ex1 + ey1 * ey1) + ez1 * ez1;
-        if (d0.x < dmin) { dmin = d0.x; qmin = q0 + j; }
-        if (d0.y < dmin) { dmin = d0.y; qmin = q0 + j + 1; }
-        if (d1.x < dmin) { dmin = d1.x; qmin = q0 + j + 2; }
-        if (d1.y < dmin) { dmin = d1.y; qmin = q0 + j + 3; }
+      // SIXTEEN candidates per trip, their twelve LDS reads issued before the first use: a symmetric row's workgroup is one
+      // wave per SIMD with nobody to run under an LDS round trip, and with one read-then-use group of four per trip the scan
+      // cost 78 cycles per candidate — ~120 of LDS latency per trip — i.e. 85 us for a single symmetric row
+      // (tools/probe_adl.py). The tile is padded with +inf to a multiple of 16 (ADL_QTILE is one).
+      for (int j = 0; j < lim; j += 16) {
+        v4f qx[4], qy[4], qz[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          qx[u] = *reinterpret_cast<const v4f*>(&s_qx[j + 4 * u]);
+          qy[u] = *reinterpret_cast<const v4f*>(&s_qy[j + 4 * u]);
+          qz[u] = *reinterpret_cast<const v4f*>(&s_qz[j + 4 * u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const v2f ex0 = x1v - qx[u].xy, ey0 = y1v - qy[u].xy, ez0 = z1v - qz[u].xy;
+          const v2f ex1 = x1v - qx[u].zw, ey1 = y1v - qy[u].zw, ez1 = z1v - qz[u].zw;
+          const v2f d0 = (ex0 * ex0 + ey0 * ey0) + ez0 * ez0;
+          const v2f d1 = (ex1 * ex1 + ey1 * ey1) + ez1 * ez1;
+          const int q4 = q0 + j + 4 * u;
+          if (d0.x < dmin) { dmin = d0.x; qmin = q4; }
+          if (d0.y < dmin) { dmin = d0.y; qmin = q4 + 1; }
+          if (d1.x < dmin) { dmin = d1.x; qmin = q4 + 2; }
+          if (d1.y < dmin) { dmin = d1.y; qmin = q4 + 3; }
+        }
       }
     }
   }
