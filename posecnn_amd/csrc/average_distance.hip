@@ -24,6 +24,12 @@ using namespace pcnn;
 
 constexpr int ADL_THREADS = 256;
 constexpr int ADL_QTILE = 1024;
+constexpr int ADL_SUM_THREADS = 256;
+constexpr int ADL_SUM_TILE_MAX = 3072;   // adl_sum_kernel: terms of one row staged per round, at most (62 KB of LDS for the five chains)
+constexpr int ADL_SUM_PAD = 36;          // floats behind each chain's tile: the chain prefetches one trip of 16 past its end
+// the staged tile: the whole row (to a multiple of 32 floats) when it fits
+__host__ __device__ inline int adl_sum_tile(int P) { const int t = (P + 31) & ~31; return t < ADL_SUM_TILE_MAX ? t : ADL_SUM_TILE_MAX; }
+constexpr int ADL_ROW_SLOTS = 512;   // grid.y of adl_terms_kernel at most; rows are strided over it
 
 // quaternion (s,u,v,w) -> rotation, average_distance_loss_op_gpu.cu.cc:62-71
 __device__ __forceinline__ void quat_rot(float s, float u, float v, float w, float* r)
@@ -54,69 +60,129 @@ __device__ __forceinline__ int find_class(const float* __restrict__ weight, int 
 }
 
 // terms layout: [R][5][P]
-__global__ __launch_bounds__(ADL_THREADS) void adl_terms_kernel(
+// One model point through the gt rotation (:156-158): the expression the tile fill, the in-trip walk and the final
+// term all use, so the three see the same bits.
+__device__ __forceinline__ void adl_rotate3(const float* rg, float a, float b, float c, float& x, float& y, float& z) {
+  x = rg[0] * a + rg[1] * b + rg[2] * c;
+  y = rg[3] * a + rg[4] * b + rg[5] * c;
+  z = rg[6] * a + rg[7] * b + rg[8] * c;
+}
+
+// A row's class and its two quaternions in ONE round of loads: lane c reads class c's weight and both quaternions,
+// a ballot picks the first positive weight (:52-60) and v_readlane hands its eight floats to every lane. The serial form —
+// class first, then the quaternions at the address it gives — is one more dependent trip to memory in front of every
+// workgroup, and this kernel's launch is a few rounds of exactly such trips (tools/probe_adl.py: 46 us with no symmetric
+// row at all). More than 64 classes: the two-trip form. Must be called by all lanes of the wave; returns -1 for no target.
+__device__ __forceinline__ int adl_row_header(const float* __restrict__ weight, const float* __restrict__ target,
+                                              const float* __restrict__ prediction, int n, int C, float* qt, float* qp)
+{
+  const size_t row = (size_t)n * PCNN_POSE_CHANNELS * C;
+  if (C <= 64) {
+    const int c = lane_id() < C ? lane_id() : 0;
+    const float* wr = weight + row + PCNN_POSE_CHANNELS * c;
+    const float* tr = target + row + PCNN_POSE_CHANNELS * c;
+    const float* pr = prediction + row + PCNN_POSE_CHANNELS * c;
+    const float wv = wr[0];
+    float t[4], q[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { t[i] = tr[i]; q[i] = pr[i]; }
+    const unsigned long long m = __ballot(lane_id() < C && wv > 0);
+    if (!m) return -1;
+    const int cls = __ffsll((long long)m) - 1;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      qt[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t[i]), cls));
+      qp[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q[i]), cls));
+    }
+    return cls;
+  }
+  const int cls = find_class(weight, n, C);
+  if (cls < 0) return -1;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    qt[i] = target[row + PCNN_POSE_CHANNELS * cls + i];
+    qp[i] = prediction[row + PCNN_POSE_CHANNELS * cls + i];
+  }
+  return cls;
+}
+
+__device__ __forceinline__ void adl_terms_row(
     const float* __restrict__ prediction, const float* __restrict__ target,
     const float* __restrict__ weight, const float* __restrict__ point,
-    const float* __restrict__ symmetry, float* __restrict__ terms, int R_cap, int C, int P,
-    float margin, const int* __restrict__ num_rows_dev)
+    const float* __restrict__ symmetry, float* __restrict__ terms, int C, int P,
+    float margin, int R, int n, int p, float* s_qx, float* s_qy, float* s_qz)
 {
   typedef float v2f __attribute__((ext_vector_type(2)));
   typedef float v4f __attribute__((ext_vector_type(4)));
-  __shared__ __attribute__((aligned(16))) float s_qx[ADL_QTILE], s_qy[ADL_QTILE], s_qz[ADL_QTILE];   // gt-rotated model points, coordinate-major
-  const int n = blockIdx.y;
-  const int p = blockIdx.x * ADL_THREADS + threadIdx.x;
-  // R = the op's row count: the buffers' row capacity, or (capacity-sized buffers of the sync-free
-  // Hough op) the device-side count; rows past it do not exist for the loss
-  const int R = num_rows_dev ? min(R_cap, num_rows_dev[0]) : R_cap;
-  const int cls = n < R ? find_class(weight, n, C) : -1;
+  float qt[4], qp[4];
+  const int cls = adl_row_header(weight, target, prediction, n, C, qt, qp);
   float* tn = terms + (size_t)n * 5 * P;
-  if (cls < 0) return;   // no target (or past the row count): adl_sum writes this row's zeros without reading any terms
+  if (cls < 0) return;   // no target: adl_sum writes this row's zeros without reading any terms
                          // (a train-mode buffer of 3024 rows holds ~470 with targets: 134 MB of zeros were written here
                          //  and read back there)
-  const int qi = n * PCNN_POSE_CHANNELS * C + PCNN_POSE_CHANNELS * cls;
   float rg[9], ru[9];
-  quat_rot(target[qi], target[qi + 1], target[qi + 2], target[qi + 3], rg);
-  const float s = prediction[qi], u = prediction[qi + 1], v = prediction[qi + 2], w = prediction[qi + 3];
+  quat_rot(qt[0], qt[1], qt[2], qt[3], rg);
+  const float s = qp[0], u = qp[1], v = qp[2], w = qp[3];
   quat_rot(s, u, v, w, ru);
   const float* pts = point + (size_t)cls * P * 3;
   const bool valid = p < P;
+  const bool symmetric = symmetry[cls] > 0;
   float pt0 = 0, pt1 = 0, pt2 = 0;
   if (valid) { pt0 = pts[p * 3]; pt1 = pts[p * 3 + 1]; pt2 = pts[p * 3 + 2]; }
   const float x1 = ru[0] * pt0 + ru[1] * pt1 + ru[2] * pt2;
   const float y1 = ru[3] * pt0 + ru[4] * pt1 + ru[5] * pt2;
   const float z1 = ru[6] * pt0 + ru[7] * pt1 + ru[8] * pt2;
 
-  int qmin = p;
-  if (symmetry[cls] > 0) {
-    // closest gt-rotated model point, strict '<' from FLT_MAX, first wins (:155-168)
+  // the matched point: the point itself unless the class is symmetric
+  float qa = pt0, qb = pt1, qc = pt2;
+  if (symmetric) {
+    int qmin = p;
+    // closest gt-rotated model point, strict '<' from FLT_MAX, first wins (:155-168).
+    //
+    // Two steps with the same answer as the reference's one-candidate-at-a-time walk:
+    //  1. over trips of SIXTEEN consecutive candidates: m = the smallest distance of the trip (a v_min tree: exact, and a
+    //     NaN distance is ignored exactly as 'NaN < dmin' ignores it); 'if (m < dmin) { dmin = m; tmin = trip; }'. The strict
+    //     '<' keeps the FIRST trip that holds the overall minimum.
+    //  2. inside that one trip, the reference's walk itself (strict '<' from FLT_MAX): the first candidate at the minimum.
+    // The walk's compare -> select -> compare chain (a VALU write of VCC read by the next VALU instruction, twice per
+    // candidate) is what bound the kernel: a symmetric row's workgroup is one wave per SIMD, nothing runs under the chain,
+    // and the four-candidate version took 78 cycles per candidate, the sixteen-candidate version with its LDS reads
+    // issued first still 57 (tools/probe_adl.py: 90 and 63 us for ONE symmetric row). Here the chain is per trip, and a
+    // candidate costs 2.5 packed-f32 instructions of distance plus half a v_min3.
     float dmin = FLT_MAX;
+    int tmin = -1;
+    const v2f x1v = (v2f){x1, x1}, y1v = (v2f){y1, y1}, z1v = (v2f){z1, z1};
+    // the tile's model points are fetched one tile ahead, into registers: the next tile's trip to memory runs under this
+    // tile's scan instead of in front of its own
+    constexpr int NQ = ADL_QTILE / ADL_THREADS;
+    float pa[NQ][3];
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+      const int q = min((int)threadIdx.x + i * ADL_THREADS, P - 1);
+      pa[i][0] = pts[q * 3]; pa[i][1] = pts[q * 3 + 1]; pa[i][2] = pts[q * 3 + 2];
+    }
     for (int q0 = 0; q0 < P; q0 += ADL_QTILE) {
       __syncthreads();
-      for (int j = threadIdx.x; j < ADL_QTILE; j += ADL_THREADS) {
-        int q = q0 + j;
-        // past the last point: +inf coordinates -> distance +inf (or NaN), never '<' anything: the scan below runs over
-        // whole groups of four without a tail
+#pragma unroll
+      for (int i = 0; i < NQ; i++) {
+        const int j = threadIdx.x + i * ADL_THREADS;
+        // past the last point: +inf coordinates -> distance +inf (or NaN), never '<' anything: whole trips, no tail
         float qx = __builtin_inff(), qy = qx, qz = qx;
-        if (q < P) {
-          float a = pts[q * 3], b = pts[q * 3 + 1], c = pts[q * 3 + 2];
-          qx = rg[0] * a + rg[1] * b + rg[2] * c;
-          qy = rg[3] * a + rg[4] * b + rg[5] * c;
-          qz = rg[6] * a + rg[7] * b + rg[8] * c;
-        }
+        if (q0 + j < P) adl_rotate3(rg, pa[i][0], pa[i][1], pa[i][2], qx, qy, qz);
         s_qx[j] = qx; s_qy[j] = qy; s_qz[j] = qz;
       }
       __syncthreads();
+      if (q0 + ADL_QTILE < P) {
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+          const int q = min(q0 + ADL_QTILE + (int)threadIdx.x + i * ADL_THREADS, P - 1);
+          pa[i][0] = pts[q * 3]; pa[i][1] = pts[q * 3 + 1]; pa[i][2] = pts[q * 3 + 2];
+        }
+      }
       const int lim = min(ADL_QTILE, P - q0);
-      // Four candidates per trip: one 128-bit LDS read per coordinate (every lane reads the same address: a broadcast)
-      // and the squared distance of two candidates per packed-f32 instruction — v_pk_add / v_pk_mul round each half
-      // like the scalar form, so every distance is ((ex ex) + (ey ey)) + (ez ez) bit for bit (:160-163); the strict '<'
-      // walks the four in ascending q. Round 4's loop took 3 LDS reads + 14 vector instructions per candidate, this one
-      // 0.75 + ~7: the kernel is bound by exactly this instruction stream (P^2 = 6.9 M candidates per symmetric RoI).
-      const v2f x1v = (v2f){x1, x1}, y1v = (v2f){y1, y1}, z1v = (v2f){z1, z1};
-      // SIXTEEN candidates per trip, their twelve LDS reads issued before the first use: a symmetric row's workgroup is one
-      // wave per SIMD with nobody to run under an LDS round trip, and with one read-then-use group of four per trip the scan
-      // cost 78 cycles per candidate — ~120 of LDS latency per trip — i.e. 85 us for a single symmetric row
-      // (tools/probe_adl.py). The tile is padded with +inf to a multiple of 16 (ADL_QTILE is one).
+      // one 128-bit LDS read per coordinate per four candidates (every lane reads the same address: a broadcast), all
+      // twelve of a trip issued before the first use; two candidates per packed-f32 instruction — v_pk_add / v_pk_mul
+      // round each half like the scalar form, so every distance is ((ex ex) + (ey ey)) + (ez ez) bit for bit (:160-163)
       for (int j = 0; j < lim; j += 16) {
         v4f qx[4], qy[4], qz[4];
 #pragma unroll
@@ -125,23 +191,45 @@ __global__ __launch_bounds__(ADL_THREADS) void adl_terms_kernel(
           qy[u] = *reinterpret_cast<const v4f*>(&s_qy[j + 4 * u]);
           qz[u] = *reinterpret_cast<const v4f*>(&s_qz[j + 4 * u]);
         }
+        float m4[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const v2f ex0 = x1v - qx[u].xy, ey0 = y1v - qy[u].xy, ez0 = z1v - qz[u].xy;
           const v2f ex1 = x1v - qx[u].zw, ey1 = y1v - qy[u].zw, ez1 = z1v - qz[u].zw;
           const v2f d0 = (ex0 * ex0 + ey0 * ey0) + ez0 * ez0;
           const v2f d1 = (ex1 * ex1 + ey1 * ey1) + ez1 * ez1;
-          const int q4 = q0 + j + 4 * u;
-          if (d0.x < dmin) { dmin = d0.x; qmin = q4; }
-          if (d0.y < dmin) { dmin = d0.y; qmin = q4 + 1; }
-          if (d1.x < dmin) { dmin = d1.x; qmin = q4 + 2; }
-          if (d1.y < dmin) { dmin = d1.y; qmin = q4 + 3; }
+          m4[u] = __builtin_fminf(__builtin_fminf(d0.x, d0.y), __builtin_fminf(d1.x, d1.y));
+        }
+        const float m = __builtin_fminf(__builtin_fminf(m4[0], m4[1]), __builtin_fminf(m4[2], m4[3]));
+        if (m < dmin) { dmin = m; tmin = q0 + j; }
+      }
+    }
+    if (tmin >= 0) {
+      // step 2: the trip's sixteen candidates again, rotated by the expression that filled the tile (same bits); loads
+      // eight at a time, all issued before the first use (clamped addresses: a candidate past P is skipped below)
+      float dm = FLT_MAX;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        float ca[8][3];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int q = min(tmin + 8 * h + u, P - 1);
+          ca[u][0] = pts[q * 3]; ca[u][1] = pts[q * 3 + 1]; ca[u][2] = pts[q * 3 + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int q = tmin + 8 * h + u;
+          float qx, qy, qz;
+          adl_rotate3(rg, ca[u][0], ca[u][1], ca[u][2], qx, qy, qz);
+          const float ex = x1 - qx, ey = y1 - qy, ez = z1 - qz;
+          const float d = (ex * ex + ey * ey) + ez * ez;
+          if (q < P && d < dm) { dm = d; qmin = q; qa = ca[u][0]; qb = ca[u][1]; qc = ca[u][2]; }
         }
       }
     }
+    (void)qmin;
   }
   if (!valid) return;
-  const float qa = pts[qmin * 3], qb = pts[qmin * 3 + 1], qc = pts[qmin * 3 + 2];
   const float x2 = rg[0] * qa + rg[1] * qb + rg[2] * qc;
   const float y2 = rg[3] * qa + rg[4] * qb + rg[5] * qc;
   const float z2 = rg[6] * qa + rg[7] * qb + rg[8] * qc;
@@ -175,22 +263,44 @@ __global__ __launch_bounds__(ADL_THREADS) void adl_terms_kernel(
   tn[(size_t)4 * P + p] = g3;
 }
 
-// ascending-p sums; one wave per ROI, lanes 0..4 own one chain each
-__global__ __launch_bounds__(64) void adl_sum_kernel(const float* __restrict__ terms,
+__global__ __launch_bounds__(ADL_THREADS) void adl_terms_kernel(
+    const float* __restrict__ prediction, const float* __restrict__ target,
+    const float* __restrict__ weight, const float* __restrict__ point,
+    const float* __restrict__ symmetry, float* __restrict__ terms, int R_cap, int C, int P,
+    float margin, const int* __restrict__ num_rows_dev)
+{
+  __shared__ __attribute__((aligned(16))) float s_qx[ADL_QTILE], s_qy[ADL_QTILE], s_qz[ADL_QTILE];   // gt-rotated model points, coordinate-major
+  const int p = blockIdx.x * ADL_THREADS + threadIdx.x;
+  // R = the op's row count: the buffers' row capacity, or (capacity-sized buffers of the sync-free
+  // Hough op) the device-side count; rows past it do not exist for the loss
+  const int R = num_rows_dev ? min(R_cap, num_rows_dev[0]) : R_cap;
+  // Rows are strided over grid.y (ADL_ROW_SLOTS at most): a 3024-row capacity buffer with one row per grid.y launched
+  // 33 264 workgroups of which ~26 000 found "past the count" and left — 40 us of dispatch under a launch whose live
+  // rows need 6 us (tools/probe_adl.py, "1 live"). Workgroups are independent, so the row -> workgroup map is free.
+  for (int n = blockIdx.y; n < R; n += gridDim.y)
+    adl_terms_row(prediction, target, weight, point, symmetry, terms, C, P, margin, R, n, p, s_qx, s_qy, s_qz);
+}
+
+// ascending-p sums, one workgroup per RoI: all ADL_SUM_THREADS lanes stage the row's [5][P] terms in LDS (one round of
+// loads for P <= ADL_SUM_TILE), then lanes 0..4 of wave 0 own one chain each
+__global__ __launch_bounds__(ADL_SUM_THREADS) void adl_sum_kernel(const float* __restrict__ terms,
                                                      const float* __restrict__ weight,
                                                      float* __restrict__ loss_batch,
                                                      float* __restrict__ bottom_diff, int C, int P,
                                                      int R_cap, const int* __restrict__ num_rows_dev)
 {
-  extern __shared__ __attribute__((aligned(16))) float s_t[];  // tile of [5][TILE]
-  constexpr int TILE = 2048;
-  const int n = blockIdx.x, lane = threadIdx.x;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float s_t[];  // tile of [5][TS]
+  const int TILE = adl_sum_tile(P), TS = TILE + ADL_SUM_PAD;   // TS = 4 mod 32 banks: the five chains read different banks
+  const int n = blockIdx.x, tid = threadIdx.x;
   const int CH = PCNN_POSE_CHANNELS * C;
   const int R = num_rows_dev ? min(R_cap, num_rows_dev[0]) : R_cap;
   const int cls = n < R ? find_class(weight, n, C) : -1;
-  for (int c = lane; c < CH; c += 64) bottom_diff[(size_t)n * CH + c] = 0.f;
+  // zeros everywhere but the row's own class, whose four sums are written at the end (no address is written twice)
+  for (int c = tid; c < CH; c += ADL_SUM_THREADS)
+    if (cls < 0 || c / PCNN_POSE_CHANNELS != cls) bottom_diff[(size_t)n * CH + c] = 0.f;
   if (cls < 0) {         // every term of the row is +0 (never written by adl_terms): the sums are +0
-    if (lane == 0) loss_batch[n] = 0.f;
+    if (tid == 0) loss_batch[n] = 0.f;
     return;
   }
   const float* tn = terms + (size_t)n * 5 * P;
@@ -199,16 +309,31 @@ __global__ __launch_bounds__(64) void adl_sum_kernel(const float* __restrict__ t
     const int lim = min(TILE, P - p0);
     __syncthreads();
     for (int k = 0; k < 5; k++)
-      for (int j = lane; j < lim; j += 64) s_t[k * TILE + j] = tn[(size_t)k * P + p0 + j];
+      for (int j = tid; j < lim; j += ADL_SUM_THREADS) s_t[k * TS + j] = tn[(size_t)k * P + p0 + j];
     __syncthreads();
-    if (lane < 5) {
-      const float* t = s_t + lane * TILE;
-      for (int j = 0; j < lim; j++) acc += t[j];
+    if (tid < 5) {
+      // the chain itself: one add per term in ascending p, nothing else on its path — sixteen terms per trip, the NEXT
+      // trip's four 128-bit LDS reads issued before this trip's adds (the pad behind the tile keeps the last, unused,
+      // prefetch inside the allocation). With one read per add the wave sat out an LDS round trip per term: 30 us for one
+      // row (tools/probe_adl.py), most of it that
+      const float* t = s_t + tid * TS;
+      v4f a = *reinterpret_cast<const v4f*>(t), b = *reinterpret_cast<const v4f*>(t + 4);
+      v4f c = *reinterpret_cast<const v4f*>(t + 8), d = *reinterpret_cast<const v4f*>(t + 12);
+      int j = 0;
+      for (; j + 16 <= lim; j += 16) {
+        const v4f na = *reinterpret_cast<const v4f*>(t + j + 16), nb = *reinterpret_cast<const v4f*>(t + j + 20);
+        const v4f nc = *reinterpret_cast<const v4f*>(t + j + 24), nd = *reinterpret_cast<const v4f*>(t + j + 28);
+        acc += a.x; acc += a.y; acc += a.z; acc += a.w;
+        acc += b.x; acc += b.y; acc += b.z; acc += b.w;
+        acc += c.x; acc += c.y; acc += c.z; acc += c.w;
+        acc += d.x; acc += d.y; acc += d.z; acc += d.w;
+        a = na; b = nb; c = nc; d = nd;
+      }
+      for (; j < lim; j++) acc += t[j];
     }
   }
-  __syncthreads();
-  if (lane == 0) loss_batch[n] = acc;
-  if (lane >= 1 && lane < 5 && cls >= 0) bottom_diff[(size_t)n * CH + PCNN_POSE_CHANNELS * cls + (lane - 1)] = acc;
+  if (tid == 0) loss_batch[n] = acc;
+  if (tid >= 1 && tid < 5) bottom_diff[(size_t)n * CH + PCNN_POSE_CHANNELS * cls + (tid - 1)] = acc;
 }
 
 // thrust::reduce over the ROIs (:333-335), canonical order = ascending n: the wave stages 1024 terms at a
@@ -264,7 +389,6 @@ extern "C" int pcnn_average_distance_fwd(const float* prediction, const float* t
   PCNN_REQUIRE(margin >= 0, PCNN_EINVAL, "average_distance: Need margin >= 0, got %g", (double)margin);
   PCNN_REQUIRE(R >= 0 && C >= 1 && P >= 1, PCNN_EINVAL, "average_distance: bad shape R=%d C=%d P=%d", R, C, P);
   PCNN_REQUIRE((long long)R * P < (1ll << 31), PCNN_EINVAL, "average_distance: R*P overflows int32");
-  PCNN_REQUIRE(R <= 65535, PCNN_EINVAL, "average_distance: %d rows exceed the 65535 rows one launch addresses (grid.y); split the batch", R);
   PCNN_REQUIRE(loss, PCNN_ENULL, "average_distance: loss is NULL");
   hipStream_t stream = (hipStream_t)stream_;
   if (R == 0) {
@@ -276,9 +400,9 @@ extern "C" int pcnn_average_distance_fwd(const float* prediction, const float* t
                "average_distance: workspace NULL, misaligned or too small (%zu < %zu)", workspace_bytes, adl_ws(R, P));
   float* terms = (float*)workspace;
   float* loss_batch = (float*)((char*)workspace + align_up(sizeof(float) * (size_t)R * 5 * P, 256));
-  PCNN_LAUNCH(adl_terms_kernel, dim3((P + ADL_THREADS - 1) / ADL_THREADS, R), dim3(ADL_THREADS), 0,
+  PCNN_LAUNCH(adl_terms_kernel, dim3((P + ADL_THREADS - 1) / ADL_THREADS, R < ADL_ROW_SLOTS ? R : ADL_ROW_SLOTS), dim3(ADL_THREADS), 0,
                      stream, prediction, target, weight, point, symmetry, terms, R, C, P, margin, num_rows_dev);
-  PCNN_LAUNCH(adl_sum_kernel, dim3(R), dim3(64), sizeof(float) * 5 * 2048, stream, terms, weight,
+  PCNN_LAUNCH(adl_sum_kernel, dim3(R), dim3(ADL_SUM_THREADS), sizeof(float) * 5 * (adl_sum_tile(P) + ADL_SUM_PAD), stream, terms, weight,
                      loss_batch, bottom_diff, C, P, R, num_rows_dev);
   PCNN_LAUNCH(adl_total_kernel, dim3(1), dim3(64), 0, stream, loss_batch, loss, R, num_rows_dev);
   return pcnn::check_launch("average_distance_fwd");

@@ -35,5 +35,6 @@ def case(n_live, sym_rows, spread):
 
 out = {"684 live, 0 symmetric": case(684, 0, False), "684 live, 63 symmetric contiguous": case(684, 63, False),
        "684 live, 63 symmetric spread": case(684, 63, True), "63 live, all symmetric": case(63, 63, False),
-       "9 live, all symmetric": case(9, 9, False), "1 live, symmetric": case(1, 1, False)}
+       "9 live, all symmetric": case(9, 9, False), "1 live, symmetric": case(1, 1, False), "1 live, not symmetric": case(1, 0, False),
+       "63 live, 0 symmetric": case(63, 0, False)}
 print(json.dumps(out, indent=1))
