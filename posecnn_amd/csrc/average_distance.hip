@@ -22,7 +22,13 @@ namespace {
 
 using namespace pcnn;
 
+// stage clocks for tools/adl_stamp_probe.hip (which defines ADL_STAMP before including this file); nothing in the library
+#ifndef ADL_STAMP
+#define ADL_STAMP(k)
+#endif
+
 constexpr int ADL_THREADS = 256;
+constexpr int ADL_PPT = 1;            // adl_terms: points per thread
 constexpr int ADL_QTILE = 1024;
 constexpr int ADL_SUM_THREADS = 256;
 constexpr int ADL_SUM_TILE_MAX = 3072;   // adl_sum_kernel: terms of one row staged per round, at most (62 KB of LDS for the five chains)
@@ -106,16 +112,119 @@ __device__ __forceinline__ int adl_row_header(const float* __restrict__ weight, 
   return cls;
 }
 
+// Rows with a pose target, symmetric classes first. counts = {symmetric rows, rows with a target}; entry k of the list is
+// order[k] for k < counts[0] and order[R_cap - 1 - (k - counts[0])] after that: the symmetric rows are placed from the
+// front of the buffer and the others from its back, both in ascending row order, so one pass over the rows places both
+// groups without knowing their sizes (adl_order_entry below). adl_terms_kernel walks this list, so
+//  * the long workgroups (a symmetric row's nearest-neighbour scan is ~35 us, any other row's work ~2) are dispatched FIRST
+//    and round-robin over the CUs. Dispatched in row order they land wherever a slot happens to be free, some CU ends up
+//    with seven of them and the launch waits for it: 180 us against 121 for the same rows listed symmetric-first
+//    (tools/probe_adl.py, "spread" / "contiguous");
+//  * rows without a target cost no workgroup at all.
+constexpr int ADL_ORDER_THREADS = 1024;
+__global__ __launch_bounds__(ADL_ORDER_THREADS) void adl_order_kernel(const float* __restrict__ weight,
+                                                                       const float* __restrict__ symmetry, int* __restrict__ order,
+                                                                       int* __restrict__ counts, int R_cap, int C,
+                                                                       const int* __restrict__ num_rows_dev)
+{
+  __shared__ int s_wave[2][ADL_ORDER_THREADS / 64];
+  __shared__ int s_run[2];   // rows placed so far, per group
+  const int R = num_rows_dev ? min(R_cap, num_rows_dev[0]) : R_cap;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid < 2) s_run[tid] = 0;
+  __syncthreads();
+  for (int n0 = 0; n0 < R; n0 += ADL_ORDER_THREADS) {
+    const int n = n0 + tid;
+    // 0 = no target, 1 = symmetric class, 2 = any other class; the first positive weight names the class (:52-60).
+    // Sixteen weights per round of loads (a loop with an early exit is one trip to memory per class: 23 us for 684 rows)
+    int cls = -1;
+    if (n < R) {
+      const float* wr = weight + (size_t)n * PCNN_POSE_CHANNELS * C;
+      for (int c0 = 0; c0 < C && cls < 0; c0 += 16) {
+        float wv[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) wv[i] = wr[PCNN_POSE_CHANNELS * min(c0 + i, C - 1)];
+#pragma unroll
+        for (int i = 15; i >= 0; i--)
+          if (c0 + i < C && wv[i] > 0) cls = c0 + i;
+      }
+    }
+    const int k = cls < 0 ? 0 : (symmetry[cls] > 0 ? 1 : 2);
+    const unsigned long long b1 = __ballot(k == 1), b2 = __ballot(k == 2);
+    if (lane == 0) { s_wave[0][wave] = __popcll(b1); s_wave[1][wave] = __popcll(b2); }
+    __syncthreads();
+    if (k) {
+      const int g = k - 1;
+      int pos = s_run[g] + __popcll((g ? b2 : b1) & lanemask_lt());
+      for (int w = 0; w < wave; w++) pos += s_wave[g][w];
+      order[g ? R_cap - 1 - pos : pos] = n;
+    }
+    __syncthreads();
+    if (tid < 2) {
+      int t = 0;
+      for (int w = 0; w < ADL_ORDER_THREADS / 64; w++) t += s_wave[tid][w];
+      s_run[tid] += t;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) { counts[0] = s_run[0]; counts[1] = s_run[0] + s_run[1]; }
+}
+__device__ __forceinline__ int adl_order_entry(const int* __restrict__ order, const int* __restrict__ counts, int R_cap, int k)
+{
+  const int n_sym = counts[0];
+  return order[k < n_sym ? k : R_cap - 1 - (k - n_sym)];
+}
+
+// the per-point tail of adl_terms: the loss term and the four quaternion derivatives of point p, matched to model point q
+__device__ __forceinline__ void adl_point_terms(const float* rg, float s, float u, float v, float w, const float* pt,
+                                                float x1, float y1, float z1, float qa, float qb, float qc,
+                                                float margin, int R, int P, float* __restrict__ tn, int p)
+{
+  const float x2 = rg[0] * qa + rg[1] * qb + rg[2] * qc;
+  const float y2 = rg[3] * qa + rg[4] * qb + rg[5] * qc;
+  const float z2 = rg[6] * qa + rg[7] * qb + rg[8] * qc;
+  const float ex = x1 - x2, ey = y1 - y2, ez = z1 - z2;
+  const float distance = ex * ex + ey * ey + ez * ez;
+  float loss = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+  if (!(distance < margin)) {
+    loss = (float)((double)(distance - margin) / (2.0 * R * P));
+    // derivatives of Ru w.r.t. (s,u,v,w), :96-139
+    const float d0[9] = {2 * s, -2 * w, 2 * v, 2 * w, 2 * s, -2 * u, -2 * v, 2 * u, 2 * s};
+    const float d1[9] = {2 * u, 2 * v, 2 * w, 2 * v, -2 * u, -2 * s, 2 * w, 2 * s, -2 * u};
+    const float d2[9] = {-2 * v, 2 * u, 2 * s, 2 * u, 2 * v, 2 * w, -2 * s, 2 * w, -2 * v};
+    const float d3[9] = {-2 * w, -2 * s, 2 * u, 2 * s, -2 * w, 2 * v, 2 * u, 2 * v, 2 * w};
+    const float den = (float)(R * P);
+    const float df[3] = {ex, ey, ez};
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        g0 += div_rn(df[j] * pt[k] * d0[j * 3 + k], den);
+        g1 += div_rn(df[j] * pt[k] * d1[j * 3 + k], den);
+        g2 += div_rn(df[j] * pt[k] * d2[j * 3 + k], den);
+        g3 += div_rn(df[j] * pt[k] * d3[j * 3 + k], den);
+      }
+  }
+  tn[p] = loss;
+  tn[(size_t)P + p] = g0;
+  tn[(size_t)2 * P + p] = g1;
+  tn[(size_t)3 * P + p] = g2;
+  tn[(size_t)4 * P + p] = g3;
+}
+
+// One row, the workgroup's ADL_THREADS * ADL_PPT points of it: thread t owns points p0 + t + ADL_THREADS i.
 __device__ __forceinline__ void adl_terms_row(
     const float* __restrict__ prediction, const float* __restrict__ target,
     const float* __restrict__ weight, const float* __restrict__ point,
     const float* __restrict__ symmetry, float* __restrict__ terms, int C, int P,
-    float margin, int R, int n, int p, float* s_qx, float* s_qy, float* s_qz)
+    float margin, int R, int n, int p0, float* s_qx, float* s_qy, float* s_qz)
 {
   typedef float v2f __attribute__((ext_vector_type(2)));
   typedef float v4f __attribute__((ext_vector_type(4)));
+  ADL_STAMP(10);
   float qt[4], qp[4];
   const int cls = adl_row_header(weight, target, prediction, n, C, qt, qp);
+  ADL_STAMP(11);
   float* tn = terms + (size_t)n * 5 * P;
   if (cls < 0) return;   // no target: adl_sum writes this row's zeros without reading any terms
                          // (a train-mode buffer of 3024 rows holds ~470 with targets: 134 MB of zeros were written here
@@ -125,18 +234,20 @@ __device__ __forceinline__ void adl_terms_row(
   const float s = qp[0], u = qp[1], v = qp[2], w = qp[3];
   quat_rot(s, u, v, w, ru);
   const float* pts = point + (size_t)cls * P * 3;
-  const bool valid = p < P;
   const bool symmetric = symmetry[cls] > 0;
-  float pt0 = 0, pt1 = 0, pt2 = 0;
-  if (valid) { pt0 = pts[p * 3]; pt1 = pts[p * 3 + 1]; pt2 = pts[p * 3 + 2]; }
-  const float x1 = ru[0] * pt0 + ru[1] * pt1 + ru[2] * pt2;
-  const float y1 = ru[3] * pt0 + ru[4] * pt1 + ru[5] * pt2;
-  const float z1 = ru[6] * pt0 + ru[7] * pt1 + ru[8] * pt2;
+  float pt[ADL_PPT][3], x1[ADL_PPT], y1[ADL_PPT], z1[ADL_PPT];
+  float qm[ADL_PPT][3];   // the matched point: the point itself unless the class is symmetric
+#pragma unroll
+  for (int i = 0; i < ADL_PPT; i++) {
+    const int p = p0 + (int)threadIdx.x + ADL_THREADS * i;
+    pt[i][0] = pt[i][1] = pt[i][2] = 0.f;
+    if (p < P) { pt[i][0] = pts[p * 3]; pt[i][1] = pts[p * 3 + 1]; pt[i][2] = pts[p * 3 + 2]; }
+    adl_rotate3(ru, pt[i][0], pt[i][1], pt[i][2], x1[i], y1[i], z1[i]);
+    qm[i][0] = pt[i][0]; qm[i][1] = pt[i][1]; qm[i][2] = pt[i][2];
+  }
+  ADL_STAMP(12);
 
-  // the matched point: the point itself unless the class is symmetric
-  float qa = pt0, qb = pt1, qc = pt2;
   if (symmetric) {
-    int qmin = p;
     // closest gt-rotated model point, strict '<' from FLT_MAX, first wins (:155-168).
     //
     // Two steps with the same answer as the reference's one-candidate-at-a-time walk:
@@ -144,14 +255,24 @@ __device__ __forceinline__ void adl_terms_row(
     //     NaN distance is ignored exactly as 'NaN < dmin' ignores it); 'if (m < dmin) { dmin = m; tmin = trip; }'. The strict
     //     '<' keeps the FIRST trip that holds the overall minimum.
     //  2. inside that one trip, the reference's walk itself (strict '<' from FLT_MAX): the first candidate at the minimum.
-    // The walk's compare -> select -> compare chain (a VALU write of VCC read by the next VALU instruction, twice per
-    // candidate) is what bound the kernel: a symmetric row's workgroup is one wave per SIMD, nothing runs under the chain,
-    // and the four-candidate version took 78 cycles per candidate, the sixteen-candidate version with its LDS reads
-    // issued first still 57 (tools/probe_adl.py: 90 and 63 us for ONE symmetric row). Here the chain is per trip, and a
-    // candidate costs 2.5 packed-f32 instructions of distance plus half a v_min3.
-    float dmin = FLT_MAX;
-    int tmin = -1;
-    const v2f x1v = (v2f){x1, x1}, y1v = (v2f){y1, y1}, z1v = (v2f){z1, z1};
+    // Step 1 is where the time goes (P^2 = 6.9 M distances per symmetric RoI); what shaped it, all measured
+    // (tools/probe_adl.py, tools/adl_stamp_probe.hip, tools/valu_rate_probe.hip):
+    //  * the walk's compare -> select chain (a VALU write of VCC read by the next VALU instruction) runs at 12.6 cycles per
+    //    instruction, 25 per candidate; a v_min tree has no chain and the compare is per trip;
+    //  * a candidate is the same for every lane, and handing it to 64 lanes through LDS costs the LDS pipe the full 64-lane
+    //    bandwidth: a 128-bit "broadcast" read holds it 8 cycles, a trip's twelve reads 96, against ~60 cycles of a CU's
+    //    VALU time for the trip's sixteen distances. So a lane carries TWO points against each candidate it reads;
+    //  * packed f32 (two candidates per instruction) is worth its encoding here: a lone wave on its SIMD issues a v_pk_add
+    //    every 5.3 cycles and a v_add every 4.7, so half the instructions is nearly half the time for the few workgroups
+    //    of a launch's tail; with the SIMD full the two forms cost the same per distance.
+    float dmin[ADL_PPT];
+    int tmin[ADL_PPT];
+    v2f xv[ADL_PPT], yv[ADL_PPT], zv[ADL_PPT];
+#pragma unroll
+    for (int i = 0; i < ADL_PPT; i++) {
+      dmin[i] = FLT_MAX; tmin[i] = -1;
+      xv[i] = (v2f){x1[i], x1[i]}; yv[i] = (v2f){y1[i], y1[i]}; zv[i] = (v2f){z1[i], z1[i]};
+    }
     // the tile's model points are fetched one tile ahead, into registers: the next tile's trip to memory runs under this
     // tile's scan instead of in front of its own
     constexpr int NQ = ADL_QTILE / ADL_THREADS;
@@ -172,6 +293,7 @@ __device__ __forceinline__ void adl_terms_row(
         s_qx[j] = qx; s_qy[j] = qy; s_qz[j] = qz;
       }
       __syncthreads();
+      if (q0 == 0) ADL_STAMP(13);
       if (q0 + ADL_QTILE < P) {
 #pragma unroll
         for (int i = 0; i < NQ; i++) {
@@ -180,31 +302,40 @@ __device__ __forceinline__ void adl_terms_row(
         }
       }
       const int lim = min(ADL_QTILE, P - q0);
-      // one 128-bit LDS read per coordinate per four candidates (every lane reads the same address: a broadcast), all
-      // twelve of a trip issued before the first use; two candidates per packed-f32 instruction — v_pk_add / v_pk_mul
-      // round each half like the scalar form, so every distance is ((ex ex) + (ey ey)) + (ez ez) bit for bit (:160-163)
+      // one 128-bit LDS read per coordinate per four candidates, all twelve of a trip issued before the first use; two
+      // candidates per packed-f32 instruction — v_pk_add / v_pk_mul round each half like the scalar form, so every
+      // distance is ((ex ex) + (ey ey)) + (ez ez) bit for bit (:160-163)
       for (int j = 0; j < lim; j += 16) {
         v4f qx[4], qy[4], qz[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          qx[u] = *reinterpret_cast<const v4f*>(&s_qx[j + 4 * u]);
-          qy[u] = *reinterpret_cast<const v4f*>(&s_qy[j + 4 * u]);
-          qz[u] = *reinterpret_cast<const v4f*>(&s_qz[j + 4 * u]);
+        for (int c = 0; c < 4; c++) {
+          qx[c] = *reinterpret_cast<const v4f*>(&s_qx[j + 4 * c]);
+          qy[c] = *reinterpret_cast<const v4f*>(&s_qy[j + 4 * c]);
+          qz[c] = *reinterpret_cast<const v4f*>(&s_qz[j + 4 * c]);
         }
-        float m4[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const v2f ex0 = x1v - qx[u].xy, ey0 = y1v - qy[u].xy, ez0 = z1v - qz[u].xy;
-          const v2f ex1 = x1v - qx[u].zw, ey1 = y1v - qy[u].zw, ez1 = z1v - qz[u].zw;
-          const v2f d0 = (ex0 * ex0 + ey0 * ey0) + ez0 * ez0;
-          const v2f d1 = (ex1 * ex1 + ey1 * ey1) + ez1 * ez1;
-          m4[u] = __builtin_fminf(__builtin_fminf(d0.x, d0.y), __builtin_fminf(d1.x, d1.y));
+        for (int i = 0; i < ADL_PPT; i++) {
+          // (wave-uniform) all 64 of this wave's i-th points past the row's last one: the row's last workgroup
+          if (p0 + (int)(threadIdx.x & ~63u) + ADL_THREADS * i >= P) continue;
+          float m4[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            const v2f ex0 = xv[i] - qx[c].xy, ey0 = yv[i] - qy[c].xy, ez0 = zv[i] - qz[c].xy;
+            const v2f ex1 = xv[i] - qx[c].zw, ey1 = yv[i] - qy[c].zw, ez1 = zv[i] - qz[c].zw;
+            const v2f d0 = (ex0 * ex0 + ey0 * ey0) + ez0 * ez0;
+            const v2f d1 = (ex1 * ex1 + ey1 * ey1) + ez1 * ez1;
+            m4[c] = __builtin_fminf(__builtin_fminf(d0.x, d0.y), __builtin_fminf(d1.x, d1.y));
+          }
+          const float m = __builtin_fminf(__builtin_fminf(m4[0], m4[1]), __builtin_fminf(m4[2], m4[3]));
+          if (m < dmin[i]) { dmin[i] = m; tmin[i] = q0 + j; }
         }
-        const float m = __builtin_fminf(__builtin_fminf(m4[0], m4[1]), __builtin_fminf(m4[2], m4[3]));
-        if (m < dmin) { dmin = m; tmin = q0 + j; }
       }
+      if (q0 == 0) ADL_STAMP(14);
     }
-    if (tmin >= 0) {
+    ADL_STAMP(15);
+#pragma unroll
+    for (int i = 0; i < ADL_PPT; i++) {
+      if (tmin[i] < 0) continue;
       // step 2: the trip's sixteen candidates again, rotated by the expression that filled the tile (same bits); loads
       // eight at a time, all issued before the first use (clamped addresses: a candidate past P is skipped below)
       float dm = FLT_MAX;
@@ -212,73 +343,47 @@ __device__ __forceinline__ void adl_terms_row(
       for (int h = 0; h < 2; h++) {
         float ca[8][3];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const int q = min(tmin + 8 * h + u, P - 1);
-          ca[u][0] = pts[q * 3]; ca[u][1] = pts[q * 3 + 1]; ca[u][2] = pts[q * 3 + 2];
+        for (int c = 0; c < 8; c++) {
+          const int q = min(tmin[i] + 8 * h + c, P - 1);
+          ca[c][0] = pts[q * 3]; ca[c][1] = pts[q * 3 + 1]; ca[c][2] = pts[q * 3 + 2];
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const int q = tmin + 8 * h + u;
+        for (int c = 0; c < 8; c++) {
+          const int q = tmin[i] + 8 * h + c;
           float qx, qy, qz;
-          adl_rotate3(rg, ca[u][0], ca[u][1], ca[u][2], qx, qy, qz);
-          const float ex = x1 - qx, ey = y1 - qy, ez = z1 - qz;
+          adl_rotate3(rg, ca[c][0], ca[c][1], ca[c][2], qx, qy, qz);
+          const float ex = x1[i] - qx, ey = y1[i] - qy, ez = z1[i] - qz;
           const float d = (ex * ex + ey * ey) + ez * ez;
-          if (q < P && d < dm) { dm = d; qmin = q; qa = ca[u][0]; qb = ca[u][1]; qc = ca[u][2]; }
+          if (q < P && d < dm) { dm = d; qm[i][0] = ca[c][0]; qm[i][1] = ca[c][1]; qm[i][2] = ca[c][2]; }
         }
       }
     }
-    (void)qmin;
+    ADL_STAMP(16);
   }
-  if (!valid) return;
-  const float x2 = rg[0] * qa + rg[1] * qb + rg[2] * qc;
-  const float y2 = rg[3] * qa + rg[4] * qb + rg[5] * qc;
-  const float z2 = rg[6] * qa + rg[7] * qb + rg[8] * qc;
-  const float ex = x1 - x2, ey = y1 - y2, ez = z1 - z2;
-  const float distance = ex * ex + ey * ey + ez * ez;
-  float loss = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
-  if (!(distance < margin)) {
-    loss = (float)((double)(distance - margin) / (2.0 * R * P));
-    // derivatives of Ru w.r.t. (s,u,v,w), :96-139
-    const float d0[9] = {2 * s, -2 * w, 2 * v, 2 * w, 2 * s, -2 * u, -2 * v, 2 * u, 2 * s};
-    const float d1[9] = {2 * u, 2 * v, 2 * w, 2 * v, -2 * u, -2 * s, 2 * w, 2 * s, -2 * u};
-    const float d2[9] = {-2 * v, 2 * u, 2 * s, 2 * u, 2 * v, 2 * w, -2 * s, 2 * w, -2 * v};
-    const float d3[9] = {-2 * w, -2 * s, 2 * u, 2 * s, -2 * w, 2 * v, 2 * u, 2 * v, 2 * w};
-    const float den = (float)(R * P);
-    const float pt[3] = {pt0, pt1, pt2};
-    const float df[3] = {ex, ey, ez};
 #pragma unroll
-    for (int j = 0; j < 3; j++)
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        g0 += div_rn(df[j] * pt[k] * d0[j * 3 + k], den);
-        g1 += div_rn(df[j] * pt[k] * d1[j * 3 + k], den);
-        g2 += div_rn(df[j] * pt[k] * d2[j * 3 + k], den);
-        g3 += div_rn(df[j] * pt[k] * d3[j * 3 + k], den);
-      }
+  for (int i = 0; i < ADL_PPT; i++) {
+    const int p = p0 + (int)threadIdx.x + ADL_THREADS * i;
+    if (p < P) adl_point_terms(rg, s, u, v, w, pt[i], x1[i], y1[i], z1[i], qm[i][0], qm[i][1], qm[i][2], margin, R, P, tn, p);
   }
-  tn[p] = loss;
-  tn[(size_t)P + p] = g0;
-  tn[(size_t)2 * P + p] = g1;
-  tn[(size_t)3 * P + p] = g2;
-  tn[(size_t)4 * P + p] = g3;
+  ADL_STAMP(17);
 }
 
 __global__ __launch_bounds__(ADL_THREADS) void adl_terms_kernel(
     const float* __restrict__ prediction, const float* __restrict__ target,
     const float* __restrict__ weight, const float* __restrict__ point,
     const float* __restrict__ symmetry, float* __restrict__ terms, int R_cap, int C, int P,
-    float margin, const int* __restrict__ num_rows_dev)
+    float margin, const int* __restrict__ num_rows_dev, const int* __restrict__ order, const int* __restrict__ counts)
 {
   __shared__ __attribute__((aligned(16))) float s_qx[ADL_QTILE], s_qy[ADL_QTILE], s_qz[ADL_QTILE];   // gt-rotated model points, coordinate-major
-  const int p = blockIdx.x * ADL_THREADS + threadIdx.x;
+  const int p0 = blockIdx.x * (ADL_THREADS * ADL_PPT);
   // R = the op's row count: the buffers' row capacity, or (capacity-sized buffers of the sync-free
   // Hough op) the device-side count; rows past it do not exist for the loss
   const int R = num_rows_dev ? min(R_cap, num_rows_dev[0]) : R_cap;
-  // Rows are strided over grid.y (ADL_ROW_SLOTS at most): a 3024-row capacity buffer with one row per grid.y launched
-  // 33 264 workgroups of which ~26 000 found "past the count" and left — 40 us of dispatch under a launch whose live
-  // rows need 6 us (tools/probe_adl.py, "1 live"). Workgroups are independent, so the row -> workgroup map is free.
-  for (int n = blockIdx.y; n < R; n += gridDim.y)
-    adl_terms_row(prediction, target, weight, point, symmetry, terms, C, P, margin, R, n, p, s_qx, s_qy, s_qz);
+  // The rows with a target (adl_order_kernel's list, symmetric classes first) are strided over grid.y (ADL_ROW_SLOTS at
+  // most): workgroups are independent, so the row -> workgroup map is free
+  const int n_rows = counts[1];
+  for (int k = blockIdx.y; k < n_rows; k += gridDim.y)
+    adl_terms_row(prediction, target, weight, point, symmetry, terms, C, P, margin, R, adl_order_entry(order, counts, R_cap, k), p0, s_qx, s_qy, s_qz);
 }
 
 // ascending-p sums, one workgroup per RoI: all ADL_SUM_THREADS lanes stage the row's [5][P] terms in LDS (one round of
@@ -295,7 +400,9 @@ __global__ __launch_bounds__(ADL_SUM_THREADS) void adl_sum_kernel(const float* _
   const int n = blockIdx.x, tid = threadIdx.x;
   const int CH = PCNN_POSE_CHANNELS * C;
   const int R = num_rows_dev ? min(R_cap, num_rows_dev[0]) : R_cap;
+  ADL_STAMP(0);
   const int cls = n < R ? find_class(weight, n, C) : -1;
+  ADL_STAMP(1);
   // zeros everywhere but the row's own class, whose four sums are written at the end (no address is written twice)
   for (int c = tid; c < CH; c += ADL_SUM_THREADS)
     if (cls < 0 || c / PCNN_POSE_CHANNELS != cls) bottom_diff[(size_t)n * CH + c] = 0.f;
@@ -304,13 +411,38 @@ __global__ __launch_bounds__(ADL_SUM_THREADS) void adl_sum_kernel(const float* _
     return;
   }
   const float* tn = terms + (size_t)n * 5 * P;
+  const bool vec4 = (P & 3) == 0 && (reinterpret_cast<size_t>(terms) & 15) == 0;   // every chain of every row starts 16-byte aligned
   float acc = 0.f;
   for (int p0 = 0; p0 < P; p0 += TILE) {
     const int lim = min(TILE, P - p0);
     __syncthreads();
-    for (int k = 0; k < 5; k++)
-      for (int j = tid; j < lim; j += ADL_SUM_THREADS) s_t[k * TS + j] = tn[(size_t)k * P + p0 + j];
+    if (vec4 && (lim & 3) == 0) {
+      // every load of the round issued before the first LDS write (a tile is at most 3 x 256 float4 per chain): with the
+      // plain loop below the compiler pairs each load with its LDS store, 51 trips to memory one after the other — 13.6 of
+      // the row's 27 us (tools/adl_stamp_probe.hip)
+      static_assert(ADL_SUM_TILE_MAX <= 3 * ADL_SUM_THREADS * 4, "adl_sum_kernel: three float4 per thread per chain");
+      const int nq = lim >> 2;
+      v4f r[5][3];
+#pragma unroll
+      for (int k = 0; k < 5; k++)
+#pragma unroll
+        for (int h = 0; h < 3; h++) {
+          const int j4 = tid + h * ADL_SUM_THREADS;
+          if (j4 < nq) r[k][h] = *reinterpret_cast<const v4f*>(tn + (size_t)k * P + p0 + 4 * j4);
+        }
+#pragma unroll
+      for (int k = 0; k < 5; k++)
+#pragma unroll
+        for (int h = 0; h < 3; h++) {
+          const int j4 = tid + h * ADL_SUM_THREADS;
+          if (j4 < nq) *reinterpret_cast<v4f*>(s_t + k * TS + 4 * j4) = r[k][h];
+        }
+    } else {
+      for (int k = 0; k < 5; k++)
+        for (int j = tid; j < lim; j += ADL_SUM_THREADS) s_t[k * TS + j] = tn[(size_t)k * P + p0 + j];
+    }
     __syncthreads();
+    ADL_STAMP(2);
     if (tid < 5) {
       // the chain itself: one add per term in ascending p, nothing else on its path — sixteen terms per trip, the NEXT
       // trip's four 128-bit LDS reads issued before this trip's adds (the pad behind the tile keeps the last, unused,
@@ -332,6 +464,7 @@ __global__ __launch_bounds__(ADL_SUM_THREADS) void adl_sum_kernel(const float* _
       for (; j < lim; j++) acc += t[j];
     }
   }
+  ADL_STAMP(3);
   if (tid == 0) loss_batch[n] = acc;
   if (tid >= 1 && tid < 5) bottom_diff[(size_t)n * CH + PCNN_POSE_CHANNELS * cls + (tid - 1)] = acc;
 }
@@ -366,7 +499,12 @@ __global__ __launch_bounds__(256) void adl_bwd_kernel(const float* __restrict__ 
     out[i] = g * bottom_diff[i];
 }
 
-size_t adl_ws(int R, int P) { return align_up(sizeof(float) * (size_t)R * 5 * P, 256) + align_up(sizeof(float) * (size_t)(R > 0 ? R : 1), 256); }
+// workspace: terms [R][5][P] | loss_batch [R] | order [R] + counts [2]
+size_t adl_ws(int R, int P)
+{
+  const size_t r = (size_t)(R > 0 ? R : 1);
+  return align_up(sizeof(float) * (size_t)R * 5 * P, 256) + align_up(sizeof(float) * r, 256) + align_up(sizeof(int) * (r + 2), 256);
+}
 
 }  // namespace
 
@@ -400,8 +538,11 @@ extern "C" int pcnn_average_distance_fwd(const float* prediction, const float* t
                "average_distance: workspace NULL, misaligned or too small (%zu < %zu)", workspace_bytes, adl_ws(R, P));
   float* terms = (float*)workspace;
   float* loss_batch = (float*)((char*)workspace + align_up(sizeof(float) * (size_t)R * 5 * P, 256));
-  PCNN_LAUNCH(adl_terms_kernel, dim3((P + ADL_THREADS - 1) / ADL_THREADS, R < ADL_ROW_SLOTS ? R : ADL_ROW_SLOTS), dim3(ADL_THREADS), 0,
-                     stream, prediction, target, weight, point, symmetry, terms, R, C, P, margin, num_rows_dev);
+  int* order = (int*)((char*)loss_batch + align_up(sizeof(float) * (size_t)R, 256));
+  int* counts = order + R;
+  PCNN_LAUNCH(adl_order_kernel, dim3(1), dim3(ADL_ORDER_THREADS), 0, stream, weight, symmetry, order, counts, R, C, num_rows_dev);
+  PCNN_LAUNCH(adl_terms_kernel, dim3((P + ADL_THREADS * ADL_PPT - 1) / (ADL_THREADS * ADL_PPT), R < ADL_ROW_SLOTS ? R : ADL_ROW_SLOTS), dim3(ADL_THREADS), 0,
+                     stream, prediction, target, weight, point, symmetry, terms, R, C, P, margin, num_rows_dev, order, counts);
   PCNN_LAUNCH(adl_sum_kernel, dim3(R), dim3(ADL_SUM_THREADS), sizeof(float) * 5 * (adl_sum_tile(P) + ADL_SUM_PAD), stream, terms, weight,
                      loss_batch, bottom_diff, C, P, R, num_rows_dev);
   PCNN_LAUNCH(adl_total_kernel, dim3(1), dim3(64), 0, stream, loss_batch, loss, R, num_rows_dev);

@@ -33,6 +33,9 @@ def case(n_live, sym_rows, spread):
     return {k: round(v["avg_us"], 1) for k, v in rep.items()}
 
 
+only = os.environ.get("ADL_PROBE_ONLY")   # one case (for a rocprofv3 --pmc pass)
+if only == "63 live, all symmetric":
+    print(json.dumps({only: case(63, 63, False)})); sys.exit(0)
 out = {"684 live, 0 symmetric": case(684, 0, False), "684 live, 63 symmetric contiguous": case(684, 63, False),
        "684 live, 63 symmetric spread": case(684, 63, True), "63 live, all symmetric": case(63, 63, False),
        "9 live, all symmetric": case(9, 9, False), "1 live, symmetric": case(1, 1, False), "1 live, not symmetric": case(1, 0, False),
