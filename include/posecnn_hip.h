@@ -483,6 +483,16 @@ int pcnn_upscore_softmax_argmax_fwd(const float* z, const float* bias, int batch
                                     int width, int num_classes, int kernel, int stride, int relu,
                                     float* score_out, float* prob, int32_t* label, void* stream);
 
+/* pcnn_upscore_softmax_argmax_fwd that also evaluates the "Hardlabel" op (lib/hard_label_layer/hard_label_op.cc:143-188,
+ * hard_label_op_gpu.cu.cc:17-29) on the probabilities it has just computed — the training graph feeds that op
+ * prob_normalized and gt_label_2d (vgg16_convs.py:148-149): hard f32 [B,H*s,W*s,C] = pcnn_hard_label_fwd(prob, gt,
+ * threshold), same bits, without a second pass over the probabilities. gt int32 [B,H*s,W*s]; threshold > 0 (the op's
+ * attribute check, hard_label_op.cc:150-155); gt and hard must not be NULL; prob / score_out may be. */
+int pcnn_upscore_softmax_argmax_hard_fwd(const float* z, const float* bias, int batch, int height,
+                                         int width, int num_classes, int kernel, int stride, int relu,
+                                         float* score_out, float* prob, int32_t* label,
+                                         const int32_t* gt, float threshold, float* hard, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * smooth_l1_loss_vertex (lib/fcn/train.py:564-573), the vertex regression loss of the training
  * graph, over n = B*H*W*3C elements of pred / target / weight (f32):

@@ -95,6 +95,7 @@ SIGNATURES = {
     "pcnn_deconv_bilinear_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
     "pcnn_bias_act_fwd": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
     "pcnn_upscore_softmax_argmax_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "pcnn_upscore_softmax_argmax_hard_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P, _P]),
     "pcnn_icp_backproject_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, _P, _P]),
     "pcnn_icp_refine_workspace_bytes": (c_int, [c_int, c_int, c_int, POINTER(c_size_t)]),
     "pcnn_icp_refine_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, c_float,

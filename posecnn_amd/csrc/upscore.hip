@@ -239,6 +239,48 @@ __global__ __launch_bounds__(256) void bias_relu_pool2_kernel(const float* __res
   }
 }
 
+// one segment's npx * C floats from LDS to a contiguous run of global memory
+__device__ __forceinline__ void up_copy_out(float* __restrict__ o, const float* s_out, int nfl, int tid, int nthreads, int seg_floats)
+{
+  if (((nfl | seg_floats) & 3) == 0 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+    // the segment's run of npx * C floats starts 16-byte aligned: dwordx4 stores (4x fewer store instructions)
+    for (int i = tid * 4; i < nfl; i += nthreads * 4)
+      *reinterpret_cast<float4*>(o + i) = *reinterpret_cast<const float4*>(s_out + i);
+  } else {
+    for (int i = tid; i < nfl; i += nthreads) o[i] = s_out[i];
+  }
+}
+
+// The hard-example label weights of the segment (TF1 op "Hardlabel", hard_label_op_gpu.cu.cc:17-29, fed prob_normalized
+// and gt_label_2d by vgg16_convs.py:148-149) while its probabilities are still in LDS: out[pixel][c] = 1 for the pixel's
+// ground-truth class g if g > 0 or prob[g] < threshold, 0 everywhere else. As its own launch (pcnn_hard_label_fwd) the op
+// is 432 MB of stores per 16 frames behind a kernel that is bound by its arithmetic: 93 us that fit under the label
+// head's own 169. Must be called by every thread of the workgroup; s_out holds the probabilities [npx][C] on entry.
+__device__ __forceinline__ void up_hard_label_rows(float* s_out, const int* __restrict__ gt, float* __restrict__ hard,
+                                                   long long pix0, int tid, int npx, int C, float threshold, int nthreads)
+{
+  int hot = -1;
+  if (tid < npx) {
+    const int g = gt[pix0 + tid];
+    // labels outside [-1, C) index out of bounds in the reference — ignored here, as in hard_label.hip
+    if (g >= 0 && g < C && (g > 0 || s_out[tid * C + g] < threshold)) hot = g;
+  }
+  __syncthreads();   // the probabilities have been read (and copied out)
+  if (tid < npx) {
+    // the row is zeros with at most one 1: wide zero stores, then the one
+    float* row = s_out + tid * C;
+    if ((C & 1) == 0) {
+      typedef float f2z __attribute__((ext_vector_type(2)));
+      for (int c = 0; c < C; c += 2) *reinterpret_cast<f2z*>(row + c) = (f2z){0.f, 0.f};   // (tid * C is even)
+    } else {
+      for (int c = 0; c < C; c++) row[c] = 0.f;
+    }
+    if (hot >= 0) row[hot] = 1.f;
+  }
+  __syncthreads();
+  up_copy_out(hard + pix0 * C, s_out, npx * C, tid, nthreads, nthreads * C);
+}
+
 // Label head epilogue. A workgroup owns SEG consecutive output pixels of one output row; the
 // (<= 2) x (SEG/s + 2) low-resolution cells it needs sit in LDS; every thread owns one pixel:
 // C interpolated scores in registers -> softmax -> argmax; prob / score rows are parked in LDS and
@@ -249,7 +291,7 @@ template <int CMAX>
 __global__ __launch_bounds__(UP_SEG) void upscore_softmax_argmax_kernel(
     const float* __restrict__ z, const float* __restrict__ bias, float* __restrict__ score_out,
     float* __restrict__ prob, int* __restrict__ label, int H, int W, int C, int k, int s, int relu,
-    int nseg, int s_out_off)
+    int nseg, int s_out_off, const int* __restrict__ gt, float* __restrict__ hard, float threshold)
 {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int pad = (k - s) / 2;
@@ -337,21 +379,15 @@ __global__ __launch_bounds__(UP_SEG) void upscore_softmax_argmax_kernel(
       }
     label[((long long)b * Ho + oy) * Wo + ox] = best;
   }
-  if (prob) {
+  if (prob || hard) {
     if (tid < npx)
 #pragma unroll
       for (int c = 0; c < CMAX; c++)
         if (c < C) s_out[tid * C + c] = e[c];
     __syncthreads();
-    float* o = prob + (((long long)b * Ho + oy) * Wo + ox0) * C;
-    const int nfl = npx * C;
-    if (((nfl | (UP_SEG * C)) & 3) == 0 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
-      // the segment's run of npx * C floats starts 16-byte aligned: dwordx4 stores (4x fewer store instructions)
-      for (int i = tid * 4; i < nfl; i += UP_SEG * 4)
-        *reinterpret_cast<float4*>(o + i) = *reinterpret_cast<const float4*>(s_out + i);
-    } else {
-      for (int i = tid; i < nfl; i += UP_SEG) o[i] = s_out[i];
-    }
+    const long long pix0 = ((long long)b * Ho + oy) * Wo + ox0;
+    if (prob) up_copy_out(prob + pix0 * C, s_out, npx * C, tid, UP_SEG, UP_SEG * C);
+    if (hard) up_hard_label_rows(s_out, gt, hard, pix0, tid, npx, C, threshold, UP_SEG);
   }
 }
 
@@ -406,7 +442,8 @@ __device__ __forceinline__ f2 exp_softmax_f32x2(f2 x0)
 template <int C>
 __global__ __launch_bounds__(UP_SEG) void upscore_softmax_argmax_fixed_kernel(
     const float* __restrict__ z, const float* __restrict__ bias, float* __restrict__ score_out,
-    float* __restrict__ prob, int* __restrict__ label, int H, int W, int k, int s, int relu, int nseg, int s_out_off)
+    float* __restrict__ prob, int* __restrict__ label, int H, int W, int k, int s, int relu, int nseg, int s_out_off,
+    const int* __restrict__ gt, float* __restrict__ hard, float threshold)
 {
   static_assert(C % 2 == 0 && C >= 2, "even class counts");
   constexpr int C2 = C / 2;
@@ -506,21 +543,16 @@ __global__ __launch_bounds__(UP_SEG) void upscore_softmax_argmax_fixed_kernel(
     }
     label[((long long)b * Ho + oy) * Wo + ox] = best;
   }
-  if (prob) {
+  if (prob || hard) {
     if (tid < npx) {
       f2* so = reinterpret_cast<f2*>(s_out + tid * C);
 #pragma unroll
       for (int c = 0; c < C2; c++) so[c] = e[c];
     }
     __syncthreads();
-    float* o = prob + (((long long)b * Ho + oy) * Wo + ox0) * C;
-    const int nfl = npx * C;
-    if (((nfl | (UP_SEG * C)) & 3) == 0 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
-      for (int i = tid * 4; i < nfl; i += UP_SEG * 4)
-        *reinterpret_cast<float4*>(o + i) = *reinterpret_cast<const float4*>(s_out + i);
-    } else {
-      for (int i = tid; i < nfl; i += UP_SEG) o[i] = s_out[i];
-    }
+    const long long pix0 = ((long long)b * Ho + oy) * Wo + ox0;
+    if (prob) up_copy_out(prob + pix0 * C, s_out, npx * C, tid, UP_SEG, UP_SEG * C);
+    if (hard) up_hard_label_rows(s_out, gt, hard, pix0, tid, npx, C, threshold, UP_SEG);
   }
 }
 
@@ -606,36 +638,58 @@ extern "C" int pcnn_bias_relu_pool2_fwd(const float* x, const float* bias, int B
   return check_launch("bias_relu_pool2_fwd");
 }
 
-extern "C" int pcnn_upscore_softmax_argmax_fwd(const float* z, const float* bias, int B, int H,
-                                               int W, int C, int k, int s, int relu,
-                                               float* score_out, float* prob, int32_t* label,
-                                               void* stream_)
+namespace {
+int upscore_softmax_argmax_impl(const char* who, const float* z, const float* bias, int B, int H, int W, int C, int k, int s,
+                                int relu, float* score_out, float* prob, int32_t* label, const int32_t* gt, float threshold,
+                                float* hard, void* stream_)
 {
   int st = validate(B, H, W, C, k, s);
   if (st != PCNN_OK) return st;
-  PCNN_REQUIRE(C <= PCNN_MAX_CLASSES, PCNN_EINVAL, "upscore_softmax_argmax: num_classes must be <= %d (got %d)", PCNN_MAX_CLASSES, C);
-  PCNN_REQUIRE(k <= 64, PCNN_EINVAL, "upscore_softmax_argmax: kernel size must be <= 64 (got %d)", k);
-  PCNN_REQUIRE(z && bias && label, PCNN_ENULL, "upscore_softmax_argmax: NULL pointer");
+  PCNN_REQUIRE(C <= PCNN_MAX_CLASSES, PCNN_EINVAL, "%s: num_classes must be <= %d (got %d)", who, PCNN_MAX_CLASSES, C);
+  PCNN_REQUIRE(k <= 64, PCNN_EINVAL, "%s: kernel size must be <= 64 (got %d)", who, k);
+  PCNN_REQUIRE(z && bias && label, PCNN_ENULL, "%s: NULL pointer", who);
   hipStream_t stream = (hipStream_t)stream_;
   const int Wo = W * s, Ho = H * s;
   const int nseg = (Wo + UP_SEG - 1) / UP_SEG;
   const long long blocks = (long long)B * Ho * nseg;
-  PCNN_REQUIRE(blocks < (1ll << 31), PCNN_EINVAL, "upscore_softmax_argmax: grid too large");
+  PCNN_REQUIRE(blocks < (1ll << 31), PCNN_EINVAL, "%s: grid too large", who);
   const int rows = (k + s - 1) / s;                      // input rows per output row
   const int ncx_max = (UP_SEG - 1) / s + rows + 1;       // input columns per segment
   const int s_out_off = (rows * ncx_max * C + 3) / 4 * 4;
   const size_t sh = sizeof(float) * ((size_t)s_out_off + (size_t)UP_SEG * C);
-  PCNN_REQUIRE(sh <= 160 * 1024, PCNN_EINVAL, "upscore_softmax_argmax: tile does not fit LDS");
+  PCNN_REQUIRE(sh <= 160 * 1024, PCNN_EINVAL, "%s: tile does not fit LDS", who);
   // class counts known at compile time (even; 8-byte aligned operands): the unrolled packed-f32 kernel
   const bool al8 = ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(bias)) & 7) == 0 && s_out_off % 2 == 0;
-#define UP_FIXED(CC) PCNN_LAUNCH(upscore_softmax_argmax_fixed_kernel<CC>, dim3((unsigned)blocks), dim3(UP_SEG), sh, stream, z, bias, score_out, prob, label, H, W, k, s, relu, nseg, s_out_off)
+#define UP_FIXED(CC) PCNN_LAUNCH(upscore_softmax_argmax_fixed_kernel<CC>, dim3((unsigned)blocks), dim3(UP_SEG), sh, stream, z, bias, score_out, prob, label, H, W, k, s, relu, nseg, s_out_off, gt, hard, threshold)
   if (al8 && C == 22) UP_FIXED(22);
   else if (al8 && C == 14) UP_FIXED(14);
   else if (al8 && C == 16) UP_FIXED(16);
 #undef UP_FIXED
   else if (C <= 24)
-    PCNN_LAUNCH(upscore_softmax_argmax_kernel<24>, dim3((unsigned)blocks), dim3(UP_SEG), sh, stream, z, bias, score_out, prob, label, H, W, C, k, s, relu, nseg, s_out_off);
+    PCNN_LAUNCH(upscore_softmax_argmax_kernel<24>, dim3((unsigned)blocks), dim3(UP_SEG), sh, stream, z, bias, score_out, prob, label, H, W, C, k, s, relu, nseg, s_out_off, gt, hard, threshold);
   else
-    PCNN_LAUNCH(upscore_softmax_argmax_kernel<64>, dim3((unsigned)blocks), dim3(UP_SEG), sh, stream, z, bias, score_out, prob, label, H, W, C, k, s, relu, nseg, s_out_off);
-  return check_launch("upscore_softmax_argmax_fwd");
+    PCNN_LAUNCH(upscore_softmax_argmax_kernel<64>, dim3((unsigned)blocks), dim3(UP_SEG), sh, stream, z, bias, score_out, prob, label, H, W, C, k, s, relu, nseg, s_out_off, gt, hard, threshold);
+  return check_launch(who);
+}
+}  // namespace
+
+extern "C" int pcnn_upscore_softmax_argmax_fwd(const float* z, const float* bias, int B, int H,
+                                               int W, int C, int k, int s, int relu,
+                                               float* score_out, float* prob, int32_t* label,
+                                               void* stream_)
+{
+  return upscore_softmax_argmax_impl("upscore_softmax_argmax_fwd", z, bias, B, H, W, C, k, s, relu, score_out, prob, label,
+                                     nullptr, 0.f, nullptr, stream_);
+}
+
+extern "C" int pcnn_upscore_softmax_argmax_hard_fwd(const float* z, const float* bias, int B, int H,
+                                                    int W, int C, int k, int s, int relu,
+                                                    float* score_out, float* prob, int32_t* label,
+                                                    const int32_t* gt, float threshold, float* hard, void* stream_)
+{
+  // attribute check of the Hardlabel op, hard_label_op.cc:150-155
+  PCNN_REQUIRE(threshold > 0, PCNN_EINVAL, "upscore_softmax_argmax_hard: Need threshold > 0, got %g", (double)threshold);
+  PCNN_REQUIRE(gt && hard, PCNN_ENULL, "upscore_softmax_argmax_hard: NULL pointer");
+  return upscore_softmax_argmax_impl("upscore_softmax_argmax_hard_fwd", z, bias, B, H, W, C, k, s, relu, score_out, prob, label,
+                                     gt, threshold, hard, stream_);
 }

@@ -187,12 +187,13 @@ def im_segment_batch(net, data, K, extents, points, symmetry, data_p=None, plant
     if data_p is not None:
         feed["data_p"] = data_p
     # run the graph up to vertex_pred, then the padded Hough + pooled head without a host sync
-    saved = (net.vertex_reg_2d,)
+    saved = (net.vertex_reg_2d, net.fuse_hard_label)
     net.vertex_reg_2d = False
+    net.fuse_hard_label = bool(with_losses)   # gt_label_weight rides in the label head's launch (Network._fused_hard_gt)
     try:
         net.run(feed, planted=planted)
     finally:
-        net.vertex_reg_2d = saved[0]
+        net.vertex_reg_2d, net.fuse_hard_label = saved
     label_2d = net.get_output("label_2d")
     B = label_2d.shape[0]
     is_train = int(net.is_train)

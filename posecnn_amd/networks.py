@@ -549,8 +549,22 @@ class Network(object):
     def _deconv_bilinear(self, x, k, s, add1=None, add2=None, bias=None, relu=False):
         return ops.deconv_bilinear(x, k, s, add1=add1, add2=add2, bias=bias, relu=relu)
 
-    def _upscore_softmax_argmax(self, z, bias, k, s, relu=True, want_score=False, want_prob=True):
-        return ops.upscore_softmax_argmax(z, bias, k, s, relu=relu, want_score=want_score, want_prob=want_prob)
+    def _upscore_softmax_argmax(self, z, bias, k, s, relu=True, want_score=False, want_prob=True, hard_gt=None):
+        return ops.upscore_softmax_argmax(z, bias, k, s, relu=relu, want_score=want_score, want_prob=want_prob,
+                                          hard_gt=hard_gt, hard_threshold=self.threshold_label if hard_gt is not None else None)
+
+    def _fused_hard_gt(self, z, k, s):
+        """gt_label_2d when the `gt_label_weight` layer (hard_label on prob_normalized, vgg16_convs.py:148-149) can ride in
+        the label head's launch: the layer is wanted (a with_losses graph, or fcn.im_segment_batch(with_losses=True) via
+        `fuse_hard_label`), everything is on the GPU and nothing records a graph for autograd (the op's gradient is zero,
+        but prob_normalized's own producer is then a framework op)."""
+        if not (self.with_losses or self.fuse_hard_label) or torch.is_grad_enabled():
+            return None
+        g = self.layers.get('gt_label_2d')
+        if not (isinstance(g, torch.Tensor) and g.is_cuda and z.is_cuda and g.dtype == torch.int32):
+            return None
+        B, H, W, _ = z.shape
+        return g if tuple(g.shape) == (B, H * s, W * s) else None
 
     @layer
     def fc(self, input, num_out, name, num_in=-1, height=-1, width=-1, channel=-1, reuse=None, relu=True, trainable=True):
@@ -794,6 +808,7 @@ class vgg16_convs(Network):
         self.planted = None
         self.grouped_towers = True    # RGB-D inference: both towers as one grouped launch sequence
         self.merge_head_convs = True  # COLOR: the label and vertex 1x1 convolutions of a source as one product (fc_rows_split)
+        self.fuse_hard_label = False  # fcn.im_segment_batch(with_losses=True) on a graph built without the loss layers: gt_label_weight from the label head's launch
         self.mfma_heads = True        # big batches: add_score / add_score_vertex + the 1/8-resolution `score` / `vertex_pred` products in one launch per head
         self.head_gemm = True         # 1x1 head convs (incl. the RGB-D concat) on the library's own fp32-MFMA row kernel
         self._head_wt = {}
@@ -1170,8 +1185,12 @@ class vgg16_convs(Network):
             # [B,480,640,64] `upscore` or the full-resolution `score` to HBM.
             z, b = small if small is not None else self._conv1x1_lowres(self.get_output('dropout'), 'score', self.num_classes, self.num_units)
             k, s = int(16 * self.scale), int(8 * self.scale)
-            score, prob, label = self._upscore_softmax_argmax(z, b, k, s, relu=True, want_score=self.with_losses,
-                                                             want_prob=self.want_prob)
+            hard_gt = self._fused_hard_gt(z, k, s)
+            out = self._upscore_softmax_argmax(z, b, k, s, relu=True, want_score=self.with_losses,
+                                               want_prob=self.want_prob, hard_gt=hard_gt)
+            score, prob, label = out[:3]
+            if hard_gt is not None:
+                self.layers['gt_label_weight'] = out[3]
             if score is not None:
                 self.layers['score'] = score
             self.layers['prob_normalized'] = prob
@@ -1193,7 +1212,7 @@ class vgg16_convs(Network):
                  .softmax_high_dimension(self.num_classes, name='prob_normalized')
                  .argmax_2d(name='label_2d'))
 
-        if self.with_losses:
+        if self.with_losses and 'gt_label_weight' not in self.layers:   # (else: it left the label head's launch)
             (self.feed('prob_normalized', 'gt_label_2d')
                  .hard_label(threshold=self.threshold_label, name='gt_label_weight'))
 

@@ -919,9 +919,12 @@ def smooth_l1_loss_vertex(vertex_pred, vertex_targets, vertex_weights, sigma=1.0
     return _SmoothL1VertexFn.apply(pred, target, weight, float(sigma))[0]
 
 
-def upscore_softmax_argmax(z, bias, kernel, stride, relu=True, want_score=False, want_prob=True):
+def upscore_softmax_argmax(z, bias, kernel, stride, relu=True, want_score=False, want_prob=True, hard_gt=None,
+                           hard_threshold=None):
     """Label-head epilogue in one pass: score = [ReLU](deconv(z) + bias) -> softmax -> first argmax.
-    z [B,H,W,C] f32. Returns (score or None, prob or None, label int32 [B,H*s,W*s])."""
+    z [B,H,W,C] f32. Returns (score or None, prob or None, label int32 [B,H*s,W*s]); with `hard_gt` (int32
+    [B,H*s,W*s]) and `hard_threshold` a fourth element: hard_label(prob, hard_gt, hard_threshold) f32 [B,H*s,W*s,C]
+    from the same launch (no gradient flows through the Hardlabel op: hard_label_op_gpu.cu.cc:55-63)."""
     z = _dev(z, "z", torch.float32)
     bias = _dev(bias, "bias", torch.float32)
     B, H, W, C = z.shape
@@ -930,6 +933,18 @@ def upscore_softmax_argmax(z, bias, kernel, stride, relu=True, want_score=False,
     score = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=dev) if want_score else None
     prob = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=dev) if want_prob else None
     label = torch.empty((B, Ho, Wo), dtype=torch.int32, device=dev)
+    if hard_gt is not None:
+        # the Hardlabel op on the probabilities of the same launch (vgg16_convs.py:148-149): same bits as
+        # hard_label(prob, gt, threshold), 432 MB of stores per 16 frames that fit under the head's own arithmetic
+        gt = _dev(hard_gt, "hard_gt", torch.int32)
+        if tuple(gt.shape) != (B, Ho, Wo):
+            raise ValueError("hard_gt must be int32 [B, H*stride, W*stride]")
+        hard = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=dev)
+        check("pcnn_upscore_softmax_argmax_hard_fwd",
+              lib().pcnn_upscore_softmax_argmax_hard_fwd(_ptr(z), _ptr(bias), B, H, W, C, int(kernel), int(stride),
+                                                         1 if relu else 0, _ptr(score), _ptr(prob), _ptr(label),
+                                                         _ptr(gt), float(hard_threshold), _ptr(hard), _stream(z)))
+        return score, prob, label, hard
     check("pcnn_upscore_softmax_argmax_fwd",
           lib().pcnn_upscore_softmax_argmax_fwd(_ptr(z), _ptr(bias), B, H, W, C, int(kernel), int(stride),
                                                 1 if relu else 0, _ptr(score), _ptr(prob), _ptr(label), _stream(z)))

@@ -36,7 +36,8 @@ class vgg16_convs_cpu(vgg16_convs):
         n = lambda t: None if t is None else t.numpy()
         return torch.from_numpy(oracle.deconv_bilinear(x.numpy(), k, s, n(add1), n(add2), n(bias), relu))
 
-    def _upscore_softmax_argmax(self, z, bias, k, s, relu=True, want_score=False, want_prob=True):
+    def _upscore_softmax_argmax(self, z, bias, k, s, relu=True, want_score=False, want_prob=True, hard_gt=None):
+        assert hard_gt is None   # (the fused Hardlabel is a GPU-path choice: Network._fused_hard_gt)
         score, prob, label = oracle.upscore_softmax_argmax(z.numpy(), bias.numpy(), k, s, relu)
         return (torch.from_numpy(score) if want_score else None, torch.from_numpy(prob) if want_prob else None,
                 torch.from_numpy(label))

@@ -257,3 +257,69 @@ def test_merged_head_convs_equal_the_separate_products(gpu):
                                                       "add_score_vertex", "label_2d", "vertex_pred_lowres", "rois", "poses_tanh")})
     for n in outs[0]:
         same(outs[0][n], outs[1][n], n)
+
+
+@pytest.mark.parametrize("shape,k,s", [((2, 30, 40, 22), 16, 8), ((1, 7, 9, 22), 16, 8), ((1, 5, 21, 40), 16, 8), ((1, 6, 7, 3), 16, 8),
+                                       ((1, 9, 5, 14), 4, 2)])
+def test_hard_label_from_the_label_heads_launch_equals_the_op(gpu, shape, k, s):
+    """pcnn_upscore_softmax_argmax_hard_fwd: the Hardlabel op (hard_label_op_gpu.cu.cc:17-29) evaluated on the probabilities
+    while they are still in LDS. Same bits as the op run on the prob tensor afterwards and as the CPU checker, for the
+    compile-time class counts (22, 14), the generic kernels (40 -> <64>, 3 -> <24>), a ragged last segment (21 * 8 = 168
+    columns = 128 + 40), ground-truth labels -1 (no label), 0 (background: hot only below the threshold), out of range
+    (ignored); prob / score / label themselves unchanged by the extra output; prob not requested at all."""
+    import torch
+    from posecnn_amd import ops
+    import oracle
+    B, H, W, C = shape
+    rng = np.random.default_rng(31)
+    z = (rng.standard_normal(shape) * 2).astype(np.float32)
+    bias = rng.standard_normal(C).astype(np.float32)
+    gt = rng.integers(-1, C, (B, H * s, W * s)).astype(np.int32)
+    gt[rng.random(gt.shape) < 0.4] = 0           # plenty of background pixels: the prob[0] < threshold branch
+    gt[0, 0, :3] = [C, C + 5, -7]                # out of range: no channel is set
+    for thr in (1.0 / C, 0.5, 1.5):              # below / around / above every probability
+        score, prob, label, hard = ops.upscore_softmax_argmax(T(gpu, z), T(gpu, bias), k, s, relu=True, want_score=True,
+                                                              hard_gt=T(gpu, gt), hard_threshold=thr)
+        s0, p0, l0 = ops.upscore_softmax_argmax(T(gpu, z), T(gpu, bias), k, s, relu=True, want_score=True)
+        same(N(score), N(s0), "score"); same(N(prob), N(p0), "prob"); same(N(label), N(l0), "label")
+        want = ops.hard_label(p0, T(gpu, gt), thr)
+        same(N(hard), N(want), "hard label (fused vs op) thr=%g" % thr)
+        same(N(hard), oracle.hard_label(N(p0), gt, thr), "hard label (fused vs CPU checker) thr=%g" % thr)
+        in_range = (gt >= 0) & (gt < C)
+        assert np.array_equal(N(hard).sum(-1) > 0, in_range & ((gt > 0) | (np.take_along_axis(N(p0), np.clip(gt, 0, C - 1)[..., None], -1)[..., 0] < thr)))
+        _, p1, l1, h1 = ops.upscore_softmax_argmax(T(gpu, z), T(gpu, bias), k, s, relu=True, want_prob=False, hard_gt=T(gpu, gt),
+                                                   hard_threshold=thr)
+        assert p1 is None
+        same(N(h1), N(want), "hard label without the prob output"); same(N(l1), N(l0), "label")
+    with pytest.raises(Exception, match="threshold"):
+        ops.upscore_softmax_argmax(T(gpu, z), T(gpu, bias), k, s, hard_gt=T(gpu, gt), hard_threshold=0.0)
+
+
+def test_pipeline_takes_gt_label_weight_from_the_label_head(gpu):
+    """fcn.im_segment_batch(with_losses=True): `gt_label_weight` (vgg16_convs.py:148-149) comes out of the label head's launch —
+    on a graph built with the loss layers and on one built without them — and equals the Hardlabel op on prob_normalized."""
+    import torch
+    from posecnn_amd import fcn, ops, _lib
+    from posecnn_amd.networks import vgg16_convs
+    C, B, H, W = 22, 2, 96, 128
+    K = config.DEMO_INTRINSICS.copy(); K[:2] *= W / 640.0
+    pts = synth.make_model_points(C, 32)
+    g = torch.Generator().manual_seed(5)
+    data, data_p = _rgbd_batch(g, B, H, W)
+    planted_np, scenes = synth.make_planted_batch(7, B, H=H, W=W, K=K, C=C, n_obj=2)
+    gtp = synth.make_gt_poses(scenes, K, seed=3)
+    for graph_losses in (True, False):
+        net = vgg16_convs("RGBD", C, 64, (1.0,), 1.0, -1.0, vertex_reg_2d=True, pose_reg=True, trainable=False, is_train=True,
+                          seed=3, init="he", with_losses=graph_losses, device=gpu)
+        synth.init_calibrated(net)
+        _lib.profile_enable(True)
+        with torch.no_grad():
+            fcn.im_segment_batch(net, T(gpu, data.numpy()), K, config.LOV_EXTENTS, pts, config.LOV_SYMMETRY, data_p=T(gpu, data_p.numpy()),
+                                 planted={k: T(gpu, v) for k, v in planted_np.items()}, with_losses=True, gt_poses=T(gpu, gtp))
+        torch.cuda.synchronize()
+        rep = _lib.profile_report(); _lib.profile_enable(False)
+        assert not any(k.startswith("hard_label") for k in rep), sorted(rep)   # no separate launch
+        hard = net.get_output("gt_label_weight")
+        want = ops.hard_label(net.get_output("prob_normalized"), net.get_output("gt_label_2d"), net.threshold_label)
+        same(N(hard), N(want), "gt_label_weight")
+        assert float(hard.sum()) > 0
