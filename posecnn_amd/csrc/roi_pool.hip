@@ -226,14 +226,24 @@ __global__ __launch_bounds__(128) void roi_pool_add2_perbin(
 // (14 KB of output), a row past the device-side count costs one wide zero fill — or nothing at all with KEEP_DEAD, the
 // variant the network uses: fc6 (csrc/fc_mfma.hip, csrc/fc_skinny.hip) masks rows at or past the same count itself, so
 // `pool_score`'s rows past it are never read. Same per-value expressions as the per-bin kernel -> same bits.
+constexpr int RP_XCDS = 8;     // workgroup w is dispatched to XCD w % 8 (MI355X: 8 XCDs, 32 CUs and one 4 MB L2 each)
+constexpr int RP_GROUP = 9;    // consecutive rois that share an XCD
 template <bool KEEP_DEAD>
 __global__ __launch_bounds__(256) void roi_pool_add2_rows(
     const float* __restrict__ data_a, int Ha, int Wa, float scale_a,
     const float* __restrict__ data_b, int Hb, int Wb, float scale_b,
     const float* __restrict__ rois, float* __restrict__ out, int B, int C, int roi_cols, int PH,
-    int PW, const int* __restrict__ num_rows_dev)
+    int PW, const int* __restrict__ num_rows_dev, int R)
 {
-  const int ph = blockIdx.x % PH, n = blockIdx.x / PH;
+  // Workgroup -> (roi, bin row), XCD-aware. Consecutive rows of the RoI buffer overlap: the Hough layer's training mode
+  // emits a box and its 8 jitters as 9 consecutive rows (hough_voting_gpu_op.cu.cc:440-466), and test-mode neighbours are at
+  // least boxes of the same image. Workgroup w runs on XCD w % 8, each with its own L2; with w = roi * PH + ph the same bin
+  // row of the 9 jittered boxes landed on 8 different XCDs and every XCD fetched the cells for itself (FETCH_SIZE 490 MB per
+  // launch for 196 MB of feature maps). Here RP_GROUP consecutive rois x one bin row are consecutive workgroups of ONE XCD.
+  const int w = blockIdx.x, xcd = w % RP_XCDS, q = w / RP_XCDS;
+  const int k = (q / RP_GROUP) * RP_XCDS + xcd;          // chunk = (roi group, bin row)
+  const int ph = k % PH, n = (k / PH) * RP_GROUP + q % RP_GROUP;
+  if (n >= R) return;                                    // (padding of the last group / of the chunk count to 8)
   const bool live = num_rows_dev == nullptr || n < num_rows_dev[0];
   if (KEEP_DEAD && !live) return;
   const float* roi = rois + (size_t)n * roi_cols;
@@ -427,14 +437,16 @@ static int roi_pool_add2_impl(const float* data_a, int Ha, int Wa, float scale_a
                "roi_pool_add2: tensors must be 16-byte aligned");
   PCNN_REQUIRE(!keep_dead || num_rows_dev, PCNN_ENULL, "roi_pool_add2_live: needs the device-side row count");
   hipStream_t stream = (hipStream_t)stream_;
-  const long long blocks = (long long)R * PH;
+  // (roi groups x bin rows) chunks, padded to a multiple of the XCD count, RP_GROUP workgroups each
+  const long long chunks = (((long long)(R + RP_GROUP - 1) / RP_GROUP * PH + RP_XCDS - 1) / RP_XCDS) * RP_XCDS;
+  const long long blocks = chunks * RP_GROUP;
   PCNN_REQUIRE(blocks < (1ll << 31), PCNN_EINVAL, "roi_pool_add2: too many bin rows (%lld)", blocks);
   if (keep_dead)
     PCNN_LAUNCH(roi_pool_add2_rows<true>, dim3((unsigned)blocks), dim3(256), 0, stream, data_a, Ha, Wa, scale_a, data_b, Hb,
-                Wb, scale_b, rois, out, B, C, roi_cols, PH, PW, num_rows_dev);
+                Wb, scale_b, rois, out, B, C, roi_cols, PH, PW, num_rows_dev, R);
   else
     PCNN_LAUNCH(roi_pool_add2_rows<false>, dim3((unsigned)blocks), dim3(256), 0, stream, data_a, Ha, Wa, scale_a, data_b, Hb,
-                Wb, scale_b, rois, out, B, C, roi_cols, PH, PW, num_rows_dev);
+                Wb, scale_b, rois, out, B, C, roi_cols, PH, PW, num_rows_dev, R);
   return check_launch("roi_pool_add2_fwd");
 }
 
