@@ -242,10 +242,14 @@ __global__ __launch_bounds__(256) void bias_relu_pool2_kernel(const float* __res
 // one segment's npx * C floats from LDS to a contiguous run of global memory
 __device__ __forceinline__ void up_copy_out(float* __restrict__ o, const float* s_out, int nfl, int tid, int nthreads, int seg_floats)
 {
+  typedef float v4f __attribute__((ext_vector_type(4)));
   if (((nfl | seg_floats) & 3) == 0 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
     // the segment's run of npx * C floats starts 16-byte aligned: dwordx4 stores (4x fewer store instructions)
+    // Non-temporal: 432 MB per 16 frames of probabilities (and as much again of label weights) that nothing in the
+    // step reads back — kept out of the L2 / MALL lines the feature maps live in. Measured in the step: this kernel
+    // 224 -> 212 us, everything else unchanged (two runs each way).
     for (int i = tid * 4; i < nfl; i += nthreads * 4)
-      *reinterpret_cast<float4*>(o + i) = *reinterpret_cast<const float4*>(s_out + i);
+      __builtin_nontemporal_store(*reinterpret_cast<const v4f*>(s_out + i), reinterpret_cast<v4f*>(o + i));
   } else {
     for (int i = tid; i < nfl; i += nthreads) o[i] = s_out[i];
   }
