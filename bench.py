@@ -673,6 +673,10 @@ def main(argv=None):
         "hard_label_fwd_kernel": 4.0 * B * H * W * (2 + C),
         "upscore_softmax_argmax": 4.0 * B * H * W * (C + 1) + act(8, C),     # (generic kernel or the compile-time-C instance)
     }
+    if a.losses != "none" and "hard_label_fwd_kernel" not in kern:
+        # the Hardlabel op rides in the label head's launch (pcnn_upscore_softmax_argmax_hard_fwd): its label map in,
+        # its C-wide weights out, in the same kernel's bytes
+        hbm["upscore_softmax_argmax"] += 4.0 * B * H * W * (1 + C)
     hbm.update(net.hbm_table(B, H, W)) if hasattr(net, "hbm_table") else None
     if G3 > 0:   # writes data + flag [G^3, 64] and label [G^3, C], reads label_3d [G^3, C]
         hbm["backproject_fused_kernel"] = 4.0 * B * G3 ** 3 * (2 * 64 + 2 * C)
