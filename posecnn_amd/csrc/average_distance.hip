@@ -6,11 +6,14 @@
 //
 // The reference writes 54 floats of per-(roi, point) rotation scratch, 88 floats of per-point
 // gradient scratch and a loss per point to global memory (~1.5 MB per ROI), then sums them with one
-// thread per output channel. Here:
-//   adl_terms   grid (point slabs, rois): rotations live in registers; for a symmetric class the
-//               nearest-neighbour search walks the gt-rotated model points staged through LDS in
-//               1024-point tiles (every lane reads the same LDS address -> broadcast); per point
-//               only the 5 non-zero terms {loss, dq_s, dq_u, dq_v, dq_w} go to the workspace.
+// thread per output channel. Here (DESIGN.md 3.5 has the measurements behind each choice):
+//   adl_order   one workgroup: the rows that have a pose target, symmetric classes first (their workgroups are ~15x
+//               longer than any other row's and must be dispatched first to spread over the CUs).
+//   adl_terms   grid (point slabs, listed rows): rotations live in registers; for a symmetric class the
+//               nearest-neighbour search runs over the gt-rotated model points staged through LDS in
+//               1024-point tiles — trip minima over sixteen candidates (v_min tree), the reference's strict-'<'
+//               walk only inside the winning trip; per point only the 5 non-zero terms
+//               {loss, dq_s, dq_u, dq_v, dq_w} go to the workspace.
 //   adl_sum     grid (rois): the canonical ascending-p sums (sum_losses_gradients :237-248) from
 //               an LDS copy of the ROI's 5 x P terms; writes the whole 4C-wide gradient row.
 //   adl_total   thrust::reduce over ROIs (:333-335), ascending.
