@@ -116,33 +116,55 @@ __global__ __launch_bounds__(256) void head_lowres_mfma_kernel(
   // bilinear_at — rows ascending, columns ascending, acc = acc + (wy wx) in — so add_score keeps the bits of
   // deconv_bilinear_kernel + the two adds. (The scalar form of this phase made the kernel 196 us for the vertex head at 16
   // frames: 32 trips of 4 dependent scalar loads per thread.)
+  // Round 5 (second pass): a workgroup lived 35 us of a 57 us launch, three quarters of its wave cycles waiting — every trip
+  // of this loop was a round of loads followed by its own store, U / 16 (4 or 8) rounds one after the other, then one
+  // more trip to L2 per K group of the filter, then 4 NT scattered 4-byte stores per lane. Now: the loads of FOUR trips are
+  // issued together (addresses of absent taps are clamped onto present ones and their terms skipped, so the sums keep
+  // their order and their bits), the filter fragments of the next K group are requested before this group's MFMAs, and the
+  // product leaves through LDS as one contiguous run.
   const int U4 = U >> 2;
-  for (int idx = tid; idx < HM_PX * U4; idx += 256) {
-    const int p = idx / U4, c = (idx - p * U4) * 4;
-    const long long gp = gp0 + p;
-    v4f t = (v4f){0.f, 0.f, 0.f, 0.f};
-    if (gp < total) {
+  const int ntrip = (HM_PX * U4) / 256;          // U / 16
+  for (int i0 = 0; i0 < ntrip; i0 += 4) {
+    v4f tp[4][4], av[4], pv[4];
+    float wg[4][4];
+    bool on[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int idx = min(tid + (i0 + u) * 256, HM_PX * U4 - 1);   // (a trip past the last one: valid addresses, unused values)
+      const int p = idx / U4, c = (idx - p * U4) * 4;
+      const long long gp = min(gp0 + p, total - 1);
       const Taps ty = s_ty[p], tx = s_tx[p];
       const float* inb = b5 + (size_t)s_img[p] * h5 * w5 * U + c;
-      v4f up = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int jy = 0; jy < 4; jy++) {
-        if (jy < ty.n) {
-          const float* row = inb + (size_t)(ty.i0 + jy) * w5 * U;
+      for (int jy = 0; jy < 2; jy++)
 #pragma unroll
-          for (int jx = 0; jx < 4; jx++) {
-            if (jx < tx.n) {
-              const float wgt = ty.w[jy] * tx.w[jx];
-              up = up + wgt * *reinterpret_cast<const v4f*>(row + (size_t)(tx.i0 + jx) * U);
-            }
-          }
+        for (int jx = 0; jx < 2; jx++) {
+          const int yy = ty.i0 + max(min(jy, ty.n - 1), 0), xx = tx.i0 + max(min(jx, tx.n - 1), 0);
+          tp[u][jy * 2 + jx] = *reinterpret_cast<const v4f*>(inb + ((size_t)yy * w5 + xx) * U);
+          wg[u][jy * 2 + jx] = ty.w[jy] * tx.w[jx];
+          on[u][jy * 2 + jx] = jy < ty.n && jx < tx.n;
         }
-      }
-      t = *reinterpret_cast<const v4f*>(a + gp * U + c) + up;                       // add_score = score_conv4 + upscore_conv5   (tf.add_n order)
-      if (planted) t = t + *reinterpret_cast<const v4f*>(planted + gp * U + c);     // bench aid: the planted scene
-      *reinterpret_cast<v4f*>(add_out + gp * U + c) = t;
+      av[u] = *reinterpret_cast<const v4f*>(a + gp * U + c);
+      if (planted) pv[u] = *reinterpret_cast<const v4f*>(planted + gp * U + c);
     }
-    *reinterpret_cast<v4f*>(tL + p * LD + c) = t;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (i0 + u >= ntrip) break;
+      const int idx = tid + (i0 + u) * 256;
+      const int p = idx / U4, c = (idx - p * U4) * 4;
+      const long long gp = gp0 + p;
+      v4f t = (v4f){0.f, 0.f, 0.f, 0.f};
+      if (gp < total) {
+        v4f up = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (on[u][j]) up = up + wg[u][j] * tp[u][j];     // rows ascending, columns ascending: bilinear_at's order
+        t = av[u] + up;                                    // add_score = score_conv4 + upscore_conv5   (tf.add_n order)
+        if (planted) t = t + pv[u];                        // bench aid: the planted scene
+        *reinterpret_cast<v4f*>(add_out + gp * U + c) = t;
+      }
+      *reinterpret_cast<v4f*>(tL + p * LD + c) = t;
+    }
   }
   __syncthreads();
   const int lr = lane & 15, lk = lane >> 4;
@@ -151,28 +173,37 @@ __global__ __launch_bounds__(256) void head_lowres_mfma_kernel(
   for (int nt = 0; nt < NT; nt++) acc[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
   const float* arow = tL + (16 * wave + lr) * LD + 4 * lk;
   const float* brow = wN + (size_t)lr * U + 4 * lk;
-  for (int g = 0; g < U / 16; g++) {
-    const v4f av = *reinterpret_cast<const v4f*>(arow + 16 * g);
-    v4f bv[NT];
+  v4f bv[NT], bn[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) bv[nt] = *reinterpret_cast<const v4f*>(brow + (size_t)(16 * nt) * U + 16 * g);
+  for (int nt = 0; nt < NT; nt++) bv[nt] = *reinterpret_cast<const v4f*>(brow + (size_t)(16 * nt) * U);
+  const int ng = U / 16;
+  for (int g = 0; g < ng; g++) {
+    const v4f avv = *reinterpret_cast<const v4f*>(arow + 16 * g);
+    const int gn = min(g + 1, ng - 1);
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) bn[nt] = *reinterpret_cast<const v4f*>(brow + (size_t)(16 * nt) * U + 16 * gn);
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-      for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[nt][i], acc[nt], 0, 0, 0);
+      for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(avv[i], bv[nt][i], acc[nt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) bv[nt] = bn[nt];
   }
-  // lane (column lr of tile nt, lk) holds pixels 16 wave + 4 lk + i
+  // lane (column lr of tile nt, lk) holds pixels 16 wave + 4 lk + i: through LDS ([px][Cout], the t tile is dead), out as one run
+  __syncthreads();
+  float* zL = smem;
 #pragma unroll
   for (int nt = 0; nt < NT; nt++) {
     const int co = 16 * nt + lr;
     if (co < Cout) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const long long gp = gp0 + 16 * wave + 4 * lk + i;
-        if (gp < total) z[gp * Cout + co] = acc[nt][i];
-      }
+      for (int i = 0; i < 4; i++) zL[(16 * wave + 4 * lk + i) * Cout + co] = acc[nt][i];
     }
   }
+  __syncthreads();
+  const long long npx = min((long long)HM_PX, total - gp0);
+  float* zo = z + gp0 * Cout;
+  for (int i = tid; i < (int)npx * Cout; i += 256) zo[i] = zL[i];
 }
 
 // `poses_mul = poses_tanh * poses_weight; poses_pred = l2_normalize(poses_mul, dim = 1)` (vgg16_convs.py:195-197,
@@ -270,7 +301,8 @@ extern "C" int pcnn_head_lowres_mfma_fwd(const float* score4, const float* score
   PCNN_REQUIRE(score4 && score5 && weights_nk && add_out && z, PCNN_ENULL, "head_lowres_mfma: NULL pointer");
   PCNN_REQUIRE(aligned16(weights_nk) && aligned16(score4) && aligned16(score5) && aligned16(planted) && aligned16(add_out), PCNN_EINVAL,
                "head_lowres_mfma: score4, score5, planted, the filter and add_out must be 16-byte aligned");
-  const size_t lds = sizeof(float) * (size_t)HM_PX * (units + 4);
+  // the t tile [64][units + 4], reused for the product [64][out_channels] on its way out
+  const size_t lds = sizeof(float) * (size_t)HM_PX * (units + 4 > out_channels ? units + 4 : out_channels);
   PCNN_REQUIRE(lds <= 60 * 1024, PCNN_EINVAL, "head_lowres_mfma: %d units exceed the kernel's LDS", units);
   hipStream_t stream = (hipStream_t)stream_;
   const long long total = (long long)B * h * w;
