@@ -934,6 +934,8 @@ def upscore_softmax_argmax(z, bias, kernel, stride, relu=True, want_score=False,
     prob = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=dev) if want_prob else None
     label = torch.empty((B, Ho, Wo), dtype=torch.int32, device=dev)
     if hard_gt is not None:
+        if hard_threshold is None:
+            raise ValueError("hard_gt needs hard_threshold (the Hardlabel op's `threshold` attribute)")
         # the Hardlabel op on the probabilities of the same launch (vgg16_convs.py:148-149): same bits as
         # hard_label(prob, gt, threshold), 432 MB of stores per 16 frames that fit under the head's own arithmetic
         gt = _dev(hard_gt, "hard_gt", torch.int32)
