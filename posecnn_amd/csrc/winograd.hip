@@ -238,6 +238,20 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restri
     const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
     const float* xb = x + b * H * W * (long long)C + c;
     VT tmp[6][6];  // tmp[i][s] = (B^T d)[i][s]
+    // The patch's 36 loads are issued together, from clamped (always valid) addresses, and the pixels outside the image
+    // are zeroed afterwards. With `if (inside) load` every load sat under its own exec branch and the compiler waited for
+    // each patch column before transforming it: six trips to memory per thread, one after the other, at two waves per
+    // SIMD (round 5; same values, same arithmetic).
+    VT d[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const int yy = min(max(y0 + r, 0), H - 1);
+#pragma unroll
+      for (int s2 = 0; s2 < 6; s2++) {
+        const int xx = min(max(x0 + s2, 0), W - 1);
+        d[r][s2] = *reinterpret_cast<const VT*>(xb + ((long long)yy * W + xx) * C);
+      }
+    }
 #pragma unroll
     for (int s2 = 0; s2 < 6; s2++) {
       const int xx = x0 + s2;
@@ -245,10 +259,8 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 6; r++) {
         const int yy = y0 + r;
-        VT val = {};
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W)
-          val = *reinterpret_cast<const VT*>(xb + ((long long)yy * W + xx) * C);
-        col[r] = val;
+        const VT zero = {};
+        col[r] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? d[r][s2] : zero;
       }
       VT o[6];
       bt6(col, o);
