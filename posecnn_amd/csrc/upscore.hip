@@ -317,12 +317,23 @@ __global__ __launch_bounds__(UP_SEG) void upscore_softmax_argmax_kernel(
   float* s_out = smem + s_out_off;         // [UP_SEG][C]
   // a row's ncx cells x C channels are one contiguous run of z: straight copies, no index arithmetic per element
   const int rowlen = ncx * C;
+  {
+    // four loads per thread issued before the first LDS write (see the compile-time-C kernel below)
+    const int tot = ty.n * rowlen;
+    const float* src0 = z + (((long long)b * H + ty.i0) * W + cx0) * C;
+    for (int e0 = tid; e0 < tot; e0 += 4 * UP_SEG) {
+      float v[4];
 #pragma unroll
-  for (int ry = 0; ry < 4; ry++)      // (constant indices into the tap structs: see the note on scratch memory below)
-    if (ry < ty.n) {
-      const float* src = z + (((long long)b * H + ty.i0 + ry) * W + cx0) * C;
-      for (int i = tid; i < rowlen; i += UP_SEG) s_z[ry * rowlen + i] = src[i];
+      for (int j = 0; j < 4; j++) {
+        const int e = min(e0 + j * UP_SEG, tot - 1);
+        const int ry = e / rowlen, i = e - ry * rowlen;
+        v[j] = src0[(long long)ry * W * C + i];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (e0 + j * UP_SEG < tot) s_z[e0 + j * UP_SEG] = v[j];
     }
+  }
   __syncthreads();
 
   const int ox = ox0 + tid;
@@ -473,13 +484,25 @@ __global__ __launch_bounds__(UP_SEG) void upscore_softmax_argmax_fixed_kernel(
   float* s_z = smem;                       // [ty.n][ncx][C]
   float* s_out = smem + s_out_off;         // [UP_SEG][C]
   const int rowlen = ncx * C;              // even: copied as float2
+  {
+    // the segment's ty.n rows of ncx cells: FOUR loads per thread issued before the first LDS write (a row-by-row copy loop
+    // is a load, a wait and a store per trip — four trips to memory in sequence in front of every workgroup's first barrier)
+    const int nrow2 = rowlen / 2, tot = ty.n * nrow2;
+    const float* src0 = z + (((long long)b * H + ty.i0) * W + cx0) * C;
+    f2* dst = reinterpret_cast<f2*>(s_z);
+    for (int e0 = tid; e0 < tot; e0 += 4 * UP_SEG) {
+      f2 v[4];
 #pragma unroll
-  for (int ry = 0; ry < 4; ry++)
-    if (ry < ty.n) {
-      const f2* src = reinterpret_cast<const f2*>(z + (((long long)b * H + ty.i0 + ry) * W + cx0) * C);
-      f2* dst = reinterpret_cast<f2*>(s_z + ry * rowlen);
-      for (int i = tid; i < rowlen / 2; i += UP_SEG) dst[i] = src[i];
+      for (int j = 0; j < 4; j++) {
+        const int e = min(e0 + j * UP_SEG, tot - 1);
+        const int ry = e / nrow2, i = e - ry * nrow2;
+        v[j] = *reinterpret_cast<const f2*>(src0 + (long long)ry * W * C + 2 * i);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (e0 + j * UP_SEG < tot) dst[e0 + j * UP_SEG] = v[j];
     }
+  }
   __syncthreads();
 
   const int ox = ox0 + tid;
