@@ -81,4 +81,40 @@ __device__ __forceinline__ float bilinear_at(const float* __restrict__ inb, cons
   return acc;
 }
 
+// bilinear_at for THREE consecutive channels c, c+1, c+2 of one output pixel (the Hough layer's (u, v, log d) triple): the
+// twelve loads of the <= 2 x 2 taps are issued together (absent taps read a present one's address and are skipped in the
+// sums) instead of one trip to memory per tap and channel behind a guard each. Per channel the same terms in the same
+// order as bilinear_at: same bits.
+__device__ __forceinline__ void bilinear_at3(const float* __restrict__ inb, const Taps& ty, const Taps& tx, int W, int C,
+                                             int c, float& o0, float& o1, float& o2)
+{
+  if (ty.n >= 1 && ty.n <= 2 && tx.n >= 1 && tx.n <= 2) {
+    float v[4][3];
+#pragma unroll
+    for (int jy = 0; jy < 2; jy++)
+#pragma unroll
+      for (int jx = 0; jx < 2; jx++) {
+        const int yy = ty.i0 + (jy < ty.n ? jy : ty.n - 1), xx = tx.i0 + (jx < tx.n ? jx : tx.n - 1);
+        const float* q = inb + ((size_t)yy * W + xx) * C + c;
+        v[jy * 2 + jx][0] = q[0]; v[jy * 2 + jx][1] = q[1]; v[jy * 2 + jx][2] = q[2];
+      }
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int jy = 0; jy < 2; jy++)
+#pragma unroll
+      for (int jx = 0; jx < 2; jx++)
+        if (jy < ty.n && jx < tx.n) {
+          const float w = ty.w[jy] * tx.w[jx];
+          a0 = a0 + w * v[jy * 2 + jx][0];
+          a1 = a1 + w * v[jy * 2 + jx][1];
+          a2 = a2 + w * v[jy * 2 + jx][2];
+        }
+    o0 = a0; o1 = a1; o2 = a2;
+  } else {
+    o0 = bilinear_at(inb, ty, tx, W, C, c);
+    o1 = bilinear_at(inb, ty, tx, W, C, c + 1);
+    o2 = bilinear_at(inb, ty, tx, W, C, c + 2);
+  }
+}
+
 }  // namespace pcnn

@@ -222,10 +222,17 @@ __global__ __launch_bounds__(256) void hv_hist_kernel(const int* __restrict__ la
 
   const int base = chunk * HV_CHUNK;
   const int* lab = label + (size_t)n * HW;
+  // (the chunk's labels first: with the load inside the ballot loop below each of the 8 rounds waited for its own)
+  int lv[HV_CHUNK / 256];
+#pragma unroll
+  for (int k = 0; k < HV_CHUNK / 256; k++) {
+    const int i = base + k * 256 + tid;
+    lv[k] = lab[i < HW ? i : HW - 1];
+  }
 #pragma unroll
   for (int k = 0; k < HV_CHUNK / 256; k++) {
     int i = base + k * 256 + tid;
-    int l = i < HW ? lab[i] : 0;
+    int l = i < HW ? lv[k] : 0;
     bool valid = l > 0 && l < C;
     unsigned long long mask = __ballot(valid);
     while (mask) {
@@ -270,12 +277,20 @@ __global__ __launch_bounds__(256) void hv_scatter_kernel(
   if (tid < PCNN_MAX_CLASSES) { s_pre[tid] = 0; s_tot[tid] = 0; s_kmax[tid] = 0; }
   __syncthreads();
   const int* h = hist + (size_t)n * nchunk * C;
-  for (int idx = tid; idx < nchunk * C; idx += 256) {
-    int v = h[idx];
-    if (v) {
-      int k = idx / C, c = idx - k * C;
-      atomicAdd(&s_tot[c], v);
-      if (k < chunk) atomicAdd(&s_pre[c], v);
+  // (round 5) eight histogram entries per thread and round of loads: one entry per trip was a load, a wait and a branch —
+  // 13 trips to L2 in sequence in front of every block of a 16-frame launch (nchunk * C = 3300 entries)
+  for (int i0 = tid; i0 < nchunk * C; i0 += 8 * 256) {
+    int hv[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) hv[j] = h[min(i0 + j * 256, nchunk * C - 1)];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int idx = i0 + j * 256, v = hv[j];
+      if (idx < nchunk * C && v) {
+        int k = idx / C, c = idx - k * C;
+        atomicAdd(&s_tot[c], v);
+        if (k < chunk) atomicAdd(&s_pre[c], v);
+      }
     }
   }
   __syncthreads();
@@ -389,9 +404,10 @@ __global__ __launch_bounds__(256) void hv_scatter_kernel(
           const Taps tx = make_taps(x, vs.k, vs.s, pad, vs.Wl);
           const float* zb = vs.z + (size_t)n * vs.Hl * vs.Wl * VC;
           const int c0 = PCNN_VERTEX_CHANNELS * l;
-          u = bilinear_at(zb, ty, tx, vs.Wl, VC, c0) + vs.bias[c0];
-          v = bilinear_at(zb, ty, tx, vs.Wl, VC, c0 + 1) + vs.bias[c0 + 1];
-          logd = bilinear_at(zb, ty, tx, vs.Wl, VC, c0 + 2) + vs.bias[c0 + 2];
+          // (round 5) the triple's twelve tap loads together: hv_scatter's ISA had 53 `s_waitcnt vmcnt(0)` for 62 loads
+          const float b0 = vs.bias[c0], b1 = vs.bias[c0 + 1], b2 = vs.bias[c0 + 2];
+          bilinear_at3(zb, ty, tx, vs.Wl, VC, c0, u, v, logd);
+          u = u + b0; v = v + b1; logd = logd + b2;
         }
         float d = exp_f32(logd);
         float n1 = sqrt_rn(u * u + v * v);
