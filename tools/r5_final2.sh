@@ -1,10 +1,10 @@
 # round 5, final evidence run on the final build (after the average_distance / label head / roi_pool work): step PMC, profile
 # set, the three ADL / VALU probes, full GPU suite, smoke
 set -x
-O=/root/repo/gpurun_out/r5fin2; mkdir -p $O
+O=/root/repo/gpurun_out/r5fin3; mkdir -p $O
 cd /root/repo
 bash tools/collect_pmc_step.sh $O/pmc > $O/pmc.log 2>&1
-bash tools/collect_profiles_r5.sh r5fin2 > $O/collect.log 2>&1
+bash tools/collect_profiles_r5.sh r5fin3 > $O/collect.log 2>&1
 python tools/probe_adl.py > $O/adl_probe.json 2> $O/adl_probe.err
 tools/adl_stamp_probe 1 > $O/adl_stamp_probe.txt 2>&1; tools/adl_stamp_probe 0 >> $O/adl_stamp_probe.txt 2>&1
 tools/valu_rate_probe > $O/valu_rate_probe.txt 2>&1
