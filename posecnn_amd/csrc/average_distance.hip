@@ -31,7 +31,7 @@ using namespace pcnn;
 #endif
 
 constexpr int ADL_THREADS = 256;
-constexpr int ADL_PPT = 1;            // adl_terms: points per thread
+constexpr int ADL_PPT = 1;            // adl_terms: points per thread (2 measured slower: see the symmetric scan's notes)
 constexpr int ADL_QTILE = 1024;
 constexpr int ADL_SUM_THREADS = 256;
 constexpr int ADL_SUM_TILE_MAX = 3072;   // adl_sum_kernel: terms of one row staged per round, at most (62 KB of LDS for the five chains)
@@ -262,9 +262,12 @@ __device__ __forceinline__ void adl_terms_row(
     // (tools/probe_adl.py, tools/adl_stamp_probe.hip, tools/valu_rate_probe.hip):
     //  * the walk's compare -> select chain (a VALU write of VCC read by the next VALU instruction) runs at 12.6 cycles per
     //    instruction, 25 per candidate; a v_min tree has no chain and the compare is per trip;
-    //  * a candidate is the same for every lane, and handing it to 64 lanes through LDS costs the LDS pipe the full 64-lane
-    //    bandwidth: a 128-bit "broadcast" read holds it 8 cycles, a trip's twelve reads 96, against ~60 cycles of a CU's
-    //    VALU time for the trip's sixteen distances. So a lane carries TWO points against each candidate it reads;
+    //  * a candidate is the same for every lane; handing it to 64 lanes through LDS costs the LDS pipe the full 64-lane
+    //    bandwidth (a 128-bit "broadcast" read holds it 8 cycles, a trip's twelve reads 96) — but that is NOT the bound: the
+    //    trip's 64 packed-f32 + 10 v_min instructions are (counters: the vector ALU busy 58 % of a launch of symmetric rows,
+    //    the LDS a third). Two or four points per lane against each read (ADL_PPT; four with the waves splitting the
+    //    candidates) measured 130 / 117 us against 100 for 63 symmetric rows: fewer, longer workgroups balance worse over
+    //    the CUs. ADL_PPT stays 1;
     //  * packed f32 (two candidates per instruction) is worth its encoding here: a lone wave on its SIMD issues a v_pk_add
     //    every 5.3 cycles and a v_add every 4.7, so half the instructions is nearly half the time for the few workgroups
     //    of a launch's tail; with the SIMD full the two forms cost the same per distance.
