@@ -73,6 +73,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the short configs[1] (batch-1 latency) and configs[4] (LINEMOD 1280x960 + backproject) runs whose "
                          "summaries the default single-GPU invocation appends under `secondary`")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed regions of --steps steps run back to back: the FIRST is `value` / `ms_per_step` (the driver's contract, as in "
+                         "every earlier round); all of them give value_median / value_min / value_max, so one run says whether a 2 %% "
+                         "change is a change (VERDICT r5 #3: five boxes read 793-827 on one build)")
     ap.add_argument("--nbuf", type=int, default=2, help="distinct synthetic batches cycled through")
     ap.add_argument("--prewarm-seconds", type=float, default=8.0,
                     help="untimed sustained-load warm-up between the cold and the headline measurement")
@@ -158,14 +162,44 @@ def dry_run(a, pdist):
             retire(inflight.pop(0))
     while inflight:
         retire(inflight.pop(0))
+    local = time.perf_counter() - t0
     pdist.barrier()
     elapsed = pdist.max_over_ranks(time.perf_counter() - t0, torch.device("cpu"))
+    rank_elapsed = pdist.gather_over_ranks(local, torch.device("cpu"))
     if rank == 0:
         print(json.dumps({"metric": "dry-run (no GPU work)", "value": B * world * a.steps / max(elapsed, 1e-9), "unit": "frames/s",
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "dry_run": True,
+                          **spread_fields(B * world * a.steps, [max(elapsed, 1e-9)], a.steps),
+                          "per_rank": per_rank_fields(rank_elapsed, a.steps, 1 << 20),
                           "detections_gathered_per_step": seen / a.steps, "ranks_seen": ranks_seen, "batches_in_flight": lanes,
                           "process_group": bool(torch.distributed.is_initialized())}), flush=True)
     pdist.shutdown()
+
+
+def spread_fields(frames, elapsed_all, steps):
+    """value_median / value_min / value_max over the R timed regions (frames/s; the first region is `value`)."""
+    vals = sorted(frames / e for e in elapsed_all)
+    med = vals[len(vals) // 2] if len(vals) % 2 else 0.5 * (vals[len(vals) // 2 - 1] + vals[len(vals) // 2])
+    return {"repeats": len(vals), "value_median": med, "value_min": vals[0], "value_max": vals[-1],
+            "value_spread_rel": (vals[-1] - vals[0]) / med if med else None,
+            "value_all": [round(frames / e, 2) for e in elapsed_all],
+            "ms_per_step_all": [round(1000.0 * e / steps, 4) for e in elapsed_all],
+            "repeats_note": "R timed regions of K steps back to back, each bracketed by barrier + synchronize, MAX over ranks; `value` / "
+                            "`ms_per_step` are the FIRST region (the contract), the rest is its spread on this box"}
+
+
+def per_rank_fields(rank_elapsed, steps, h2d_bytes):
+    """Per-rank step times of the headline region (min / median / max over ranks, not only the MAX the contract asks for) and
+    the host-to-device rate each rank sustained — so that a multi-GPU run explains itself (VERDICT r5 #7)."""
+    ms = sorted(1000.0 * e / steps for e in rank_elapsed)
+    med = ms[len(ms) // 2] if len(ms) % 2 else 0.5 * (ms[len(ms) // 2 - 1] + ms[len(ms) // 2])
+    out = {"ranks": len(ms), "ms_per_step_min": ms[0], "ms_per_step_median": med, "ms_per_step_max": ms[-1],
+           "ms_per_step_by_rank": [round(1000.0 * e / steps, 4) for e in rank_elapsed]}
+    if h2d_bytes:
+        out["h2d_GBps_per_rank"] = [round(h2d_bytes / (e / steps) / 1e9, 3) for e in rank_elapsed]
+        out["h2d_note"] = ("bytes uploaded per step / this rank's own step time: the host-to-device rate every rank sustained at the same "
+                           "time (8 ranks share the host's memory and PCIe root complexes)")
+    return out
 
 
 def make_host_inputs(first, B, H, W, C, input_format, nbuf, extents, K, train, raw=False):
@@ -496,6 +530,7 @@ def main(argv=None):
         t0 = time.perf_counter()
         ndet = run(n)
         torch.cuda.synchronize()
+        last["local_elapsed"] = time.perf_counter() - t0     # this rank's own K steps (before it waits for the others)
         pdist.barrier()
         return pdist.max_over_ranks(time.perf_counter() - t0, dev), ndet
 
@@ -559,6 +594,7 @@ def main(argv=None):
         first_timed = seq["i"]
         elapsed, ndet = timed(a.steps)
         host_launch_ms = 1000.0 * last["host_launch_s"] / a.steps
+        rank_elapsed = pdist.gather_over_ranks(last["local_elapsed"], dev)   # the headline region, rank by rank
         equal_serial = check_equal_serial(first_timed)
         if sep_profile:
             # per-kernel events cannot be recorded inside a graph replay, and with two streams a kernel's
@@ -579,6 +615,11 @@ def main(argv=None):
         conv_flops = sum(f for _, f, _, _, _ in net.conv_timing)
         conv_direct_flops = sum(f for _, _, f, _, _ in net.conv_timing)
         net.conv_timing = None
+        # (3) the same region R - 1 more times (same barrier + sync + MAX-over-ranks bracket, kernel timing off again): the
+        # spread of the number, measured where the number is. `value` stays the FIRST region.
+        elapsed_all = [elapsed]
+        for _ in range(max(1, a.repeats) - 1):
+            elapsed_all.append(timed(a.steps)[0])
         if a.latency:
             # per-frame latency: one batch at a time, upload -> kernels -> D2H -> host NMS, synchronously
             times = []
@@ -737,6 +778,7 @@ def main(argv=None):
                    "h2d_MB_per_step": None if a.resident_inputs else round(h2d_bytes / 1e6, 1),
                    "parallelism": "dp%d (frames sharded, 1 all-gather of detections)" % world,
                    "detections_per_step": ndet / a.steps, "adl_rows_with_targets": adl_rows},
+        **spread_fields(frames, elapsed_all, a.steps),
         "value_cold": frames / elapsed_cold,
         "value_note": "value: after %g s of untimed sustained-load pre-warm (GPU clocks ramp for seconds); value_cold: the same K "
                       "steps right after the W warm-up steps of a fresh process" % a.prewarm_seconds,
@@ -784,6 +826,7 @@ def main(argv=None):
                              "world_size": world, "collective": "all_gather_into_tensor of the packed detection block, once per step"}
                             if torch.distributed.is_initialized() else
                             {"backend": None, "ranks_seen": 1, "world_size": 1, "collective": "none (single process; --force-process-group runs it through RCCL)"})
+    out["per_rank"] = per_rank_fields(rank_elapsed, a.steps, 0 if a.resident_inputs else h2d_bytes)
     out["process_group"]["shared_device"] = bool(a.shared_device)
     out["process_group"]["host_numa"] = ({"node": numa[0], "cpus": numa[1]} if numa else None)
     # the collective by itself: latency of one all-gather of the packed block, outside the timed region. A

@@ -242,6 +242,19 @@ def shutdown():
         dist.destroy_process_group()
 
 
+def gather_over_ranks(value, device):
+    """Every rank's python float, in rank order (bench.py's per-rank step times: the MAX alone cannot say whether one
+    rank or all of them were slow). A collective: every rank calls it."""
+    if not dist.is_initialized():
+        return [float(value)]
+    if dist.get_backend() == "gloo":
+        device = torch.device("cpu")
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = torch.empty(dist.get_world_size(), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(out, t)
+    return [float(v) for v in out.cpu().tolist()]
+
+
 def max_over_ranks(value, device):
     """MAX all-reduce of a python float (timing contract of bench.py)."""
     if not dist.is_initialized():

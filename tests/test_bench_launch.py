@@ -44,6 +44,23 @@ def test_gpus2_self_spawns_two_ranks_and_gathers_on_gloo():
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["process_group"] is True
     assert out["detections_gathered_per_step"] == 6   # 3 rows from each of the 2 ranks
     assert out["ranks_seen"] == 2 and out["batches_in_flight"] == 2   # --streams 2: two collectives in flight, issued in the same order on every rank
+    # round 6: the spread fields and the per-rank step times travel with the line at world > 1
+    pr = out["per_rank"]
+    assert pr["ranks"] == 2 and len(pr["ms_per_step_by_rank"]) == 2 and len(pr["h2d_GBps_per_rank"]) == 2
+    assert pr["ms_per_step_min"] <= pr["ms_per_step_median"] <= pr["ms_per_step_max"]
+    assert out["repeats"] == 1 and out["value_min"] <= out["value_median"] <= out["value_max"]
+
+
+def test_spread_and_per_rank_fields():
+    import bench
+    f = bench.spread_fields(320, [0.40, 0.42, 0.39, 0.41, 0.40], 20)
+    assert f["repeats"] == 5 and f["value_all"][0] == 800.0 and abs(f["value_median"] - 800.0) < 1e-9
+    assert abs(f["value_min"] - 320 / 0.42) < 1e-9 and abs(f["value_max"] - 320 / 0.39) < 1e-9
+    assert f["ms_per_step_all"] == [20.0, 21.0, 19.5, 20.5, 20.0]
+    r = bench.per_rank_fields([0.40, 0.44, 0.42, 0.48], 20, 118_000_000)
+    assert r["ms_per_step_min"] == 20.0 and r["ms_per_step_max"] == 24.0 and abs(r["ms_per_step_median"] - 21.5) < 1e-9
+    assert r["h2d_GBps_per_rank"][0] == 5.9
+    assert "h2d_GBps_per_rank" not in bench.per_rank_fields([0.4], 20, 0)
 
 
 def test_gpus2_single_lane_and_three_lanes():
