@@ -537,7 +537,10 @@ static int backproject_fwd_impl(const float* data, const float* label, const flo
   const long long nvox = (long long)B * G * G * G;
   const bool vec = (Cd % 4 == 0) && aligned16(data) && aligned16(top_data) && aligned16(top_flag);
   const int lpv = Cd >= 64 ? 16 : Cd / 4;
-  const bool fused = vec && ksize <= 3 && G <= 1024 && 7ll * W < 65536 && ((long long)H + 8) * W * (Cd > Cl ? Cd : Cl) < (1ll << 31) && (Cd % 64 == 0 || Cd == 32 || Cd == 16 || Cd == 8 || Cd == 4);
+  // Cl <= 256: phase C of the fused kernel maps ceil(Cl / 4) class quads of a voxel onto the 64 lanes of a wave (64 / nq voxels
+  // per step) — more quads than lanes would make that step count 0 (the loop then never advances); wider label
+  // rows take the per-channel kernels below
+  const bool fused = vec && Cl <= 256 && ksize <= 3 && G <= 1024 && 7ll * W < 65536 && ((long long)H + 8) * W * (Cd > Cl ? Cd : Cl) < (1ll << 31) && (Cd % 64 == 0 || Cd == 32 || Cd == 16 || Cd == 8 || Cd == 4);
   if (fused) {
     float2* wrange = nullptr;
     if (ws) {

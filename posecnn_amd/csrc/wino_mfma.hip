@@ -97,7 +97,7 @@ __device__ __forceinline__ void at6_col(const float* m, float* t)
 // stages and VALU time is paid in full next to the MFMAs). Same bits: 0 + a b either way.
 // `mode` bit 0: XCD x owns channel block x (launches with ncb == 8 whose filter bank outweighs their transformed input,
 // i.e. the deep layers of a single frame: every XCD then streams ITS eighth of U once instead of all of U).
-// Measured and dropped in round 4 (tools/r4_wino_modes.sh, 12-layer totals at 2 x 16 frames):
+// Measured and dropped in round 4 (tools/archive/r4_wino_modes.sh, 12-layer totals at 2 x 16 frames):
 //   * s_setprio 3 / 0 by the workgroup's slot on the CU (HW_ID.TG_ID), so that one of the two co-resident workgroups runs
 //     as if alone and the other fills the matrix pipe's gaps: 14.62 -> 14.71 / 14.90 ms for the two polarities — the
 //     symmetric pair is the better schedule;

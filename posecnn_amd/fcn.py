@@ -70,16 +70,28 @@ def nms(dets, thresh):
     inter = w * h
     with np.errstate(divide="ignore", invalid="ignore"):
         ovr = inter / (areas[:, None] + areas[None, :] - inter)
-    sup = ((ovr > thresh) & (cls[:, None] == cls[None, :])).tolist()
-    keep, dead = [], [False] * n
+    sup = (ovr > thresh) & (cls[:, None] == cls[None, :])
+    if n <= 16:
+        # a frame's handful of boxes: plain Python on nested lists beats n numpy calls of ~1 us each
+        sup_l = sup.tolist()
+        keep, dead = [], [False] * n
+        for i in order.tolist():
+            if dead[i]:
+                continue
+            keep.append(i)
+            row = sup_l[i]
+            for j in range(n):
+                if row[j]:
+                    dead[j] = True
+        return keep
+    # hundreds of rows (train mode, a gathered multi-rank set): one vector OR per KEPT box, nothing per pair in Python
+    # (the nested-list walk was O(n^2) Python objects + O(n * kept) interpreter iterations)
+    keep, dead = [], np.zeros(n, dtype=bool)
     for i in order.tolist():
         if dead[i]:
             continue
         keep.append(i)
-        row = sup[i]
-        for j in range(n):
-            if row[j]:
-                dead[j] = True
+        dead |= sup[i]
     return keep
 
 

@@ -225,3 +225,21 @@ def test_configs2_batch_custom_ops_bit_exact_on_the_steps_own_buffers(configs2, 
     same(np.ravel(g["loss_pose"])[:1], wl, "the step's own loss_pose")
     same(N(diff)[:n], wd, "bottom_diff on the step's buffers")
     assert not N(diff)[n:].any()
+
+
+# ---- label rows wider than 256 classes must not reach the fused backproject kernel -------------
+@pytest.mark.parametrize("Cl", [256, 257, 300])
+def test_backproject_wide_label_rows(gpu, Cl):
+    """`backproject_fused_kernel` hands ceil(Cl / 4) class quads of a voxel to the 64 lanes of a wave; Cl > 256 (more quads
+    than lanes) used to give it 0 voxels per step — a loop that never advanced, i.e. a hung GPU — through the public
+    pcnn_backproject_fwd / pcnn_backproject_ws_fwd. Such rows now take the per-channel kernels; 256 is the last fused size
+    (reference: lib/backprojecting_layer/backprojecting_op_gpu.cu.cc:17-126 handles any class count)."""
+    from posecnn_amd import ops
+    from test_gpu_ops import backproject_case
+    rng = np.random.default_rng(66)
+    B, H, W, Cd, G, k = 1, 20, 24, 64, 6, 2
+    data, label, depth, meta, label3d = backproject_case(rng, B, H, W, Cd, Cl, G)
+    td, tl, tf = ops.backproject(T(gpu, data), T(gpu, label), T(gpu, depth), T(gpu, meta.reshape(B, 1, 1, 48)), T(gpu, label3d), G, k, 0.05)
+    wd, wl, wf = oracle.backproject(data, label, depth, meta, label3d, G, k, 0.05)
+    assert wf.sum() > 0
+    same(N(td), wd, "top_data"); same(N(tf), wf, "top_flag"); same(N(tl), wl, "top_label")

@@ -13,6 +13,19 @@ from posecnn_amd import config, dist as pdist, fcn
 F = np.float32
 
 
+def test_nms_matches_the_reference_on_golden_sets():
+    """survivors AND their order against lib/utils/nms.py itself on 33 seeded sets (tests/golden/nms.npz, written by
+    tests/golden/make_nms_golden.py importing the reference): n up to 600, duplicates, equal scores, degenerate boxes."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nms.npz"))
+    big = 0
+    for k in range(int(d["cases"])):
+        dets, thresh, want = d["dets_%d" % k], float(d["thresh_%d" % k]), d["keep_%d" % k].tolist()
+        assert fcn.nms(dets, thresh) == want, "case %d (n = %d, thresh %g)" % (k, dets.shape[0], thresh)
+        big += dets.shape[0] > 16
+    assert big >= 20     # both walks (nested lists for a frame's few boxes, vector OR for large sets) are covered
+
+
 def test_nms_is_class_aware_and_score_ordered():
     # lib/utils/nms.py:3-32
     dets = np.array([
