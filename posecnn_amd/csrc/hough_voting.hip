@@ -62,7 +62,7 @@ struct __attribute__((aligned(16))) HvMax {
 struct HvLayout {
   int nchunk, ntx, nty, ntiles, reccap, cap, capmax, nlm;
   size_t off_hist, off_tot, off_slots, off_nslots, off_recoff, off_kmax, off_rec, off_tilemax, off_maxima,
-      off_nmax, off_hs, off_chunkcnt, off_chunkcand, off_flags, total;
+      off_nmax, off_hs, off_chunkcnt, off_chunkcand, off_flags, off_order, off_rowstart, total;
 };
 
 HvLayout hv_layout(int B, int H, int W, int C, bool need_hs, int skip, int rois_per_image)
@@ -86,6 +86,8 @@ HvLayout hv_layout(int B, int H, int W, int C, bool need_hs, int skip, int rois_
   L.off_nslots = take(sizeof(int) * (size_t)B);
   L.off_recoff = take(sizeof(int) * (size_t)B * C);
   L.off_kmax = take(sizeof(int) * (size_t)B * C);   // f32 bits: largest vote window thr of a class' records
+  L.off_order = take(sizeof(int) * ((size_t)B * (C - 1) + 4));   // hv_order: {-, live pairs, -, -} + the pairs, heaviest first
+  L.off_rowstart = take(sizeof(int) * (size_t)B * (C - 1) * (H + 1));   // hv_order: per (image, slot): first record at or below row y
   L.off_rec = take(sizeof(HvRec) * (size_t)B * L.reccap);
   L.off_tilemax = take(sizeof(int2) * (size_t)B * (C - 1) * H);   // per Hough ROW: (max votes, first cell)
   L.off_maxima = take(sizeof(HvMax) * (size_t)B * L.capmax);
@@ -470,6 +472,12 @@ __device__ __forceinline__ void vote_row(const float4 a, const float4 b, const f
   const int w_lo = max(x - kx, 0), w_hi = min(x + kx, W - 1);   // vote window, clipped to the row
   if (w_lo > w_hi) return;
   const int mode = (int)c.w;
+  // (round 6) a cone that opens away from this row: mode 1 is the interval BETWEEN the two roots and exists only on the side
+  // of the pixel the direction points to (dy * g > 0, below) — for every other row it is L = 1 > R = -1, no sure cell and no
+  // uncertain one. ~70 % of the records are mode 1 and half of their rows are on the wrong side; the records of a 64-record
+  // slice are neighbours in the image and point the same way, so whole waves leave here instead of walking the
+  // closed form to an empty result (88 M vector instructions per launch, the kernel's actual bound: bench.py `valu_frac`).
+  if (mode == 1 && dyi != 0 && !(dy * c.z > 0.f)) return;
   bool per_cell = (mode == 0);
   // sure interval [lo, hi] of columns and two ranges [ul0, ul1], [ur0, ur1] of columns too close to
   // an interval end to trust the closed form: those are decided by the exact predicate. The f32
@@ -539,107 +547,61 @@ __device__ __forceinline__ void vote_row(const float4 a, const float4 b, const f
   }
 }
 
-// first index i in [0, m) with rec[i].a.y >= yq (m if none); records are sorted by y. One wave, 64-ary.
-__device__ __forceinline__ int first_record_at_or_below_row(const HvRec* __restrict__ r0, int m, float yq)
+// Difference array of one Hough row -> votes, by ONE wave: lane owns a contiguous strip of the row, a wave-wide exclusive
+// scan of the strip sums carries the votes in; the row maximum (most votes, lowest column among equals) comes out of the same
+// pass. (round 6) The strip is an ODD number of cells (lane l starts at bank l * per: an even stride — 10 for W = 640 — puts
+// four lanes on every bank, an odd one two, the minimum for 64 lanes on 32 banks); strips of up to 16 cells stay in registers
+// between the two passes; and the votes go back to LDS only when the caller wants the Hough space itself (`hrow`,
+// threshold_vote > 0): the default path needs the maximum alone. 25 us of the launch were this epilogue (ablation).
+__device__ __forceinline__ void scan_row_votes(int* drow, int W, int yrow, float* hrow, int2* rowmax_out)
 {
-  int lo = 0, hi = m;   // answer in [lo, hi]
   const int lane = lane_id();
-  while (hi - lo > 0) {
-    const int span = hi - lo;
-    const int step = (span + 63) / 64;
-    const int i = lo + lane * step;                 // probes lo, lo + step, ...
-    const bool ge = i < hi ? (r0[i].a.y >= yq) : true;
-    const unsigned long long mask = __ballot(ge);   // monotone: 0..0 1..1
-    const int f = mask ? __ffsll((long long)mask) - 1 : 64;
-    // the answer lies in (probe f-1, probe f]
-    const int nlo = f == 0 ? lo : lo + (f - 1) * step + 1;
-    const int nhi = f == 64 ? hi : min(lo + f * step, hi);
-    if (step == 1) return nhi;
-    lo = nlo;
-    hi = nhi;
-  }
-  return lo;
-}
-
-__global__ __launch_bounds__(64 * HV_BAND, 8) void hv_vote_kernel(
-    const HvRec* __restrict__ rec, const int* __restrict__ nslots_g,
-    const int* __restrict__ slots_g, const int* __restrict__ tot_g,
-    const int* __restrict__ recoff_g, const int* __restrict__ kmax_g, int2* __restrict__ rowmax,
-    float* __restrict__ hs, int H, int W, int C, int skip, float inlier, int reccap, int need_hs, int wpr)
-{
-  const int n = blockIdx.z, s = blockIdx.y, band = blockIdx.x;
-  if (s >= nslots_g[n]) return;
-  // `wpr` waves share a row (each takes every wpr-th 64-record slice of a chunk): the launch ends with its
-  // longest workgroup — a band through the middle of a large object — so the records of a row are spread
-  // over more lanes rather than the band over more rows
-  const int nwaves = blockDim.x >> 6;
-  const int nrows = nwaves / wpr;      // rows of this band (fewer for very wide images)
-  const int cls = slots_g[n * C + s];
-  const int m = (tot_g[n * C + cls] + skip - 1) / skip;
-  const HvRec* r0 = rec + (size_t)n * reccap + recoff_g[n * C + cls];
-
-  extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [HV_BAND][W + 1] difference arrays
-  __shared__ float4 sA[HV_RCHUNK], sB[HV_RCHUNK], sC[HV_RCHUNK];
-  __shared__ int s_range[2];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int W1 = W + 1;
-  const int y0 = band * nrows;
-  const int row = wave % nrows, part = wave / nrows;
-  const int yrow = y0 + row;
-  int* drow = s_dyn + row * W1;
-  for (int i = tid; i < nrows * W1; i += 64 * nwaves) s_dyn[i] = 0;
-
-  // records that can reach the band: y in (y0 - kmax - 1, y0 + HV_BAND - 1 + kmax + 1), kmax = the class'
-  // largest window half-size ceil(thr) - 1 (|dy| < thr  <=>  |dy| <= ceil(thr) - 1)
-  const float tmax = __int_as_float(kmax_g[n * C + cls]);   // max thr of the class' records (>= 0, finite)
-  const float kmaxf = fminf(ceilf(tmax) - 1.f, 65536.f);
-  if (wave == 0) {
-    const int lo = first_record_at_or_below_row(r0, m, (float)y0 - kmaxf);
-    if (lane == 0) s_range[0] = lo;
-  }
-  if (wave == nwaves - 1) {
-    const int hi = first_record_at_or_below_row(r0, m, (float)(y0 + nrows - 1) + kmaxf + 1.f);
-    if (lane == 0) s_range[1] = hi;
-  }
-  __syncthreads();
-  const int lo = s_range[0], hi = s_range[1];
-
-  for (int b0 = lo; b0 < hi; b0 += HV_RCHUNK) {
-    const int cnt = min(HV_RCHUNK, hi - b0);
-    for (int k = tid; k < cnt; k += 64 * nwaves) {
-      sA[k] = r0[b0 + k].a;
-      sB[k] = r0[b0 + k].b;
-      sC[k] = r0[b0 + k].c;
-    }
-    __syncthreads();
-    if (yrow < H)
-      for (int k = part * 64 + lane; k < cnt; k += 64 * wpr) vote_row(sA[k], sB[k], sC[k], yrow, W, inlier, drow);
-    __syncthreads();
-  }
-
-  // difference array -> votes: lane owns a contiguous strip of the row, wave-wide exclusive scan of
-  // the strip sums; the row maximum (most votes, lowest column among equals) comes out of the same pass
-  if (yrow >= H || part != 0) return;
-  const int per = (W + 63) / 64;
+  const int per = ((W + 63) / 64) | 1;
   const int c0 = lane * per, c1 = min(c0 + per, W);
-  int sum = 0;
-  for (int cx = c0; cx < c1; cx++) sum += drow[cx];
-  int pre = sum;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int o = __shfl_up(pre, off);
-    if (lane >= off) pre += o;
-  }
-  int acc = pre - sum;   // votes carried into the strip
   int bv = -1, bi = 0x7fffffff;
-  for (int cx = c0; cx < c1; cx++) {
-    acc += drow[cx];
-    drow[cx] = acc;      // votes (same-wave LDS: in order)
-    if (acc > bv) { bv = acc; bi = yrow * W + cx; }
+  if (per <= 16) {
+    int d[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) d[i] = (i < per && c0 + i < W) ? drow[c0 + i] : 0;
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) sum += d[i];
+    int pre = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(pre, off);
+      if (lane >= off) pre += o;
+    }
+    int acc = pre - sum;   // votes carried into the strip
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      acc += d[i];
+      d[i] = acc;
+      if (i < per && c0 + i < W && acc > bv) { bv = acc; bi = yrow * W + c0 + i; }
+    }
+    if (hrow) {
+#pragma unroll
+      for (int i = 0; i < 16; i++)
+        if (i < per && c0 + i < W) drow[c0 + i] = d[i];
+    }
+  } else {
+    int sum = 0;
+    for (int cx = c0; cx < c1; cx++) sum += drow[cx];
+    int pre = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(pre, off);
+      if (lane >= off) pre += o;
+    }
+    int acc = pre - sum;
+    for (int cx = c0; cx < c1; cx++) {
+      acc += drow[cx];
+      drow[cx] = acc;      // votes (same-wave LDS: in order)
+      if (acc > bv) { bv = acc; bi = yrow * W + cx; }
+    }
   }
-  if (need_hs) {
+  if (hrow) {
     __builtin_amdgcn_wave_barrier();
-    float* hrow = hs + ((size_t)n * (C - 1) + s) * ((size_t)H * W) + (size_t)yrow * W;
     for (int cx = lane; cx < W; cx += 64) hrow[cx] = (float)drow[cx];
   }
 #pragma unroll
@@ -647,7 +609,148 @@ __global__ __launch_bounds__(64 * HV_BAND, 8) void hv_vote_kernel(
     const int ov = __shfl_xor(bv, off), oi = __shfl_xor(bi, off);
     if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
   }
-  if (lane == 0) rowmax[((size_t)n * (C - 1) + s) * H + yrow] = make_int2(bv, bi);
+  if (lane == 0) *rowmax_out = make_int2(bv, bi);
+}
+
+// hv_order: what hv_vote needs to start a workgroup without searching or idling (round 6).
+//   workgroup 0      the live (image, class slot) pairs of the batch, heaviest class first: a counting sort on
+//                    floor(log2(records)) — the order inside a bucket is whatever the atomics give, which is fine: hv_vote
+//                    only wants the long items dispatched before the short ones, every order gives the same votes;
+//   workgroup 1 + p  pair p = (image, slot): rowstart[y] = index of the class' first record with pixel row >= y, for
+//                    y = 0 .. H (the records are sorted by row): the range of records that can reach a band of Hough rows
+//                    is two table reads instead of two 64-ary searches — two dependent trips to L2 and a workgroup
+//                    barrier in front of every one of hv_vote's 9 000 workgroups (2.9 us each in the trace).
+constexpr int HV_ORDER_THREADS = 256;
+constexpr int HV_ORDER_SPLIT = 8;
+__global__ __launch_bounds__(HV_ORDER_THREADS) void hv_order_kernel(const HvRec* __restrict__ rec, const int* __restrict__ nslots_g,
+                                                                    const int* __restrict__ slots_g, const int* __restrict__ tot_g,
+                                                                    const int* __restrict__ recoff_g, int* __restrict__ order,
+                                                                    int* __restrict__ rowstart, int B, int C, int H, int skip, int reccap)
+{
+  const int tid = threadIdx.x;
+  if (blockIdx.x > 0) {
+    // HV_ORDER_SPLIT workgroups per pair, interleaved over the records: a class of 6 000 records is three trips to L2 per
+    // thread instead of twenty-four one after the other (one workgroup per pair: 22 us for this kernel)
+    const int pair = (blockIdx.x - 1) / HV_ORDER_SPLIT, sub = (blockIdx.x - 1) % HV_ORDER_SPLIT;
+    const int n = pair / (C - 1), s = pair - n * (C - 1);
+    if (s >= nslots_g[n]) return;
+    const int cls = slots_g[n * C + s];
+    const int m = (tot_g[n * C + cls] + skip - 1) / skip;
+    const HvRec* r0 = rec + (size_t)n * reccap + recoff_g[n * C + cls];
+    int* rs = rowstart + (size_t)pair * (H + 1);
+    // record i starts the rows (y of record i - 1, y of record i]; "record m" = the end of the list starts every row left
+    for (int i = sub * HV_ORDER_THREADS + tid; i <= m; i += HV_ORDER_THREADS * HV_ORDER_SPLIT) {
+      const int y_prev = i > 0 ? (int)r0[i - 1].a.y : -1;
+      const int y_cur = i < m ? (int)r0[i].a.y : H;
+      for (int y = max(y_prev + 1, 0); y <= min(y_cur, H); y++) rs[y] = i;
+    }
+    return;
+  }
+  __shared__ int s_hist[32], s_base[32];
+  if (tid < 32) s_hist[tid] = 0;
+  __syncthreads();
+  const int total = B * (C - 1);
+  for (int i = tid; i < total; i += HV_ORDER_THREADS) {
+    const int n = i / (C - 1), s = i - n * (C - 1);
+    if (s < nslots_g[n]) {
+      const int m = (tot_g[n * C + slots_g[n * C + s]] + skip - 1) / skip;
+      atomicAdd(&s_hist[31 - __clz(max(m, 1))], 1);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int b = 31; b >= 0; b--) { s_base[b] = run; run += s_hist[b]; }
+    order[0] = 0;
+    order[1] = run;    // live pairs
+  }
+  __syncthreads();
+  for (int i = tid; i < total; i += HV_ORDER_THREADS) {
+    const int n = i / (C - 1), s = i - n * (C - 1);
+    if (s < nslots_g[n]) {
+      const int m = (tot_g[n * C + slots_g[n * C + s]] + skip - 1) / skip;
+      order[4 + atomicAdd(&s_base[31 - __clz(max(m, 1))], 1)] = i;
+    }
+  }
+}
+
+// hv_vote (round 6: heaviest class first, no empty dispatches in between). One workgroup = one ITEM = (image, class slot,
+// band of `nrows` Hough rows), and workgroup i takes item i of hv_order's list: the hardware hands workgroups out in index
+// order, so the bands of the class with the most records start first and the short items fill the end of the launch; the
+// workgroups past the last live item (16 of 21 class slots are empty in a typical frame) leave at once, all of them AFTER
+// the live ones. A trace of the round-5 launch (one workgroup per (band, slot, image) in grid order, wall_clock64 stamps:
+// DESIGN §3.1) showed what its 197 us were: 9 120 live workgroups whose durations sum to 108 ms·wg — 105 us of a full
+// chip —, 750-800 of 1 024 slots occupied while 31 200 empty workgroups were dispatched in between, and a 50 us TAIL of the
+// one class with 5 113 records (50-60 us per band), which happened to belong to the last image.
+// (A persistent grid pulling items off an atomic counter measured 269 us: one device-scope atomic per item, 10 000 per
+// launch on one address, and the loop-carried state pushed the kernel into spills.)
+__global__ __launch_bounds__(64 * HV_BAND, 8) void hv_vote_kernel(
+    const HvRec* __restrict__ rec, const int* __restrict__ slots_g,
+    const int* __restrict__ recoff_g, const int* __restrict__ kmax_g, const int* __restrict__ order,
+    const int* __restrict__ rowstart, int2* __restrict__ rowmax,
+    float* __restrict__ hs, int H, int W, int C, float inlier, int reccap, int need_hs, int wpr, int nbands)
+{
+  const int item = blockIdx.x;
+  if (item >= order[1] * nbands) return;
+  const int pair = order[4 + item / nbands], band = item % nbands;
+  const int n = pair / (C - 1), s = pair - n * (C - 1);
+  // `wpr` waves share a row (each takes every wpr-th 64-record slice of a chunk): the launch ends with its
+  // longest workgroup — a band through the middle of a large object — so the records of a row are spread
+  // over more lanes rather than the band over more rows
+  const int nwaves = blockDim.x >> 6;
+  const int nrows = nwaves / wpr;      // rows of this band (fewer for very wide images)
+  const int cls = slots_g[n * C + s];
+  const HvRec* r0 = rec + (size_t)n * reccap + recoff_g[n * C + cls];
+
+  extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [HV_BAND][W + 1] difference arrays
+  // two chunk buffers: chunk i + 1 travels L2 -> registers while chunk i is voted and lands in the OTHER buffer: one
+  // workgroup barrier per chunk, and no trip to memory is waited for with nothing else to do
+  __shared__ float4 sA[2][HV_RCHUNK], sB[2][HV_RCHUNK], sC[2][HV_RCHUNK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int W1 = W + 1;
+  const int y0 = band * nrows;
+  const int row = wave % nrows, part = wave / nrows;
+  const int yrow = y0 + row;
+  int* drow = s_dyn + row * W1;
+
+  // records that can reach the band: pixel rows y0 - kmax .. y0 + nrows - 1 + kmax, kmax = the class' largest window
+  // half-size ceil(thr) - 1 (|dy| < thr  <=>  |dy| <= ceil(thr) - 1); hv_order's table turns the two rows into indices
+  const float tmax = __int_as_float(kmax_g[n * C + cls]);   // max thr of the class' records (>= 0, finite)
+  const int kmax = (int)fminf(ceilf(tmax) - 1.f, 65536.f);
+  const int* rs = rowstart + (size_t)pair * (H + 1);
+  const int lo = rs[min(max(y0 - kmax, 0), H)], hi = rs[min(max(y0 + nrows + kmax, 0), H)];
+  if (lo >= hi) {
+    // no record reaches the band (a third of the live items): every cell has 0 votes, the row maximum is its first cell
+    if (tid < nrows && y0 + tid < H) rowmax[((size_t)n * (C - 1) + s) * H + y0 + tid] = make_int2(0, (y0 + tid) * W);
+    if (need_hs) {
+      float* h0 = hs + ((size_t)n * (C - 1) + s) * ((size_t)H * W) + (size_t)y0 * W;
+      const int cells = min(nrows, H - y0) * W;
+      for (int i = tid; i < cells; i += 64 * nwaves) h0[i] = 0.f;
+    }
+    return;
+  }
+  for (int i = tid; i < nrows * W1; i += 64 * nwaves) s_dyn[i] = 0;   // (the first chunk's barrier comes before any vote)
+
+  // thread t < CH carries record t of the chunk in flight (CH = HV_RCHUNK, or the workgroup's size when a very wide
+  // image leaves it fewer threads than that)
+  const int CH = min(HV_RCHUNK, 64 * nwaves);
+  float4 pa, pb, pc;
+  if (tid < CH && lo + tid < hi) { pa = r0[lo + tid].a; pb = r0[lo + tid].b; pc = r0[lo + tid].c; }
+  int buf = 0;
+  for (int b0 = lo; b0 < hi; b0 += CH, buf ^= 1) {
+    const int cnt = min(CH, hi - b0);
+    if (tid < cnt) { sA[buf][tid] = pa; sB[buf][tid] = pb; sC[buf][tid] = pc; }
+    __syncthreads();                     // (also: every wave has left the votes of chunk i - 1, which read the other buffer)
+    const int kn = b0 + CH + tid;
+    if (tid < CH && kn < hi) { pa = r0[kn].a; pb = r0[kn].b; pc = r0[kn].c; }
+    if (yrow < H)
+      for (int k = part * 64 + lane; k < cnt; k += 64 * wpr) vote_row(sA[buf][k], sB[buf][k], sC[buf][k], yrow, W, inlier, drow);
+  }
+  __syncthreads();                       // the row's other waves are done adding
+
+  if (yrow >= H || part != 0) return;
+  scan_row_votes(drow, W, yrow, need_hs ? hs + ((size_t)n * (C - 1) + s) * ((size_t)H * W) + (size_t)yrow * W : nullptr,
+                 rowmax + ((size_t)n * (C - 1) + s) * H + yrow);
 }
 
 constexpr int WCD_CAP = 1024;  // floats of LDS per wave for wave_cell_data
@@ -1307,13 +1410,19 @@ int hough_fwd_impl(const int32_t* label, const HvVertexSrc vs,
   PCNN_LAUNCH(hv_scatter_kernel, dim3(L.nchunk, B), dim3(256), 0, stream, label, vs,
                      extents, meta, hist, tot, slots, nslots, recoff, kmax, rec, HW, W, C, L.nchunk,
                      skip, label_thr, num_meta, L.reccap, inlier);
-  // rows per band: HV_BAND, fewer when 8 difference arrays of W + 1 counters would not fit 48 KB of LDS
+  // rows per band: HV_BAND / HV_WPR, fewer when the difference arrays of W + 1 counters would not fit 48 KB of LDS
   const int wpr = HV_WPR;
   int band_rows = HV_BAND / wpr;
   while (band_rows > 1 && sizeof(int) * band_rows * (size_t)(W + 1) > 48 * 1024) band_rows--;
-  PCNN_LAUNCH(hv_vote_kernel, dim3((H + band_rows - 1) / band_rows, C - 1, B), dim3(64 * band_rows * wpr),
-              sizeof(int) * band_rows * (size_t)(W + 1), stream, rec, nslots, slots, tot, recoff, kmax, tilemax, hs,
-              H, W, C, skip, inlier, L.reccap, need_hs ? 1 : 0, wpr);
+  const int nbands = (H + band_rows - 1) / band_rows;
+  int* order = (int*)(ws + L.off_order);
+  int* rowstart = (int*)(ws + L.off_rowstart);
+  PCNN_LAUNCH(hv_order_kernel, dim3(1 + B * (C - 1) * HV_ORDER_SPLIT), dim3(HV_ORDER_THREADS), 0, stream, rec, nslots, slots, tot, recoff, order, rowstart,
+              B, C, H, skip, L.reccap);
+  const long long max_items = (long long)B * (C - 1) * nbands;
+  PCNN_REQUIRE(max_items < (1ll << 31), PCNN_EINVAL, "hough_voting: B * (C - 1) * bands = %lld overflows the grid", max_items);
+  PCNN_LAUNCH(hv_vote_kernel, dim3((unsigned)max_items), dim3(64 * band_rows * wpr), sizeof(int) * band_rows * (size_t)(W + 1), stream,
+              rec, slots, recoff, kmax, order, rowstart, tilemax, hs, H, W, C, inlier, L.reccap, need_hs ? 1 : 0, wpr, nbands);
   if (!need_hs) {
     PCNN_LAUNCH(hv_select_kernel, dim3(C - 1, B), dim3(HV_SEL_NT), 0, stream, rec, nslots, slots,
                        tot, recoff, tilemax, extents, meta, maxima, nmax, W, C, skip, inlier,
