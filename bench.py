@@ -655,13 +655,13 @@ def main(argv=None):
     achieved = alg_bytes / (hv["avg_us"] * 1e-6) / 1e9 if hv["calls"] else float("nan")
     hough_us = sum(v["avg_us"] for k, v in kern.items() if k.startswith("hv_"))
     # PMC counters: collected offline in separate rocprofv3 --pmc passes (they cannot share a run with the timed region) at this
-    # same workload (tools/collect_pmc_step.sh -> profiles/r05_step_pmc.json); every kernel's entry is reported only while
+    # same workload (tools/collect_pmc_step.sh -> profiles/r06_step_pmc.json); every kernel's entry is reported only while
     # the source file the kernel lives in still hashes to what the counters were collected on
     import hashlib
     pmc, pmc_src = {}, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_step_pmc.json")))
-        pmc_src = "profiles/r05_step_pmc.json"
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r06_step_pmc.json")))
+        pmc_src = "profiles/r06_step_pmc.json"
     except Exception:
         pass
     sha_now = {}

@@ -92,18 +92,21 @@ def test_world1_force_process_group_runs_the_collective():
 
 
 def test_step_pmc_file_belongs_to_this_build_of_the_kernels():
-    """bench.py's `roofline.traffic`, `valu_frac` and `roofline_dominant.mfma_busy_share` come from
-    PMC counters collected in separate rocprofv3 passes (profiles/r05_step_pmc.json, tools/collect_pmc_step.sh). The file
+    """bench.py's `roofline.traffic`, `valu_frac` and `roofline_dominant.mfma_busy_share` come
+    from PMC counters collected in separate rocprofv3 passes (profiles/r06_step_pmc.json, tools/collect_pmc_step.sh). The file
     records the hash of every kernel source it was collected on; bench.py drops a kernel's counters when its source
-    differs from the build it runs — and this test fails, so a change to the Hough or trunk kernels cannot silently keep
-    quoting another build's counters."""
+    differs from the build it runs — and this test fails for EVERY source the file names (round 5 checked the Hough and trunk
+    files only, and a comment-only commit to average_distance.hip silently dropped the loss kernels' counters)."""
     import hashlib
     import json
-    pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_step_pmc.json")))
-    for kernel in ("hv_vote_kernel", "wino43_mfma_kernel"):
-        ent = pmc[kernel]
-        src = ent["_src"]
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "r06_step_pmc.json")))
+    assert {"hough_voting.hip", "wino_mfma.hip", "conv_first.hip", "winograd.hip", "average_distance.hip", "roi_pool.hip",
+            "fc_mfma.hip", "upscore.hip"} <= set(pmc["_source_sha16"])
+    for src, want in pmc["_source_sha16"].items():
         sha = hashlib.sha256(open(os.path.join(ROOT, "posecnn_amd", "csrc", src), "rb").read()).hexdigest()[:16]
-        assert pmc["_source_sha16"][src] == sha, "profiles/r05_step_pmc.json was collected on another build of %s" % src
-        assert ent["SQ_INSTS_VALU"] > 0 and ent["FETCH_SIZE_KB"] > 0 and ent["WRITE_SIZE_KB"] > 0
+        assert want == sha, "profiles/r06_step_pmc.json was collected on another build of %s: re-run tools/collect_pmc_step.sh" % src
+    for kernel in ("hv_vote_kernel", "wino43_mfma_kernel", "conv12_wino43_fused_kernel", "adl_terms_kernel", "roi_pool_add2_rows"):
+        ent = pmc[kernel]
+        assert ent["_src"] in pmc["_source_sha16"]
+        assert ent["SQ_INSTS_VALU"] > 0 and ent["FETCH_SIZE_KB"] > 0 and ent["WRITE_SIZE_KB"] > 0, kernel
     assert pmc["wino43_mfma_kernel"]["SQ_VALU_MFMA_BUSY_CYCLES"] > 0 and pmc["wino43_mfma_kernel"]["SQ_INSTS_MFMA"] > 0

@@ -1,10 +1,10 @@
 #!/bin/bash
 # PMC counters of the kernels of ONE bench.py step (configs[2], single stream) of THIS build -> $O/step_pmc.json (copy to
-# profiles/r05_step_pmc.json: bench.py's roofline.traffic / valu_frac / mfma_busy_share read it, gated per kernel by the
+# profiles/r06_step_pmc.json: bench.py's roofline.traffic / valu_frac / mfma_busy_share read it, gated per kernel by the
 # hash of the source file the kernel lives in — tests/test_bench_launch.py fails when a gated source changes without a
 # re-collection). Separate rocprofv3 --pmc passes with --kernel-trace only (MI355X_MICROARCH.md, HBM / rocprofv3 section).
-#   bash tools/collect_pmc_step.sh gpurun_out/r5pmc        (on the GPU box)
-O=${1:-gpurun_out/r5pmc}; mkdir -p $O; O=$(cd $O && pwd)
+#   bash tools/collect_pmc_step.sh gpurun_out/r6pmc        (on the GPU box)
+O=${1:-gpurun_out/r6pmc}; mkdir -p $O; O=$(cd $O && pwd)
 R=$(cd $(dirname $0)/.. && pwd)
 cd /tmp && export TMPDIR=/tmp
 : > $O/step_pmc.csv
@@ -21,7 +21,7 @@ python - <<PY
 import csv, hashlib, json, os
 R = "$R"
 sha = lambda f: hashlib.sha256(open(os.path.join(R, "posecnn_amd", "csrc", f), "rb").read()).hexdigest()[:16]
-src_of = {"hv_": "hough_voting.hip", "wino43_mfma": "wino_mfma.hip", "conv12_": "conv_first.hip", "wino43_input": "winograd.hip",
+src_of = {"hv_": "hough_voting.hip", "backproject": "backproject.hip", "deconv_": "upscore.hip", "det_": "heads_small.hip", "pose_": "heads_small.hip", "fc_skinny": "fc_skinny.hip", "wino43_mfma": "wino_mfma.hip", "conv12_": "conv_first.hip", "wino43_input": "winograd.hip",
           "fc_rows": "fc_mfma.hip", "adl_": "average_distance.hip", "roi_pool": "roi_pool.hip", "upscore_": "upscore.hip",
           "hard_label": "hard_label.hip", "head_lowres": "heads_small.hip"}
 out = {"_source": "rocprofv3 --pmc <set> --kernel-trace -- python bench.py --steps 3 --warmup 1 --prewarm-seconds 0 --streams 1 (five separate passes; "
