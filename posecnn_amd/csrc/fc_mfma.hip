@@ -44,20 +44,40 @@ __device__ __forceinline__ void fc_glds16_s(const char* sbase, unsigned voff, un
 // workgroups — fc6 at 75 rows: 128 for 512 slots, each streaming its 6.4 MB weight slab through a
 // 2-deep ring, i.e. bound by HBM latency (0.92 ms for 411 MB). Splitting K over up to `smax` workgroups
 // multiplies the loads in flight; the partial products meet in a fixed-order reduction (deterministic).
-__device__ __forceinline__ int fc_split(int count, int ncb, int NK, int smax, int ws_rows)
+// (round 6) A second reason to split: a launch a little larger than the chip's 512 workgroup slots. fc6 / fc7 of the train
+// batch: 684 live rows = 11 row blocks x 64 column blocks = 704 workgroups = 1.375 rounds — the last 192 run alone on
+// their CUs at ~65 % of the pair's rate while 320 slots idle (the same shape of loss as the trunk's conv5_x, traced in
+// profiles/r06_wino_mfma_trace.txt). Two half-length splits are 1 408 workgroups = 2.75 rounds, i.e. 3 half rounds
+// instead of 2 whole ones. The smallest S whose rounds-per-split figure ceil(live S / 512) / S beats S = 1 by 15 % (the
+// price of the reduction pass) is taken. Measured (tools/bench_fc_rows.py, same box A / B): fc6 at 684 rows 1.42 -> 1.355 ms
+// (99 -> 104 TFLOP/s; the kernel does 131 at 1 500 rows = three exact rounds, so most of the quantisation loss is still
+// there: half-length workgroups pay their prologue and 17-us epilogue twice), at 468 rows 0.88 -> 0.87.
+// `wscap` = rows the workspace holds over all splits; a split needs S x roundup64(count) of them.
+__device__ __forceinline__ int fc_split(int count, int ncb, int NK, int smax, int wscap)
 {
-  if (smax <= 1 || count > ws_rows) return 1;
-  const int live = ((count + 63) >> 6) * ncb;
-  int S = min(smax, 1024 / max(live, 1));
-  S = min(S, NK / 8);            // at least 8 stages (512 of K) per split
-  return max(S, 1);
+  if (smax <= 1) return 1;
+  const int rows64 = ((count + 63) >> 6) << 6;
+  const int live = (rows64 >> 6) * ncb;
+  const int s_fit = min(min(smax, wscap / max(rows64, 64)), NK / 8);   // at least 8 stages (512 of K) per split
+  if (s_fit <= 1) return 1;
+  if (live <= 512) return max(min(s_fit, 1024 / max(live, 1)), 1);   // few workgroups: up to two rounds' worth of them
+  if (NK < 128) return 1;   // fc7 (64 stages per workgroup): half-length workgroups + the reduction measured 0.22 -> 0.25 ms at 684 rows
+  int best = 1;
+  float best_cost = (float)((live + 511) / 512);
+  for (int S = 2; S <= min(s_fit, 4); S++) {
+    const float cost = (float)((live * S + 511) / 512) / (float)S;
+    if (cost < 0.85f * best_cost) { best = S; best_cost = cost / 0.85f; }   // (a later S must beat the one taken outright)
+  }
+  return best;
 }
+// rows between two splits' partial outputs in the workspace
+__device__ __forceinline__ int fc_split_stride(int count) { return ((count + 63) >> 6) << 6; }
 
 __global__ __launch_bounds__(512, 4) void fc_rows_mfma_kernel(
     const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
     const float* __restrict__ addend, float* __restrict__ y, int K, int N, int Mcap, int relu,
     const int* __restrict__ num_rows_dev, int nbm, int ncb, int tall, float* __restrict__ part,
-    int smax, int ws_rows, int ldy, int nvalid, float* __restrict__ y2, int split_col, float* __restrict__ y_b, int relu_b)
+    int smax, int wscap, int ldy, int nvalid, float* __restrict__ y2, int split_col, float* __restrict__ y_b, int relu_b)
 {
   // split_col / y_b (pcnn_fc_rows_split_fwd): output columns [split_col, N) go to a SECOND tensor y_b [Mcap][N - split_col] with
   // their own ReLU flag — two layers that read the same rows (score_conv4 and score_conv4_vertex on conv4_3) as one product.
@@ -84,7 +104,7 @@ __global__ __launch_bounds__(512, 4) void fc_rows_mfma_kernel(
   const int m0 = tb * 64;
   const int count = num_rows_dev ? min(Mcap, num_rows_dev[0]) : Mcap;
   const int ks = blockIdx.y;
-  const int S = fc_split(count, ncb, K / 64, smax, ws_rows);
+  const int S = fc_split(count, ncb, K / 64, smax, wscap);
   if (ks >= S) return;
   if (m0 >= count) {
     // rows that do not exist: zeros, no operand traffic
@@ -220,7 +240,7 @@ __global__ __launch_bounds__(512, 4) void fc_rows_mfma_kernel(
     const int m = m0 + row;
     if (S > 1) {   // partial product of this K range; bias, addend, ReLU and the zero rows belong to the reduction
       if (m < count)
-        *reinterpret_cast<v4f*>(part + ((size_t)ks * ws_rows + m) * N + cb * 64 + c4) = *reinterpret_cast<const v4f*>(&sY[row * 64 + c4]);
+        *reinterpret_cast<v4f*>(part + ((size_t)ks * fc_split_stride(count) + m) * N + cb * 64 + c4) = *reinterpret_cast<const v4f*>(&sY[row * 64 + c4]);
       continue;
     }
     if (m < Mcap && cb * 64 + c4 < nvalid) {
@@ -252,10 +272,10 @@ __global__ __launch_bounds__(512, 4) void fc_rows_mfma_kernel(
 __global__ __launch_bounds__(256) void fc_rows_reduce_kernel(
     const float* __restrict__ part, const float* __restrict__ bias, const float* __restrict__ addend,
     float* __restrict__ y, int K, int N, int Mcap, int relu, const int* __restrict__ num_rows_dev, int ncb,
-    int smax, int ws_rows)
+    int smax, int wscap)
 {
   const int count = num_rows_dev ? min(Mcap, num_rows_dev[0]) : Mcap;
-  const int S = fc_split(count, ncb, K / 64, smax, ws_rows);
+  const int S = fc_split(count, ncb, K / 64, smax, wscap);
   if (S <= 1) return;
   const int n4 = N >> 2;
   const long long total = (long long)min(Mcap, ((count + 63) >> 6) << 6) * n4;
@@ -263,7 +283,7 @@ __global__ __launch_bounds__(256) void fc_rows_reduce_kernel(
     const int m = (int)(i / n4), c4 = (int)(i - (long long)m * n4) * 4;
     v4f val = (v4f){0.f, 0.f, 0.f, 0.f};
     if (m < count) {
-      for (int ks = 0; ks < S; ks++) val += *reinterpret_cast<const v4f*>(part + ((size_t)ks * ws_rows + m) * N + c4);
+      for (int ks = 0; ks < S; ks++) val += *reinterpret_cast<const v4f*>(part + ((size_t)ks * fc_split_stride(count) + m) * N + c4);
       val += *reinterpret_cast<const v4f*>(bias + c4);
       if (addend) val += *reinterpret_cast<const v4f*>(addend + (size_t)m * N + c4);
       if (relu) {
@@ -318,16 +338,18 @@ extern "C" int pcnn_fc_rows_fwd(const float* x, const float* wt, const float* bi
   const int ws_rows = rows_capacity < FC_WS_ROWS ? (rows_capacity + 63) / 64 * 64 : FC_WS_ROWS;
   const size_t need = sizeof(float) * (size_t)FC_SMAX * ws_rows * out_features;
   // grid.y = the most splits a launch may use; every split of every block is a workgroup that must at least
-  // be launched to find out that it has nothing to do, so a big capacity (train mode: 48 x 64 blocks) gets none
-  const int smax_cap = (int)std::min<long long>(FC_SMAX, std::max<long long>(1, 4096 / ((long long)nbm * ncb)));
+  // be launched to find out that it has nothing to do: a big capacity (train mode: 48 x 64 blocks) gets 2 — what
+  // the balance split above can use — and a small one up to FC_SMAX
+  const int smax_cap = (int)std::min<long long>(FC_SMAX, std::max<long long>(2, 4096 / ((long long)nbm * ncb)));
   const int smax = (workspace && workspace_bytes >= need && fc_can_split(rows_capacity, in_features, out_features) && aligned16(workspace)) ? smax_cap : 1;
   float* part = smax > 1 ? static_cast<float*>(workspace) : nullptr;
+  const int wscap = FC_SMAX * ws_rows;   // rows of partial outputs the workspace holds
   PCNN_LAUNCH(fc_rows_mfma_kernel, dim3((unsigned)blocks, smax), dim3(512), 0, stream, x, wt, bias, addend, y, in_features,
-              out_features, rows_capacity, relu, num_rows_dev, nbm, ncb, tall, part, smax, ws_rows, out_features, out_features, (float*)nullptr, 0, (float*)nullptr, 0);
+              out_features, rows_capacity, relu, num_rows_dev, nbm, ncb, tall, part, smax, wscap, out_features, out_features, (float*)nullptr, 0, (float*)nullptr, 0);
   if (smax > 1) {
-    const long long items = (long long)ws_rows * (out_features / 4);
+    const long long items = (long long)std::min(rows_capacity, wscap / 2) * (out_features / 4);   // (a split launch has at most wscap / 2 live rows)
     PCNN_LAUNCH(fc_rows_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, part, bias, addend, y,
-                in_features, out_features, rows_capacity, relu, num_rows_dev, ncb, smax, ws_rows);
+                in_features, out_features, rows_capacity, relu, num_rows_dev, ncb, smax, wscap);
   }
   return check_launch("fc_rows_fwd");
 }
