@@ -340,7 +340,9 @@ extern "C" int pcnn_fc_rows_fwd(const float* x, const float* wt, const float* bi
   // grid.y = the most splits a launch may use; every split of every block is a workgroup that must at least
   // be launched to find out that it has nothing to do: a big capacity (train mode: 48 x 64 blocks) gets 2 — what
   // the balance split above can use — and a small one up to FC_SMAX
-  const int smax_cap = (int)std::min<long long>(FC_SMAX, std::max<long long>(2, 4096 / ((long long)nbm * ncb)));
+  // (a short-K layer — fc7: 64 stages — never takes the balance split: no second grid row, no reduction launch for it)
+  const long long floor_s = in_features / 64 >= 128 ? 2 : 1;
+  const int smax_cap = (int)std::min<long long>(FC_SMAX, std::max<long long>(floor_s, 4096 / ((long long)nbm * ncb)));
   const int smax = (workspace && workspace_bytes >= need && fc_can_split(rows_capacity, in_features, out_features) && aligned16(workspace)) ? smax_cap : 1;
   float* part = smax > 1 ? static_cast<float*>(workspace) : nullptr;
   const int wscap = FC_SMAX * ws_rows;   // rows of partial outputs the workspace holds
