@@ -93,6 +93,18 @@ def parse_args(argv=None):
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: launch / rendezvous / collective / JSON plumbing on gloo")
     ap.add_argument("--master-port", type=int, default=0)
     a = ap.parse_args(argv)
+    # PCNN_BENCH_INPUTS = raw | resident | pinned: the frame hand-over of a line whose command is not ours to change (the driver's
+    # `bench.py --gpus 8 --steps K --warmup W`): raw = --raw-inputs (24.6 MB per step and rank instead of 118), resident =
+    # --resident-inputs. Unset: what the flags say (default: pinned f32 blobs, the same per-rank workload as the 1-GPU line)
+    env_in = os.environ.get("PCNN_BENCH_INPUTS", "").strip().lower()
+    if env_in == "raw":
+        a.raw_inputs, a.resident_inputs = True, False
+    elif env_in == "resident":
+        a.resident_inputs, a.raw_inputs = True, False
+    elif env_in == "pinned":
+        a.resident_inputs = a.raw_inputs = False
+    elif env_in:
+        raise SystemExit("bench.py: PCNN_BENCH_INPUTS must be raw, resident or pinned (got %r)" % env_in)
     if a.streams is None:
         a.streams = 1 if a.graph else 3
     if a.graph_upload is None:
@@ -704,6 +716,12 @@ def main(argv=None):
                                    "instruction of either wave on the SIMD is paid in matrix time (SQ_VALU_MFMA_COEXEC_CYCLES = 0 on gfx950, DESIGN §3.2c)")
         if "SQ_WAIT_ANY" in ent and ent.get("SQ_WAVE_CYCLES"):
             o["wave_cycles_waiting"] = ent["SQ_WAIT_ANY"] / float(ent["SQ_WAVE_CYCLES"])
+        if "SQ_ACTIVE_INST_VALU" in ent:
+            # round 6: the vector ALUs' busy share as the counter itself has it. SQ_ACTIVE_INST_VALU counts, like SQ_WAVE_CYCLES, in
+            # units of 4 cycles (MI355X_MICROARCH.md); summed over the SIMDs and divided by SIMDs x clock x duration it is the share
+            # of the launch with a vector instruction executing. For hv_vote it reads ~1.0 where valu_frac (2 issue cycles per
+            # instruction) reads 0.5: a dependent stream holds the pipe ~4 cycles per instruction (profiles/r05_valu_rate_probe.txt).
+            o["valu_active_share"] = 4.0 * ent["SQ_ACTIVE_INST_VALU"] / cyc
         return o
     adl_rows = int((last["poses_weight"].sum(dim=1) > 0).sum().item()) if a.losses != "none" and last.get("poses_weight") is not None else 0
 

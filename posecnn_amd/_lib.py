@@ -153,6 +153,11 @@ def lib():
                 "libposecnn_hip.so not found at %s — build it with "
                 "`python -c 'import __graft_entry__ as g; g.build()'` or "
                 "`make -C posecnn_amd/csrc`. There is no CPU/PyTorch fallback." % LIB_PATH)
+        # The HIP runtime the process uses must be ONE: torch ships its own libamdhip64 under torch/lib, this library names the
+        # system's by soname. Loaded after torch, the soname resolves to torch's already-mapped copy; loaded BEFORE it, the
+        # process ends up with two runtimes and every launch on a torch stream fails with "no ROCm-capable device is detected"
+        # (round 6: `build()` followed by `smoke()` in one process did exactly that). So torch's goes in first, always.
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is missing: fail loudly

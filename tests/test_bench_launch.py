@@ -4,6 +4,8 @@ print one JSON line from rank 0. `--dry-run` keeps everything except the GPU wor
 import json
 import os
 import subprocess
+
+import pytest
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -49,6 +51,18 @@ def test_gpus2_self_spawns_two_ranks_and_gathers_on_gloo():
     assert pr["ranks"] == 2 and len(pr["ms_per_step_by_rank"]) == 2 and len(pr["h2d_GBps_per_rank"]) == 2
     assert pr["ms_per_step_min"] <= pr["ms_per_step_median"] <= pr["ms_per_step_max"]
     assert out["repeats"] == 1 and out["value_min"] <= out["value_median"] <= out["value_max"]
+
+
+def test_inputs_env_override(monkeypatch):
+    """VERDICT r5 #7: the frame hand-over of the driver's fixed `bench.py --gpus 8 ...` line is selectable through the environment."""
+    import bench
+    for val, want in (("raw", (True, False)), ("resident", (False, True)), ("pinned", (False, False)), ("", (False, False))):
+        monkeypatch.setenv("PCNN_BENCH_INPUTS", val)
+        a = bench.parse_args(["--gpus", "8"])
+        assert (a.raw_inputs, a.resident_inputs) == want, val
+    monkeypatch.setenv("PCNN_BENCH_INPUTS", "floppy")
+    with pytest.raises(SystemExit):
+        bench.parse_args([])
 
 
 def test_spread_and_per_rank_fields():

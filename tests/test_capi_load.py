@@ -100,3 +100,15 @@ def test_plain_c_consumer_of_the_header_links_and_runs(L):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "capi_consumer ok" in r.stdout
+
+
+def test_library_is_loaded_after_torchs_hip_runtime():
+    """Round 6: `build()` followed by `smoke()` in ONE process failed on the GPU box with "no ROCm-capable device is detected" — the
+    ctypes load of libposecnn_hip.so pulled in the system's libamdhip64 before torch had mapped its own copy, and the process had two
+    HIP runtimes. `_lib.lib()` now imports torch first; this holds it to that in a fresh interpreter."""
+    import subprocess
+    import sys
+    code = ("import sys; assert 'torch' not in sys.modules; from posecnn_amd import _lib; _lib.lib(); "
+            "assert 'torch' in sys.modules; print('ok')")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr

@@ -272,3 +272,12 @@ def test_label_margin_sweep(gpu, capsys):
     with capsys.disabled():
         print("\nlabel margin sweep: 0 flips on all f32 trunks down to amplitude %s; first flips at amplitude %s; largest float64 gap at a "
               "flipped pixel %.3g" % (res["smallest_amplitude_with_zero_flips_on_all_f32_trunks"], first_flip, res["flip_gap_max_overall"]))
+
+
+def test_build_then_smoke_in_one_process():
+    """`python __graft_entry__.py smoke` = build() and smoke() in ONE interpreter: the order in which the two HIP runtimes of the
+    process (torch's bundled copy, the system's) get mapped must not matter (posecnn_amd/_lib.py loads torch's first). Before the
+    fix this failed with "hough_voting_fwd: no ROCm-capable device is detected" while smoke() alone passed."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "__graft_entry__.py"), "smoke"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
