@@ -188,6 +188,7 @@ class Network(object):
         self.winograd_min_channels = 64
         self.winograd_tile = 4
         self._wino_u = {}
+        self._fc_cache = {}    # transposed / zero-padded fc weights (not in the Winograd filter cache)
         # F(4x4,3x3) layers with Cin, Cout multiples of 64: the 36 contractions + output transform run in
         # the library's own fp32-MFMA kernel (csrc/wino_mfma.hip); False = library batched GEMM + transform kernel
         self.winograd_mfma = True
@@ -610,10 +611,10 @@ class Network(object):
     def _fc_wt(self, name, w):
         """The TF weight variable [in, out] transposed to [out, in] (K contiguous rows for the kernels), cached."""
         key = (w.data_ptr(), w._version)
-        hit = self._wino_u.get(("fc", name))
+        hit = self._fc_cache.get(("fc", name))
         if hit is None or hit[0] != key:
             hit = (key, w.detach().t().contiguous())
-            self._wino_u[("fc", name)] = hit
+            self._fc_cache[("fc", name)] = hit
         return hit[1]
 
     def _fc_skinny_ok(self, feed_in, dim, w):
@@ -638,7 +639,7 @@ class Network(object):
                 and num_out % 4 == 0 and not (torch.is_grad_enabled() and (w.requires_grad or x.requires_grad))):
             # more rows than the skinny kernel takes (a batch): the row kernel on a zero-padded filter, tanh in its epilogue
             key = (w.data_ptr(), w._version, b.data_ptr(), b._version)
-            hit = self._wino_u.get(("fc_pad", name))
+            hit = self._fc_cache.get(("fc_pad", name))
             if hit is None or hit[0] != key:
                 npad = (num_out + 63) // 64 * 64
                 wp = torch.zeros((npad, dim), dtype=torch.float32, device=w.device)
@@ -646,7 +647,7 @@ class Network(object):
                 bp = torch.zeros((npad,), dtype=torch.float32, device=w.device)
                 bp[:num_out] = b.detach()
                 hit = (key, wp, bp)
-                self._wino_u[("fc_pad", name)] = hit
+                self._fc_cache[("fc_pad", name)] = hit
             y, t = ops.fc_rows_cols(x.contiguous(), hit[1], hit[2], num_out, "tanh", num_rows=self.rows_count)
             self.layers[name], self.layers[tanh_name] = y, t
             return self.feed(t)
