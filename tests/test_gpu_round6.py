@@ -281,3 +281,55 @@ def test_build_then_smoke_in_one_process():
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(ROOT, "__graft_entry__.py"), "smoke"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ---- hv_order / hv_vote: the launch order is free, the answer is not ------------------------------------------------
+def _paint(label, vertex, cls, box, centre, z, rng, dir_noise=0.03):
+    y0, y1, x0, x1 = box
+    yy, xx = np.mgrid[y0:y1, x0:x1]
+    label[y0:y1, x0:x1] = cls
+    ang = np.arctan2(centre[1] - yy, centre[0] - xx) + rng.standard_normal(yy.shape) * dir_noise
+    vertex[y0:y1, x0:x1, 3 * cls + 0] = np.cos(ang)
+    vertex[y0:y1, x0:x1, 3 * cls + 1] = np.sin(ang)
+    vertex[y0:y1, x0:x1, 3 * cls + 2] = np.log(z) + rng.standard_normal(yy.shape) * 0.01
+
+
+@pytest.mark.parametrize("vote_thr", [-1.0, 4.0])
+def test_hough_order_extremes(gpu, vote_thr):
+    """Round 6 reordered the vote launch (hv_order: heaviest class first, a row -> first-record table per class, bands that no
+    record reaches answered without voting). Votes are order-free, so every output must still equal the oracle's — on a batch
+    built to stress exactly that machinery: an image with NO class over the label threshold between live ones, one class covering
+    a whole image (5 000+ records: the heaviest, in the LAST image), twenty classes each barely over the threshold in one image,
+    an object hugging the bottom border (its bands end the table), a class whose pixels are two far-apart blobs (rows without
+    records in the middle of its table), and record counts spanning three power-of-two buckets of the counting sort.
+    Reference: lib/hough_voting_gpu_layer/hough_voting_gpu_op.cu.cc:174-333, 386-576."""
+    from test_gpu_hough import both
+    rng = np.random.default_rng(606)
+    B, H, W, C = 6, 240, 320, 22
+    K = config.DEMO_INTRINSICS.copy(); K[:2] *= W / 640.0
+    label = np.zeros((B, H, W), np.int32)
+    vertex = (rng.standard_normal((B, H, W, 3 * C)) * 0.1).astype(F)
+    # image 0: a small object and a large one
+    _paint(label[0], vertex[0], 3, (20, 60, 30, 70), (50, 40), 0.9, rng)
+    _paint(label[0], vertex[0], 7, (70, 230, 100, 300), (200, 150), 0.7, rng)
+    # image 1: nothing above the threshold (199 pixels of class 5, threshold 200)
+    label[1].reshape(-1)[1000:1199] = 5
+    # image 2: twenty classes, 14 x 15 = 210 pixels each
+    for i, cls in enumerate(range(1, 21)):
+        r, c = divmod(i, 5)
+        _paint(label[2], vertex[2], cls, (10 + 55 * r, 24 + 55 * r, 10 + 60 * c, 25 + 60 * c), (17 + 60 * c, 17 + 55 * r), 1.0, rng)
+    # image 3: an object on the bottom border, and a class made of two blobs 150 rows apart
+    _paint(label[3], vertex[3], 11, (200, 240, 120, 220), (170, 225), 0.8, rng)
+    _paint(label[3], vertex[3], 2, (5, 25, 10, 40), (160, 100), 1.1, rng)
+    _paint(label[3], vertex[3], 2, (175, 195, 270, 300), (160, 100), 1.1, rng)
+    # image 4: empty altogether; image 5: one class over the whole frame (76 800 pixels -> 7 680 records at skip 10)
+    _paint(label[5], vertex[5], 21, (0, H, 0, W), (W / 2, H / 2), 0.6, rng)
+    meta = np.stack([config.make_meta_data(K)] * B)
+    got = both(gpu, label, vertex, config.LOV_EXTENTS, meta, vote_thr=vote_thr, per_thr=0.01, label_thr=200)
+    n = int(got[5][1])
+    imgs = set(int(b) for b in got[0][:n, 0])
+    assert {0, 2, 3, 5} <= imgs and 1 not in imgs and 4 not in imgs and n >= 24
+    # and in train mode (9 rows per maximum, targets from gt poses) through the same launch order
+    gt = np.array([[0, 7, 0, 0, 0, 0, 1, 0, 0, 0, 0.05, 0.02, 0.7], [5, 21, 0, 0, 0, 0, 1, 0, 0, 0, 0.0, 0.0, 0.6]], F)
+    if vote_thr < 0:
+        both(gpu, label, vertex, config.LOV_EXTENTS, meta, gt=gt, is_train=1, vote_thr=vote_thr, per_thr=0.01, label_thr=200)
