@@ -333,3 +333,38 @@ def test_hough_order_extremes(gpu, vote_thr):
     gt = np.array([[0, 7, 0, 0, 0, 0, 1, 0, 0, 0, 0.05, 0.02, 0.7], [5, 21, 0, 0, 0, 0, 1, 0, 0, 0, 0.0, 0.0, 0.6]], F)
     if vote_thr < 0:
         both(gpu, label, vertex, config.LOV_EXTENTS, meta, gt=gt, is_train=1, vote_thr=vote_thr, per_thr=0.01, label_thr=200)
+
+
+# ---- fc_rows: the balance split (a launch a little over the chip's 512 workgroup slots) ------------------------------
+@pytest.mark.parametrize("M,K,N,count,relu", [(3024, 8192, 4096, 684, True),     # 704 workgroups, K = 128 stages: S = 2 (the fc6 case, shorter K)
+                                             (3024, 8192, 4096, 513, False),    # 9 row blocks = 576 workgroups: S = 2 as well
+                                             (3024, 8192, 4096, 1500, True),    # 1 536 workgroups = three exact rounds: no split
+                                             (3024, 4096, 4096, 684, True),     # fc7: 64 stages, never the balance split
+                                             (1100, 8192, 2048, 1100, True)])   # 18 x 32 = 576 workgroups, no device count, capacity over the workspace's half
+def test_fc_rows_balance_split_matches_float64(gpu, M, K, N, count, relu):
+    """`fc_split` (csrc/fc_mfma.hip) now also splits K when the live workgroups are a little over the chip's 512 slots (round 6).
+    Same contract as every fc_rows path: rows below the device count equal x W + b to f32 summation-order noise against a
+    float64 product (no worse than 3 x the library GEMM's error), rows at or past it are exactly zero whatever the buffer
+    holds, and two runs give the same bits (the partial products meet in a fixed order). Reference: `Network.fc`,
+    lib/networks/network.py:392-422."""
+    import torch
+    from posecnn_amd import ops
+    torch.backends.cuda.matmul.allow_tf32 = False
+    g = torch.Generator(device="cpu").manual_seed(M + K + count)
+    x = torch.randn((M, K), generator=g).to(gpu)
+    w = (torch.randn((K, N), generator=g) / K ** 0.5).to(gpu)
+    b = torch.randn((N,), generator=g).to(gpu)
+    if count < M:
+        x[count:] = float("nan")
+    cnt = torch.tensor([count], dtype=torch.int32, device=gpu) if count < M else None
+    wt = w.t().contiguous()
+    y = ops.fc_rows(x, wt, b, relu, num_rows=cnt)
+    ref = x[:count].double() @ w.double() + b.double()
+    lib = torch.addmm(b, x[:count], w)
+    if relu:
+        ref, lib = torch.relu(ref), torch.relu(lib)
+    scale = float(ref.abs().max())
+    err, err_lib = float((y[:count].double() - ref).abs().max()), float((lib.double() - ref).abs().max())
+    assert err <= max(3.0 * err_lib, 4e-6 * scale), (err, err_lib, scale)
+    assert not y[count:].cpu().numpy().view(np.uint32).any()
+    assert torch.equal(y, ops.fc_rows(x, wt, b, relu, num_rows=cnt))
