@@ -582,31 +582,44 @@ class Network(object):
         w = self.make_var(name + "/weights", (dim, num_out), self._weight_init(dim), trainable)
         b = self.make_var(name + "/biases", (num_out,), lambda s: torch.zeros(s), trainable)
         rows = getattr(self, "rows_count", None)
-        if self._fc_skinny_ok(feed_in, dim, w):
+        route = self._fc_route(feed_in.is_cuda, feed_in.shape[0] if feed_in.dim() == 2 else None, dim, num_out,
+                               self._fc_wants_grad(w, layer_trainable=trainable, feed_requires_grad=feed_in.requires_grad), rows is not None)
+        if route == "skinny":
             # a handful of rows (the single-frame loop): the layer is a weight stream — csrc/fc_skinny.hip
             return ops.fc_skinny(feed_in.contiguous(), self._fc_wt(name, w), b, "relu" if relu else "none", num_rows=rows)
-        if rows is not None and self._fc_rows_ok(feed_in, dim, num_out, w):
+        if route == "rows":
             # capacity-sized rows behind the sync-free Hough layer: only the first *rows_count rows exist
             return ops.fc_rows(feed_in.contiguous(), self._fc_wt(name, w), b, relu, num_rows=rows)
         y = torch.addmm(b, feed_in, w)
         return F.relu(y) if relu else y
 
-    @staticmethod
-    def _fc_rows_ok(feed_in, dim, num_out, w):
-        return (feed_in.is_cuda and dim % 64 == 0 and dim >= 128 and num_out % 64 == 0
-                and not (torch.is_grad_enabled() and (w.requires_grad or feed_in.requires_grad)))
+    def _fc_wants_grad(self, w, layer_trainable=True, feed_requires_grad=False):
+        """Will a product with this weight be recorded for autograd? `w` may not exist yet (None) or may not carry its flag
+        yet: `make_var` turns it on at the layer's first call when both the network and the layer are trainable."""
+        will = (w is not None and w.requires_grad) or (self.trainable and layer_trainable and (w is None or w.is_leaf))
+        return torch.is_grad_enabled() and (will or feed_requires_grad)
+
+    def _fc_route(self, is_cuda, n_rows, dim, num_out, wants_grad, has_count):
+        """Which implementation `fc` takes — ONE predicate for `fc` itself and for `fc_masks_dead_rows` (the two used
+        to restate it separately): "skinny" (csrc/fc_skinny.hip: a device-counted buffer of at most SKINNY_MAX_ROWS rows),
+        "rows" (csrc/fc_mfma.hip: any device-counted buffer whose shapes the kernel takes) or "addmm" (the framework: every
+        trainable graph under autograd, CPU tensors, odd shapes). The two library routes never read a row at or past the count."""
+        if not is_cuda or wants_grad or not has_count:
+            return "addmm"
+        if self.fc_skinny and n_rows is not None and 1 <= n_rows <= ops.SKINNY_MAX_ROWS and dim % 16 == 0:
+            return "skinny"
+        if dim % 64 == 0 and dim >= 128 and num_out % 64 == 0:
+            return "rows"
+        return "addmm"
 
     def fc_masks_dead_rows(self, name, dim, num_out, rows=None):
-        """Will `fc(name)` on a capacity-sized, device-counted row buffer run on the library's row kernels — which
+        """Will `fc(name)` on a capacity-sized, device-counted row buffer of `rows` rows run on the library's row kernels — which
         never read the rows at or past the count — or on the framework's addmm, which reads all of them? The caller
-        (fcn.im_segment_batch) leaves dead rows of the pooled features unwritten only in the first case. Same predicate
-        as `fc` / `_fc_skinny_ok` (a variable that does not exist yet is created by `fc` with this network's
-        `trainable`; the pooled features never require gradients on this path)."""
+        (fcn.im_segment_batch) leaves dead rows of the pooled features unwritten only in the first case. Decided by `fc`'s own
+        predicate (`_fc_route`), with the gradient flag the variable WILL have once `fc` has created / flagged it."""
         w = self.vars.get(name + "/weights")
-        wants_grad = (self.trainable if w is None else w.requires_grad) and torch.is_grad_enabled()
         dev_ok = torch.device(self.device).type == "cuda"
-        skinny = self.fc_skinny and rows is not None and 1 <= rows <= ops.SKINNY_MAX_ROWS and dim % 16 == 0
-        return dev_ok and not wants_grad and (skinny or (dim % 64 == 0 and dim >= 128 and num_out % 64 == 0))
+        return self._fc_route(dev_ok, rows, dim, num_out, self._fc_wants_grad(w), True) != "addmm"
 
     def _fc_wt(self, name, w):
         """The TF weight variable [in, out] transposed to [out, in] (K contiguous rows for the kernels), cached."""

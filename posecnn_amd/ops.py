@@ -685,6 +685,10 @@ def _ticket_buffer(device, n):
     return buf
 
 
+# The crossover between the two few-row paths of fc6 / fc7 / fc8: at or below it csrc/fc_skinny.hip streams the
+# weights with split-K over the whole chip; above it `fc_rows` / `fc_rows_cols` take the layer on 64-row blocks. fc8 through
+# `fc_rows_cols` has no split-K: with tens of live rows a couple of workgroups stream its padded 128 x 4096 filter (2 MB) —
+# ~10 us, launch-bound either way, and only cheaper per row from there.
 SKINNY_MAX_ROWS = 32
 
 
