@@ -113,6 +113,13 @@ def test_bench_reports_outputs_equal_serial(gpu):
     d = out["outputs_equal_serial_detail"]
     assert d["batches_compared"] == 6 and d["mismatches"] == 0 and min(d["rows_per_batch"]) > 0
     assert "3 HIP streams" in out["step_submission"]
+    # round 6: the spread of the timed region and the per-rank block travel with every line (--repeats defaults to 5)
+    assert out["repeats"] == 5 and len(out["value_all"]) == 5 and abs(out["value_all"][0] - out["value"]) < 0.01
+    assert out["value_min"] <= out["value_median"] <= out["value_max"] and out["value_min"] > 0.8 * out["value_max"]
+    pr = out["per_rank"]
+    assert pr["ranks"] == 1 and abs(pr["ms_per_step_by_rank"][0] - out["ms_per_step"]) < 0.05 * out["ms_per_step"] and pr["h2d_GBps_per_rank"][0] > 1.0
+    # the Hough counters are this build's (source-hash gate) and say what bounds the vote kernel: its vector ALUs
+    assert out["roofline"]["traffic"] and 0.5 < out["roofline"]["valu_active_share"] < 1.3
 
 
 def test_two_ranks_on_one_gpu_through_the_real_launcher(gpu):
@@ -134,6 +141,8 @@ def test_two_ranks_on_one_gpu_through_the_real_launcher(gpu):
     assert out["outputs_equal_serial"] is True, out["outputs_equal_serial_detail"]
     assert out["config"]["detections_per_step"] >= 2 * 3 * 16    # both ranks' frames carry their planted objects
     assert pg["all_gather_us"] is not None and pg["all_gather_us"] > 0
+    assert out["per_rank"]["ranks"] == 2 and len(out["per_rank"]["ms_per_step_by_rank"]) == 2 and len(out["per_rank"]["h2d_GBps_per_rank"]) == 2
+    assert out["per_rank"]["ms_per_step_max"] <= out["ms_per_step"] * 1.02    # the contract's MAX over ranks (taken after the barrier) bounds them
 
 
 def test_head_lowres_mfma_equals_the_op_sequence_it_replaces(gpu):
