@@ -100,10 +100,9 @@ def test_average_distance_symmetric_heavy_rows_strided(gpu):
 
 
 # ---- (b), (c) one literal configs[2] batch ------------------------------------------------------------------------
-@pytest.fixture(scope="module")
-def configs2(gpu):
-    """bench.py's default step on its own first batch (rank 0, batch index 0): GPU outputs + the CPU restatement's,
-    frame by frame (B = 1 per CPU run: the reference's own loop, and 16 frames of CPU activations never coexist)."""
+def _bench_batch(gpu, B, H, W, C, ext, symm):
+    """bench.py's step on its own first batch (rank 0, batch index 0) at one of its presets: GPU outputs + the CPU restatement's,
+    frame by frame (B = 1 per CPU run: the reference's own loop, and a batch of CPU activations never coexists)."""
     import torch
     sys.path.insert(0, ROOT)
     import bench
@@ -112,9 +111,8 @@ def configs2(gpu):
     from posecnn_amd.networks import vgg16_convs
     torch.backends.cuda.matmul.allow_tf32 = False
     torch.backends.cudnn.allow_tf32 = False
-    B, H, W, C = 16, 480, 640, 22
     K = config.DEMO_INTRINSICS.copy()
-    ext, symm = config.LOV_EXTENTS, config.LOV_SYMMETRY
+    K[:2] *= W / 640.0   # (bench.py's rule = lib/fcn/test.py:130-131)
     kw = dict(vertex_reg_2d=True, pose_reg=True, trainable=False, is_train=True, seed=3, init="he", with_losses=False)
     net = vgg16_convs("RGBD", C, 64, (1.0,), 1.0, -1.0, device=gpu, **kw)
     synth.init_calibrated(net)
@@ -152,13 +150,35 @@ def configs2(gpu):
     return g, frames, scenes
 
 
+@pytest.fixture(scope="module")
+def configs2(gpu):
+    return _bench_batch(gpu, 16, 480, 640, 22, config.LOV_EXTENTS, config.LOV_SYMMETRY)
+
+
+@pytest.fixture(scope="module")
+def configs4(gpu):
+    """`bench.py --config linemod` (BASELINE configs[4] on one GPU): 4 frames of 1280 x 960 RGB-D, 13 LINEMOD classes + background."""
+    return _bench_batch(gpu, 4, 960, 1280, 14, config.LINEMOD_EXTENTS, config.LINEMOD_SYMMETRY)
+
+
 def test_configs2_batch_matches_cpu_restatement_frame_by_frame(configs2, capsys):
-    g, frames, scenes = configs2
+    _compare_with_cpu_restatement(configs2, 3024, 512, "configs[2]", capsys)
+
+
+def test_configs4_linemod_batch_matches_cpu_restatement_frame_by_frame(configs4, capsys):
+    """The same end-to-end statement at the LINEMOD preset's size (4 x 960 x 1280 RGB-D, C = 14; the graph of
+    lib/networks/vgg16_convs.py:36-200 with `lib/datasets/linemod.py`'s extents): 4.9 M label decisions, train-mode Hough with
+    planted gt poses on 1 281-column Hough rows, RoI pooling on 120 x 160 / 60 x 80 maps, the loss with the symmetric class 10."""
+    _compare_with_cpu_restatement(configs4, 4 * 13 * 9, 64, "configs[4]", capsys)
+
+
+def _compare_with_cpu_restatement(fix, cap_want, min_live, what, capsys):
+    g, frames, scenes = fix
     B = len(frames)
     n = g["n"]
-    assert g["cap"] == 3024 and n % 9 == 0
+    assert g["cap"] == cap_want and n % 9 == 0
     live = int((g["poses_weight"][:n].sum(axis=1) > 0).sum())
-    assert live > 512, "the headline batch holds more rows with targets than ADL_ROW_SLOTS (bench: 684), got %d" % live
+    assert live > min_live, "%s: %d rows with targets (the headline batch must hold more than ADL_ROW_SLOTS = 512; bench: 684)" % (what, live)
     # label maps: bit-exact (north_star), all 16 x 480 x 640 decisions
     flips = sum(int((g["label_2d"][b] != frames[b]["label_2d"][0]).sum()) for b in range(B))
     assert flips == 0, "%d label pixels differ from the CPU restatement" % flips
@@ -196,8 +216,8 @@ def test_configs2_batch_matches_cpu_restatement_frame_by_frame(configs2, capsys)
     loss_g = float(np.ravel(g["loss_pose"])[0])
     assert loss_g > 0 and abs(loss_g - float(wl[0])) <= 1e-4 * abs(float(wl[0])), (loss_g, float(wl[0]))
     with capsys.disabled():
-        print("\nconfigs[2] batch vs CPU restatement: 0 label flips / %d px, %d rows (%d with targets), box diff %.3g px, "
-              "|dq| %.3g, |dt| %.3g m, loss_pose %.9g vs %.9g" % (g["label_2d"].size, n, live, box_d, quat_d, trans_d, loss_g, float(wl[0])))
+        print("\n%s batch vs CPU restatement: 0 label flips / %d px, %d rows (%d with targets), box diff %.3g px, "
+              "|dq| %.3g, |dt| %.3g m, loss_pose %.9g vs %.9g" % (what, g["label_2d"].size, n, live, box_d, quat_d, trans_d, loss_g, float(wl[0])))
 
 
 def test_configs2_batch_custom_ops_bit_exact_on_the_steps_own_buffers(configs2, gpu):
@@ -206,6 +226,7 @@ def test_configs2_batch_custom_ops_bit_exact_on_the_steps_own_buffers(configs2, 
     from posecnn_amd import ops
     g, _, _ = configs2
     n, cap = g["n"], g["cap"]
+    assert cap == 3024
     t = g["t"]
     # (c) roi_pool_add2(conv5_3 @ 1/16, conv4_3 @ 1/8) with the device-side count: live rows bit-exact
     rows_cnt = torch.tensor([n], dtype=torch.int32, device=gpu)
