@@ -389,3 +389,45 @@ def test_fc_rows_balance_split_matches_float64(gpu, M, K, N, count, relu):
     assert err <= max(3.0 * err_lib, 4e-6 * scale), (err, err_lib, scale)
     assert not y[count:].cpu().numpy().view(np.uint32).any()
     assert torch.equal(y, ops.fc_rows(x, wt, b, relu, num_rows=cnt))
+
+
+def test_configs1_single_colour_frame_matches_cpu_restatement(gpu, capsys):
+    """BASELINE configs[1] at its own size: ONE 640 x 480 RGB frame, test mode (the single-frame loop of lib/fcn/test.py:1867-1888:
+    fc6-8 on the few-row weight-streaming kernel, Cin-split deep trunk launches, one-launch heads) end to end against the CPU
+    restatement: label map bit-exact, detections' classes / boxes / vote counts exact, quaternions and translations within 1e-4."""
+    import torch
+    from cpu_reference import run_cpu_pipeline, vgg16_convs_cpu
+    from posecnn_amd import dist as pdist, fcn
+    from posecnn_amd.networks import vgg16_convs
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    B, H, W, C = 1, 480, 640, 22
+    kw = dict(vertex_reg_2d=True, pose_reg=True, trainable=False, is_train=False, seed=3, init="he", with_losses=False)
+    net = vgg16_convs("COLOR", C, 64, (1.0,), 1.0, -1.0, device=gpu, **kw)
+    synth.init_calibrated(net)
+    cpu = vgg16_convs_cpu("COLOR", C, 64, (1.0,), 1.0, -1.0, **kw)
+    K = config.DEMO_INTRINSICS.copy()
+    g = torch.Generator(device="cpu").manual_seed(4242)
+    data = (torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8).float() - torch.from_numpy(config.PIXEL_MEANS)).float().numpy()
+    planted_np, scenes = synth.make_planted_batch(9100, B, H=H, W=W, K=K, C=C, extents=config.LOV_EXTENTS)
+    pts = synth.make_model_points(C, 256)
+    with torch.no_grad():
+        det = fcn.im_segment_batch(net, T(gpu, data), K, config.LOV_EXTENTS, T(gpu, pts), config.LOV_SYMMETRY,
+                                   planted={k: T(gpu, v) for k, v in planted_np.items()})
+        rows, counts = pdist.all_gather_detections(det.rows, det.count)
+    flat = pdist.flatten_gathered(rows, counts)
+    g_rois, g_poses = fcn.finalize_batch(flat, flat.shape[0])
+    cpu.share_weights(net)
+    ref = run_cpu_pipeline(cpu, data, K, config.LOV_EXTENTS, pts, config.LOV_SYMMETRY, planted=planted_np)
+    flips = int((N(det.label_2d) != ref["label_2d"]).sum())
+    assert flips == 0, "%d label pixels differ from the CPU restatement" % flips
+    want_cls = sorted((b, o[0]) for b, s in enumerate(scenes) for o in s["objects"] if (s["label_lowres"] == o[0]).sum() * 64 > 500)
+    assert sorted((int(r[0]), int(r[1])) for r in g_rois) == want_cls and len(want_cls) >= 3
+    og = np.lexsort((g_rois[:, 1], g_rois[:, 0])); oc = np.lexsort((ref["final_rois"][:, 1], ref["final_rois"][:, 0]))
+    gr, gp, cr, cp = g_rois[og], g_poses[og], ref["final_rois"][oc], ref["final_poses"][oc]
+    assert np.array_equal(gr[:, :2], cr[:, :2]) and np.array_equal(gr[:, 6], cr[:, 6])
+    box_d, quat_d, trans_d = float(np.abs(gr[:, 2:6] - cr[:, 2:6]).max()), float(np.abs(gp[:, :4] - cp[:, :4]).max()), float(np.abs(gp[:, 4:] - cp[:, 4:]).max())
+    assert box_d < 1e-3 and quat_d < 1e-4 and trans_d < 1e-4, (box_d, quat_d, trans_d)
+    with capsys.disabled():
+        print("\nconfigs[1] frame vs CPU restatement: 0 label flips / %d px, %d detections, box diff %.3g px, |dq| %.3g, |dt| %.3g m"
+              % (H * W, len(want_cls), box_d, quat_d, trans_d))
