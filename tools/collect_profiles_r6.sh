@@ -22,7 +22,7 @@ python tools/bench_fc_rows.py > $O/fc_rows.txt 2>&1
 python tools/bench_ops.py > $O/ops.json 2> $O/ops.err
 python tools/bench_wino_mfma.py --no-library > $O/layers_mfma.json 2> $O/layers_mfma.err
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py --steps 10 --warmup 3 --prewarm-seconds 4 --no-cpu-baseline --no-secondary > $O/bench_traced.json 2> $O/prof.log
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py --steps 10 --warmup 3 --prewarm-seconds 4 --repeats 1 --no-cpu-baseline --no-secondary > $O/bench_traced.json 2> $O/prof.log
 python $R/tools/rocprof_summary.py $O/prof/bench_results.db --marker hv_emit_kernel --steps 8 > $O/bench_kernel_stats.csv 2> $O/kernel_stats.err
 rm -rf $O/prof
 cd $R
